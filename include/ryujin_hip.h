@@ -1,0 +1,269 @@
+/*
+ * ryujin_hip.h -- C ABI of the MI355X-native hyperbolic update.
+ *
+ * This is the drop-in boundary for ONE hot path of conservation-laws/ryujin:
+ * HyperbolicModule::prepare_state_vector() + HyperbolicModule::step<stages>()
+ * (reference: source/hyperbolic_module.h:110-278,
+ *  source/hyperbolic_module.template.h:96-193,234-1211).
+ *
+ * The reference has no FFI layer; its boundary is the C++ class template
+ * ryujin::HyperbolicModule<Description,dim,Number>. A maintainer binds this
+ * header from a thin C++ shim with the same member signatures (shown in
+ * INTEGRATION.md, shipped as ryujin_amd/csrc/hyperbolic_module_shim.hpp).
+ *
+ * Conventions
+ *  - plain C, no torch / HIP types in any signature;
+ *  - every function returns an int status (never throws across the ABI);
+ *  - all arrays are HOST pointers in the reference's own layouts (cited per
+ *    field); the library converts them once to its device layout in create();
+ *  - state vectors live in device memory behind integer handles; the caller
+ *    moves data explicitly with state_upload()/state_download().
+ */
+#ifndef RYUJIN_HIP_H
+#define RYUJIN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ------------------------------------------------------- */
+#define RYUJIN_OK 0
+/* invariant-domain violation with id_violation_strategy == warn
+ * (hyperbolic_module.template.h:1198-1202: n_warnings_++) */
+#define RYUJIN_WARN 1
+/* ... with id_violation_strategy == raise_exception; the C++ shim converts
+ * this into `throw Restart()` (hyperbolic_module.template.h:1203-1205) */
+#define RYUJIN_RESTART 2
+/* tau_max is NaN/inf/<=0 (AssertThrow at hyperbolic_module.template.h:573) */
+#define RYUJIN_ERR_TAU (-1)
+#define RYUJIN_ERR_ARG (-2)
+#define RYUJIN_ERR_HIP (-3)
+#define RYUJIN_ERR_COMM (-4)
+#define RYUJIN_ERR_UNSUPPORTED (-5)
+
+/* ---- enums -------------------------------------------------------------- */
+/* Description (source/<eq>/description.h) */
+enum { RYUJIN_EQ_EULER = 0, RYUJIN_EQ_SHALLOW_WATER = 1 };
+
+/* ryujin::Boundary (source/discretization.h:28-112) */
+enum {
+  RYUJIN_BC_DO_NOTHING = 0,
+  RYUJIN_BC_PERIODIC = 1,
+  RYUJIN_BC_SLIP = 2,
+  RYUJIN_BC_NO_SLIP = 3,
+  RYUJIN_BC_DIRICHLET = 4,
+  RYUJIN_BC_DYNAMIC = 5,
+  RYUJIN_BC_DIRICHLET_MOMENTUM = 6
+};
+
+/* IDViolationStrategy (source/hyperbolic_module.h:32-47) */
+enum { RYUJIN_IDV_WARN = 0, RYUJIN_IDV_RAISE_EXCEPTION = 1 };
+
+/* ---- run-time parameters ------------------------------------------------ */
+/*
+ * Everything the reference keeps in ParameterAcceptor subsections that the
+ * hot path reads. Defaults (ryujin_hip_default_params) are the reference's.
+ */
+typedef struct ryujin_hip_params {
+  int equation; /* RYUJIN_EQ_* */
+  int dim;      /* 1, 2, 3 */
+
+  /* "B - Equation" Euler: source/euler/hyperbolic_system.h:665-699 */
+  double gamma;                          /* 7/5 */
+  double reference_density;              /* 1 */
+  double vacuum_state_relaxation_small;  /* 1e2 */
+  double vacuum_state_relaxation_large;  /* 1e4 */
+
+  /* "B - Equation" shallow water: source/shallow_water/hyperbolic_system.h:643-673 */
+  double gravity;                        /* 9.81 */
+  double manning_friction_coefficient;   /* 0 */
+  double reference_water_depth;          /* 1 */
+  double dry_state_relaxation_factor;    /* 0.2 */
+  double dry_state_relaxation_small;     /* 1e2 */
+  double dry_state_relaxation_large;     /* 1e4 */
+
+  /* HyperbolicModule: hyperbolic_module.template.h:36,45 */
+  double cfl;                /* 0.2 until the TimeIntegrator sets it */
+  int id_violation_strategy; /* RYUJIN_IDV_WARN */
+
+  /* "/indicator": source/euler/indicator.h:28 */
+  double indicator_evc_factor; /* 1 */
+
+  /* "/limiter": source/euler/limiter.h:26-49, shallow_water/limiter.h:27-59 */
+  int limiter_iterations;             /* 2, must be in [0,2] */
+  double limiter_newton_tolerance;    /* 1e-10 */
+  int limiter_newton_max_iterations;  /* 2 */
+  double limiter_relaxation_factor;   /* 1 */
+  int limiter_limit_on_kinetic_energy;  /* SW: 0 */
+  int limiter_limit_on_square_velocity; /* SW: 1 */
+
+  /* "/riemann solver": source/euler/riemann_solver.h:27-38 */
+  int riemann_newton_max_iterations; /* 0 */
+  double riemann_newton_tolerance;   /* 1e-10 */
+} ryujin_hip_params;
+
+/* ---- offline data (input contract) ------------------------------------- */
+/*
+ * Read-only stencil/geometry data, the output of OfflineData::prepare()
+ * (source/offline_data.h:121-264), in the reference's local numbering
+ *    [0,n_export) c [0,n_internal) c [0,n_owned) c [0,n_relevant)
+ * (source/offline_data.template.h:210-272) and in the SparsityPatternSIMD
+ * storage scheme (source/sparse_matrix_simd.h:311-350,403-418):
+ *   rows [0,n_internal): groups of simd_length rows of equal length,
+ *     entry (row,col_idx,comp) at
+ *       data[(row_starts[row/sl] + col_idx*sl)*n_comp + comp*sl + row%sl]
+ *     column index at columns[row_starts[row/sl] + col_idx*sl + row%sl];
+ *     row_starts has one entry per group, i.e. indices 0..n_internal/sl;
+ *   rows [n_internal,n_relevant): plain CSR,
+ *       data[(row_starts[row] + col_idx)*n_comp + comp],
+ *     where row_starts is indexed by the row itself (the reference re-bases
+ *     row_starts[n_internal] := row_starts[n_internal/sl],
+ *     sparse_matrix_simd.template.h:127).
+ *   row_starts therefore has n_relevant+1 entries of which only
+ *   [0, n_internal/sl] and [n_internal, n_relevant] are meaningful.
+ *   simd_length == 1 (or n_internal == 0) is plain CSR.
+ * Column 0 of every row is the diagonal, the rest ascend by local index
+ * (deal.II square SparsityPattern; relied on at
+ * hyperbolic_module.template.h:394-396). Ghost rows [n_owned,n_relevant)
+ * hold the diagonal and those entries whose transpose is locally owned
+ * (sparse_matrix_simd.template.h:61-74).
+ */
+typedef struct ryujin_hip_offline {
+  uint32_t n_export, n_internal, n_owned, n_relevant;
+  uint32_t simd_length;
+  const uint64_t *row_starts; /* [n_relevant+1], see above */
+  const uint32_t *columns;    /* [nnz] */
+  const double *cij;          /* [nnz*dim]  c_ij = int phi_i grad phi_j  (offline_data.template.h:566-576) */
+  const double *mij;          /* [nnz]      m_ij = int phi_i phi_j */
+  const double *mi;           /* [n_relevant] lumped mass  (offline_data.template.h:790-802) */
+  const double *mi_inv;       /* [n_relevant] */
+  double measure_of_omega;
+
+  /* boundary_map() (offline_data.h:66-72), SoA, in application order */
+  uint32_t n_bdry;
+  const uint32_t *b_i;      /* [n_bdry] local index (owned) */
+  const double *b_normal;   /* [n_bdry*dim] unit normal */
+  const uint8_t *b_id;      /* [n_bdry] RYUJIN_BC_* */
+
+  /* coupling_boundary_pairs() (offline_data.h:74-82) */
+  uint32_t n_pairs;
+  const uint32_t *p_i, *p_col, *p_j; /* [n_pairs] each */
+
+  /* initial_precomputed (shallow water bathymetry Z_i); NULL for Euler.
+   * hyperbolic_module.template.h:84-85 */
+  const double *initial_precomputed; /* [n_relevant * n_initial_precomputed] */
+
+  /*
+   * Exchange pattern (all zero / NULL for a single rank). Neighbour ranks in
+   * ascending order. Vector exchange = dealii Partitioner semantics
+   * (ghost range sorted by owner, receive in place):
+   *   send to nbr p the owned entries send_idx[send_off[p]..send_off[p+1]),
+   *   receive from nbr p into ghost rows [recv_off[p], recv_off[p+1])
+   *   (recv_off[0] == n_owned, recv_off[n_nbr] == n_relevant).
+   * Matrix ghost-row exchange (sparse_matrix_simd.h:649-763):
+   *   send to nbr p the entries (row_send_row[e], row_send_col[e]),
+   *   e in [row_send_off[p], row_send_off[p+1]); received values fill the
+   *   ghost rows of that neighbour contiguously in storage order.
+   */
+  int n_nbr;
+  const int *nbr_rank;       /* [n_nbr] */
+  const uint32_t *send_off;  /* [n_nbr+1] */
+  const uint32_t *send_idx;  /* [send_off[n_nbr]] */
+  const uint32_t *recv_off;  /* [n_nbr+1] */
+  const uint32_t *row_send_off; /* [n_nbr+1] */
+  const uint32_t *row_send_row; /* [row_send_off[n_nbr]] */
+  const uint32_t *row_send_col; /* [row_send_off[n_nbr]] */
+} ryujin_hip_offline;
+
+typedef struct ryujin_hip_ctx ryujin_hip_ctx; /* opaque; one per (rank, GPU) */
+
+/* ---- communicator (RCCL over xGMI) -------------------------------------- */
+/*
+ * One process per GPU. Rank 0 calls comm_unique_id(), the caller broadcasts
+ * the 128 bytes by whatever means it has (MPI_Bcast in ryujin, a
+ * torch.distributed broadcast in bench.py), every rank calls comm_init().
+ * Replaces the reference's MPI calls listed in SURVEY.md section 2.2.
+ */
+#define RYUJIN_HIP_UNIQUE_ID_BYTES 128
+typedef struct ryujin_hip_comm ryujin_hip_comm;
+int ryujin_hip_comm_unique_id(char id[RYUJIN_HIP_UNIQUE_ID_BYTES]);
+int ryujin_hip_comm_init(ryujin_hip_comm **comm, const char id[RYUJIN_HIP_UNIQUE_ID_BYTES],
+                         int rank, int n_ranks, int device);
+void ryujin_hip_comm_destroy(ryujin_hip_comm *comm);
+
+/* ---- lifecycle ----------------------------------------------------------- */
+void ryujin_hip_default_params(ryujin_hip_params *params, int equation, int dim);
+
+/* HyperbolicModule ctor + prepare() (hyperbolic_module.template.h:28-86).
+ * `comm` may be NULL for a single rank. `device` is the HIP device ordinal. */
+int ryujin_hip_create(ryujin_hip_ctx **ctx, const ryujin_hip_offline *offline,
+                      const ryujin_hip_params *params, ryujin_hip_comm *comm, int device);
+void ryujin_hip_destroy(ryujin_hip_ctx *ctx);
+
+/* ---- state vectors (StateVector = U + precomputed, source/state_vector.h:47-51) */
+int ryujin_hip_state_alloc(ryujin_hip_ctx *ctx, int *handle);
+int ryujin_hip_state_free(ryujin_hip_ctx *ctx, int handle);
+/* U_aos: MultiComponentVector layout U[i*k + d], i < n_relevant
+ * (source/multicomponent_vector.h:55-183) */
+int ryujin_hip_state_upload(ryujin_hip_ctx *ctx, int handle, const double *U_aos);
+int ryujin_hip_state_download(ryujin_hip_ctx *ctx, int handle, double *U_aos);
+int ryujin_hip_state_download_precomputed(ryujin_hip_ctx *ctx, int handle, double *prec_aos);
+
+/* ---- the hot path -------------------------------------------------------- */
+/*
+ * prepare_state_vector(state_vector, t) (hyperbolic_module.template.h:96-193).
+ * dirichlet_aos: [n_bdry*k] the value of initial_values_->initial_state(
+ * position, t) for every boundary_map entry (only read for dirichlet /
+ * dynamic / dirichlet_momentum ids); may be NULL if none of those ids occur
+ * or to re-use the data passed in the previous call.
+ */
+int ryujin_hip_prepare_state_vector(ryujin_hip_ctx *ctx, int handle, double t,
+                                    const double *dirichlet_aos);
+
+/*
+ * step<stages>(old, stage_state_vectors, stage_weights, new, tau, tau_max)
+ * (hyperbolic_module.template.h:234-1211). stages in [0,4]. Writes only
+ * new.U on [0,n_owned). *tau_out = the tau actually used. Returns RYUJIN_OK,
+ * RYUJIN_WARN, RYUJIN_RESTART or RYUJIN_ERR_TAU; counters as the reference.
+ */
+int ryujin_hip_step(ryujin_hip_ctx *ctx, int h_old, int stages, const int *h_stage,
+                    const double *stage_weights, int h_new, double tau_in,
+                    double tau_max_in, double *tau_out);
+
+/* TimeIntegrator helpers that touch the device-resident vectors:
+ * sadd(dst,s,b,src): dst.U = s*dst.U + b*src.U (time_integrator.template.h:18-25) */
+int ryujin_hip_sadd(ryujin_hip_ctx *ctx, int h_dst, double s, double b, int h_src);
+
+/* ---- accessors of HyperbolicModule (hyperbolic_module.h:225-278) --------- */
+int ryujin_hip_set_cfl(ryujin_hip_ctx *ctx, double cfl);
+int ryujin_hip_get_cfl(ryujin_hip_ctx *ctx, double *cfl);
+int ryujin_hip_set_id_violation_strategy(ryujin_hip_ctx *ctx, int strategy);
+int ryujin_hip_get_alpha(ryujin_hip_ctx *ctx, double *alpha /* [n_relevant] */);
+int ryujin_hip_get_counters(ryujin_hip_ctx *ctx, unsigned *n_restarts, unsigned *n_warnings);
+
+/* ---- introspection for parity tests and profiling ------------------------ */
+/* Module-owned intermediates of the LAST step() in the reference's logical
+ * (row, col_idx) order as plain CSR over owned rows (nnz_owned entries):
+ * what: 0 d_ij, 1 l_ij (after the last pass = lij_matrix_), 2 p_ij (k comps),
+ *       3 bounds (n_bounds per row), 4 r_i (k per row), 5 lij_next */
+int ryujin_hip_debug_fetch(ryujin_hip_ctx *ctx, int what, double *out, size_t n_doubles);
+/* wall time [ms] of each of the 7 sweeps of the last step (hipEvent pairs; names as
+ * the reference's Scope timers "time step [H] 1..7"); enable = nonzero switches the
+ * event recording on (off by default). */
+int ryujin_hip_set_timers(ryujin_hip_ctx *ctx, int enable);
+int ryujin_hip_get_timers(ryujin_hip_ctx *ctx, double ms[8]);
+/* Block until all device work of this context has finished. */
+int ryujin_hip_synchronize(ryujin_hip_ctx *ctx);
+/* Record start/stop HIP events on the context's compute stream and read the elapsed ms. */
+int ryujin_hip_event_record(ryujin_hip_ctx *ctx, int which /*0 start, 1 stop*/);
+int ryujin_hip_event_elapsed_ms(ryujin_hip_ctx *ctx, double *ms);
+const char *ryujin_hip_last_error(void);
+const char *ryujin_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RYUJIN_HIP_H */

@@ -1,0 +1,446 @@
+// ORACLE -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+//
+// C ABI of the CPU restatement: the same call surface as include/ryujin_hip.h with
+// the prefix ryujin_oracle_ (so the parity tests drive both through one wrapper), plus
+// function-level entry points used to pin the restatement against the reference's
+// golden outputs. Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+// leg load this library.
+
+#include <cstring>
+#include <memory>
+#include <string>
+
+#include <xmmintrin.h>
+#include <pmmintrin.h>
+
+#include "hyperbolic_module.hpp"
+#include "shallow_water.hpp"
+
+using namespace oracle;
+
+namespace
+{
+  thread_local std::string g_error;
+
+  struct Ctx {
+    std::unique_ptr<ModuleBase> m;
+  };
+
+  Ctx *C(void *p) { return static_cast<Ctx *>(p); }
+
+  template <typename F>
+  int guarded(F &&f)
+  {
+    try {
+      return f();
+    } catch (const std::exception &e) {
+      g_error = e.what();
+      return RYUJIN_ERR_ARG;
+    }
+  }
+} // namespace
+
+extern "C" {
+
+void ryujin_oracle_default_params(ryujin_hip_params *p, int equation, int dim)
+{
+  std::memset(p, 0, sizeof(*p));
+  p->equation = equation;
+  p->dim = dim;
+  p->gamma = 7. / 5.;
+  p->reference_density = 1.;
+  p->vacuum_state_relaxation_small = 1.e2;
+  p->vacuum_state_relaxation_large = 1.e4;
+  p->gravity = 9.81;
+  p->manning_friction_coefficient = 0.;
+  p->reference_water_depth = 1.;
+  p->dry_state_relaxation_factor = 2.e-1;
+  p->dry_state_relaxation_small = 1.e2;
+  p->dry_state_relaxation_large = 1.e4;
+  p->cfl = 0.2;
+  p->id_violation_strategy = RYUJIN_IDV_WARN;
+  p->indicator_evc_factor = 1.;
+  p->limiter_iterations = 2;
+  p->limiter_newton_tolerance = 1.e-10;
+  p->limiter_newton_max_iterations = 2;
+  p->limiter_relaxation_factor = 1.;
+  p->limiter_limit_on_kinetic_energy = 0;
+  p->limiter_limit_on_square_velocity = 1;
+  p->riemann_newton_max_iterations = 0;
+  p->riemann_newton_tolerance = 1.e-10;
+}
+
+/* FTZ/DAZ as the reference sets in main (source/main.cc:26-36) */
+void ryujin_oracle_set_flush_denormals(int on)
+{
+  _MM_SET_FLUSH_ZERO_MODE(on ? _MM_FLUSH_ZERO_ON : _MM_FLUSH_ZERO_OFF);
+  _MM_SET_DENORMALS_ZERO_MODE(on ? _MM_DENORMALS_ZERO_ON : _MM_DENORMALS_ZERO_OFF);
+}
+
+int ryujin_oracle_create(void **ctx, const ryujin_hip_offline *offline,
+                         const ryujin_hip_params *params, void * /*comm*/, int /*device*/)
+{
+  return guarded([&]() {
+    auto c = std::make_unique<Ctx>();
+    const int dim = params->dim;
+    if (params->equation == RYUJIN_EQ_EULER) {
+      if (dim == 1)
+        c->m = std::make_unique<EulerModule<1>>(*offline, *params);
+      else if (dim == 2)
+        c->m = std::make_unique<EulerModule<2>>(*offline, *params);
+      else if (dim == 3)
+        c->m = std::make_unique<EulerModule<3>>(*offline, *params);
+    } else if (params->equation == RYUJIN_EQ_SHALLOW_WATER) {
+      if (dim == 1)
+        c->m = std::make_unique<ShallowWaterModule<1>>(*offline, *params);
+      else if (dim == 2)
+        c->m = std::make_unique<ShallowWaterModule<2>>(*offline, *params);
+    }
+    if (!c->m) {
+      g_error = "unsupported equation/dimension";
+      return RYUJIN_ERR_UNSUPPORTED;
+    }
+    *ctx = c.release();
+    return RYUJIN_OK;
+  });
+}
+
+void ryujin_oracle_destroy(void *ctx)
+{
+  delete C(ctx);
+}
+
+void ryujin_oracle_set_exchange(void *ctx, exchange_fn fn, void *user)
+{
+  C(ctx)->m->exchange = fn;
+  C(ctx)->m->exchange_user = user;
+}
+
+void ryujin_oracle_set_expensive_bounds_check(void *ctx, int on)
+{
+  C(ctx)->m->expensive_bounds_check = on != 0;
+}
+
+int ryujin_oracle_state_alloc(void *ctx, int *handle)
+{
+  return guarded([&]() {
+    *handle = C(ctx)->m->state_alloc();
+    return RYUJIN_OK;
+  });
+}
+
+int ryujin_oracle_state_free(void *ctx, int handle)
+{
+  return guarded([&]() {
+    C(ctx)->m->state_free(handle);
+    return RYUJIN_OK;
+  });
+}
+
+int ryujin_oracle_state_upload(void *ctx, int handle, const double *U)
+{
+  return guarded([&]() {
+    auto &m = *C(ctx)->m;
+    std::memcpy(m.state_U(handle), U, sizeof(double) * (size_t)m.n_relevant * m.k());
+    return RYUJIN_OK;
+  });
+}
+
+int ryujin_oracle_state_download(void *ctx, int handle, double *U)
+{
+  return guarded([&]() {
+    auto &m = *C(ctx)->m;
+    std::memcpy(U, m.state_U(handle), sizeof(double) * (size_t)m.n_relevant * m.k());
+    return RYUJIN_OK;
+  });
+}
+
+int ryujin_oracle_state_download_precomputed(void *ctx, int handle, double *prec)
+{
+  return guarded([&]() {
+    auto &m = *C(ctx)->m;
+    std::memcpy(prec, m.state_prec(handle), sizeof(double) * (size_t)m.n_relevant * m.n_prec());
+    return RYUJIN_OK;
+  });
+}
+
+int ryujin_oracle_prepare_state_vector(void *ctx, int handle, double t, const double *dirichlet)
+{
+  return guarded([&]() {
+    C(ctx)->m->prepare_state_vector(handle, t, dirichlet);
+    return RYUJIN_OK;
+  });
+}
+
+int ryujin_oracle_step(void *ctx, int h_old, int stages, const int *h_stage, const double *w,
+                       int h_new, double tau_in, double tau_max_in, double *tau_out)
+{
+  return guarded([&]() {
+    if (stages < 0 || stages > 4)
+      return RYUJIN_ERR_ARG;
+    return C(ctx)->m->step(h_old, stages, h_stage, w, h_new, tau_in, tau_max_in, tau_out);
+  });
+}
+
+int ryujin_oracle_sadd(void *ctx, int h_dst, double s, double b, int h_src)
+{
+  return guarded([&]() {
+    C(ctx)->m->sadd(h_dst, s, b, h_src);
+    return RYUJIN_OK;
+  });
+}
+
+int ryujin_oracle_set_cfl(void *ctx, double cfl)
+{
+  C(ctx)->m->params.cfl = cfl;
+  return RYUJIN_OK;
+}
+
+int ryujin_oracle_get_cfl(void *ctx, double *cfl)
+{
+  *cfl = C(ctx)->m->params.cfl;
+  return RYUJIN_OK;
+}
+
+int ryujin_oracle_set_id_violation_strategy(void *ctx, int s)
+{
+  C(ctx)->m->params.id_violation_strategy = s;
+  return RYUJIN_OK;
+}
+
+int ryujin_oracle_get_alpha(void *ctx, double *alpha)
+{
+  auto &m = *C(ctx)->m;
+  std::memcpy(alpha, m.alpha.data(), sizeof(double) * m.n_relevant);
+  return RYUJIN_OK;
+}
+
+int ryujin_oracle_get_counters(void *ctx, unsigned *n_restarts, unsigned *n_warnings)
+{
+  *n_restarts = C(ctx)->m->n_restarts;
+  *n_warnings = C(ctx)->m->n_warnings;
+  return RYUJIN_OK;
+}
+
+int ryujin_oracle_debug_fetch(void *ctx, int what, double *out, size_t n)
+{
+  return guarded([&]() { return C(ctx)->m->debug_fetch(what, out, n); });
+}
+
+const char *ryujin_oracle_last_error(void)
+{
+  return g_error.c_str();
+}
+
+/* ------------------------------------------------------------------------
+ * Function-level entry points (golden-vector tests)
+ * ---------------------------------------------------------------------- */
+
+/* Euler RiemannSolver::compute(riemann_data_i, riemann_data_j) with trace.
+ * out[0..4] = p_star_two_rarefaction, p_star_failsafe, p*_tilde, phi(p*_tilde), lambda_max
+ * out[5..8] = p_1, p_2, gap, lambda_max at start of the Newton iteration
+ * out[9] = converged_after (-1 if never), out[10] = number of recorded iterations
+ * iters[8*n..] = phi_p_1, phi_p_2, dphi_p_1, dphi_p_2, p_1, p_2, gap, lambda_max */
+int ryujin_oracle_euler_riemann(const ryujin_hip_params *p, const double rd_i[4],
+                                const double rd_j[4], double out[11], double *iters,
+                                int max_iters)
+{
+  euler::RiemannSolver rs(*p);
+  euler::RiemannTrace tr;
+  const euler::primitive_type a{{rd_i[0], rd_i[1], rd_i[2], rd_i[3]}};
+  const euler::primitive_type b{{rd_j[0], rd_j[1], rd_j[2], rd_j[3]}};
+  rs.compute(a, b, &tr);
+  out[0] = tr.p_star_two_rarefaction;
+  out[1] = tr.p_star_failsafe;
+  out[2] = tr.p_star_tilde;
+  out[3] = tr.phi_p_star_tilde;
+  out[4] = tr.lambda_max;
+  out[5] = tr.p_1_start;
+  out[6] = tr.p_2_start;
+  out[7] = tr.gap_start;
+  out[8] = tr.lambda_max_start;
+  out[9] = tr.converged_after;
+  out[10] = (double)tr.iterations.size();
+  for (size_t n = 0; n < tr.iterations.size() && (int)n < max_iters; ++n) {
+    const auto &it = tr.iterations[n];
+    const double v[8] = {it.phi_p_1, it.phi_p_2, it.dphi_p_1, it.dphi_p_2,
+                         it.p_1,     it.p_2,     it.gap,      it.lambda_max};
+    std::memcpy(iters + 8 * n, v, sizeof(v));
+  }
+  return RYUJIN_OK;
+}
+
+/* lambda_max from conserved states and a unit normal (RiemannSolver::compute(U_i,U_j,i,js,n_ij)) */
+double ryujin_oracle_euler_lambda_max(const ryujin_hip_params *p, const double *U_i,
+                                      const double *U_j, const double *n_ij)
+{
+  euler::RiemannSolver rs(*p);
+  const int dim = p->dim;
+  if (dim == 1) {
+    return rs.compute<1>({{U_i[0], U_i[1], U_i[2]}}, {{U_j[0], U_j[1], U_j[2]}}, {{n_ij[0]}});
+  } else if (dim == 2) {
+    return rs.compute<2>({{U_i[0], U_i[1], U_i[2], U_i[3]}}, {{U_j[0], U_j[1], U_j[2], U_j[3]}},
+                         {{n_ij[0], n_ij[1]}});
+  }
+  return rs.compute<3>({{U_i[0], U_i[1], U_i[2], U_i[3], U_i[4]}},
+                       {{U_j[0], U_j[1], U_j[2], U_j[3], U_j[4]}}, {{n_ij[0], n_ij[1], n_ij[2]}});
+}
+
+/* Euler Limiter::limit in 1-D (the reference's unit test is dim = 1).
+ * out[0]=l, out[1]=success, out[2]=t_l start, out[3]=t_r start, out[4..7]= violation flags
+ * (density low, density high, entropy low, entropy high), out[8] = n recorded iterations
+ * iters[7*n..] = kind, psi_l, psi_r, dpsi_l, dpsi_r, t_l, t_r */
+int ryujin_oracle_euler_limit_1d(const ryujin_hip_params *p, int expensive_bounds_check,
+                                 const double bounds[3], const double U[3], const double P[3],
+                                 double out[9], double *iters, int max_iters)
+{
+  euler::View<1> view(*p);
+  euler::Limiter<1> lim(view, *p);
+  lim.expensive_bounds_check = expensive_bounds_check != 0;
+  euler::LimiterTrace tr;
+  const auto [l, success] = lim.limit({{bounds[0], bounds[1], bounds[2]}}, {{U[0], U[1], U[2]}},
+                                      {{P[0], P[1], P[2]}}, 0., 1., &tr);
+  out[0] = l;
+  out[1] = success ? 1. : 0.;
+  out[2] = tr.t_l_start;
+  out[3] = tr.t_r_start;
+  out[4] = tr.density_violation_low_order;
+  out[5] = tr.density_violation_high_order;
+  out[6] = tr.entropy_violation_low_order;
+  out[7] = tr.entropy_violation_high_order;
+  out[8] = (double)tr.iterations.size();
+  for (size_t n = 0; n < tr.iterations.size() && (int)n < max_iters; ++n) {
+    const auto &it = tr.iterations[n];
+    const double v[7] = {(double)it.kind, it.psi_l, it.psi_r, it.dpsi_l, it.dpsi_r, it.t_l, it.t_r};
+    std::memcpy(iters + 7 * n, v, sizeof(v));
+  }
+  return RYUJIN_OK;
+}
+
+/* generic-dim limiter (parity tests of the HIP device function) */
+int ryujin_oracle_euler_limit(const ryujin_hip_params *p, const double *bounds, const double *U,
+                              const double *P, double *l, int *success)
+{
+  auto run = [&](auto dim_tag) {
+    constexpr int dim = decltype(dim_tag)::value;
+    euler::View<dim> view(*p);
+    euler::Limiter<dim> lim(view, *p);
+    typename euler::View<dim>::state_type u, pp;
+    for (int q = 0; q < dim + 2; ++q) {
+      u[q] = U[q];
+      pp[q] = P[q];
+    }
+    const auto [t, s] = lim.limit({{bounds[0], bounds[1], bounds[2]}}, u, pp);
+    *l = t;
+    *success = s;
+  };
+  if (p->dim == 1)
+    run(std::integral_constant<int, 1>{});
+  else if (p->dim == 2)
+    run(std::integral_constant<int, 2>{});
+  else
+    run(std::integral_constant<int, 3>{});
+  return RYUJIN_OK;
+}
+
+/* Euler HyperbolicSystemView scalar functions for state U in dimension p->dim:
+ * out layout: internal_energy, internal_energy_derivative[k], pressure, specific_entropy,
+ * harten_entropy, harten_entropy_derivative[k], mathematical_entropy,
+ * mathematical_entropy_derivative[k], f[k*dim], speed_of_sound */
+int ryujin_oracle_euler_view(const ryujin_hip_params *p, const double *U, double *out)
+{
+  auto run = [&](auto dim_tag) {
+    constexpr int dim = decltype(dim_tag)::value;
+    constexpr int k = dim + 2;
+    euler::View<dim> v(*p);
+    typename euler::View<dim>::state_type u;
+    for (int q = 0; q < k; ++q)
+      u[q] = U[q];
+    double *o = out;
+    *o++ = v.internal_energy(u);
+    for (auto x : v.internal_energy_derivative(u))
+      *o++ = x;
+    *o++ = v.pressure(u);
+    *o++ = v.specific_entropy(u);
+    *o++ = v.harten_entropy(u);
+    for (auto x : v.harten_entropy_derivative(u))
+      *o++ = x;
+    *o++ = v.mathematical_entropy(u);
+    for (auto x : v.mathematical_entropy_derivative(u))
+      *o++ = x;
+    const auto f = v.f(u);
+    for (int q = 0; q < k; ++q)
+      for (int d = 0; d < dim; ++d)
+        *o++ = f[q][d];
+    *o++ = v.speed_of_sound(u);
+  };
+  if (p->dim == 1)
+    run(std::integral_constant<int, 1>{});
+  else if (p->dim == 2)
+    run(std::integral_constant<int, 2>{});
+  else
+    run(std::integral_constant<int, 3>{});
+  return RYUJIN_OK;
+}
+
+/* boundary conditions on a single state (dim from params) */
+int ryujin_oracle_euler_apply_bc(const ryujin_hip_params *p, int id, const double *U,
+                                 const double *normal, const double *U_dirichlet, double *out)
+{
+  auto run = [&](auto dim_tag) {
+    constexpr int dim = decltype(dim_tag)::value;
+    constexpr int k = dim + 2;
+    euler::View<dim> v(*p);
+    typename euler::View<dim>::state_type u, ud;
+    std::array<double, dim> n;
+    for (int q = 0; q < k; ++q) {
+      u[q] = U[q];
+      ud[q] = U_dirichlet[q];
+    }
+    for (int d = 0; d < dim; ++d)
+      n[d] = normal[d];
+    const auto r = v.apply_boundary_conditions(id, u, n, ud);
+    for (int q = 0; q < k; ++q)
+      out[q] = r[q];
+  };
+  if (p->dim == 1)
+    run(std::integral_constant<int, 1>{});
+  else if (p->dim == 2)
+    run(std::integral_constant<int, 2>{});
+  else
+    run(std::integral_constant<int, 3>{});
+  return RYUJIN_OK;
+}
+
+/* shallow water Riemann solver on 1-D riemann data {h, u, a}: out = {h_star, lambda_max} */
+int ryujin_oracle_sw_riemann(const ryujin_hip_params *p, const double rd_i[3], const double rd_j[3],
+                             double out[2])
+{
+  shallow_water::RiemannSolver rs(*p);
+  double h_star = 0.;
+  out[1] = rs.compute({{rd_i[0], rd_i[1], rd_i[2]}}, {{rd_j[0], rd_j[1], rd_j[2]}}, &h_star);
+  out[0] = h_star;
+  return RYUJIN_OK;
+}
+
+/* import check: logical CSR view (ptr, col, transposed position) of a reference layout */
+int ryujin_oracle_import_csr(const ryujin_hip_offline *o, uint64_t *ptr, uint32_t *col,
+                             uint64_t *transpose, const double *data, uint32_t n_comp, double *out)
+{
+  return guarded([&]() {
+    CSR csr;
+    csr.import(*o);
+    std::copy(csr.ptr.begin(), csr.ptr.end(), ptr);
+    if (col)
+      std::copy(csr.col.begin(), csr.col.end(), col);
+    if (transpose)
+      std::copy(csr.transpose.begin(), csr.transpose.end(), transpose);
+    if (data && out) {
+      const auto g = csr.gather(*o, data, n_comp);
+      std::copy(g.begin(), g.end(), out);
+    }
+    return RYUJIN_OK;
+  });
+}
+
+} /* extern "C" */

@@ -1,0 +1,77 @@
+"""Initial/Dirichlet state recipes used as synthetic inputs (formulas restated from
+source/euler/initial_state_{uniform,radial_contrast,isentropic_vortex}.h and
+source/euler/hyperbolic_system.h:1255-1272 `from_primitive_state`)."""
+from __future__ import annotations
+
+import numpy as np
+
+
+def euler_from_primitive(rho, vel, p, gamma=1.4):
+    """vel: [..., dim]. Returns conserved [..., dim+2] = (rho, rho v, p/(gamma-1) + rho |v|^2/2)."""
+    rho = np.asarray(rho, dtype=np.float64)
+    vel = np.asarray(vel, dtype=np.float64)
+    p = np.asarray(p, dtype=np.float64)
+    U = np.empty(vel.shape[:-1] + (vel.shape[-1] + 2,), dtype=np.float64)
+    U[..., 0] = rho
+    U[..., 1:-1] = rho[..., None] * vel
+    U[..., -1] = p / (gamma - 1.0) + 0.5 * rho * np.sum(vel * vel, axis=-1)
+    return U
+
+
+def euler_uniform(positions, rho=1.4, u=3.0, p=1.0, gamma=1.4, direction=None):
+    """initial_state_uniform.h:36-50: primitive (rho,u,p) along `direction` (default +x)."""
+    n, dim = positions.shape
+    vel = np.zeros((n, dim))
+    d = np.zeros(dim)
+    d[0] = 1.0
+    if direction is not None:
+        d = np.asarray(direction, dtype=np.float64)
+        d = d / np.linalg.norm(d)
+    vel[:] = u * d
+    return euler_from_primitive(np.full(n, rho), vel, np.full(n, p), gamma)
+
+
+def euler_radial_contrast(positions, inner=(1.0, 0.0, 100.0), outer=(1.0, 0.0, 0.1), radius=0.1,
+                          gamma=1.4, center=None):
+    """initial_state_radial_contrast.h:29-62 (|x| <= radius -> inner state)."""
+    n, dim = positions.shape
+    x = positions if center is None else positions - np.asarray(center)
+    r = np.linalg.norm(x, axis=1)
+    inside = r <= radius
+    rho = np.where(inside, inner[0], outer[0])
+    p = np.where(inside, inner[2], outer[2])
+    vel = np.zeros((n, dim))
+    return euler_from_primitive(rho, vel, p, gamma)
+
+
+def euler_isentropic_vortex(positions, t, mach=1.0, beta=5.0, gamma=1.4, direction=(1.0, 1.0),
+                            position=(-1.0, -1.0)):
+    """initial_state_isentropic_vortex.h:54-92 composed with the affine transform of
+    initial_values.template.h:66-148 (translate by `position`, rotate onto `direction`)."""
+    n, dim = positions.shape
+    d = np.asarray(direction, dtype=np.float64)
+    d = d / np.linalg.norm(d)
+    nx, ny = d[0], d[1]
+    x = positions[:, 0] - position[0]
+    y = positions[:, 1] - position[1]
+    # affine_transform: rotate the point back into the vortex frame
+    xr = nx * x + ny * y
+    yr = -ny * x + nx * y
+    xb = xr - mach * t
+    yb = yr
+    r2 = xb * xb + yb * yb
+    factor = beta / (2.0 * np.pi) * np.exp(0.5 - 0.5 * r2)
+    T = 1.0 - (gamma - 1.0) / (2.0 * gamma) * factor * factor
+    u = mach - factor * yb
+    v = factor * xb
+    rho = T ** (1.0 / (gamma - 1.0))
+    p = rho ** gamma
+    E = p / (gamma - 1.0) + 0.5 * rho * (u * u + v * v)
+    # affine_transform_vector: rotate the momentum into the lab frame
+    mx, my = rho * u, rho * v
+    U = np.zeros((n, dim + 2))
+    U[:, 0] = rho
+    U[:, 1] = nx * mx - ny * my
+    U[:, 2] = ny * mx + nx * my
+    U[:, -1] = E
+    return U

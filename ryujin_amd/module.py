@@ -1,0 +1,278 @@
+"""Host-side mirror of ryujin::HyperbolicModule / ryujin::TimeIntegrator over the C ABI.
+
+Same member names, argument meaning and error behaviour as the reference
+(source/hyperbolic_module.h:110-278, source/time_integrator.h:279-302) so that the
+parity tests read like the reference's own. The production shim is the C++ header
+ryujin_amd/csrc/hyperbolic_module_shim.hpp; this Python twin exists for pytest/bench.py.
+
+The class is backend-agnostic: `backend="hip"` binds libryujin_hip.so (the product);
+tests may pass a (lib, prefix) pair for the CPU oracle, which exports the same call
+surface. There is NO silent fallback: a missing HIP library raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+
+class Restart(Exception):
+    """Mirror of ryujin::Restart (source/hyperbolic_module.h:49-57)."""
+
+
+class TauError(RuntimeError):
+    """tau_max is NaN/inf/<=0 (AssertThrow at hyperbolic_module.template.h:573-576)."""
+
+
+class StateVector:
+    """Device-resident (U, precomputed) pair behind an integer handle (source/state_vector.h:47-51)."""
+
+    def __init__(self, module: "HyperbolicModule"):
+        self.module = module
+        h = C.c_int(-1)
+        module._check(module._f("state_alloc")(module._ctx, C.byref(h)))
+        self.handle = h.value
+
+    def upload(self, U: np.ndarray) -> None:
+        U = np.ascontiguousarray(U, dtype=np.float64)
+        assert U.size == self.module.n_relevant * self.module.k
+        self.module._check(self.module._f("state_upload")(
+            self.module._ctx, self.handle, capi.as_ptr(U, capi.c_double_p)))
+
+    def download(self) -> np.ndarray:
+        U = np.empty((self.module.n_relevant, self.module.k), dtype=np.float64)
+        self.module._check(self.module._f("state_download")(
+            self.module._ctx, self.handle, capi.as_ptr(U, capi.c_double_p)))
+        return U
+
+    def download_precomputed(self) -> np.ndarray:
+        P = np.empty((self.module.n_relevant, self.module.n_prec), dtype=np.float64)
+        self.module._check(self.module._f("state_download_precomputed")(
+            self.module._ctx, self.handle, capi.as_ptr(P, capi.c_double_p)))
+        return P
+
+    def free(self) -> None:
+        if self.handle >= 0 and self.module._ctx:
+            self.module._f("state_free")(self.module._ctx, self.handle)
+        self.handle = -1
+
+
+class HyperbolicModule:
+    def __init__(self, offline, params: capi.Params | None = None, *, equation=capi.EQ_EULER,
+                 backend="hip", comm=None, device: int = 0):
+        if backend == "hip":
+            self._lib, self._prefix = capi.load_hip(), "ryujin_hip_"
+        else:
+            self._lib, self._prefix = backend  # (ctypes lib, prefix): the test oracle
+        self.offline = offline
+        self.dim = offline.dim
+        if params is None:
+            params = self.default_params(equation, self.dim)
+        self.params = params
+        self.equation = params.equation
+        self.k = self.dim + 2 if self.equation == capi.EQ_EULER else self.dim + 1
+        self.n_prec = 2
+        self.n_bounds = 3 if self.equation == capi.EQ_EULER else 5
+        self.n_owned, self.n_relevant = offline.n_owned, offline.n_relevant
+        self._ctx = C.c_void_p()
+        self._comm = comm
+        rc = self._f("create")(C.byref(self._ctx), offline.c, C.byref(params),
+                               comm if comm is not None else None, device)
+        self._check(rc)
+
+    # ------------------------------------------------------------------ plumbing
+    def _f(self, name):
+        return getattr(self._lib, self._prefix + name)
+
+    def _check(self, rc: int) -> int:
+        if rc < 0:
+            msg = self._f("last_error")()
+            raise RuntimeError(f"{self._prefix}* failed with status {rc}: {msg.decode() if msg else ''}")
+        return rc
+
+    def default_params(self, equation, dim) -> capi.Params:
+        p = capi.Params()
+        self._f("default_params")(C.byref(p), equation, dim)
+        return p
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._f("destroy")(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ reference API
+    def new_state_vector(self, U: np.ndarray | None = None) -> StateVector:
+        sv = StateVector(self)
+        if U is not None:
+            sv.upload(U)
+        return sv
+
+    def prepare_state_vector(self, state: StateVector, t: float, dirichlet: np.ndarray | None = None):
+        ptr = None
+        if dirichlet is not None:
+            dirichlet = np.ascontiguousarray(dirichlet, dtype=np.float64)
+            assert dirichlet.size == self.offline.n_bdry * self.k
+            ptr = capi.as_ptr(dirichlet, capi.c_double_p)
+        self._check(self._f("prepare_state_vector")(self._ctx, state.handle, float(t), ptr))
+
+    def step(self, old: StateVector, stage_state_vectors, stage_weights, new: StateVector,
+             tau: float = 0.0, tau_max: float = np.finfo(np.float64).max) -> float:
+        """step<stages>(): returns the tau used; raises Restart like the reference."""
+        stages = len(stage_state_vectors)
+        assert stages == len(stage_weights)
+        hs = (C.c_int * max(stages, 1))(*[s.handle for s in stage_state_vectors])
+        ws = (C.c_double * max(stages, 1))(*[float(w) for w in stage_weights])
+        tau_out = C.c_double(0.0)
+        rc = self._f("step")(self._ctx, old.handle, stages, hs, ws, new.handle, float(tau),
+                             float(tau_max), C.byref(tau_out))
+        if rc == capi.RYUJIN_ERR_TAU:
+            raise TauError("I'm sorry, Dave. I'm afraid I can't do that. We crashed.")
+        self._check(rc)
+        self.last_status = rc
+        if rc == capi.RYUJIN_RESTART:
+            raise Restart()
+        return tau_out.value
+
+    def sadd(self, dst: StateVector, s: float, b: float, src: StateVector):
+        self._check(self._f("sadd")(self._ctx, dst.handle, float(s), float(b), src.handle))
+
+    @property
+    def cfl(self) -> float:
+        v = C.c_double()
+        self._check(self._f("get_cfl")(self._ctx, C.byref(v)))
+        return v.value
+
+    @cfl.setter
+    def cfl(self, value: float):
+        self._check(self._f("set_cfl")(self._ctx, float(value)))
+
+    @property
+    def id_violation_strategy(self):
+        return self._idv if hasattr(self, "_idv") else self.params.id_violation_strategy
+
+    @id_violation_strategy.setter
+    def id_violation_strategy(self, s: int):
+        self._idv = s
+        self._check(self._f("set_id_violation_strategy")(self._ctx, int(s)))
+
+    def alpha(self) -> np.ndarray:
+        a = np.empty(self.n_relevant, dtype=np.float64)
+        self._check(self._f("get_alpha")(self._ctx, capi.as_ptr(a, capi.c_double_p)))
+        return a
+
+    def _counters(self):
+        r, w = C.c_uint(), C.c_uint()
+        self._check(self._f("get_counters")(self._ctx, C.byref(r), C.byref(w)))
+        return r.value, w.value
+
+    def n_restarts(self) -> int:
+        return self._counters()[0]
+
+    def n_warnings(self) -> int:
+        return self._counters()[1]
+
+    # ------------------------------------------------------------------ introspection
+    def debug_fetch(self, what: str) -> np.ndarray:
+        codes = {"dij": 0, "lij": 1, "pij": 2, "bounds": 3, "r": 4, "lij_next": 5}
+        rs = self.offline.row_starts
+        nnz_owned = int(rs[self.n_owned])
+        sizes = {"dij": nnz_owned, "lij": nnz_owned, "pij": nnz_owned * self.k,
+                 "bounds": self.n_owned * self.n_bounds, "r": self.n_owned * self.k,
+                 "lij_next": nnz_owned}
+        out = np.empty(sizes[what], dtype=np.float64)
+        self._check(self._f("debug_fetch")(self._ctx, codes[what], capi.as_ptr(out, capi.c_double_p),
+                                           out.size))
+        return out
+
+
+class TimeIntegrator:
+    """Explicit schemes of ryujin::TimeIntegrator that consist solely of
+    prepare_state_vector + step<s> + sadd (source/time_integrator.template.h:279-470)."""
+
+    def __init__(self, module: HyperbolicModule, scheme: str = "erk 33", cfl_min=0.45, cfl_max=0.90,
+                 cfl_recovery_strategy: str = "bang bang control", dirichlet_fn=None):
+        self.m = module
+        self.scheme = scheme
+        self.cfl_min, self.cfl_max = cfl_min, cfl_max
+        self.cfl_recovery_strategy = cfl_recovery_strategy
+        self.dirichlet_fn = dirichlet_fn  # t -> [n_bdry, k] array or None
+        self.temp = [module.new_state_vector() for _ in range(3)]
+        # TimeIntegrator::prepare(): hyperbolic_module_->cfl(cfl_max_)  (:150)
+        module.cfl = cfl_max
+
+    def _prepare(self, sv, t):
+        self.m.prepare_state_vector(sv, t, self.dirichlet_fn(t) if self.dirichlet_fn else None)
+
+    def step(self, state: StateVector, t: float, t_final: float = np.finfo(np.float64).max):
+        """Returns (new_state, tau). The handles are swapped like state_vector.swap(temp)."""
+        tau_max = t_final - t
+        single = {"ssprk 22": self._ssprk22, "ssprk 33": self._ssprk33, "erk 11": self._erk11,
+                  "erk 22": self._erk22, "erk 33": self._erk33}[self.scheme]
+        if self.cfl_recovery_strategy == "bang bang control":
+            self.m.id_violation_strategy = capi.IDV_RAISE_EXCEPTION
+            self.m.cfl = self.cfl_max
+        try:
+            return single(state, t, tau_max)
+        except Restart:
+            if self.cfl_recovery_strategy == "none":
+                raise
+            self.m.id_violation_strategy = capi.IDV_WARN
+            self.m.cfl = self.cfl_min
+            return single(state, t, tau_max)
+
+    def _swap(self, state, idx):
+        new = self.temp[idx]
+        self.temp[idx] = state
+        return new
+
+    def _erk11(self, sv, t, tau_max):
+        self._prepare(sv, t)
+        tau = self.m.step(sv, [], [], self.temp[0], 0.0, tau_max)
+        return self._swap(sv, 0), tau
+
+    def _ssprk22(self, sv, t, tau_max):
+        T = self.temp
+        self._prepare(sv, t)
+        tau = self.m.step(sv, [], [], T[0], 0.0, tau_max)
+        self._prepare(T[0], t + 1.0 * tau)
+        self.m.step(T[0], [], [], T[1], tau)
+        self.m.sadd(T[1], 1.0 / 2.0, 1.0 / 2.0, sv)
+        return self._swap(sv, 1), tau
+
+    def _ssprk33(self, sv, t, tau_max):
+        T = self.temp
+        self._prepare(sv, t)
+        tau = self.m.step(sv, [], [], T[0], 0.0, tau_max)
+        self._prepare(T[0], t + 1.0 * tau)
+        self.m.step(T[0], [], [], T[1], tau)
+        self.m.sadd(T[1], 1.0 / 4.0, 3.0 / 4.0, sv)
+        self._prepare(T[1], t + 0.5 * tau)
+        self.m.step(T[1], [], [], T[0], tau)
+        self.m.sadd(T[0], 2.0 / 3.0, 1.0 / 3.0, sv)
+        return self._swap(sv, 0), tau
+
+    def _erk22(self, sv, t, tau_max):
+        T = self.temp
+        self._prepare(sv, t)
+        tau = self.m.step(sv, [], [], T[0], 0.0, tau_max / 2.0)
+        self._prepare(T[0], t + 1.0 * tau)
+        self.m.step(T[0], [sv], [-1.0], T[1], tau)
+        return self._swap(sv, 1), 2.0 * tau
+
+    def _erk33(self, sv, t, tau_max):
+        T = self.temp
+        self._prepare(sv, t)
+        tau = self.m.step(sv, [], [], T[0], 0.0, tau_max / 3.0)
+        self._prepare(T[0], t + 1.0 * tau)
+        self.m.step(T[0], [sv], [-1.0], T[1], tau)
+        self._prepare(T[1], t + 2.0 * tau)
+        self.m.step(T[1], [sv, T[0]], [0.75, -2.0], T[2], tau)
+        return self._swap(sv, 2), 3.0 * tau

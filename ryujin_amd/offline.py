@@ -1,0 +1,177 @@
+"""Synthetic OfflineData (structured Q1 meshes) -- Python handle over libryujin_synth.so.
+
+Mesh recipes for the BASELINE.json configurations live here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import capi
+
+
+@dataclass
+class MeshSpec:
+    dim: int
+    n_cells: tuple
+    lower: tuple
+    upper: tuple
+    bc: tuple  # ids on -x,+x,-y,+y,-z,+z
+    cut_kind: int = capi.CUT_NONE
+    cut_lo: tuple = (0.0, 0.0, 0.0)
+    cut_hi: tuple = (0.0, 0.0, 0.0)
+    cyl_center: tuple = (0.0, 0.0)
+    cyl_radius: float = 0.0
+    cut_bc: int = capi.BC_SLIP
+    n_ranks: int = 1
+    rank: int = 0
+    name: str = field(default="mesh")
+
+    def to_c(self) -> capi.SynthSpec:
+        s = capi.SynthSpec()
+        s.dim = self.dim
+        pad3 = lambda t, fill: tuple(t) + (fill,) * (3 - len(t))  # noqa: E731
+        s.n_cells = (C.c_uint32 * 3)(*pad3(self.n_cells, 1))
+        s.lower = (C.c_double * 3)(*pad3(self.lower, 0.0))
+        s.upper = (C.c_double * 3)(*pad3(self.upper, 1.0))
+        bc = tuple(self.bc) + (capi.BC_DO_NOTHING,) * (6 - len(self.bc))
+        s.bc = (C.c_int * 6)(*bc)
+        s.cut_kind = self.cut_kind
+        s.cut_lo = (C.c_double * 3)(*pad3(self.cut_lo, 0.0))
+        s.cut_hi = (C.c_double * 3)(*pad3(self.cut_hi, 0.0))
+        s.cyl_center = (C.c_double * 2)(*self.cyl_center)
+        s.cyl_radius = self.cyl_radius
+        s.cut_bc = self.cut_bc
+        s.n_ranks = self.n_ranks
+        s.rank = self.rank
+        return s
+
+
+class SyntheticOffline:
+    """Owns a ryujin_synth handle; `.c` is the ryujin_hip_offline view passed to create()."""
+
+    def __init__(self, spec: MeshSpec):
+        self.spec = spec
+        self._lib = capi.load_synth()
+        cs = spec.to_c()
+        self._h = self._lib.ryujin_synth_build(C.byref(cs))
+        if not self._h:
+            raise RuntimeError("ryujin_synth_build: " + self._lib.ryujin_synth_last_error().decode())
+        self.c = self._lib.ryujin_synth_offline(self._h)  # POINTER(Offline)
+        o = self.c.contents
+        self.dim = spec.dim
+        self.n_export, self.n_internal = o.n_export, o.n_internal
+        self.n_owned, self.n_relevant = o.n_owned, o.n_relevant
+        self.nnz = int(self._lib.ryujin_synth_nnz(self._h))
+        self.n_global = int(self._lib.ryujin_synth_n_global(self._h))
+        self.measure_of_omega = o.measure_of_omega
+        self.n_bdry, self.n_pairs = o.n_bdry, o.n_pairs
+
+    def close(self):
+        if self._h:
+            self._lib.ryujin_synth_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # numpy copies of the arrays (tests / initial data)
+    def _arr(self, ptr, n, dtype):
+        return capi.np_from_ptr(ptr, n, dtype)
+
+    @property
+    def row_starts(self):
+        return self._arr(self.c.contents.row_starts, self.n_relevant + 1, np.uint64)
+
+    @property
+    def columns(self):
+        return self._arr(self.c.contents.columns, self.nnz, np.uint32)
+
+    @property
+    def cij(self):
+        return self._arr(self.c.contents.cij, self.nnz * self.dim, np.float64).reshape(-1, self.dim)
+
+    @property
+    def mij(self):
+        return self._arr(self.c.contents.mij, self.nnz, np.float64)
+
+    @property
+    def mi(self):
+        return self._arr(self.c.contents.mi, self.n_relevant, np.float64)
+
+    @property
+    def positions(self):
+        return self._arr(self._lib.ryujin_synth_positions(self._h), self.n_relevant * self.dim,
+                         np.float64).reshape(-1, self.dim)
+
+    @property
+    def global_ids(self):
+        return self._arr(self._lib.ryujin_synth_global_ids(self._h), self.n_relevant, np.uint64)
+
+    @property
+    def b_i(self):
+        return self._arr(self.c.contents.b_i, self.n_bdry, np.uint32)
+
+    @property
+    def b_id(self):
+        return self._arr(self.c.contents.b_id, self.n_bdry, np.uint8)
+
+    @property
+    def b_normal(self):
+        return self._arr(self.c.contents.b_normal, self.n_bdry * self.dim, np.float64).reshape(-1, self.dim)
+
+    @property
+    def b_positions(self):
+        return self._arr(self._lib.ryujin_synth_bdry_positions(self._h), self.n_bdry * self.dim,
+                         np.float64).reshape(-1, self.dim)
+
+    @property
+    def pairs(self):
+        o = self.c.contents
+        return (self._arr(o.p_i, self.n_pairs, np.uint32), self._arr(o.p_col, self.n_pairs, np.uint32),
+                self._arr(o.p_j, self.n_pairs, np.uint32))
+
+
+# ------------------------------------------------------------------ mesh recipes
+
+def rectangle_2d(n: int, lower=(0.0, 0.0), upper=(1.0, 1.0), bc=capi.BC_SLIP, n_ranks=1, rank=0,
+                 ny: int | None = None) -> MeshSpec:
+    bcs = (bc,) * 4 if isinstance(bc, int) else tuple(bc)
+    return MeshSpec(2, (n, ny or n), lower, upper, bcs, n_ranks=n_ranks, rank=rank, name="rectangle")
+
+
+def mach3_step_2d(cells_per_unit: int, length_units: int = 3, n_ranks=1, rank=0) -> MeshSpec:
+    """[0,L]x[0,1] minus [0.6,L]x[0,0.2]: forward-facing step
+    (geometry: source/geometry_step.h:41-93 without the rounded corner; data:
+    prm/benchmarks/euler-mach3-forward-facing-step.prm). Left dirichlet, right do-nothing,
+    everything else slip. cells_per_unit must be a multiple of 5 so that the step is grid aligned.
+    For weak scaling the channel is lengthened (length_units) and slab-partitioned along x."""
+    assert cells_per_unit % 5 == 0
+    L = float(length_units)
+    return MeshSpec(2, (cells_per_unit * length_units, cells_per_unit), (0.0, 0.0), (L, 1.0),
+                    (capi.BC_DIRICHLET, capi.BC_DO_NOTHING, capi.BC_SLIP, capi.BC_SLIP),
+                    cut_kind=capi.CUT_BOX, cut_lo=(0.6, -1.0, 0.0), cut_hi=(L + 1.0, 0.2, 0.0),
+                    cut_bc=capi.BC_SLIP, n_ranks=n_ranks, rank=rank, name="mach3-step-2d")
+
+
+def box_3d(n: int, lower=(-1.0, -1.0, -1.0), upper=(1.0, 1.0, 1.0), bc=capi.BC_SLIP, n_ranks=1, rank=0,
+           nx: int | None = None) -> MeshSpec:
+    bcs = (bc,) * 6 if isinstance(bc, int) else tuple(bc)
+    return MeshSpec(3, (nx or n, n, n), lower, upper, bcs, n_ranks=n_ranks, rank=rank, name="box-3d")
+
+
+def cylinder_channel_3d(cells_per_unit: int, length_units: int = 4, n_ranks=1, rank=0) -> MeshSpec:
+    """[0,L]x[-1,1]x[-1,1] minus a staircase cylinder r=0.25 at x=0.6 (axis along z);
+    prm/benchmarks/euler-mach3-cylinder-3d.prm."""
+    L = float(length_units)
+    return MeshSpec(3, (cells_per_unit * length_units, 2 * cells_per_unit, 2 * cells_per_unit),
+                    (0.0, -1.0, -1.0), (L, 1.0, 1.0),
+                    (capi.BC_DIRICHLET, capi.BC_DO_NOTHING, capi.BC_SLIP, capi.BC_SLIP, capi.BC_SLIP,
+                     capi.BC_SLIP),
+                    cut_kind=capi.CUT_CYLINDER, cyl_center=(0.6, 0.0), cyl_radius=0.25,
+                    cut_bc=capi.BC_SLIP, n_ranks=n_ranks, rank=rank, name="mach3-cylinder-3d")

@@ -1,0 +1,25 @@
+#!/bin/sh
+# Generating script for tests/golden/: copies the reference's own golden OUTPUT
+# data files (numdiff baselines: numbers only, no source) for the hot path.
+# Run in the build container, where /root/reference exists. The files are data
+# fixtures (expected outputs of the reference's tests); test INPUTS are restated
+# in tests/*.py with a citation of the reference test they come from.
+set -e
+R=/root/reference/tests
+D=$(dirname "$0")
+cp $R/euler/riemann_solver.output              $D/euler_riemann_solver.output
+cp $R/euler/riemann_solver-iterated-2.output   $D/euler_riemann_solver-iterated-2.output
+cp $R/euler/riemann_solver-iterated-10.output  $D/euler_riemann_solver-iterated-10.output
+cp $R/euler/riemann_solver-simd.output         $D/euler_riemann_solver-simd.output
+cp $R/euler/limiter.output                     $D/euler_limiter.output
+cp $R/euler/hyperbolic_system.output           $D/euler_hyperbolic_system.output
+cp $R/euler/check-mass-conservation_01.output  $D/euler_check-mass-conservation_01.output
+for l in 5 6; do
+  cp $R/euler/verification-isentropic_vortex-2d-ssprk33-l$l.output $D/euler_verification-isentropic_vortex-2d-ssprk33-l$l.output
+  cp $R/euler/verification-isentropic_vortex-2d-erk33-l$l.output   $D/euler_verification-isentropic_vortex-2d-erk33-l$l.output
+done
+cp $R/shallow_water/riemann_solver.output      $D/shallow_water_riemann_solver.output
+cp $R/common/sparse_matrix_simd.output.sse2    $D/common_sparse_matrix_simd.output.sse2
+cp $R/common/sparse_matrix_simd.output.avx2    $D/common_sparse_matrix_simd.output.avx2
+cp $R/common/sparse_matrix_simd.output.avx512  $D/common_sparse_matrix_simd.output.avx512
+cp "$R/common/sparsity_pattern_simd_01.mpirun=4.output" $D/common_sparsity_pattern_simd_01.mpirun4.output

@@ -1,0 +1,258 @@
+"""Pin the CPU oracle (oracle/euler.hpp) against the reference's own golden outputs.
+
+Inputs are restated from the reference's unit tests (cited per test); expected values
+are parsed from the committed numdiff baselines under tests/golden/.
+Tolerance: 1e-13 relative at function level (reference builds
+themselves differ in the last digits between std::pow and vcl::pow).
+"""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from ryujin_amd import capi
+
+RTOL = 1e-13
+
+# tests/euler/riemann_solver.cc:79-98 -- (rho, u, p) left / right
+RIEMANN_CASES = [
+    ((1.0, 0.0, 2.0 / 30.0), (1.0e-3, 0.0, 2.0 / 3.0 * 1.0e-10)),   # Leblanc
+    ((1.0, 0.0, 1.0), (0.125, 0.0, 0.1)),                              # Sod
+    ((0.445, 0.698, 3.528), (0.5, 0.0, 0.571)),                        # Lax
+    ((1.0, 1.0e1, 1.0e3), (1.0, 10.0, 0.01)),                          # fast shock 1
+    ((5.99924, 19.5975, 460.894), (5.99242, -6.19633, 46.0950)),       # fast shock 2
+    ((1.0, 0.0, 0.01), (1.0, 0.0, 1.0e2)),                             # fast expansion 1
+    ((1.0, -1.0, 0.01), (1.0, -1.0, 1.0e2)),                           # fast expansion 2
+    ((1.0, -2.18, 0.01), (1.0, -2.18, 100.0)),                         # fast expansion 3
+    ((1.0e-2, 0.0, 1.0e-2), (1.0e3, 0.0, 1.0e3)),                      # case 9
+    ((1.0, 2.18, 1.0e2), (1.0, 2.18, 0.01)),                           # case 10
+]
+
+NUM = r"([-+]?\d+\.\d+(?:e[-+]\d+)?)"
+
+
+def _blocks(path):
+    text = open(path).read()
+    blocks = re.split(r"\n\n\n", text.split("\n\n", 1)[1])
+    return [b for b in blocks if "lambda_max" in b]
+
+
+def _grab(block, label):
+    return [float(x) for x in re.findall(re.escape(label) + r"\s*" + NUM, block)]
+
+
+def _riemann_data(state, gamma):
+    rho, u, p = state
+    return np.array([rho, u, p, np.sqrt(gamma * p / rho)])
+
+
+def _run_riemann(oracle, params, left, right, max_iters=16):
+    lib = oracle.load()
+    rd_i = _riemann_data(left, params.gamma)
+    rd_j = _riemann_data(right, params.gamma)
+    out = np.zeros(11)
+    iters = np.zeros(8 * max_iters)
+    lib.ryujin_oracle_euler_riemann(C.byref(params), capi.as_ptr(rd_i, capi.c_double_p),
+                                    capi.as_ptr(rd_j, capi.c_double_p),
+                                    capi.as_ptr(out, capi.c_double_p),
+                                    capi.as_ptr(iters, capi.c_double_p), max_iters)
+    return rd_i, rd_j, out, iters.reshape(-1, 8)[: int(out[10])]
+
+
+def test_riemann_solver_default(oracle, golden_dir):
+    """tests/euler/riemann_solver.{cc,output}: newton max iterations = 0 (the default)."""
+    params = oracle.default_params(capi.EQ_EULER, 1)
+    blocks = _blocks(os.path.join(golden_dir, "euler_riemann_solver.output"))
+    assert len(blocks) == len(RIEMANN_CASES)
+    expected_lambda = [1.5084890784907763, 1.7620896140769147, 2.6335650740600323,
+                       34.018686867258801, 12.617757915202823, 11.832159566199232,
+                       10.832159566199232, 9.7758781271580943, 6.6963146691962327,
+                       9.7758781271580943]
+    for (left, right), block, lam in zip(RIEMANN_CASES, blocks, expected_lambda):
+        rd_i, rd_j, out, _ = _run_riemann(oracle, params, left, right)
+        assert np.isclose(rd_i[3], _grab(block, "a_left:")[0], rtol=RTOL, atol=0)
+        assert np.isclose(rd_j[3], _grab(block, "a_right:")[0], rtol=RTOL, atol=0)
+        assert np.isclose(out[0], _grab(block, "p_star_two_rarefaction =")[0], rtol=RTOL, atol=0)
+        assert np.isclose(out[1], _grab(block, "p_star_failsafe =")[0], rtol=RTOL, atol=0)
+        assert np.isclose(out[2], _grab(block, "p^*_tilde  =")[0], rtol=RTOL, atol=0)
+        # phi(p*) is a difference of O(1) terms: absolute tolerance
+        assert np.isclose(out[3], _grab(block, "phi(p_*_t) =")[0], rtol=1e-12, atol=1e-13)
+        assert np.isclose(out[4], _grab(block, "-> lambda_max =")[0], rtol=RTOL, atol=0)
+        assert np.isclose(out[4], lam, rtol=RTOL, atol=0)
+
+
+@pytest.mark.parametrize("n_newton", [2, 10])
+def test_riemann_solver_iterated(oracle, golden_dir, n_newton):
+    """tests/euler/riemann_solver-iterated-{2,10}.output: Newton path incl. per-iteration values."""
+    params = oracle.default_params(capi.EQ_EULER, 1)
+    params.riemann_newton_max_iterations = n_newton
+    blocks = _blocks(os.path.join(golden_dir, f"euler_riemann_solver-iterated-{n_newton}.output"))
+    assert len(blocks) == len(RIEMANN_CASES)
+    for (left, right), block in zip(RIEMANN_CASES, blocks):
+        _, _, out, iters = _run_riemann(oracle, params, left, right)
+        # printed with fixed 16 decimals: absolute tolerance on top of the relative one
+        close = lambda a, b: np.isclose(a, b, rtol=1e-12, atol=2e-16 + 1e-13 * abs(b))  # noqa: E731
+        assert close(out[5], _grab(block, "p_1: (start)")[0])
+        assert close(out[6], _grab(block, "p_2: (start)")[0])
+        assert close(out[7], _grab(block, "gap: (start)")[0])
+        assert close(out[8], _grab(block, "l_m: (start)")[0])
+        g_phi1 = _grab(block, "\nphi_p_1:")
+        g_phi2 = _grab(block, "\nphi_p_2:")
+        g_dphi1 = _grab(block, "\ndphi_p_1:")
+        g_dphi2 = _grab(block, "\ndphi_p_2:")
+        g_gap = _grab(block, "gap:        ")
+        g_lm = _grab(block, "l_m:        ")
+        assert len(g_phi1) == len(iters), "number of Newton iterations differs from the reference"
+        for n, it in enumerate(iters):
+            # phi values are differences of O(1..1e3) terms -> absolute floor 1e-11
+            assert np.isclose(it[0], g_phi1[n], rtol=1e-10, atol=1e-11)
+            assert np.isclose(it[1], g_phi2[n], rtol=1e-10, atol=1e-11)
+            assert np.isclose(it[2], g_dphi1[n], rtol=1e-10, atol=1e-11)
+            assert np.isclose(it[3], g_dphi2[n], rtol=1e-10, atol=1e-11)
+            assert np.isclose(it[6], g_gap[n], rtol=1e-9, atol=1e-12)
+            assert np.isclose(it[7], g_lm[n], rtol=1e-11, atol=1e-13)
+        if "converged after" in block:
+            n_conv = int(re.search(r"converged after (\d+) iterations", block).group(1))
+            assert int(out[9]) == n_conv
+        assert np.isclose(out[4], _grab(block, "-> lambda_max =")[0], rtol=1e-12, atol=1e-15)
+
+
+# tests/euler/limiter.cc:61-139 -- (label, U, P, bounds)
+LIMITER_CASES = [
+    ("Minimum density violation:", (0.8, 1.4, 3.0), (-0.1, 0.1, 0.1), (0.9, 1.1, 2.0)),
+    ("Minimum density violation (eps):", (0.9 - 1.0e-10, 1.4, 3.0), (-1.0e-20, 0.1, 0.1), (0.9, 1.1, 2.0)),
+    ("Maximum density violation:", (1.2, 1.4, 3.0), (0.1, 0.1, 0.1), (0.9, 1.1, 2.0)),
+    ("Maximum density violation (eps):", (1.1 + 1.0e-10, 1.4, 3.0), (1.0e-20, 0.1, 0.1), (0.9, 1.1, 2.0)),
+    ("Minimum entropy violation:", (1.0, 1.4, 2.8), (0.1, 0.1, -0.1), (0.9, 1.1, 2.0)),
+    ("Minimum entropy violation (eps):", (1.0, 1.4, 2.8), (0.1, 0.1, -1.0e-20), (0.9, 1.1, 1.82 + 1.0e-10)),
+    ("Minimum density bound", (1.0, 1.4, 3.0), (-0.2, 0.1, 0.1), (0.9, 1.1, 2.0)),
+    ("Minimum density bound (eps):", (0.9 + 1.0e-10, 1.4, 3.0), (-5.0e-10, 0.1, 0.1), (0.9, 1.1, 2.0)),
+    ("Maximum density bound", (1.0, 1.4, 3.0), (0.2, 0.1, 0.1), (0.9, 1.1, 1.0)),
+    ("Maximum density bound (eps):", (1.1 - 1.0e-10, 1.4, 3.0), (5.0e-10, 0.1, 0.1), (0.9, 1.1, 1.0)),
+    ("Minimum entropy bound", (1.0, 1.4, 2.8), (0.1, 0.1, -0.3), (0.9, 1.1, 1.8)),
+    ("Minimum entropy bound (eps):", (1.0, 1.4, 2.8), (0.1, 0.1, -4.0e-10), (0.9, 1.1, 1.82 - 1.0e-10)),
+]
+
+
+def _limiter_blocks(path):
+    text = open(path).read()
+    parts = re.split(r"\n(?=[A-Z][a-z]+imum [a-z]+ [a-z]+(?: \(eps\))?:?\n)", text)
+    return [p for p in parts if p.startswith(("Minimum", "Maximum"))]
+
+
+def _run_limit(oracle, params, expensive, U, P, bounds, max_iters=8):
+    lib = oracle.load()
+    out = np.zeros(9)
+    iters = np.zeros(7 * max_iters)
+    a = lambda t: capi.as_ptr(np.array(t, dtype=np.float64), capi.c_double_p)  # noqa: E731
+    Ua, Pa, Ba = (np.array(x, dtype=np.float64) for x in (U, P, bounds))
+    lib.ryujin_oracle_euler_limit_1d(C.byref(params), int(expensive),
+                                     capi.as_ptr(Ba, capi.c_double_p), capi.as_ptr(Ua, capi.c_double_p),
+                                     capi.as_ptr(Pa, capi.c_double_p), capi.as_ptr(out, capi.c_double_p),
+                                     capi.as_ptr(iters, capi.c_double_p), max_iters)
+    return out, iters.reshape(-1, 7)[: int(out[8])]
+
+
+def test_limiter_golden(oracle, golden_dir):
+    """tests/euler/limiter.{cc,output}: compiled with EXPENSIVE_BOUNDS_CHECK (limiter.cc:10)."""
+    params = oracle.default_params(capi.EQ_EULER, 1)
+    blocks = _limiter_blocks(os.path.join(golden_dir, "euler_limiter.output"))
+    assert len(blocks) == len(LIMITER_CASES)
+    for (label, U, P, bounds), block in zip(LIMITER_CASES, blocks):
+        assert block.startswith(label)
+        out, iters = _run_limit(oracle, params, True, U, P, bounds)
+        l_ref = _grab(block, "\nl:")[0]
+        assert abs(out[0] - l_ref) <= 2e-16 + 1e-12 * abs(l_ref), (label, out[0], l_ref)
+        assert bool(out[1]) == ("Success!" in block), label
+        assert abs(out[3] - _grab(block, "t_r: (start)")[0]) <= 2e-16
+        assert bool(out[4]) == ("low-order density (critical)" in block)
+        assert bool(out[5]) == ("high-order density!" in block)
+        assert bool(out[6]) == ("low-order specific entropy (critical)" in block)
+        assert bool(out[7]) == ("high-order specific entropy!" in block)
+        # full Newton trace
+        g_psi_l = _grab(block, "\npsi_l:")
+        g_psi_r = _grab(block, "\npsi_r:")
+        g_dpsi_l = _grab(block, "\ndpsi_l:")
+        g_dpsi_r = _grab(block, "\ndpsi_r:")
+        g_tl = re.findall(r"t_l: \(  \d+  \) " + NUM, block)
+        g_tr = re.findall(r"t_r: \(  \d+  \) " + NUM, block)
+        assert len(iters) == len(g_psi_l) == len(g_tl)
+        n_newton = 0
+        for n, it in enumerate(iters):
+            assert abs(it[1] - g_psi_l[n]) <= 1e-15 + 1e-12 * abs(g_psi_l[n])
+            assert abs(it[2] - g_psi_r[n]) <= 1e-15 + 1e-12 * abs(g_psi_r[n])
+            assert abs(it[5] - float(g_tl[n])) <= 2e-16 + 1e-12
+            assert abs(it[6] - float(g_tr[n])) <= 2e-16 + 1e-12
+            if int(it[0]) == 2:
+                assert abs(it[3] - g_dpsi_l[n_newton]) <= 1e-15 + 1e-12 * abs(g_dpsi_l[n_newton])
+                assert abs(it[4] - g_dpsi_r[n_newton]) <= 1e-15 + 1e-12 * abs(g_dpsi_r[n_newton])
+                n_newton += 1
+        assert n_newton == len(g_dpsi_l)
+
+
+def test_limiter_survey_values(oracle):
+    """The l values SURVEY.md 8c quotes from tests/euler/limiter.output."""
+    params = oracle.default_params(capi.EQ_EULER, 1)
+    expected = [0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.4999999999999993, 0.1999999188484877,
+                0.4999999999999998, 0.1999999188484877, 0.0336589067585305, 0.0000000003370627]
+    for (label, U, P, bounds), l_ref in zip(LIMITER_CASES, expected):
+        out, _ = _run_limit(oracle, params, True, U, P, bounds)
+        assert abs(out[0] - l_ref) <= 5e-16 + 1e-12 * abs(l_ref), label
+        assert bool(out[1]) == (l_ref != 0.0 or False) or label.startswith(("Minimum density v", "Maximum density v", "Minimum entropy v"))
+
+
+def test_limiter_production_flow_agrees_when_in_bounds(oracle):
+    """Without EXPENSIVE_BOUNDS_CHECK (the production control flow, limiter.template.h:183-217) the
+    limiter returns the same l for the in-bounds cases; for violated low-order states both report
+    failure whenever the check variant flags the *low-order* state."""
+    params = oracle.default_params(capi.EQ_EULER, 1)
+    for label, U, P, bounds in LIMITER_CASES[6:]:
+        chk, _ = _run_limit(oracle, params, True, U, P, bounds)
+        prod, _ = _run_limit(oracle, params, False, U, P, bounds)
+        assert abs(chk[0] - prod[0]) <= 1e-10, label  # newton tolerance (Appendix E-3)
+        assert bool(prod[1])
+
+
+def _view(oracle, dim, U):
+    lib = oracle.load()
+    params = oracle.default_params(capi.EQ_EULER, dim)
+    k = dim + 2
+    out = np.zeros(1 + k + 1 + 1 + 1 + k + 1 + k + k * dim + 1)
+    Ua = np.array(U, dtype=np.float64)
+    lib.ryujin_oracle_euler_view(C.byref(params), capi.as_ptr(Ua, capi.c_double_p),
+                                 capi.as_ptr(out, capi.c_double_p))
+    o = iter(out)
+    take = lambda n: np.array([next(o) for _ in range(n)])  # noqa: E731
+    return dict(internal_energy=take(1), internal_energy_derivative=take(k), pressure=take(1),
+                specific_entropy=take(1), harten_entropy=take(1), harten_entropy_derivative=take(k),
+                mathematical_entropy=take(1), mathematical_entropy_derivative=take(k),
+                f=take(k * dim), speed_of_sound=take(1))
+
+
+def test_hyperbolic_system_golden(oracle, golden_dir):
+    """tests/euler/hyperbolic_system.{cc:41-77,output:4-40}: state rho=gamma, u=3, p=1 in dim 1/2/3."""
+    text = open(os.path.join(golden_dir, "euler_hyperbolic_system.output")).read()
+    dbl = text.split("double:")[1].split("float:")[0]
+    for dim in (1, 2, 3):
+        sec = dbl.split(f"dim = {dim}\n")[1].split("dim = ")[0]
+        gamma = 7.0 / 5.0
+        rho, u, p = gamma, 3.0, 1.0
+        U = np.zeros(dim + 2)
+        U[0] = rho
+        U[1] = rho * u
+        U[dim + 1] = p / (gamma - 1.0) + 0.5 * rho * u * u
+        got = _view(oracle, dim, U)
+        names = {"internal_energy": "internal_energy", "internal_energy_derivative": "internal_energy_derivative",
+                 "pressure": "pressure", "specific_entropy": "specific_entropy",
+                 "harten entropy": "harten_entropy", "harten_entropy_derivative": "harten_entropy_derivative",
+                 "mathematical entropy": "mathematical_entropy",
+                 "mathematical_entropy_derivative": "mathematical_entropy_derivative", "f": "f"}
+        for label, key in names.items():
+            line = re.search(r"^" + re.escape(label) + r" = (.*)$", sec, flags=re.M).group(1)
+            ref = np.array([float(x) for x in line.split()])
+            # printed with 10 digits
+            np.testing.assert_allclose(got[key], ref, rtol=1e-10, atol=1e-10, err_msg=f"dim {dim} {label}")
+        mom = re.search(r"^momentum = (.*)$", sec, flags=re.M).group(1)
+        np.testing.assert_allclose(U[1:dim + 1], [float(x) for x in mom.split()], rtol=1e-10)
