@@ -1,0 +1,265 @@
+#!/usr/bin/env python3
+"""bench.py -- the hot path (prepare_state_vector + step<0>, one forward-Euler update per "step")
+on the BASELINE.json workload: 2-D Euler Mach-3 forward-facing step, ~10M DoFs (k=4, ~2.5M Q1
+gridpoints) per GPU, SSPRK33 stage sequence, synthetic structured mesh, data resident in HBM.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: launched by torch.distributed.run, one rank per GPU; the mesh is lengthened N-fold and
+   slab-partitioned by DoF ownership: weak scaling; ghost exchange over RCCL inside the library,
+   torch.distributed(gloo) only carries the 128-byte RCCL id, the barriers and the max-reduction)
+
+Prints ONE JSON line on rank 0. `value` = k * N_q(all ranks) * K / t_max-over-ranks / 1e6.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def algorithmic_bytes(dim: int, k: int, S: float, n_prec: int = 2, n_bounds: int = 3) -> dict:
+    """ALGORITHMIC bytes per gridpoint-update and sweep:
+    every array of the reference's 7-sweep structure touched once per sweep, neighbour gathers free."""
+    d, p, b = dim, n_prec, n_bounds
+    return {
+        "1 prepare_state_vector": 8 * k + 8 * p,
+        "2 dij_alpha": (8 * k + 8 * p + 4 * S + 8 * d * S + 8) + (8 * S + 8),
+        "3 dij_diag_tau": (4 * S + 4 * S + 8 * S + 8) + 8 * S,
+        "4 low_order": (8 * k + 8 * p + 8 + 16 + 4 * S + 8 * S + 8 * d * S) + (8 * k + 8 * k + 8 * b + 8 * k * S),
+        "5 pij_lij": (8 * b + 16 + 8 * k + 8 * k + 4 * S + 8 * S + 8 * k * S) + (8 * k * S + 8 * S),
+        "6 high_order_next_lij": (8 * k + 8 * S + 4 * S + 8 * k * S + 8 * b) + (8 * k + 8 * S),
+        "7 high_order": (8 * k + 8 * S + 4 * S + 8 * k * S) + 8 * k,
+    }
+
+
+class Ssprk33Stages:
+    """SSPRK33 (time_integrator.template.h:302-328) unrolled into single forward-Euler updates."""
+
+    def __init__(self, module, U0, dirichlet):
+        self.m = module
+        self.U = module.new_state_vector(U0)
+        self.T = [module.new_state_vector(), module.new_state_vector()]
+        self.dirichlet = dirichlet
+        self.stage = 0
+        self.tau = 0.0
+        self.t = 0.0
+        self.first = True
+
+    def update(self):
+        m, U, T = self.m, self.U, self.T
+        d = self.dirichlet if self.first else None  # constant Dirichlet data: upload once
+        self.first = False
+        if self.stage == 0:
+            m.prepare_state_vector(U, self.t, d)
+            self.tau = m.step(U, [], [], T[0], 0.0)
+        elif self.stage == 1:
+            m.prepare_state_vector(T[0], self.t + self.tau, d)
+            m.step(T[0], [], [], T[1], self.tau)
+            m.sadd(T[1], 1.0 / 4.0, 3.0 / 4.0, U)
+        else:
+            m.prepare_state_vector(T[1], self.t + 0.5 * self.tau, d)
+            m.step(T[1], [], [], T[0], self.tau)
+            m.sadd(T[0], 2.0 / 3.0, 1.0 / 3.0, U)
+            self.U, self.T[0] = T[0], U
+            self.t += self.tau
+        self.stage = (self.stage + 1) % 3
+
+
+def cpu_baseline(spec, U0, dirichlet, budget_s: float = 15.0) -> dict:
+    """The CPU restatement of the reference path (oracle/, OpenMP over all host cores) timed on a
+    bounded sample of the SAME workload: n forward-Euler updates of the same mesh."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import subprocess
+
+    import oracle_py
+    from ryujin_amd import HyperbolicModule, _build, capi, offline
+
+    native = os.path.join(ROOT, "oracle", "build", "libryujin_oracle_native.so")
+    path = None
+    try:
+        os.makedirs(os.path.dirname(native), exist_ok=True)
+        subprocess.run(["g++", "-O3", "-march=native", "-std=c++17", "-fPIC", "-shared", "-fopenmp",
+                        "-ffp-contract=off", "-I" + _build.INCLUDE, "-I" + _build.ORACLE,
+                        os.path.join(_build.ORACLE, "oracle_capi.cc"), "-o", native],
+                       check=True, capture_output=True, timeout=300)
+        path = native
+    except Exception:
+        path = None  # fall back to the portable build shipped with the snapshot
+    lib = oracle_py.load(path)
+    lib.ryujin_oracle_set_flush_denormals(1)  # source/main.cc:26-36
+    cores = os.cpu_count() or 1
+    off = offline.SyntheticOffline(spec)
+    m = HyperbolicModule(off, equation=capi.EQ_EULER, backend=(lib, "ryujin_oracle_"))
+    m.cfl = 0.9
+    drv = Ssprk33Stages(m, U0, dirichlet)
+    t0 = time.perf_counter()
+    drv.update()
+    one = time.perf_counter() - t0
+    n = int(max(3, min(60, budget_s / max(one, 1e-3))))
+    t0 = time.perf_counter()
+    for _ in range(n):
+        drv.update()
+    dt = time.perf_counter() - t0
+    k = off.dim + 2
+    return {"value": k * off.n_owned * n / dt / 1e6, "unit": "MDoF-updates/s", "cores": cores,
+            "kind": "port",
+            "sample": f"{n} forward-Euler updates (SSPRK33 stages) of the same mesh "
+                      f"({off.n_owned} gridpoints), OpenMP on {cores} threads, "
+                      f"{'-march=native' if path else 'portable'} build, {dt:.1f} s",
+            "mq_per_s": off.n_owned * n / dt / 1e6}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=12)
+    ap.add_argument("--cells-per-unit", type=int, default=995,
+                    help="mesh resolution h=1/N of the step geometry (995 -> ~2.5M gridpoints, ~10M DoFs per GPU)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=15.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    n_gpus = max(1, world)
+
+    dist = None
+    if n_gpus > 1:
+        # torch must be imported BEFORE libryujin_hip.so so that one copy of the ROCm runtime is used
+        import torch  # noqa: F401
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    import ctypes as C
+
+    import numpy as np
+
+    from ryujin_amd import HyperbolicModule, capi, offline
+    from ryujin_amd.initial_states import euler_uniform
+
+    # ---- workload: BASELINE.json configs[1] per GPU, lengthened channel for N GPUs (weak scaling)
+    spec = offline.mach3_step_2d(args.cells_per_unit, length_units=3 * n_gpus, n_ranks=n_gpus, rank=rank)
+    off = offline.SyntheticOffline(spec)
+    rng = np.random.default_rng(42 + rank)
+    U0 = euler_uniform(off.positions)
+    U0 *= 1.0 + 1e-3 * rng.uniform(-1.0, 1.0, size=U0.shape)  # initial_values.template.h:198-218
+    dirichlet = euler_uniform(off.b_positions) if off.n_bdry else None
+
+    lib = capi.load_hip()
+    comm = None
+    if n_gpus > 1:
+        import torch
+        uid = C.create_string_buffer(capi.UNIQUE_ID_BYTES)
+        if rank == 0:
+            assert lib.ryujin_hip_comm_unique_id(uid) == 0, lib.ryujin_hip_last_error()
+        t = torch.frombuffer(bytearray(uid.raw), dtype=torch.uint8).clone()
+        dist.broadcast(t, src=0)
+        uid = C.create_string_buffer(bytes(t.tolist()), capi.UNIQUE_ID_BYTES)
+        comm = C.c_void_p()
+        rc = lib.ryujin_hip_comm_init(C.byref(comm), uid, rank, world, local_rank)
+        assert rc == 0, lib.ryujin_hip_last_error()
+
+    m = HyperbolicModule(off, equation=capi.EQ_EULER, backend="hip", comm=comm, device=local_rank)
+    m.cfl = 0.9
+    drv = Ssprk33Stages(m, U0, dirichlet)
+    ctx = m._ctx
+
+    def barrier():
+        lib.ryujin_hip_synchronize(ctx)
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        drv.update()
+
+    lib.ryujin_hip_set_timers(ctx, 1)
+    sweep_ms = np.zeros(8)
+    tmp = (C.c_double * 8)()
+    barrier()
+    t0 = time.perf_counter()
+    lib.ryujin_hip_event_record(ctx, 0)
+    for _ in range(args.steps):
+        drv.update()
+        lib.ryujin_hip_get_timers(ctx, tmp)
+        sweep_ms += np.array(tmp[:])
+    lib.ryujin_hip_event_record(ctx, 1)
+    barrier()
+    wall = time.perf_counter() - t0
+    ev_ms = C.c_double()
+    lib.ryujin_hip_event_elapsed_ms(ctx, C.byref(ev_ms))
+
+    n_q_local = off.n_owned
+    if dist is not None:
+        import torch
+        tt = torch.tensor([wall], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall = float(tt[0])
+        nn = torch.tensor([n_q_local], dtype=torch.int64)
+        dist.all_reduce(nn, op=dist.ReduceOp.SUM)
+        n_q_total = int(nn[0])
+    else:
+        n_q_total = n_q_local
+
+    if rank != 0:
+        return
+
+    k = off.dim + 2
+    rs = off.row_starts
+    S = float(rs[off.n_owned]) / off.n_owned
+    alg = algorithmic_bytes(off.dim, k, S)
+    b_alg = sum(alg.values())
+    # per-sweep mean kernel durations of rank 0 (hipEvent pairs on the library's stream); sweep 1
+    # (prepare_state_vector) is not bracketed separately: it is the remainder of the event time
+    per_sweep = {name: sweep_ms[i + 1] / args.steps for i, name in enumerate(list(alg)[1:])}
+    per_sweep["1 prepare_state_vector"] = max(0.0, ev_ms.value / args.steps - sum(per_sweep.values()))
+    dom = max((n for n in alg if n != "1 prepare_state_vector"), key=lambda n: per_sweep[n])
+    dom_gbs = alg[dom] * n_q_local / (per_sweep[dom] * 1e-3) / 1e9
+    upd_gbs = b_alg * n_q_local / (ev_ms.value / args.steps * 1e-3) / 1e9
+
+    out = {
+        "metric": "MDoF-updates/s per Euler forward step; achieved HBM GB/s vs roofline",
+        "value": k * n_q_total * args.steps / wall / 1e6,
+        "unit": "MDoF-updates/s",
+        "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": wall / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "2D Euler Mach-3 forward-facing step, Q1, SSPRK33 stage sequence "
+                               "(BASELINE.json configs[1])",
+                   "gridpoints_per_gpu": n_q_local, "gridpoints_total": n_q_total,
+                   "dofs_total": k * n_q_total, "nnz_per_row": round(S, 3),
+                   "cells_per_unit": args.cells_per_unit, "partition": f"x-slabs x{n_gpus}",
+                   "cfl": 0.9, "limiter_iterations": 2},
+        "mq_per_s": n_q_total * args.steps / wall / 1e6,
+        "roofline": {"bound": "hbm", "kernel": dom, "achieved": dom_gbs, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": dom_gbs / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_gridpoint": alg[dom],
+                     "mean_launch_ms": per_sweep[dom]},
+        "roofline_update": {"bound": "hbm", "achieved": upd_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": upd_gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_gridpoint": b_alg,
+                            "device_ms_per_update": ev_ms.value / args.steps},
+        "sweep_ms": {n: round(v, 4) for n, v in sorted(per_sweep.items())},
+        "n_warnings": m.n_warnings(),
+    }
+    if not args.no_cpu_baseline and n_gpus == 1:
+        try:
+            out["cpu_baseline"] = cpu_baseline(spec, U0, dirichlet, args.cpu_budget)
+        except Exception as e:  # the baseline must never take the GPU number down with it
+            out["cpu_baseline"] = {"value": None, "error": repr(e)}
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

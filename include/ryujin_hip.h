@@ -260,6 +260,13 @@ int ryujin_hip_synchronize(ryujin_hip_ctx *ctx);
 /* Record start/stop HIP events on the context's compute stream and read the elapsed ms. */
 int ryujin_hip_event_record(ryujin_hip_ctx *ctx, int which /*0 start, 1 stop*/);
 int ryujin_hip_event_elapsed_ms(ryujin_hip_ctx *ctx, double *ms);
+/* Host-only check of the layout import (no GPU needed): converts `offline` into the device layout
+ * (SELL-64 + ghost CSR) and back, and reports the logical (row, col_idx) view over ALL n_relevant
+ * rows: ptr [n_relevant+1], col [nnz], transposed [nnz] = logical index of the (j,i) entry.
+ * If data != NULL, the n_comp-component matrix `data` (reference layout) is scattered into the
+ * device layout and gathered back into out [nnz*n_comp] (AoS per entry). Any pointer may be NULL. */
+int ryujin_hip_debug_layout(const ryujin_hip_offline *offline, uint64_t *ptr, uint32_t *col,
+                            uint64_t *transposed, const double *data, uint32_t n_comp, double *out);
 const char *ryujin_hip_last_error(void);
 const char *ryujin_hip_version(void);
 

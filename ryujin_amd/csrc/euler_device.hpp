@@ -1,0 +1,571 @@
+// Device-side Euler "Description": pointwise arithmetic inlined into the sweep kernels.
+//
+// Restates (operation order preserved, so that results agree with the reference's scalar
+// path to the last bits up to pow()):
+//   HyperbolicSystemView  source/euler/hyperbolic_system.h:750-1216
+//   RiemannSolver         source/euler/riemann_solver.template.h:21-597
+//   Indicator             source/euler/indicator.h:187-258
+//   Limiter               source/euler/limiter.h:255-363, limiter.template.h:15-327
+//   quadratic_newton_step source/newton.h:37-101
+// All loops run over compile-time bounds and are fully unrolled: states live in registers.
+
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+
+namespace ryujin_hip
+{
+  struct EulerParams {
+    double gamma, gamma_inverse, gamma_plus_one_inverse, gamma_minus_one_inverse;
+    double reference_density, vacuum_small, vacuum_large;
+    double evc_factor;
+    double lim_newton_tolerance, lim_relaxation_factor;
+    int lim_newton_max_iterations;
+    int riemann_newton_max_iterations;
+    double riemann_newton_tolerance;
+  };
+
+#define RYUJIN_DEV __device__ __forceinline__
+
+  RYUJIN_DEV double dev_pow(double x, double y) { return pow(x, y); }
+  RYUJIN_DEV double positive_part(double x) { return fmax(0., x); }
+  RYUJIN_DEV double negative_part(double x) { return -fmin(0., x); }
+
+  /* source/newton.h:37-101 */
+  RYUJIN_DEV void quadratic_newton_step(double &p_1, double &p_2, const double phi_p_1,
+                                        const double phi_p_2, const double dphi_p_1,
+                                        const double dphi_p_2, const double sign)
+  {
+    constexpr double eps = DBL_EPSILON;
+    const double scaling = 1. / (p_2 - p_1 + eps);
+
+    const double dd_11 = dphi_p_1;
+    const double dd_12 = (phi_p_2 - phi_p_1) * scaling;
+    const double dd_22 = dphi_p_2;
+
+    const double dd_112 = (dd_12 - dd_11) * scaling;
+    const double dd_122 = (dd_22 - dd_12) * scaling;
+
+    const double discriminant_1 = fabs(dphi_p_1 * dphi_p_1 - 4. * phi_p_1 * dd_112);
+    const double discriminant_2 = fabs(dphi_p_2 * dphi_p_2 - 4. * phi_p_2 * dd_122);
+
+    const double denominator_1 = dphi_p_1 + sign * sqrt(discriminant_1);
+    const double denominator_2 = dphi_p_2 + sign * sqrt(discriminant_2);
+
+    double t_1 = p_1 - (fabs(denominator_1) < eps ? 0. : 2. * phi_p_1 / denominator_1);
+    double t_2 = p_2 - (fabs(denominator_2) < eps ? 0. : 2. * phi_p_2 / denominator_2);
+
+    t_1 = fmax(p_1, t_1);
+    t_1 = fmin(p_2, t_1);
+    t_2 = fmax(p_1, t_2);
+    t_2 = fmin(p_2, t_2);
+
+    p_1 = fmin(t_1, t_2);
+    p_2 = fmax(t_1, t_2);
+  }
+
+
+  template <int DIM>
+  struct Euler {
+    static constexpr int K = DIM + 2;
+    static constexpr int NB = 3;
+
+    /* hyperbolic_system.h:783-792 */
+    static RYUJIN_DEV double internal_energy(const double (&U)[K])
+    {
+      const double rho_inverse = 1. / U[0];
+      double m2 = U[1] * U[1];
+#pragma unroll
+      for (int d = 1; d < DIM; ++d)
+        m2 += U[1 + d] * U[1 + d];
+      return U[1 + DIM] - 0.5 * m2 * rho_inverse;
+    }
+
+    static RYUJIN_DEV double momentum_norm_square(const double (&U)[K])
+    {
+      double m2 = U[1] * U[1];
+#pragma unroll
+      for (int d = 1; d < DIM; ++d)
+        m2 += U[1 + d] * U[1 + d];
+      return m2;
+    }
+
+    /* hyperbolic_system.h:844-850 */
+    static RYUJIN_DEV double specific_entropy(const EulerParams &P, const double (&U)[K])
+    {
+      const double rho_inverse = 1. / U[0];
+      return internal_energy(U) * dev_pow(rho_inverse, P.gamma);
+    }
+
+    /* hyperbolic_system.h:855-865 */
+    static RYUJIN_DEV double harten_entropy(const EulerParams &P, const double (&U)[K])
+    {
+      const double rho_rho_e = U[0] * U[1 + DIM] - 0.5 * momentum_norm_square(U);
+      return dev_pow(rho_rho_e, P.gamma_plus_one_inverse);
+    }
+
+    /* hyperbolic_system.h:870-902 */
+    static RYUJIN_DEV void harten_entropy_derivative(const EulerParams &P, const double (&U)[K],
+                                                     double (&result)[K])
+    {
+      const double rho = U[0];
+      const double E = U[1 + DIM];
+      const double rho_rho_e = rho * E - 0.5 * momentum_norm_square(U);
+      const double factor =
+          P.gamma_plus_one_inverse * dev_pow(rho_rho_e, -P.gamma * P.gamma_plus_one_inverse);
+      result[0] = factor * E;
+#pragma unroll
+      for (int d = 0; d < DIM; ++d)
+        result[1 + d] = -factor * U[1 + d];
+      result[DIM + 1] = factor * rho;
+    }
+
+    /* f(U): hyperbolic_system.h:1164-1181 */
+    static RYUJIN_DEV void flux(const EulerParams &P, const double (&U)[K], double (&f)[K][DIM])
+    {
+      const double rho_inverse = 1. / U[0];
+      const double p = (P.gamma - 1.) * internal_energy(U);
+      const double E = U[1 + DIM];
+#pragma unroll
+      for (int d = 0; d < DIM; ++d)
+        f[0][d] = U[1 + d];
+#pragma unroll
+      for (int i = 0; i < DIM; ++i) {
+        const double s = U[1 + i] * rho_inverse;
+#pragma unroll
+        for (int d = 0; d < DIM; ++d)
+          f[1 + i][d] = U[1 + d] * s;
+        f[1 + i][i] += p;
+      }
+      const double s = rho_inverse * (E + p);
+#pragma unroll
+      for (int d = 0; d < DIM; ++d)
+        f[DIM + 1][d] = U[1 + d] * s;
+    }
+
+    /* -contract(add(flux_i, flux_j), c_ij): hyperbolic_system.h:1208-1216 */
+    static RYUJIN_DEV void flux_divergence(const double (&fi)[K][DIM], const double (&fj)[K][DIM],
+                                           const double (&c)[DIM], double (&out)[K])
+    {
+#pragma unroll
+      for (int q = 0; q < K; ++q) {
+        double s = (fi[q][0] + fj[q][0]) * c[0];
+#pragma unroll
+        for (int d = 1; d < DIM; ++d)
+          s += (fi[q][d] + fj[q][d]) * c[d];
+        out[q] = -s;
+      }
+    }
+
+    /* hyperbolic_system.h:750-759 */
+    static RYUJIN_DEV double filter_vacuum_density(const EulerParams &P, const double rho)
+    {
+      const double rho_cutoff_large = P.reference_density * P.vacuum_large * DBL_EPSILON;
+      return fabs(rho) < rho_cutoff_large ? 0. : rho;
+    }
+
+    /* ------------------------------------------------------------------ Riemann solver */
+
+    struct RiemannData {
+      double rho, u, p, a;
+    };
+
+    /* riemann_solver.template.h:377-403 */
+    static RYUJIN_DEV RiemannData riemann_data_from_state(const EulerParams &P, const double (&U)[K],
+                                                          const double (&n)[DIM])
+    {
+      const double rho = U[0];
+      const double rho_inverse = 1.0 / rho;
+      double proj_m = n[0] * U[1];
+#pragma unroll
+      for (int d = 1; d < DIM; ++d)
+        proj_m += n[d] * U[1 + d];
+      double perp2;
+      {
+        const double perp = U[1] - proj_m * n[0];
+        perp2 = perp * perp;
+      }
+#pragma unroll
+      for (int d = 1; d < DIM; ++d) {
+        const double perp = U[1 + d] - proj_m * n[d];
+        perp2 += perp * perp;
+      }
+      const double E = U[1 + DIM] - 0.5 * perp2 * rho_inverse;
+      const double rho_e = E - 0.5 * (proj_m * proj_m) * (1. / rho);
+      const double p = (P.gamma - 1.) * rho_e;
+      const double a = sqrt(P.gamma * p * (1. / rho));
+      return {rho, proj_m * rho_inverse, p, a};
+    }
+
+    /* :21-46 */
+    static RYUJIN_DEV double rs_f(const EulerParams &P, const RiemannData &rd, const double p_star)
+    {
+      const double Az = 2. / (rd.rho * (P.gamma + 1.));
+      const double Bz = (P.gamma - 1.) / (P.gamma + 1.) * rd.p;
+      const double radicand = Az / (p_star + Bz);
+      const double true_value = (p_star - rd.p) * sqrt(radicand);
+      const double exponent = 0.5 * (P.gamma - 1.) / P.gamma;
+      const double factor = dev_pow(p_star / rd.p, exponent) - 1.;
+      const double false_value = 2. * rd.a * factor / (P.gamma - 1.);
+      return p_star >= rd.p ? true_value : false_value;
+    }
+
+    /* :49-84 */
+    static RYUJIN_DEV double rs_df(const EulerParams &P, const RiemannData &rd, const double p_star)
+    {
+      const double radicand_inverse =
+          0.5 * rd.rho * ((P.gamma + 1.) * p_star + (P.gamma - 1.) * rd.p);
+      const double denominator = (p_star + (P.gamma - 1.) * P.gamma_plus_one_inverse * rd.p);
+      const double true_value =
+          (denominator - 0.5 * (p_star - rd.p)) / (denominator * sqrt(radicand_inverse));
+      const double exponent = (-1. - P.gamma) * 0.5 * P.gamma_inverse;
+      const double factor =
+          (P.gamma - 1.) * 0.5 * P.gamma_inverse * dev_pow(p_star / rd.p, exponent) / rd.p;
+      const double false_value = factor * 2. * rd.a * P.gamma_minus_one_inverse;
+      return p_star >= rd.p ? true_value : false_value;
+    }
+
+    /* :164-205 */
+    static RYUJIN_DEV double lambda1_minus(const EulerParams &P, const RiemannData &rd,
+                                           const double p_star)
+    {
+      const double factor = (P.gamma + 1.0) * 0.5 * P.gamma_inverse;
+      const double inv_p = 1.0 / rd.p;
+      const double tmp = positive_part((p_star - rd.p) * inv_p);
+      return rd.u - rd.a * sqrt(1.0 + factor * tmp);
+    }
+    static RYUJIN_DEV double lambda3_plus(const EulerParams &P, const RiemannData &rd,
+                                          const double p_star)
+    {
+      const double factor = (P.gamma + 1.0) * 0.5 * P.gamma_inverse;
+      const double inv_p = 1.0 / rd.p;
+      const double tmp = positive_part((p_star - rd.p) * inv_p);
+      return rd.u + rd.a * sqrt(1.0 + factor * tmp);
+    }
+
+    /* :217-238 */
+    static RYUJIN_DEV void compute_gap(const EulerParams &P, const RiemannData &rd_i,
+                                       const RiemannData &rd_j, const double p_1, const double p_2,
+                                       double &gap, double &lambda_max)
+    {
+      const double nu_11 = lambda1_minus(P, rd_i, p_2 /*SIC!*/);
+      const double nu_12 = lambda1_minus(P, rd_i, p_1 /*SIC!*/);
+      const double nu_31 = lambda3_plus(P, rd_j, p_1);
+      const double nu_32 = lambda3_plus(P, rd_j, p_2);
+      lambda_max = fmax(positive_part(nu_32), negative_part(nu_11));
+      gap = fmax(fabs(nu_32 - nu_31), fabs(nu_12 - nu_11));
+    }
+
+    /* :406-582 */
+    static RYUJIN_DEV double riemann_compute(const EulerParams &P, const RiemannData &rd_i,
+                                             const RiemannData &rd_j)
+    {
+      const double p_max = fmax(rd_i.p, rd_j.p);
+
+      /* p_star_two_rarefaction :274-319 */
+      double rarefaction;
+      {
+        const double inv_p_j = 1. / rd_j.p;
+        const double factor = (P.gamma - 1.) * 0.5;
+        const double numerator = positive_part(rd_i.a + rd_j.a - factor * (rd_j.u - rd_i.u));
+        const double denominator =
+            rd_i.a * dev_pow(rd_i.p * inv_p_j, -factor * P.gamma_inverse) + rd_j.a;
+        const double exponent = 2.0 * P.gamma * P.gamma_minus_one_inverse;
+        rarefaction = rd_j.p * dev_pow(numerator / denominator, exponent);
+      }
+
+      /* p_star_failsafe :330-374 */
+      double failsafe;
+      {
+        double radicand_i = 2. * p_max;
+        radicand_i /= rd_i.rho * ((P.gamma + 1.) * p_max + (P.gamma - 1.) * rd_i.p);
+        const double x_i = sqrt(radicand_i);
+        double radicand_j = 2. * p_max;
+        radicand_j /= rd_j.rho * ((P.gamma + 1.) * p_max + (P.gamma - 1.) * rd_j.p);
+        const double x_j = sqrt(radicand_j);
+        const double a = x_i + x_j;
+        const double b = rd_j.u - rd_i.u;
+        const double c = -rd_i.p * x_i - rd_j.p * x_j;
+        const double base = (-b + sqrt(b * b - 4. * a * c)) / (2. * a);
+        failsafe = base * base;
+      }
+      const double p_star_tilde = fmin(rarefaction, failsafe);
+
+      /* phi_of_p_max :122-149 */
+      double phi_p_max;
+      {
+        const double radicand_inverse_i =
+            0.5 * rd_i.rho * ((P.gamma + 1.) * p_max + (P.gamma - 1.) * rd_i.p);
+        const double value_i = (p_max - rd_i.p) / sqrt(radicand_inverse_i);
+        const double radicand_inverse_j =
+            0.5 * rd_j.rho * ((P.gamma + 1.) * p_max + (P.gamma - 1.) * rd_j.p);
+        const double value_j = (p_max - rd_j.p) / sqrt(radicand_inverse_j);
+        phi_p_max = value_i + value_j + rd_j.u - rd_i.u;
+      }
+
+      double p_2 = phi_p_max < 0. ? p_star_tilde : fmin(p_max, p_star_tilde);
+
+      if (P.riemann_newton_max_iterations == 0) {
+        /* compute_lambda :252-263 */
+        const double nu_11 = lambda1_minus(P, rd_i, p_2);
+        const double nu_32 = lambda3_plus(P, rd_j, p_2);
+        return fmax(positive_part(nu_32), negative_part(nu_11));
+      }
+
+      const double p_min = fmin(rd_i.p, rd_j.p);
+      double p_1 = phi_p_max < 0. ? p_max : p_min;
+      p_1 = p_1 <= p_2 ? p_1 : p_2;
+
+      double gap, lambda_max;
+      compute_gap(P, rd_i, rd_j, p_1, p_2, gap, lambda_max);
+
+      for (int it = 0; it < P.riemann_newton_max_iterations; ++it) {
+        if (fmax(0., gap - P.riemann_newton_tolerance) == 0.)
+          break;
+        const double phi_p_1 = rs_f(P, rd_i, p_1) + rs_f(P, rd_j, p_1) + rd_j.u - rd_i.u;
+        const double phi_p_2 = rs_f(P, rd_i, p_2) + rs_f(P, rd_j, p_2) + rd_j.u - rd_i.u;
+        const double dphi_p_1 = rs_df(P, rd_i, p_1) + rs_df(P, rd_j, p_1);
+        const double dphi_p_2 = rs_df(P, rd_i, p_2) + rs_df(P, rd_j, p_2);
+        quadratic_newton_step(p_1, p_2, phi_p_1, phi_p_2, dphi_p_1, dphi_p_2, 1.0);
+        compute_gap(P, rd_i, rd_j, p_1, p_2, gap, lambda_max);
+      }
+      return lambda_max;
+    }
+
+    /* d_ij = |c| * lambda_max(U_i, U_j, c/|c|): hyperbolic_module.template.h:402-406 */
+    static RYUJIN_DEV double dij_from_states(const EulerParams &P, const double (&U_i)[K],
+                                             const double (&U_j)[K], const double (&c)[DIM])
+    {
+      double norm2 = c[0] * c[0];
+#pragma unroll
+      for (int d = 1; d < DIM; ++d)
+        norm2 += c[d] * c[d];
+      const double norm = sqrt(norm2);
+      double n[DIM];
+#pragma unroll
+      for (int d = 0; d < DIM; ++d)
+        n[d] = c[d] / norm;
+      const RiemannData rd_i = riemann_data_from_state(P, U_i, n);
+      const RiemannData rd_j = riemann_data_from_state(P, U_j, n);
+      return norm * riemann_compute(P, rd_i, rd_j);
+    }
+
+    /* ------------------------------------------------------------------ Limiter::limit */
+
+    /* limiter.template.h:15-327, production control flow (no EXPENSIVE_BOUNDS_CHECK).
+     * Per-thread early exits: a converged lane is a fixed point of quadratic_newton_step,
+     * see SURVEY.md Appendix E-3. */
+    static RYUJIN_DEV double limit(const EulerParams &P, const double rho_min, const double rho_max,
+                                   const double s_min, const double (&U)[K], const double (&Pij)[K],
+                                   bool &success)
+    {
+      constexpr double t_min = 0., t_max = 1.;
+      success = true;
+      double t_r = t_max;
+
+      constexpr double eps = DBL_EPSILON;
+      const double relax_small = 1. + P.vacuum_small * eps;
+      const double relax = 1. + P.vacuum_large * eps;
+
+      {
+        const double rho_U = U[0];
+        const double rho_P = Pij[0];
+
+        const double test_min = filter_vacuum_density(P, fmax(0., rho_U - relax * rho_max));
+        const double test_max = filter_vacuum_density(P, fmax(0., rho_min - relax * rho_U));
+        if (!(test_min == 0. && test_max == 0.))
+          success = false;
+
+        const double denominator = 1. / (fabs(rho_P) + eps * rho_max);
+
+        t_r = rho_max < rho_U + t_r * rho_P ? (rho_max - rho_U) * denominator : t_r;
+        t_r = rho_U + t_r * rho_P < rho_min ? (rho_U - rho_min) * denominator : t_r;
+
+        t_r = fmin(t_r, t_max);
+        t_r = fmax(t_r, t_min);
+      }
+
+      double t_l = t_min;
+      const double gamma = P.gamma;
+      const double gp1 = gamma + 1.;
+
+      for (int n = 0; n < P.lim_newton_max_iterations; ++n) {
+        double U_r[K];
+#pragma unroll
+        for (int q = 0; q < K; ++q)
+          U_r[q] = U[q] + t_r * Pij[q];
+        const double rho_r = U_r[0];
+        const double rho_r_gamma = dev_pow(rho_r, gamma);
+        const double rho_e_r = internal_energy(U_r);
+        const double psi_r = relax_small * rho_r * rho_e_r - s_min * rho_r * rho_r_gamma;
+
+        t_l = psi_r > 0. ? t_r : t_l;
+        if (t_l == t_r)
+          break;
+
+        double U_l[K];
+#pragma unroll
+        for (int q = 0; q < K; ++q)
+          U_l[q] = U[q] + t_l * Pij[q];
+        const double rho_l = U_l[0];
+        const double rho_l_gamma = dev_pow(rho_l, gamma);
+        const double rho_e_l = internal_energy(U_l);
+        const double psi_l = relax_small * rho_l * rho_e_l - s_min * rho_l * rho_l_gamma;
+
+        const double lower_bound = (1. - relax) * s_min * rho_l * rho_l_gamma;
+        if (n == 0 && !(fmin(0., psi_l - lower_bound) == 0.))
+          success = false;
+
+        if (fmax(0., t_r - t_l - P.lim_newton_tolerance) == 0.)
+          break;
+
+        /* internal_energy_derivative(U) * P: hyperbolic_system.h:797-819 */
+        const double drho = Pij[0];
+        double drho_e_l, drho_e_r;
+        {
+          const double rho_inverse = 1. / U_l[0];
+          double u[DIM];
+          double u2;
+#pragma unroll
+          for (int d = 0; d < DIM; ++d)
+            u[d] = U_l[1 + d] * rho_inverse;
+          u2 = u[0] * u[0];
+#pragma unroll
+          for (int d = 1; d < DIM; ++d)
+            u2 += u[d] * u[d];
+          double s = (0.5 * u2) * Pij[0];
+#pragma unroll
+          for (int d = 0; d < DIM; ++d)
+            s += (-u[d]) * Pij[1 + d];
+          s += 1. * Pij[1 + DIM];
+          drho_e_l = s;
+        }
+        {
+          const double rho_inverse = 1. / U_r[0];
+          double u[DIM];
+          double u2;
+#pragma unroll
+          for (int d = 0; d < DIM; ++d)
+            u[d] = U_r[1 + d] * rho_inverse;
+          u2 = u[0] * u[0];
+#pragma unroll
+          for (int d = 1; d < DIM; ++d)
+            u2 += u[d] * u[d];
+          double s = (0.5 * u2) * Pij[0];
+#pragma unroll
+          for (int d = 0; d < DIM; ++d)
+            s += (-u[d]) * Pij[1 + d];
+          s += 1. * Pij[1 + DIM];
+          drho_e_r = s;
+        }
+        const double dpsi_l = rho_l * drho_e_l + (rho_e_l - gp1 * s_min * rho_l_gamma) * drho;
+        const double dpsi_r = rho_r * drho_e_r + (rho_e_r - gp1 * s_min * rho_r_gamma) * drho;
+
+        quadratic_newton_step(t_l, t_r, psi_l, psi_r, dpsi_l, dpsi_r, -1.);
+      }
+      return t_l;
+    }
+
+    /* ------------------------------------------------------------------ boundary conditions */
+
+    /* hyperbolic_system.h:1040-1093 */
+    template <int component>
+    static RYUJIN_DEV void prescribe_riemann_characteristic(const EulerParams &P, const double (&U)[K],
+                                                            const double (&U_bar)[K],
+                                                            const double (&normal)[DIM],
+                                                            double (&U_new)[K])
+    {
+      const double gamma = P.gamma;
+      const double rho = U[0];
+      const double a = sqrt(gamma * ((gamma - 1.) * internal_energy(U)) * (1. / rho));
+      double mn = U[1] * normal[0];
+#pragma unroll
+      for (int d = 1; d < DIM; ++d)
+        mn += U[1 + d] * normal[d];
+      const double vn = mn / rho;
+
+      const double rho_bar = U_bar[0];
+      const double a_bar = sqrt(gamma * ((gamma - 1.) * internal_energy(U_bar)) * (1. / rho_bar));
+      double mn_bar = U_bar[1] * normal[0];
+#pragma unroll
+      for (int d = 1; d < DIM; ++d)
+        mn_bar += U_bar[1 + d] * normal[d];
+      const double vn_bar = mn_bar / rho_bar;
+
+      const double R_1 =
+          component == 1 ? vn_bar - 2. * a_bar / (gamma - 1.) : vn - 2. * a / (gamma - 1.);
+      const double R_2 =
+          component == 2 ? vn_bar + 2. * a_bar / (gamma - 1.) : vn + 2. * a / (gamma - 1.);
+
+      const double p = (gamma - 1.) * internal_energy(U);
+      const double s = p / dev_pow(rho, gamma);
+
+      double vperp[DIM];
+#pragma unroll
+      for (int d = 0; d < DIM; ++d)
+        vperp[d] = U[1 + d] / rho - vn * normal[d];
+
+      const double vn_new = 0.5 * (R_1 + R_2);
+      const double tmp = ((gamma - 1.) / 4.) * (R_2 - R_1);
+      double rho_new = 1. / (gamma * s) * (tmp * tmp);
+      rho_new = dev_pow(rho_new, 1. / (gamma - 1.));
+      const double p_new = s * dev_pow(rho_new, gamma);
+
+      U_new[0] = rho_new;
+      double vperp2 = vperp[0] * vperp[0];
+#pragma unroll
+      for (int d = 1; d < DIM; ++d)
+        vperp2 += vperp[d] * vperp[d];
+#pragma unroll
+      for (int d = 0; d < DIM; ++d)
+        U_new[1 + d] = rho_new * (vn_new * normal[d] + vperp[d]);
+      U_new[1 + DIM] = p_new / (gamma - 1.) + 0.5 * rho_new * (vn_new * vn_new + vperp2);
+    }
+
+    /* hyperbolic_system.h:1099-1159 */
+    static RYUJIN_DEV void apply_boundary_conditions(const EulerParams &P, const int id,
+                                                     const double (&U)[K], const double (&normal)[DIM],
+                                                     const double (&U_D)[K], double (&result)[K])
+    {
+#pragma unroll
+      for (int q = 0; q < K; ++q)
+        result[q] = U[q];
+      if (id == RYUJIN_BC_DIRICHLET) {
+#pragma unroll
+        for (int q = 0; q < K; ++q)
+          result[q] = U_D[q];
+      } else if (id == RYUJIN_BC_SLIP) {
+        double mn = U[1] * normal[0];
+#pragma unroll
+        for (int d = 1; d < DIM; ++d)
+          mn += U[1 + d] * normal[d];
+#pragma unroll
+        for (int d = 0; d < DIM; ++d)
+          result[1 + d] = U[1 + d] - 1. * mn * normal[d];
+      } else if (id == RYUJIN_BC_NO_SLIP) {
+#pragma unroll
+        for (int d = 0; d < DIM; ++d)
+          result[1 + d] = 0.;
+      } else if (id == RYUJIN_BC_DYNAMIC) {
+        const double rho = U[0];
+        const double a = sqrt(P.gamma * ((P.gamma - 1.) * internal_energy(U)) * (1. / rho));
+        double mn = U[1] * normal[0];
+#pragma unroll
+        for (int d = 1; d < DIM; ++d)
+          mn += U[1 + d] * normal[d];
+        const double vn = mn / rho;
+        if (vn < -a) {
+#pragma unroll
+          for (int q = 0; q < K; ++q)
+            result[q] = U_D[q];
+        }
+        if (vn >= -a && vn <= 0.)
+          prescribe_riemann_characteristic<2>(P, U_D, U, normal, result);
+        if (vn > 0. && vn <= a)
+          prescribe_riemann_characteristic<1>(P, U, U_D, normal, result);
+      }
+    }
+  };
+} // namespace ryujin_hip

@@ -1,0 +1,243 @@
+// Host-side import of the reference's SparsityPatternSIMD storage into the device layout.
+//
+// Input : ryujin_hip_offline in the reference layout (source/sparse_matrix_simd.h:311-350,
+//         403-418; SIMD-interleaved internal rows + CSR remainder, diagonal first).
+// Output: SELL-64 ("sliced ELL", slice height = one wavefront):
+//           owned rows are cut into slices of 64 consecutive rows; slice s is padded to its
+//           longest row and stored column-major, i.e. entry (row, col_idx) of a scalar matrix at
+//             pos = (slice_off[s] + col_idx) * 64 + row % 64
+//           -- the reference's own interleave with simd_length -> 64, so that lane l of a wave
+//           reads consecutive addresses for every col_idx (fully coalesced, no LDS transpose).
+//           Multi-component matrices pair components so that every lane moves 16 bytes per load:
+//             comp d of entry pos: base = (slice_off[s]+col_idx)*64*n_comp,
+//               full pair g = d/2:  base + g*128 + lane*2 + d%2
+//               odd tail component: base + g*128 + lane
+//         ghost rows (only transposes of owned entries, needed for l_ji / c_ji look-ups) are
+//         appended as plain CSR behind the SELL region; a transposed-position table addresses
+//         both regions uniformly.
+
+#pragma once
+
+#include <algorithm>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "ryujin_hip.h"
+
+namespace ryujin_hip
+{
+  constexpr uint32_t kWave = 64;
+
+  /* logical (row, col_idx) view of the reference layout */
+  struct RefView {
+    uint32_t n_internal, sl;
+    const uint64_t *row_starts;
+
+    explicit RefView(const ryujin_hip_offline &o)
+        : n_internal(o.n_internal)
+        , sl(o.simd_length ? o.simd_length : 1)
+        , row_starts(o.row_starts)
+    {
+      if (sl > 1 && n_internal % sl != 0)
+        throw std::invalid_argument("n_internal must be a multiple of simd_length");
+    }
+
+    uint32_t row_length(uint32_t row) const
+    {
+      if (row < n_internal) {
+        const uint32_t g = row / sl;
+        return (uint32_t)((row_starts[g + 1] - row_starts[g]) / sl);
+      }
+      return (uint32_t)(row_starts[row + 1] - row_starts[row]);
+    }
+
+    uint64_t scalar_pos(uint32_t row, uint32_t c) const
+    {
+      return row < n_internal ? row_starts[row / sl] + (uint64_t)c * sl + row % sl
+                              : row_starts[row] + c;
+    }
+
+    uint64_t data_pos(uint32_t row, uint32_t c, uint32_t n_comp, uint32_t d) const
+    {
+      return row < n_internal
+                 ? (row_starts[row / sl] + (uint64_t)c * sl) * n_comp + (uint64_t)d * sl + row % sl
+                 : (row_starts[row] + c) * n_comp + d;
+    }
+  };
+
+
+  struct SellLayout {
+    uint32_t n_owned = 0, n_relevant = 0, n_slices = 0, rows_padded = 0;
+    uint32_t max_row_len = 0;
+    std::vector<uint32_t> slice_off; /* [n_slices+1], in units of 64-entry columns */
+    std::vector<uint8_t> row_len;    /* [rows_padded] logical row length (0 beyond n_owned) */
+    std::vector<uint64_t> ghost_ptr; /* [n_ghost+1] */
+    uint64_t nnz_sell = 0, nnz_total = 0, nnz_owned_logical = 0;
+    std::vector<uint32_t> cols;      /* [nnz_total]; padding entries point at their own row */
+    std::vector<uint32_t> idx_t;     /* [nnz_total] position of the transposed entry */
+    std::vector<uint64_t> logical_ptr; /* [n_owned+1] logical CSR offsets (debug_fetch order) */
+
+    uint32_t n_ghost() const { return n_relevant - n_owned; }
+
+    uint64_t pos(uint32_t row, uint32_t c) const
+    {
+      if (row < n_owned)
+        return ((uint64_t)slice_off[row / kWave] + c) * kWave + row % kWave;
+      return nnz_sell + ghost_ptr[row - n_owned] + c;
+    }
+
+    /* position of component d of the n_comp matrix entry with scalar position p */
+    uint64_t comp_pos(uint64_t p, uint32_t n_comp, uint32_t d) const
+    {
+      if (p >= nnz_sell)
+        return nnz_sell * n_comp + (p - nnz_sell) * n_comp + d;
+      const uint64_t lane = p % kWave, colbase = p / kWave;
+      const uint64_t base = colbase * kWave * n_comp;
+      const uint32_t g = d / 2;
+      if (2 * g + 1 < n_comp)
+        return base + (uint64_t)g * 128 + lane * 2 + d % 2;
+      return base + (uint64_t)g * 128 + lane;
+    }
+
+    void build(const ryujin_hip_offline &o)
+    {
+      const RefView ref(o);
+      n_owned = o.n_owned;
+      n_relevant = o.n_relevant;
+      n_slices = (n_owned + kWave - 1) / kWave;
+      rows_padded = n_slices * kWave;
+
+      row_len.assign(rows_padded, 0);
+      slice_off.assign((size_t)n_slices + 1, 0);
+      logical_ptr.assign((size_t)n_owned + 1, 0);
+      max_row_len = 0;
+      for (uint32_t i = 0; i < n_owned; ++i) {
+        const uint32_t len = ref.row_length(i);
+        if (len == 0 || len > 255)
+          throw std::invalid_argument("row length must be in [1,255]");
+        row_len[i] = (uint8_t)len;
+        max_row_len = std::max(max_row_len, len);
+        logical_ptr[i + 1] = logical_ptr[i] + len;
+      }
+      nnz_owned_logical = logical_ptr[n_owned];
+      for (uint32_t s = 0; s < n_slices; ++s) {
+        uint32_t m = 0;
+        for (uint32_t l = 0; l < kWave; ++l)
+          m = std::max<uint32_t>(m, row_len[(size_t)s * kWave + l]);
+        slice_off[s + 1] = slice_off[s] + m;
+      }
+      nnz_sell = (uint64_t)slice_off[n_slices] * kWave;
+
+      ghost_ptr.assign((size_t)n_ghost() + 1, 0);
+      for (uint32_t g = 0; g < n_ghost(); ++g)
+        ghost_ptr[g + 1] = ghost_ptr[g] + ref.row_length(n_owned + g);
+      nnz_total = nnz_sell + ghost_ptr[n_ghost()];
+      if (nnz_total >= 0xFFFFFFFFull)
+        throw std::invalid_argument("more than 2^32 matrix entries per rank are not supported "
+                                    "(same limit as sparse_matrix_simd.template.h:88-92)");
+
+      /* columns; padding -> own row */
+      cols.assign(nnz_total, 0);
+      for (uint32_t s = 0; s < n_slices; ++s) {
+        const uint32_t width = slice_off[s + 1] - slice_off[s];
+        for (uint32_t l = 0; l < kWave; ++l) {
+          const uint32_t row = s * kWave + l;
+          const uint32_t self = row < n_owned ? row : (n_owned ? n_owned - 1 : 0);
+          for (uint32_t c = 0; c < width; ++c) {
+            const uint64_t p = ((uint64_t)slice_off[s] + c) * kWave + l;
+            cols[p] = (row < n_owned && c < row_len[row]) ? o.columns[ref.scalar_pos(row, c)] : self;
+          }
+        }
+      }
+      for (uint32_t i = n_owned; i < n_relevant; ++i) {
+        const uint32_t len = ref.row_length(i);
+        for (uint32_t c = 0; c < len; ++c)
+          cols[pos(i, c)] = o.columns[ref.scalar_pos(i, c)];
+      }
+      for (uint32_t i = 0; i < n_relevant; ++i)
+        if (o.columns[ref.scalar_pos(i, 0)] != i)
+          throw std::invalid_argument("row " + std::to_string(i) +
+                                      " does not start with its diagonal entry");
+
+      /* transposed positions (rows are: diagonal, then ascending columns) */
+      auto logical_len = [&](uint32_t row) {
+        return row < n_owned ? (uint32_t)row_len[row]
+                             : (uint32_t)(ghost_ptr[row - n_owned + 1] - ghost_ptr[row - n_owned]);
+      };
+      auto find_in_row = [&](uint32_t row, uint32_t target) -> int64_t {
+        const uint32_t len = logical_len(row);
+        uint32_t lo = 1, hi = len;
+        while (lo < hi) {
+          const uint32_t mid = (lo + hi) / 2;
+          if (cols[pos(row, mid)] < target)
+            lo = mid + 1;
+          else
+            hi = mid;
+        }
+        if (lo < len && cols[pos(row, lo)] == target)
+          return (int64_t)lo;
+        return -1;
+      };
+      idx_t.assign(nnz_total, 0);
+      for (uint32_t i = 0; i < n_relevant; ++i) {
+        const uint32_t len = logical_len(i);
+        for (uint32_t c = 0; c < len; ++c) {
+          const uint64_t p = pos(i, c);
+          const uint32_t j = cols[p];
+          if (c == 0 || j == i) {
+            idx_t[p] = (uint32_t)pos(i, 0);
+            continue;
+          }
+          const int64_t ct = find_in_row(j, i);
+          if (ct < 0) {
+            if (i < n_owned)
+              throw std::invalid_argument("sparsity pattern is not structurally symmetric");
+            idx_t[p] = (uint32_t)p;
+            continue;
+          }
+          idx_t[p] = (uint32_t)pos(j, (uint32_t)ct);
+        }
+      }
+      /* padding entries: transpose -> themselves */
+      for (uint32_t s = 0; s < n_slices; ++s) {
+        const uint32_t width = slice_off[s + 1] - slice_off[s];
+        for (uint32_t l = 0; l < kWave; ++l) {
+          const uint32_t row = s * kWave + l;
+          for (uint32_t c = (row < n_owned ? row_len[row] : 0); c < width; ++c) {
+            const uint64_t p = ((uint64_t)slice_off[s] + c) * kWave + l;
+            idx_t[p] = (uint32_t)p;
+          }
+        }
+      }
+    }
+
+    /* reference layout -> device layout (padding = 0) */
+    std::vector<double> scatter(const ryujin_hip_offline &o, const double *data, uint32_t n_comp) const
+    {
+      const RefView ref(o);
+      std::vector<double> out(nnz_total * n_comp, 0.);
+      for (uint32_t i = 0; i < n_relevant; ++i) {
+        const uint32_t len = ref.row_length(i);
+        for (uint32_t c = 0; c < len; ++c) {
+          const uint64_t p = pos(i, c);
+          for (uint32_t d = 0; d < n_comp; ++d)
+            out[comp_pos(p, n_comp, d)] = data[ref.data_pos(i, c, n_comp, d)];
+        }
+      }
+      return out;
+    }
+
+    /* device layout -> logical CSR over owned rows (AoS per entry) */
+    void gather_logical(const std::vector<double> &dev, uint32_t n_comp, double *out) const
+    {
+      for (uint32_t i = 0; i < n_owned; ++i)
+        for (uint32_t c = 0; c < row_len[i]; ++c) {
+          const uint64_t p = pos(i, c);
+          for (uint32_t d = 0; d < n_comp; ++d)
+            out[(logical_ptr[i] + c) * n_comp + d] = dev[comp_pos(p, n_comp, d)];
+        }
+    }
+  };
+} // namespace ryujin_hip

@@ -1,0 +1,697 @@
+// HIP kernels for HyperbolicModule::prepare_state_vector / ::step (Euler), gfx950.
+//
+// Mapping: one thread per DoF row, one wavefront (64 lanes) per SELL-64 slice. For every col_idx
+// the 64 lanes of a wave read 64 consecutive matrix entries (512 B / 1 KiB per load instruction),
+// so the c_ij / m_ij / d_ij / l_ij / p_ij streams are coalesced without an LDS transpose; states
+// U_j, r_j, alpha_j are gathered through L1/L2 (for a locality-preserving numbering consecutive
+// lanes gather consecutive j). No MFMA: the path is a bandwidth-bound stencil sweep.
+//
+// Sweeps follow the reference one to one (source/hyperbolic_module.template.h):
+//   k_apply_bc + k_precompute      step 1  :96-193
+//   k_dij_alpha                    step 2  :341-424
+//   k_dij_boundary + k_dij_diag    step 3  :432-564
+//   k_low_order                    step 4  :597-884
+//   k_pij_lij                      step 5  :892-1041
+//   k_high_order<false/true>       step 6/7 :1053-1182
+
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cstdint>
+
+#include "euler_device.hpp"
+
+namespace ryujin_hip
+{
+  struct DeviceMesh {
+    uint32_t n_owned, n_relevant, n_slices;
+    const uint32_t *slice_off; /* [n_slices+1] */
+    const uint8_t *row_len;    /* [n_slices*64] */
+    const uint32_t *cols;      /* [nnz_total] */
+    const uint32_t *idx_t;     /* [nnz_total] */
+    const double *cij;         /* paired layout, DIM comps */
+    const double *mij;
+    const double *mi, *mi_inv;
+    double measure_of_omega_inverse;
+  };
+
+  /* device scalars shared between sweeps */
+  struct DeviceScalars {
+    unsigned long long tau_max_bits; /* atomicMin over positive doubles */
+    double tau;                      /* the tau used by steps 4,5 */
+    int restart_needed;
+    int tau_invalid;
+  };
+
+  constexpr int kBlock = 256;
+  constexpr int kWavesPerBlock = kBlock / 64;
+
+  template <int K>
+  struct StatePad {
+    static constexpr int KP = (K + 1) / 2 * 2;
+  };
+
+  template <int K>
+  RYUJIN_DEV void load_state(const double *__restrict__ U, const uint32_t i, double (&v)[K])
+  {
+    constexpr int KP = StatePad<K>::KP;
+    const double2 *b = reinterpret_cast<const double2 *>(U + (size_t)i * KP);
+#pragma unroll
+    for (int g = 0; g < KP / 2; ++g) {
+      const double2 t = b[g];
+      v[2 * g] = t.x;
+      if (2 * g + 1 < K)
+        v[2 * g + 1] = t.y;
+    }
+  }
+
+  template <int K>
+  RYUJIN_DEV void store_state(double *__restrict__ U, const uint32_t i, const double (&v)[K])
+  {
+    constexpr int KP = StatePad<K>::KP;
+    double2 *b = reinterpret_cast<double2 *>(U + (size_t)i * KP);
+#pragma unroll
+    for (int g = 0; g < KP / 2; ++g) {
+      double2 t;
+      t.x = v[2 * g];
+      t.y = (2 * g + 1 < K) ? v[2 * g + 1] : 0.;
+      b[g] = t;
+    }
+  }
+
+  /* entry of an NC-component matrix in the paired SELL layout; colbase = slice_off + col_idx */
+  template <int NC>
+  RYUJIN_DEV void load_entry(const double *__restrict__ m, const uint64_t colbase,
+                             const uint32_t lane, double (&v)[NC])
+  {
+    const double *b = m + colbase * 64 * NC;
+#pragma unroll
+    for (int g = 0; g < NC / 2; ++g) {
+      const double2 t = *reinterpret_cast<const double2 *>(b + g * 128 + lane * 2);
+      v[2 * g] = t.x;
+      v[2 * g + 1] = t.y;
+    }
+    if (NC & 1)
+      v[NC - 1] = b[(NC / 2) * 128 + lane];
+  }
+
+  template <int NC>
+  RYUJIN_DEV void store_entry(double *__restrict__ m, const uint64_t colbase, const uint32_t lane,
+                              const double (&v)[NC])
+  {
+    double *b = m + colbase * 64 * NC;
+#pragma unroll
+    for (int g = 0; g < NC / 2; ++g) {
+      double2 t;
+      t.x = v[2 * g];
+      t.y = v[2 * g + 1];
+      *reinterpret_cast<double2 *>(b + g * 128 + lane * 2) = t;
+    }
+    if (NC & 1)
+      b[(NC / 2) * 128 + lane] = v[NC - 1];
+  }
+
+  RYUJIN_DEV double wave_min(double x)
+  {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+      x = fmin(x, __shfl_xor(x, off, 64));
+    return x;
+  }
+
+  struct RowCtx {
+    uint32_t slice, lane, row, len, base, width;
+    bool valid;
+  };
+
+  RYUJIN_DEV RowCtx row_context(const DeviceMesh &M)
+  {
+    RowCtx r;
+    r.lane = threadIdx.x & 63;
+    r.slice = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    r.valid = r.slice < M.n_slices;
+    if (!r.valid) {
+      r.row = r.len = r.base = r.width = 0;
+      return r;
+    }
+    r.row = r.slice * 64 + r.lane;
+    r.len = M.row_len[r.row];
+    r.base = M.slice_off[r.slice];
+    r.width = M.slice_off[r.slice + 1] - r.base;
+    return r;
+  }
+
+  /* ------------------------------------------------------------------ step 1 */
+
+  /* One thread per boundary DoF; its boundary_map entries are applied in the reference's
+   * (serial) order. grp_start[g]..grp_start[g+1] index the entry arrays sorted by DoF. */
+  template <int DIM>
+  __global__ void __launch_bounds__(kBlock)
+  k_apply_bc(const EulerParams P, const uint32_t n_groups, const uint32_t *__restrict__ grp_start,
+             const uint32_t *__restrict__ b_i, const double *__restrict__ b_normal,
+             const uint8_t *__restrict__ b_id, const double *__restrict__ dirichlet,
+             double *__restrict__ U)
+  {
+    using E = Euler<DIM>;
+    constexpr int K = E::K;
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_groups)
+      return;
+    const uint32_t e0 = grp_start[g], e1 = grp_start[g + 1];
+    const uint32_t i = b_i[e0];
+    double U_i[K];
+    load_state<K>(U, i, U_i);
+    bool touched = false;
+    for (uint32_t e = e0; e < e1; ++e) {
+      const int id = b_id[e];
+      if (id == RYUJIN_BC_DO_NOTHING)
+        continue;
+      double normal[DIM], U_D[K], result[K];
+#pragma unroll
+      for (int d = 0; d < DIM; ++d)
+        normal[d] = b_normal[(size_t)e * DIM + d];
+#pragma unroll
+      for (int q = 0; q < K; ++q)
+        U_D[q] = dirichlet ? dirichlet[(size_t)e * K + q] : 0.;
+      E::apply_boundary_conditions(P, id, U_i, normal, U_D, result);
+#pragma unroll
+      for (int q = 0; q < K; ++q)
+        U_i[q] = result[q];
+      touched = true;
+    }
+    if (touched)
+      store_state<K>(U, i, U_i);
+  }
+
+  /* precomputation_loop: source/euler/hyperbolic_system.h:702-737 */
+  template <int DIM>
+  __global__ void __launch_bounds__(kBlock)
+  k_precompute(const EulerParams P, const DeviceMesh M, const double *__restrict__ U,
+               double *__restrict__ prec)
+  {
+    using E = Euler<DIM>;
+    constexpr int K = E::K;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M.n_owned)
+      return;
+    if (M.row_len[i] == 1)
+      return;
+    double U_i[K];
+    load_state<K>(U, i, U_i);
+    double2 out;
+    out.x = E::specific_entropy(P, U_i);
+    out.y = E::harten_entropy(P, U_i);
+    reinterpret_cast<double2 *>(prec)[i] = out;
+  }
+
+  /* ------------------------------------------------------------------ step 2 */
+
+  template <int DIM>
+  __global__ void __launch_bounds__(kBlock)
+  k_dij_alpha(const EulerParams P, const DeviceMesh M, const double *__restrict__ U,
+              const double *__restrict__ prec, double *__restrict__ dij, double *__restrict__ alpha)
+  {
+    using E = Euler<DIM>;
+    constexpr int K = E::K;
+    const RowCtx r = row_context(M);
+    if (!r.valid)
+      return;
+    const bool row_active = r.len > 1;
+    const uint32_t i = row_active ? r.row : (r.row < M.n_owned ? r.row : M.n_owned - 1);
+
+    double U_i[K];
+    load_state<K>(U, i, U_i);
+    const double eta_i = prec[(size_t)i * 2 + 1];
+
+    /* Indicator::reset (indicator.h:187-208) */
+    const double rho_i_inverse = 1. / U_i[0];
+    double d_eta_i[K];
+    E::harten_entropy_derivative(P, U_i, d_eta_i);
+    d_eta_i[0] -= eta_i * rho_i_inverse;
+    double f_i[K][DIM];
+    E::flux(P, U_i, f_i);
+    double left = 0.;
+    double right[K];
+#pragma unroll
+    for (int q = 0; q < K; ++q)
+      right[q] = 0.;
+
+    for (uint32_t c = 0; c < r.width; ++c) {
+      const uint64_t colbase = (uint64_t)r.base + c;
+      const uint64_t pos = colbase * 64 + r.lane;
+      const bool active = row_active && c < r.len;
+      const uint32_t j = M.cols[pos];
+      double c_ij[DIM];
+      load_entry<DIM>(M.cij, colbase, r.lane, c_ij);
+      double U_j[K];
+      load_state<K>(U, j, U_j);
+      const double eta_j = prec[(size_t)j * 2 + 1];
+
+      if (active) {
+        /* Indicator::accumulate (indicator.h:211-238) */
+        const double rho_j_inverse = 1. / U_j[0];
+        double f_j[K][DIM];
+        E::flux(P, U_j, f_j);
+        double m_j_c = U_j[1] * c_ij[0];
+#pragma unroll
+        for (int d = 1; d < DIM; ++d)
+          m_j_c += U_j[1 + d] * c_ij[d];
+        const double entropy_flux = (eta_j * rho_j_inverse - eta_i * rho_i_inverse) * m_j_c;
+        left += entropy_flux;
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+          double component = (f_j[q][0] - f_i[q][0]) * c_ij[0];
+#pragma unroll
+          for (int d = 1; d < DIM; ++d)
+            component += (f_j[q][d] - f_i[q][d]) * c_ij[d];
+          right[q] += component;
+        }
+
+        /* upper triangle only (:394-408) */
+        if (c > 0 && j > i)
+          dij[pos] = E::dij_from_states(P, U_i, U_j, c_ij);
+      }
+    }
+
+    if (row_active) {
+      /* Indicator::alpha (indicator.h:241-258) */
+      const double hd_i = M.mi[i] * M.measure_of_omega_inverse;
+      double numerator = left;
+      double denominator = fabs(left);
+#pragma unroll
+      for (int q = 0; q < K; ++q) {
+        numerator -= d_eta_i[q] * right[q];
+        denominator += fabs(d_eta_i[q] * right[q]);
+      }
+      const double quotient = fabs(numerator) / (denominator + hd_i * fabs(eta_i));
+      alpha[i] = fmin(1., P.evc_factor * quotient);
+    }
+  }
+
+  /* ------------------------------------------------------------------ step 3 */
+
+  /* boundary pairs (:462-490): d_ij = max(d_ij, |c_ji| lambda_max(U_j, U_i, n_ji)) for j >= i */
+  template <int DIM>
+  __global__ void __launch_bounds__(kBlock)
+  k_dij_boundary(const EulerParams P, const uint32_t n_pairs, const uint32_t *__restrict__ p_i,
+                 const uint32_t *__restrict__ p_j, const uint32_t *__restrict__ p_pos,
+                 const uint32_t *__restrict__ p_pos_t, const double *__restrict__ cji,
+                 const double *__restrict__ U, double *__restrict__ dij)
+  {
+    using E = Euler<DIM>;
+    constexpr int K = E::K;
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n_pairs)
+      return;
+    const uint32_t i = p_i[q], j = p_j[q];
+    if (j < i)
+      return;
+    double U_i[K], U_j[K], c_ji[DIM];
+    load_state<K>(U, i, U_i);
+    load_state<K>(U, j, U_j);
+#pragma unroll
+    for (int d = 0; d < DIM; ++d)
+      c_ji[d] = cji[(size_t)q * DIM + d];
+    (void)p_pos_t;
+    const double d_ji = E::dij_from_states(P, U_j, U_i, c_ji);
+    const uint32_t pos = p_pos[q];
+    dij[pos] = fmax(dij[pos], d_ji);
+  }
+
+  /* symmetrise, diagonal, tau_max (:494-560) */
+  __global__ void __launch_bounds__(kBlock)
+  k_dij_diag(const DeviceMesh M, const double cfl, double *__restrict__ dij,
+             DeviceScalars *__restrict__ scalars)
+  {
+    const RowCtx r = row_context(M);
+    if (!r.valid)
+      return;
+    const bool row_active = r.len > 1;
+    const uint32_t i = r.row;
+    double d_sum = 0.;
+    for (uint32_t c = 1; c < r.width; ++c) {
+      const uint64_t pos = ((uint64_t)r.base + c) * 64 + r.lane;
+      if (row_active && c < r.len) {
+        const uint32_t j = M.cols[pos];
+        double d;
+        if (j < i) {
+          d = dij[M.idx_t[pos]];
+          dij[pos] = d;
+        } else {
+          d = dij[pos];
+        }
+        d_sum -= d;
+      }
+    }
+    double tau = DBL_MAX;
+    if (row_active) {
+      d_sum = fmin(d_sum, -1.e6 * DBL_MIN);
+      dij[(uint64_t)r.base * 64 + r.lane] = d_sum;
+      tau = cfl * M.mi[i] / (-2. * d_sum);
+    }
+    tau = wave_min(tau);
+    if (r.lane == 0 && tau < DBL_MAX)
+      atomicMin(&scalars->tau_max_bits, (unsigned long long)__double_as_longlong(tau));
+  }
+
+  /* tau = (tau_in == 0 ? tau_max : tau_in), validity check (:571-578) */
+  __global__ void k_finalize_tau(const double tau_in, DeviceScalars *__restrict__ scalars)
+  {
+    const double tau_max = __longlong_as_double((long long)scalars->tau_max_bits);
+    scalars->tau_invalid = (isnan(tau_max) || isinf(tau_max) || !(tau_max > 0.)) ? 1 : 0;
+    scalars->tau = (tau_in == 0. ? tau_max : tau_in);
+  }
+
+  /* ------------------------------------------------------------------ step 4 */
+
+  template <int DIM>
+  struct StageArgs {
+    int stages;
+    const double *U[4];
+    double w[4];
+  };
+
+  template <int DIM, bool HAS_STAGES>
+  __global__ void __launch_bounds__(kBlock)
+  k_low_order(const EulerParams P, const DeviceMesh M, const DeviceScalars *__restrict__ scalars,
+              const double weight, const StageArgs<DIM> S, const double *__restrict__ U,
+              const double *__restrict__ prec, const double *__restrict__ alpha,
+              const double *__restrict__ dij, double *__restrict__ new_U, double *__restrict__ r_out,
+              double *__restrict__ bounds, double *__restrict__ pij)
+  {
+    using E = Euler<DIM>;
+    constexpr int K = E::K;
+    const RowCtx r = row_context(M);
+    if (!r.valid)
+      return;
+    const bool row_active = r.len > 1;
+    const uint32_t i = row_active ? r.row : (r.row < M.n_owned ? r.row : M.n_owned - 1);
+    const double tau = scalars->tau;
+
+    double U_i[K], U_i_new[K], F_iH[K];
+    load_state<K>(U, i, U_i);
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+      U_i_new[q] = U_i[q];
+      F_iH[q] = 0.;
+    }
+    const double alpha_i = alpha[i];
+    const double m_i = M.mi[i];
+    const double m_i_inv = M.mi_inv[i];
+    double f_i[K][DIM];
+    E::flux(P, U_i, f_i);
+
+    /* Limiter::reset (limiter.h:255-276) */
+    double rho_min = DBL_MAX, rho_max = 0., s_min = DBL_MAX;
+    double rho_relaxation_numerator = 0., rho_relaxation_denominator = 0., s_interp_max = 0.;
+
+    for (uint32_t c = 0; c < r.width; ++c) {
+      const uint64_t colbase = (uint64_t)r.base + c;
+      const uint64_t pos = colbase * 64 + r.lane;
+      const bool active = row_active && c < r.len;
+      const uint32_t j = M.cols[pos];
+      double c_ij[DIM];
+      load_entry<DIM>(M.cij, colbase, r.lane, c_ij);
+      const double d_ij = dij[pos];
+      double U_j[K];
+      load_state<K>(U, j, U_j);
+      const double alpha_j = alpha[j];
+      const double s_j = prec[(size_t)j * 2 + 0];
+
+      if (!active)
+        continue;
+
+      const double factor = (alpha_i + alpha_j) * .5;
+      const double d_ijH = d_ij * factor;
+
+      const double regularization = 100. * DBL_MIN;
+      const double denom = fmax(d_ij, regularization);
+      double scaled_c_ij[DIM];
+#pragma unroll
+      for (int d = 0; d < DIM; ++d)
+        scaled_c_ij[d] = c_ij[d] / denom;
+
+      double f_j[K][DIM];
+      E::flux(P, U_j, f_j);
+      double flux_ij[K];
+      E::flux_divergence(f_i, f_j, c_ij, flux_ij);
+
+      double P_ij[K];
+#pragma unroll
+      for (int q = 0; q < K; ++q) {
+        U_i_new[q] += tau * m_i_inv * flux_ij[q];
+        P_ij[q] = -flux_ij[q];
+      }
+#pragma unroll
+      for (int q = 0; q < K; ++q) {
+        const double dU = U_j[q] - U_i[q];
+        U_i_new[q] += tau * m_i_inv * d_ij * dU;
+        F_iH[q] += d_ijH * dU;
+        P_ij[q] += (d_ijH - d_ij) * dU;
+      }
+
+      /* Limiter::accumulate (limiter.h:279-327) */
+      {
+        const double rho_i = U_i[0], rho_j = U_j[0];
+        double dm_c = (U_i[1] - U_j[1]) * scaled_c_ij[0];
+#pragma unroll
+        for (int d = 1; d < DIM; ++d)
+          dm_c += (U_i[1 + d] - U_j[1 + d]) * scaled_c_ij[d];
+        const double rho_ij_bar = 0.5 * (rho_i + rho_j + dm_c) + 0.;
+        rho_min = fmin(rho_min, rho_ij_bar);
+        rho_max = fmax(rho_max, rho_ij_bar);
+        s_min = fmin(s_min, s_j);
+        rho_relaxation_numerator += 1. * (rho_i + rho_j);
+        rho_relaxation_denominator += 1.;
+        double U_avg[K];
+#pragma unroll
+        for (int q = 0; q < K; ++q)
+          U_avg[q] = (U_i[q] + U_j[q]) * .5;
+        const double s_interp = E::specific_entropy(P, U_avg);
+        s_interp_max = fmax(s_interp_max, s_interp);
+      }
+
+#pragma unroll
+      for (int q = 0; q < K; ++q) {
+        F_iH[q] += weight * flux_ij[q];
+        P_ij[q] += weight * flux_ij[q];
+      }
+
+      if constexpr (HAS_STAGES) {
+        for (int s = 0; s < S.stages; ++s) {
+          double U_iHs[K], U_jHs[K];
+          load_state<K>(S.U[s], i, U_iHs);
+          load_state<K>(S.U[s], j, U_jHs);
+          double f_iHs[K][DIM], f_jHs[K][DIM];
+          E::flux(P, U_iHs, f_iHs);
+          E::flux(P, U_jHs, f_jHs);
+          double flux_s[K];
+          E::flux_divergence(f_iHs, f_jHs, c_ij, flux_s);
+          const double w = S.w[s];
+#pragma unroll
+          for (int q = 0; q < K; ++q) {
+            F_iH[q] += w * flux_s[q];
+            P_ij[q] += w * flux_s[q];
+          }
+        }
+      }
+
+      store_entry<K>(pij, colbase, r.lane, P_ij);
+    }
+
+    if (!row_active)
+      return;
+
+    store_state<K>(new_U, i, U_i_new);
+    store_state<K>(r_out, i, F_iH);
+
+    /* Limiter::bounds (limiter.h:330-363) */
+    const double hd_i = m_i * M.measure_of_omega_inverse;
+    double r_i = sqrt(hd_i);
+    if constexpr (DIM == 2) {
+      const double t = sqrt(r_i);
+      r_i = t * t * t;
+    } else if constexpr (DIM == 1) {
+      r_i = r_i * r_i * r_i;
+    }
+    r_i *= P.lim_relaxation_factor;
+    const double rho_relaxation =
+        fabs(rho_relaxation_numerator) / (fabs(rho_relaxation_denominator) + DBL_EPSILON);
+    const double relaxation = (2. * P.lim_relaxation_factor) * rho_relaxation;
+    const double rho_min_r = fmax((1. - r_i) * rho_min, rho_min - relaxation);
+    const double rho_max_r = fmin((1. + r_i) * rho_max, rho_max + relaxation);
+    const double entropy_relaxation = P.lim_relaxation_factor * (s_interp_max - s_min);
+    const double s_min_r = fmax((1. - r_i) * s_min, s_min - entropy_relaxation);
+
+    /* bounds stored SoA: [NB][rows_padded] */
+    const size_t stride = (size_t)M.n_slices * 64;
+    bounds[i] = rho_min_r;
+    bounds[stride + i] = rho_max_r;
+    bounds[2 * stride + i] = s_min_r;
+  }
+
+  /* ------------------------------------------------------------------ step 5 */
+
+  template <int DIM>
+  __global__ void __launch_bounds__(kBlock)
+  k_pij_lij(const EulerParams P, const DeviceMesh M, DeviceScalars *__restrict__ scalars,
+            const double *__restrict__ new_U, const double *__restrict__ r_in,
+            const double *__restrict__ bounds, double *__restrict__ pij, double *__restrict__ lij)
+  {
+    using E = Euler<DIM>;
+    constexpr int K = E::K;
+    const RowCtx r = row_context(M);
+    if (!r.valid)
+      return;
+    const bool row_active = r.len > 1;
+    const uint32_t i = row_active ? r.row : (r.row < M.n_owned ? r.row : M.n_owned - 1);
+    const double tau = scalars->tau;
+
+    const size_t stride = (size_t)M.n_slices * 64;
+    const double rho_min = bounds[i], rho_max = bounds[stride + i], s_min = bounds[2 * stride + i];
+    const double m_i_inv = M.mi_inv[i];
+    double U_i_new[K], F_iH[K];
+    load_state<K>(new_U, i, U_i_new);
+    load_state<K>(r_in, i, F_iH);
+    const double lambda_inv = (double)(r.len - 1);
+    const double factor = tau * m_i_inv * lambda_inv;
+    bool all_ok = true;
+
+    for (uint32_t c = 1; c < r.width; ++c) {
+      const uint64_t colbase = (uint64_t)r.base + c;
+      const uint64_t pos = colbase * 64 + r.lane;
+      const bool active = row_active && c < r.len;
+      const uint32_t j = M.cols[pos];
+      double P_ij[K];
+      load_entry<K>(pij, colbase, r.lane, P_ij);
+      double F_jH[K];
+      load_state<K>(r_in, j, F_jH);
+      const double m_j_inv = M.mi_inv[j];
+      const double m_ij = M.mij[pos];
+      if (!active)
+        continue;
+
+      const double b_ij = 0. - m_ij * m_j_inv;
+      const double b_ji = 0. - m_ij * m_i_inv;
+#pragma unroll
+      for (int q = 0; q < K; ++q) {
+        P_ij[q] += b_ij * F_jH[q] - b_ji * F_iH[q];
+        P_ij[q] *= factor;
+      }
+      store_entry<K>(pij, colbase, r.lane, P_ij);
+
+      bool success;
+      const double l_ij = E::limit(P, rho_min, rho_max, s_min, U_i_new, P_ij, success);
+      lij[pos] = l_ij;
+      all_ok = all_ok && success;
+    }
+    if (__any(!all_ok)) {
+      if (r.lane == 0)
+        atomicOr(&scalars->restart_needed, 1);
+    }
+  }
+
+  /* ------------------------------------------------------------------ steps 6, 7 */
+
+  template <int DIM, bool LAST_ROUND>
+  __global__ void __launch_bounds__(kBlock)
+  k_high_order(const EulerParams P, const DeviceMesh M, double *__restrict__ new_U,
+               const double *__restrict__ bounds, const double *__restrict__ pij,
+               const double *__restrict__ lij, double *__restrict__ lij_next)
+  {
+    using E = Euler<DIM>;
+    constexpr int K = E::K;
+    const RowCtx r = row_context(M);
+    if (!r.valid)
+      return;
+    const bool row_active = r.len > 1;
+    const uint32_t i = row_active ? r.row : (r.row < M.n_owned ? r.row : M.n_owned - 1);
+
+    double U_i_new[K];
+    load_state<K>(new_U, i, U_i_new);
+    const double lambda = 1. / (double)(r.len - 1);
+
+    for (uint32_t c = 1; c < r.width; ++c) {
+      const uint64_t colbase = (uint64_t)r.base + c;
+      const uint64_t pos = colbase * 64 + r.lane;
+      const bool active = row_active && c < r.len;
+      const double l_a = lij[pos];
+      const double l_b = lij[M.idx_t[pos]];
+      double p_ij[K];
+      load_entry<K>(pij, colbase, r.lane, p_ij);
+      if (!active)
+        continue;
+      const double l_ij = fmin(l_a, l_b);
+#pragma unroll
+      for (int q = 0; q < K; ++q)
+        U_i_new[q] += l_ij * lambda * p_ij[q];
+    }
+
+    if (row_active)
+      store_state<K>(new_U, i, U_i_new);
+
+    if constexpr (!LAST_ROUND) {
+      const size_t stride = (size_t)M.n_slices * 64;
+      const double rho_min = bounds[i], rho_max = bounds[stride + i], s_min = bounds[2 * stride + i];
+      for (uint32_t c = 1; c < r.width; ++c) {
+        const uint64_t colbase = (uint64_t)r.base + c;
+        const uint64_t pos = colbase * 64 + r.lane;
+        const bool active = row_active && c < r.len;
+        const double l_a = lij[pos];
+        const double l_b = lij[M.idx_t[pos]];
+        double p_ij[K];
+        load_entry<K>(pij, colbase, r.lane, p_ij);
+        if (!active)
+          continue;
+        const double old_l_ij = fmin(l_a, l_b);
+        double new_p_ij[K];
+#pragma unroll
+        for (int q = 0; q < K; ++q)
+          new_p_ij[q] = (1. - old_l_ij) * p_ij[q];
+        bool success;
+        const double new_l_ij = E::limit(P, rho_min, rho_max, s_min, U_i_new, new_p_ij, success);
+        lij_next[pos] = (1. - old_l_ij) * new_l_ij;
+      }
+    }
+  }
+
+  /* ------------------------------------------------------------------ helpers */
+
+  /* sadd: dst = s*dst + b*src over the whole local vector (time_integrator.template.h:18-25) */
+  __global__ void __launch_bounds__(kBlock)
+  k_sadd(const size_t n, const double s, const double b, double *__restrict__ dst,
+         const double *__restrict__ src)
+  {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n / 2; q += stride) {
+      double2 d = reinterpret_cast<double2 *>(dst)[q];
+      const double2 v = reinterpret_cast<const double2 *>(src)[q];
+      d.x = s * d.x + b * v.x;
+      d.y = s * d.y + b * v.y;
+      reinterpret_cast<double2 *>(dst)[q] = d;
+    }
+  }
+
+  /* pack owned entries of an n_comp-strided AoS vector into a contiguous send buffer */
+  __global__ void __launch_bounds__(kBlock)
+  k_pack_vector(const uint32_t n, const uint32_t *__restrict__ idx, const int stride,
+                const double *__restrict__ v, double *__restrict__ out)
+  {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n * (uint32_t)stride)
+      return;
+    const uint32_t e = q / stride, d = q % stride;
+    out[q] = v[(size_t)idx[e] * stride + d];
+  }
+
+  __global__ void __launch_bounds__(kBlock)
+  k_pack_matrix(const uint32_t n, const uint32_t *__restrict__ pos, const double *__restrict__ m,
+                double *__restrict__ out)
+  {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n)
+      out[q] = m[pos[q]];
+  }
+} // namespace ryujin_hip

@@ -1,0 +1,938 @@
+// libryujin_hip.so -- C ABI (include/ryujin_hip.h) over the HIP kernels.
+//
+// One context per (rank, GPU). Everything the module owns lives in HBM for the lifetime of
+// the context (hyperbolic_module.h:319-333: alpha, bounds, r, d_ij, l_ij, l_ij_next, p_ij);
+// state vectors are device resident behind handles. All sweeps of one step() are enqueued on
+// one HIP stream without host synchronisation; the only host<->device round trip per step is
+// the 24-byte scalar read-back (tau, restart flag) at the end.
+// Multi-GPU: ghost exchange as RCCL point-to-point (ncclSend/ncclRecv grouped per neighbour)
+// over xGMI, tau_max / restart flag as 1-element all-reduces, all stream ordered.
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "ryujin_hip.h"
+
+#include "host_layout.hpp"
+#include "kernels_euler.hpp"
+
+using namespace ryujin_hip;
+
+namespace
+{
+  thread_local std::string g_error;
+
+  struct HipError : std::runtime_error {
+    int status;
+    HipError(int status, const std::string &what)
+        : std::runtime_error(what)
+        , status(status)
+    {
+    }
+  };
+
+#define HIP_CHECK(expr)                                                                        \
+  do {                                                                                         \
+    const hipError_t err_ = (expr);                                                            \
+    if (err_ != hipSuccess)                                                                    \
+      throw HipError(RYUJIN_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(err_));     \
+  } while (0)
+
+#define NCCL_CHECK(expr)                                                                       \
+  do {                                                                                         \
+    const ncclResult_t res_ = (expr);                                                          \
+    if (res_ != ncclSuccess)                                                                   \
+      throw HipError(RYUJIN_ERR_COMM, std::string(#expr) + ": " + ncclGetErrorString(res_));   \
+  } while (0)
+
+  template <typename T>
+  struct DeviceBuffer {
+    T *ptr = nullptr;
+    size_t n = 0;
+    DeviceBuffer() = default;
+    DeviceBuffer(const DeviceBuffer &) = delete;
+    DeviceBuffer &operator=(const DeviceBuffer &) = delete;
+    ~DeviceBuffer() { release(); }
+    void release()
+    {
+      if (ptr)
+        (void)hipFree(ptr);
+      ptr = nullptr;
+      n = 0;
+    }
+    void alloc(size_t count, bool zero = true)
+    {
+      release();
+      n = count;
+      if (count == 0)
+        count = 1;
+      HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&ptr), count * sizeof(T)));
+      if (zero)
+        HIP_CHECK(hipMemset(ptr, 0, count * sizeof(T)));
+    }
+    void upload(const std::vector<T> &host)
+    {
+      alloc(host.size(), false);
+      if (!host.empty())
+        HIP_CHECK(hipMemcpy(ptr, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    }
+    void upload(const T *host, size_t count)
+    {
+      alloc(count, false);
+      if (count)
+        HIP_CHECK(hipMemcpy(ptr, host, count * sizeof(T), hipMemcpyHostToDevice));
+    }
+  };
+
+  int grid_for(size_t n, int block = kBlock) { return (int)std::max<size_t>(1, (n + block - 1) / block); }
+} // namespace
+
+struct ryujin_hip_comm {
+  ncclComm_t comm = nullptr;
+  int rank = 0, n_ranks = 1, device = 0;
+};
+
+struct ryujin_hip_ctx {
+  ryujin_hip_params params{};
+  int dim = 0, K = 0, KP = 0, NB = 3;
+  int device = 0;
+  ryujin_hip_comm *comm = nullptr;
+  hipStream_t stream = nullptr;
+
+  SellLayout L;
+  DeviceMesh mesh{};
+  EulerParams eparams{};
+
+  /* mesh arrays */
+  DeviceBuffer<uint32_t> d_slice_off, d_cols, d_idx_t;
+  DeviceBuffer<uint8_t> d_row_len;
+  DeviceBuffer<double> d_cij, d_mij, d_mi, d_mi_inv;
+
+  /* boundary data */
+  uint32_t n_bdry = 0, n_groups = 0;
+  std::vector<uint32_t> bdry_perm; /* sorted entry -> original entry */
+  DeviceBuffer<uint32_t> d_grp_start, d_b_i;
+  DeviceBuffer<double> d_b_normal, d_dirichlet;
+  DeviceBuffer<uint8_t> d_b_id;
+  bool have_dirichlet = false;
+
+  /* coupling boundary pairs */
+  uint32_t n_pairs = 0;
+  DeviceBuffer<uint32_t> d_p_i, d_p_j, d_p_pos;
+  DeviceBuffer<double> d_p_cji;
+
+  /* module-owned vectors and matrices */
+  DeviceBuffer<double> d_alpha, d_bounds, d_r, d_dij, d_lij, d_lij_next, d_pij;
+  DeviceBuffer<DeviceScalars> d_scalars;
+  DeviceScalars *h_scalars = nullptr; /* pinned */
+
+  struct State {
+    DeviceBuffer<double> U, prec;
+    bool used = false;
+  };
+  std::vector<std::unique_ptr<State>> states;
+
+  /* exchange pattern */
+  int n_nbr = 0;
+  std::vector<int> nbr_rank;
+  std::vector<uint32_t> send_off, recv_off, row_send_off;
+  std::vector<uint64_t> row_recv_off; /* offsets into the ghost CSR region */
+  DeviceBuffer<uint32_t> d_send_idx, d_row_send_pos;
+  DeviceBuffer<double> d_send_buf;
+
+  unsigned n_restarts = 0, n_warnings = 0;
+
+  /* profiling */
+  bool timers_enabled = false;
+  hipEvent_t ev[9] = {};
+  hipEvent_t ev_user[2] = {};
+  double sweep_ms[8] = {};
+
+  ~ryujin_hip_ctx()
+  {
+    if (stream)
+      (void)hipStreamSynchronize(stream);
+    for (auto &e : ev)
+      if (e)
+        (void)hipEventDestroy(e);
+    for (auto &e : ev_user)
+      if (e)
+        (void)hipEventDestroy(e);
+    if (h_scalars)
+      (void)hipHostFree(h_scalars);
+    if (stream)
+      (void)hipStreamDestroy(stream);
+  }
+
+  State &state(int h)
+  {
+    if (h < 0 || h >= (int)states.size() || !states[h] || !states[h]->used)
+      throw HipError(RYUJIN_ERR_ARG, "invalid state handle " + std::to_string(h));
+    return *states[h];
+  }
+
+  void create(const ryujin_hip_offline &o, const ryujin_hip_params &p, ryujin_hip_comm *c, int dev);
+  void exchange_vector(double *v, int stride);
+  void exchange_matrix(double *m);
+  template <int DIM>
+  void prepare_state_vector(int h, const double *dirichlet);
+  template <int DIM>
+  int step(int h_old, int stages, const int *h_stage, const double *w, int h_new, double tau_in,
+           double tau_max_in, double *tau_out);
+  void mark(int k)
+  {
+    if (timers_enabled)
+      HIP_CHECK(hipEventRecord(ev[k], stream));
+  }
+};
+
+void ryujin_hip_ctx::create(const ryujin_hip_offline &o, const ryujin_hip_params &p,
+                            ryujin_hip_comm *c, int dev)
+{
+  params = p;
+  comm = c;
+  device = dev;
+  dim = p.dim;
+  if (p.equation != RYUJIN_EQ_EULER)
+    throw HipError(RYUJIN_ERR_UNSUPPORTED, "only the Euler equations are implemented on the device");
+  if (dim < 1 || dim > 3)
+    throw HipError(RYUJIN_ERR_ARG, "dim must be 1, 2 or 3");
+  if (p.limiter_iterations < 0 || p.limiter_iterations > 2)
+    throw HipError(RYUJIN_ERR_ARG, "The number of limiter iterations must be between [0,2]");
+  K = dim + 2;
+  KP = (K + 1) / 2 * 2;
+
+  HIP_CHECK(hipSetDevice(device));
+  HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+  for (auto &e : ev)
+    HIP_CHECK(hipEventCreate(&e));
+  for (auto &e : ev_user)
+    HIP_CHECK(hipEventCreate(&e));
+  HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&h_scalars), sizeof(DeviceScalars)));
+
+  eparams.gamma = p.gamma;
+  eparams.gamma_inverse = 1. / p.gamma;
+  eparams.gamma_plus_one_inverse = 1. / (p.gamma + 1.);
+  eparams.gamma_minus_one_inverse = 1. / (p.gamma - 1.);
+  eparams.reference_density = p.reference_density;
+  eparams.vacuum_small = p.vacuum_state_relaxation_small;
+  eparams.vacuum_large = p.vacuum_state_relaxation_large;
+  eparams.evc_factor = p.indicator_evc_factor;
+  eparams.lim_newton_tolerance = p.limiter_newton_tolerance;
+  eparams.lim_relaxation_factor = p.limiter_relaxation_factor;
+  eparams.lim_newton_max_iterations = p.limiter_newton_max_iterations;
+  eparams.riemann_newton_max_iterations = p.riemann_newton_max_iterations;
+  eparams.riemann_newton_tolerance = p.riemann_newton_tolerance;
+
+  /* ---- stencil ------------------------------------------------------------- */
+  L.build(o);
+  d_slice_off.upload(L.slice_off);
+  d_row_len.upload(L.row_len);
+  d_cols.upload(L.cols);
+  d_idx_t.upload(L.idx_t);
+  {
+    const auto cij = L.scatter(o, o.cij, (uint32_t)dim);
+    d_cij.upload(cij);
+    const auto mij = L.scatter(o, o.mij, 1);
+    d_mij.upload(mij);
+
+    /* coupling boundary pairs: position of (i,col_idx) and the value of c_ji */
+    n_pairs = o.n_pairs;
+    std::vector<uint32_t> p_pos(n_pairs);
+    std::vector<double> p_cji((size_t)n_pairs * dim);
+    for (uint32_t q = 0; q < n_pairs; ++q) {
+      const uint64_t pos = L.pos(o.p_i[q], o.p_col[q]);
+      if (L.cols[pos] != o.p_j[q])
+        throw HipError(RYUJIN_ERR_ARG, "coupling_boundary_pairs do not match the sparsity pattern");
+      p_pos[q] = (uint32_t)pos;
+      const uint64_t pos_t = L.idx_t[pos];
+      for (int d = 0; d < dim; ++d)
+        p_cji[(size_t)q * dim + d] = cij[L.comp_pos(pos_t, (uint32_t)dim, (uint32_t)d)];
+    }
+    d_p_i.upload(o.p_i, n_pairs);
+    d_p_j.upload(o.p_j, n_pairs);
+    d_p_pos.upload(p_pos);
+    d_p_cji.upload(p_cji);
+  }
+  d_mi.upload(o.mi, o.n_relevant);
+  d_mi_inv.upload(o.mi_inv, o.n_relevant);
+
+  mesh.n_owned = L.n_owned;
+  mesh.n_relevant = L.n_relevant;
+  mesh.n_slices = L.n_slices;
+  mesh.slice_off = d_slice_off.ptr;
+  mesh.row_len = d_row_len.ptr;
+  mesh.cols = d_cols.ptr;
+  mesh.idx_t = d_idx_t.ptr;
+  mesh.cij = d_cij.ptr;
+  mesh.mij = d_mij.ptr;
+  mesh.mi = d_mi.ptr;
+  mesh.mi_inv = d_mi_inv.ptr;
+  mesh.measure_of_omega_inverse = 1. / o.measure_of_omega;
+
+  /* ---- boundary map: group entries by DoF, keep the original order inside a group ---- */
+  n_bdry = o.n_bdry;
+  bdry_perm.resize(n_bdry);
+  std::iota(bdry_perm.begin(), bdry_perm.end(), 0u);
+  std::stable_sort(bdry_perm.begin(), bdry_perm.end(),
+                   [&](uint32_t a, uint32_t b) { return o.b_i[a] < o.b_i[b]; });
+  {
+    std::vector<uint32_t> b_i(n_bdry), grp_start;
+    std::vector<double> b_normal((size_t)n_bdry * dim);
+    std::vector<uint8_t> b_id(n_bdry);
+    for (uint32_t e = 0; e < n_bdry; ++e) {
+      const uint32_t src = bdry_perm[e];
+      b_i[e] = o.b_i[src];
+      if (b_i[e] >= o.n_owned)
+        throw HipError(RYUJIN_ERR_ARG, "boundary_map entry refers to a non-owned DoF");
+      b_id[e] = o.b_id[src];
+      for (int d = 0; d < dim; ++d)
+        b_normal[(size_t)e * dim + d] = o.b_normal[(size_t)src * dim + d];
+      if (e == 0 || b_i[e] != b_i[e - 1])
+        grp_start.push_back(e);
+    }
+    n_groups = (uint32_t)grp_start.size();
+    grp_start.push_back(n_bdry);
+    d_grp_start.upload(grp_start);
+    d_b_i.upload(b_i);
+    d_b_normal.upload(b_normal);
+    d_b_id.upload(b_id);
+    d_dirichlet.alloc((size_t)n_bdry * K);
+  }
+
+  /* ---- module-owned storage (prepare(): hyperbolic_module.template.h:52-86) ---- */
+  d_alpha.alloc(L.n_relevant);
+  d_bounds.alloc((size_t)NB * L.rows_padded);
+  d_r.alloc((size_t)L.n_relevant * KP);
+  d_dij.alloc(L.nnz_total);
+  d_lij.alloc(L.nnz_total);
+  d_lij_next.alloc(L.nnz_total);
+  d_pij.alloc(L.nnz_total * (size_t)K);
+  d_scalars.alloc(1);
+
+  /* ---- exchange pattern ---- */
+  n_nbr = o.n_nbr;
+  if (n_nbr > 0 && !comm)
+    throw HipError(RYUJIN_ERR_COMM, "offline data has neighbour ranks but no communicator was given");
+  if (n_nbr > 0) {
+    nbr_rank.assign(o.nbr_rank, o.nbr_rank + n_nbr);
+    send_off.assign(o.send_off, o.send_off + n_nbr + 1);
+    recv_off.assign(o.recv_off, o.recv_off + n_nbr + 1);
+    row_send_off.assign(o.row_send_off, o.row_send_off + n_nbr + 1);
+    d_send_idx.upload(o.send_idx, send_off[n_nbr]);
+    std::vector<uint32_t> row_send_pos(row_send_off[n_nbr]);
+    for (uint32_t e = 0; e < row_send_off[n_nbr]; ++e)
+      row_send_pos[e] = (uint32_t)L.pos(o.row_send_row[e], o.row_send_col[e]);
+    d_row_send_pos.upload(row_send_pos);
+    row_recv_off.resize((size_t)n_nbr + 1);
+    for (int q = 0; q <= n_nbr; ++q)
+      row_recv_off[q] = L.ghost_ptr[recv_off[q] - L.n_owned];
+    const size_t buf = std::max<size_t>((size_t)send_off[n_nbr] * KP, row_send_off[n_nbr]);
+    d_send_buf.alloc(buf);
+  }
+  HIP_CHECK(hipStreamSynchronize(stream));
+}
+
+void ryujin_hip_ctx::exchange_vector(double *v, int stride)
+{
+  if (n_nbr == 0)
+    return;
+  const uint32_t n_send = send_off[n_nbr];
+  hipLaunchKernelGGL(k_pack_vector, dim3(grid_for((size_t)n_send * stride)), dim3(kBlock), 0, stream,
+                     n_send, d_send_idx.ptr, stride, v, d_send_buf.ptr);
+  NCCL_CHECK(ncclGroupStart());
+  for (int q = 0; q < n_nbr; ++q) {
+    NCCL_CHECK(ncclSend(d_send_buf.ptr + (size_t)send_off[q] * stride,
+                        (size_t)(send_off[q + 1] - send_off[q]) * stride, ncclDouble, nbr_rank[q],
+                        comm->comm, stream));
+    NCCL_CHECK(ncclRecv(v + (size_t)recv_off[q] * stride,
+                        (size_t)(recv_off[q + 1] - recv_off[q]) * stride, ncclDouble, nbr_rank[q],
+                        comm->comm, stream));
+  }
+  NCCL_CHECK(ncclGroupEnd());
+}
+
+void ryujin_hip_ctx::exchange_matrix(double *m)
+{
+  if (n_nbr == 0)
+    return;
+  const uint32_t n_send = row_send_off[n_nbr];
+  hipLaunchKernelGGL(k_pack_matrix, dim3(grid_for(n_send)), dim3(kBlock), 0, stream, n_send,
+                     d_row_send_pos.ptr, m, d_send_buf.ptr);
+  NCCL_CHECK(ncclGroupStart());
+  for (int q = 0; q < n_nbr; ++q) {
+    NCCL_CHECK(ncclSend(d_send_buf.ptr + row_send_off[q], row_send_off[q + 1] - row_send_off[q],
+                        ncclDouble, nbr_rank[q], comm->comm, stream));
+    NCCL_CHECK(ncclRecv(m + L.nnz_sell + row_recv_off[q], row_recv_off[q + 1] - row_recv_off[q],
+                        ncclDouble, nbr_rank[q], comm->comm, stream));
+  }
+  NCCL_CHECK(ncclGroupEnd());
+}
+
+template <int DIM>
+void ryujin_hip_ctx::prepare_state_vector(int h, const double *dirichlet)
+{
+  State &s = state(h);
+  if (dirichlet && n_bdry) {
+    /* permute into the grouped order, then upload */
+    std::vector<double> tmp((size_t)n_bdry * K);
+    for (uint32_t e = 0; e < n_bdry; ++e)
+      std::memcpy(&tmp[(size_t)e * K], &dirichlet[(size_t)bdry_perm[e] * K], sizeof(double) * K);
+    HIP_CHECK(hipMemcpyAsync(d_dirichlet.ptr, tmp.data(), tmp.size() * sizeof(double),
+                             hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipStreamSynchronize(stream)); /* tmp goes out of scope */
+    have_dirichlet = true;
+  }
+  if (n_groups)
+    hipLaunchKernelGGL(k_apply_bc<DIM>, dim3(grid_for(n_groups)), dim3(kBlock), 0, stream, eparams,
+                       n_groups, d_grp_start.ptr, d_b_i.ptr, d_b_normal.ptr, d_b_id.ptr,
+                       d_dirichlet.ptr, s.U.ptr);
+  exchange_vector(s.U.ptr, KP);
+  hipLaunchKernelGGL(k_precompute<DIM>, dim3(grid_for(L.n_owned)), dim3(kBlock), 0, stream, eparams,
+                     mesh, s.U.ptr, s.prec.ptr);
+  exchange_vector(s.prec.ptr, 2);
+  HIP_CHECK(hipGetLastError());
+}
+
+template <int DIM>
+int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double *w, int h_new,
+                         double tau_in, double tau_max_in, double *tau_out)
+{
+  State &old = state(h_old);
+  State &nw = state(h_new);
+  if (h_old == h_new)
+    throw HipError(RYUJIN_ERR_ARG, "old and new state vector must differ");
+
+  const dim3 block(kBlock);
+  const dim3 grid_rows((L.n_slices + kWavesPerBlock - 1) / kWavesPerBlock);
+
+  /* scalars: tau_max := tau_max_in, flags := 0 */
+  DeviceScalars init{};
+  {
+    long long bits;
+    std::memcpy(&bits, &tau_max_in, sizeof(bits));
+    init.tau_max_bits = (unsigned long long)bits;
+  }
+  *h_scalars = init;
+  HIP_CHECK(hipMemcpyAsync(d_scalars.ptr, h_scalars, sizeof(DeviceScalars), hipMemcpyHostToDevice,
+                           stream));
+
+  mark(0);
+  /* Step 2 */
+  hipLaunchKernelGGL(k_dij_alpha<DIM>, grid_rows, block, 0, stream, eparams, mesh, old.U.ptr,
+                     old.prec.ptr, d_dij.ptr, d_alpha.ptr);
+  exchange_vector(d_alpha.ptr, 1);
+  mark(1);
+
+  /* Step 3 */
+  if (n_pairs)
+    hipLaunchKernelGGL(k_dij_boundary<DIM>, dim3(grid_for(n_pairs)), block, 0, stream, eparams,
+                       n_pairs, d_p_i.ptr, d_p_j.ptr, d_p_pos.ptr, (const uint32_t *)nullptr,
+                       d_p_cji.ptr, old.U.ptr, d_dij.ptr);
+  hipLaunchKernelGGL(k_dij_diag, grid_rows, block, 0, stream, mesh, params.cfl, d_dij.ptr,
+                     d_scalars.ptr);
+  if (comm && comm->n_ranks > 1)
+    NCCL_CHECK(ncclAllReduce(&d_scalars.ptr->tau_max_bits, &d_scalars.ptr->tau_max_bits, 1,
+                             ncclDouble, ncclMin, comm->comm, stream));
+  hipLaunchKernelGGL(k_finalize_tau, dim3(1), dim3(1), 0, stream, tau_in, d_scalars.ptr);
+  mark(2);
+
+  /* Step 4 */
+  double weight;
+  {
+    double acc = -1.;
+    for (int s = 0; s < stages; ++s)
+      acc += w[s];
+    weight = -acc;
+  }
+  StageArgs<DIM> S{};
+  S.stages = stages;
+  for (int s = 0; s < stages; ++s) {
+    S.U[s] = state(h_stage[s]).U.ptr;
+    S.w[s] = w[s];
+  }
+  if (stages == 0)
+    hipLaunchKernelGGL((k_low_order<DIM, false>), grid_rows, block, 0, stream, eparams, mesh,
+                       d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_alpha.ptr, d_dij.ptr,
+                       nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
+  else
+    hipLaunchKernelGGL((k_low_order<DIM, true>), grid_rows, block, 0, stream, eparams, mesh,
+                       d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_alpha.ptr, d_dij.ptr,
+                       nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
+  exchange_vector(d_r.ptr, KP);
+  mark(3);
+
+  /* Step 5 */
+  const int n_iterations = params.limiter_iterations;
+  if (n_iterations != 0) {
+    hipLaunchKernelGGL(k_pij_lij<DIM>, grid_rows, block, 0, stream, eparams, mesh, d_scalars.ptr,
+                       nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr);
+    exchange_matrix(d_lij.ptr);
+  }
+  mark(4);
+
+  /* Steps 6, 7 */
+  for (int pass = 0; pass < n_iterations; ++pass) {
+    const bool last_round = (pass + 1 == n_iterations);
+    if (n_iterations == 2 && last_round)
+      std::swap(d_lij.ptr, d_lij_next.ptr);
+    if (last_round) {
+      hipLaunchKernelGGL((k_high_order<DIM, true>), grid_rows, block, 0, stream, eparams, mesh,
+                         nw.U.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr, d_lij_next.ptr);
+    } else {
+      hipLaunchKernelGGL((k_high_order<DIM, false>), grid_rows, block, 0, stream, eparams, mesh,
+                         nw.U.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr, d_lij_next.ptr);
+      exchange_matrix(d_lij_next.ptr);
+    }
+    mark(5 + pass);
+  }
+  for (int k = 5 + n_iterations; k <= 7; ++k)
+    mark(k);
+
+  if (comm && comm->n_ranks > 1)
+    NCCL_CHECK(ncclAllReduce(&d_scalars.ptr->restart_needed, &d_scalars.ptr->restart_needed, 1,
+                             ncclInt, ncclMax, comm->comm, stream));
+
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipMemcpyAsync(h_scalars, d_scalars.ptr, sizeof(DeviceScalars), hipMemcpyDeviceToHost,
+                           stream));
+  HIP_CHECK(hipStreamSynchronize(stream));
+
+  if (timers_enabled) {
+    for (int k = 0; k < 7; ++k) {
+      float ms = 0.f;
+      HIP_CHECK(hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
+      sweep_ms[k + 1] = ms;
+    }
+  }
+
+  if (h_scalars->tau_invalid)
+    return RYUJIN_ERR_TAU;
+  *tau_out = h_scalars->tau;
+
+  if (h_scalars->restart_needed) {
+    if (params.id_violation_strategy == RYUJIN_IDV_WARN) {
+      n_warnings++;
+      return RYUJIN_WARN;
+    }
+    n_restarts++;
+    return RYUJIN_RESTART;
+  }
+  return RYUJIN_OK;
+}
+
+/* ============================================================================ C ABI */
+
+namespace
+{
+  template <typename F>
+  int guarded(F &&f)
+  {
+    try {
+      return f();
+    } catch (const HipError &e) {
+      g_error = e.what();
+      return e.status;
+    } catch (const std::invalid_argument &e) {
+      g_error = e.what();
+      return RYUJIN_ERR_ARG;
+    } catch (const std::exception &e) {
+      g_error = e.what();
+      return RYUJIN_ERR_HIP;
+    }
+  }
+
+  template <typename F>
+  auto dispatch_dim(int dim, F &&f)
+  {
+    switch (dim) {
+    case 1: return f(std::integral_constant<int, 1>{});
+    case 2: return f(std::integral_constant<int, 2>{});
+    default: return f(std::integral_constant<int, 3>{});
+    }
+  }
+} // namespace
+
+extern "C" {
+
+const char *ryujin_hip_last_error(void)
+{
+  return g_error.c_str();
+}
+
+const char *ryujin_hip_version(void)
+{
+  return "ryujin_hip 0.1 (gfx950; Euler; SELL-64)";
+}
+
+void ryujin_hip_default_params(ryujin_hip_params *p, int equation, int dim)
+{
+  std::memset(p, 0, sizeof(*p));
+  p->equation = equation;
+  p->dim = dim;
+  p->gamma = 7. / 5.;
+  p->reference_density = 1.;
+  p->vacuum_state_relaxation_small = 1.e2;
+  p->vacuum_state_relaxation_large = 1.e4;
+  p->gravity = 9.81;
+  p->manning_friction_coefficient = 0.;
+  p->reference_water_depth = 1.;
+  p->dry_state_relaxation_factor = 2.e-1;
+  p->dry_state_relaxation_small = 1.e2;
+  p->dry_state_relaxation_large = 1.e4;
+  p->cfl = 0.2;
+  p->id_violation_strategy = RYUJIN_IDV_WARN;
+  p->indicator_evc_factor = 1.;
+  p->limiter_iterations = 2;
+  p->limiter_newton_tolerance = 1.e-10;
+  p->limiter_newton_max_iterations = 2;
+  p->limiter_relaxation_factor = 1.;
+  p->limiter_limit_on_kinetic_energy = 0;
+  p->limiter_limit_on_square_velocity = 1;
+  p->riemann_newton_max_iterations = 0;
+  p->riemann_newton_tolerance = 1.e-10;
+}
+
+int ryujin_hip_comm_unique_id(char id[RYUJIN_HIP_UNIQUE_ID_BYTES])
+{
+  return guarded([&]() {
+    static_assert(sizeof(ncclUniqueId) <= RYUJIN_HIP_UNIQUE_ID_BYTES, "unique id size");
+    ncclUniqueId uid;
+    NCCL_CHECK(ncclGetUniqueId(&uid));
+    std::memset(id, 0, RYUJIN_HIP_UNIQUE_ID_BYTES);
+    std::memcpy(id, &uid, sizeof(uid));
+    return RYUJIN_OK;
+  });
+}
+
+int ryujin_hip_comm_init(ryujin_hip_comm **comm, const char id[RYUJIN_HIP_UNIQUE_ID_BYTES], int rank,
+                         int n_ranks, int device)
+{
+  return guarded([&]() {
+    auto c = std::make_unique<ryujin_hip_comm>();
+    c->rank = rank;
+    c->n_ranks = n_ranks;
+    c->device = device;
+    HIP_CHECK(hipSetDevice(device));
+    ncclUniqueId uid;
+    std::memcpy(&uid, id, sizeof(uid));
+    NCCL_CHECK(ncclCommInitRank(&c->comm, n_ranks, uid, rank));
+    *comm = c.release();
+    return RYUJIN_OK;
+  });
+}
+
+void ryujin_hip_comm_destroy(ryujin_hip_comm *comm)
+{
+  if (!comm)
+    return;
+  if (comm->comm)
+    (void)ncclCommDestroy(comm->comm);
+  delete comm;
+}
+
+int ryujin_hip_create(ryujin_hip_ctx **ctx, const ryujin_hip_offline *offline,
+                      const ryujin_hip_params *params, ryujin_hip_comm *comm, int device)
+{
+  return guarded([&]() {
+    if (!ctx || !offline || !params)
+      throw HipError(RYUJIN_ERR_ARG, "null argument");
+    auto c = std::make_unique<ryujin_hip_ctx>();
+    c->create(*offline, *params, comm, device);
+    *ctx = c.release();
+    return RYUJIN_OK;
+  });
+}
+
+void ryujin_hip_destroy(ryujin_hip_ctx *ctx)
+{
+  delete ctx;
+}
+
+int ryujin_hip_state_alloc(ryujin_hip_ctx *ctx, int *handle)
+{
+  return guarded([&]() {
+    HIP_CHECK(hipSetDevice(ctx->device));
+    int h = -1;
+    for (size_t q = 0; q < ctx->states.size(); ++q)
+      if (!ctx->states[q]->used) {
+        h = (int)q;
+        break;
+      }
+    if (h < 0) {
+      ctx->states.push_back(std::make_unique<ryujin_hip_ctx::State>());
+      h = (int)ctx->states.size() - 1;
+      ctx->states[h]->U.alloc((size_t)ctx->L.n_relevant * ctx->KP);
+      ctx->states[h]->prec.alloc((size_t)ctx->L.n_relevant * 2);
+    }
+    ctx->states[h]->used = true;
+    *handle = h;
+    return RYUJIN_OK;
+  });
+}
+
+int ryujin_hip_state_free(ryujin_hip_ctx *ctx, int handle)
+{
+  return guarded([&]() {
+    ctx->state(handle).used = false;
+    return RYUJIN_OK;
+  });
+}
+
+int ryujin_hip_state_upload(ryujin_hip_ctx *ctx, int handle, const double *U_aos)
+{
+  return guarded([&]() {
+    auto &s = ctx->state(handle);
+    const size_t n = ctx->L.n_relevant;
+    const int K = ctx->K, KP = ctx->KP;
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (K == KP) {
+      HIP_CHECK(hipMemcpy(s.U.ptr, U_aos, n * K * sizeof(double), hipMemcpyHostToDevice));
+    } else {
+      std::vector<double> tmp(n * KP, 0.);
+      for (size_t i = 0; i < n; ++i)
+        std::memcpy(&tmp[i * KP], &U_aos[i * K], sizeof(double) * K);
+      HIP_CHECK(hipMemcpy(s.U.ptr, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    return RYUJIN_OK;
+  });
+}
+
+int ryujin_hip_state_download(ryujin_hip_ctx *ctx, int handle, double *U_aos)
+{
+  return guarded([&]() {
+    auto &s = ctx->state(handle);
+    const size_t n = ctx->L.n_relevant;
+    const int K = ctx->K, KP = ctx->KP;
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (K == KP) {
+      HIP_CHECK(hipMemcpy(U_aos, s.U.ptr, n * K * sizeof(double), hipMemcpyDeviceToHost));
+    } else {
+      std::vector<double> tmp(n * KP);
+      HIP_CHECK(hipMemcpy(tmp.data(), s.U.ptr, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < n; ++i)
+        std::memcpy(&U_aos[i * K], &tmp[i * KP], sizeof(double) * K);
+    }
+    return RYUJIN_OK;
+  });
+}
+
+int ryujin_hip_state_download_precomputed(ryujin_hip_ctx *ctx, int handle, double *prec_aos)
+{
+  return guarded([&]() {
+    auto &s = ctx->state(handle);
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    HIP_CHECK(hipMemcpy(prec_aos, s.prec.ptr, (size_t)ctx->L.n_relevant * 2 * sizeof(double),
+                        hipMemcpyDeviceToHost));
+    return RYUJIN_OK;
+  });
+}
+
+int ryujin_hip_prepare_state_vector(ryujin_hip_ctx *ctx, int handle, double /*t*/,
+                                    const double *dirichlet_aos)
+{
+  return guarded([&]() {
+    HIP_CHECK(hipSetDevice(ctx->device));
+    dispatch_dim(ctx->dim, [&](auto d) {
+      ctx->template prepare_state_vector<decltype(d)::value>(handle, dirichlet_aos);
+      return 0;
+    });
+    return RYUJIN_OK;
+  });
+}
+
+int ryujin_hip_step(ryujin_hip_ctx *ctx, int h_old, int stages, const int *h_stage,
+                    const double *stage_weights, int h_new, double tau_in, double tau_max_in,
+                    double *tau_out)
+{
+  return guarded([&]() {
+    if (stages < 0 || stages > 4 || !tau_out)
+      throw HipError(RYUJIN_ERR_ARG, "stages must be in [0,4]");
+    HIP_CHECK(hipSetDevice(ctx->device));
+    return dispatch_dim(ctx->dim, [&](auto d) {
+      return ctx->template step<decltype(d)::value>(h_old, stages, h_stage, stage_weights, h_new,
+                                                    tau_in, tau_max_in, tau_out);
+    });
+  });
+}
+
+int ryujin_hip_sadd(ryujin_hip_ctx *ctx, int h_dst, double s, double b, int h_src)
+{
+  return guarded([&]() {
+    auto &dst = ctx->state(h_dst);
+    auto &src = ctx->state(h_src);
+    const size_t n = (size_t)ctx->L.n_relevant * ctx->KP;
+    const int grid = (int)std::min<size_t>(2048, (n / 2 + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_sadd, dim3(std::max(1, grid)), dim3(kBlock), 0, ctx->stream, n, s, b,
+                       dst.U.ptr, src.U.ptr);
+    HIP_CHECK(hipGetLastError());
+    return RYUJIN_OK;
+  });
+}
+
+int ryujin_hip_set_cfl(ryujin_hip_ctx *ctx, double cfl)
+{
+  ctx->params.cfl = cfl;
+  return RYUJIN_OK;
+}
+
+int ryujin_hip_get_cfl(ryujin_hip_ctx *ctx, double *cfl)
+{
+  *cfl = ctx->params.cfl;
+  return RYUJIN_OK;
+}
+
+int ryujin_hip_set_id_violation_strategy(ryujin_hip_ctx *ctx, int strategy)
+{
+  ctx->params.id_violation_strategy = strategy;
+  return RYUJIN_OK;
+}
+
+int ryujin_hip_get_alpha(ryujin_hip_ctx *ctx, double *alpha)
+{
+  return guarded([&]() {
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    HIP_CHECK(hipMemcpy(alpha, ctx->d_alpha.ptr, (size_t)ctx->L.n_relevant * sizeof(double),
+                        hipMemcpyDeviceToHost));
+    return RYUJIN_OK;
+  });
+}
+
+int ryujin_hip_get_counters(ryujin_hip_ctx *ctx, unsigned *n_restarts, unsigned *n_warnings)
+{
+  *n_restarts = ctx->n_restarts;
+  *n_warnings = ctx->n_warnings;
+  return RYUJIN_OK;
+}
+
+int ryujin_hip_debug_fetch(ryujin_hip_ctx *ctx, int what, double *out, size_t n_doubles)
+{
+  return guarded([&]() {
+    const auto &L = ctx->L;
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    auto fetch_matrix = [&](const double *dev, uint32_t n_comp) {
+      if (n_doubles < L.nnz_owned_logical * n_comp)
+        throw HipError(RYUJIN_ERR_ARG, "output buffer too small");
+      std::vector<double> tmp(L.nnz_total * n_comp);
+      HIP_CHECK(hipMemcpy(tmp.data(), dev, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+      L.gather_logical(tmp, n_comp, out);
+    };
+    switch (what) {
+    case 0: fetch_matrix(ctx->d_dij.ptr, 1); break;
+    case 1: fetch_matrix(ctx->d_lij.ptr, 1); break;
+    case 2: fetch_matrix(ctx->d_pij.ptr, (uint32_t)ctx->K); break;
+    case 5: fetch_matrix(ctx->d_lij_next.ptr, 1); break;
+    case 3: {
+      if (n_doubles < (size_t)L.n_owned * ctx->NB)
+        throw HipError(RYUJIN_ERR_ARG, "output buffer too small");
+      std::vector<double> tmp((size_t)ctx->NB * L.rows_padded);
+      HIP_CHECK(hipMemcpy(tmp.data(), ctx->d_bounds.ptr, tmp.size() * sizeof(double),
+                          hipMemcpyDeviceToHost));
+      for (uint32_t i = 0; i < L.n_owned; ++i)
+        for (int b = 0; b < ctx->NB; ++b)
+          out[(size_t)i * ctx->NB + b] = tmp[(size_t)b * L.rows_padded + i];
+      break;
+    }
+    case 4: {
+      if (n_doubles < (size_t)L.n_owned * ctx->K)
+        throw HipError(RYUJIN_ERR_ARG, "output buffer too small");
+      std::vector<double> tmp((size_t)L.n_relevant * ctx->KP);
+      HIP_CHECK(hipMemcpy(tmp.data(), ctx->d_r.ptr, tmp.size() * sizeof(double),
+                          hipMemcpyDeviceToHost));
+      for (uint32_t i = 0; i < L.n_owned; ++i)
+        for (int q = 0; q < ctx->K; ++q)
+          out[(size_t)i * ctx->K + q] = tmp[(size_t)i * ctx->KP + q];
+      break;
+    }
+    default: throw HipError(RYUJIN_ERR_ARG, "unknown debug_fetch selector");
+    }
+    return RYUJIN_OK;
+  });
+}
+
+int ryujin_hip_debug_layout(const ryujin_hip_offline *offline, uint64_t *ptr, uint32_t *col,
+                            uint64_t *transposed, const double *data, uint32_t n_comp, double *out)
+{
+  return guarded([&]() {
+    SellLayout L;
+    L.build(*offline);
+    const RefView ref(*offline);
+    std::vector<uint64_t> lptr((size_t)L.n_relevant + 1, 0);
+    for (uint32_t i = 0; i < L.n_relevant; ++i)
+      lptr[i + 1] = lptr[i] + ref.row_length(i);
+    /* device position -> logical index */
+    std::vector<uint64_t> logical_of(L.nnz_total, ~uint64_t(0));
+    for (uint32_t i = 0; i < L.n_relevant; ++i)
+      for (uint32_t c = 0; c < ref.row_length(i); ++c)
+        logical_of[L.pos(i, c)] = lptr[i] + c;
+    std::vector<double> dev;
+    if (data && out)
+      dev = L.scatter(*offline, data, n_comp);
+    for (uint32_t i = 0; i < L.n_relevant; ++i)
+      for (uint32_t c = 0; c < ref.row_length(i); ++c) {
+        const uint64_t p = L.pos(i, c), e = lptr[i] + c;
+        if (col)
+          col[e] = L.cols[p];
+        if (transposed)
+          transposed[e] = logical_of[L.idx_t[p]];
+        if (data && out)
+          for (uint32_t d = 0; d < n_comp; ++d)
+            out[e * n_comp + d] = dev[L.comp_pos(p, n_comp, d)];
+      }
+    if (ptr)
+      std::copy(lptr.begin(), lptr.end(), ptr);
+    return RYUJIN_OK;
+  });
+}
+
+int ryujin_hip_set_timers(ryujin_hip_ctx *ctx, int enable)
+{
+  ctx->timers_enabled = enable != 0;
+  return RYUJIN_OK;
+}
+
+int ryujin_hip_get_timers(ryujin_hip_ctx *ctx, double ms[8])
+{
+  for (int k = 0; k < 8; ++k)
+    ms[k] = ctx->sweep_ms[k];
+  return RYUJIN_OK;
+}
+
+int ryujin_hip_synchronize(ryujin_hip_ctx *ctx)
+{
+  return guarded([&]() {
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return RYUJIN_OK;
+  });
+}
+
+int ryujin_hip_event_record(ryujin_hip_ctx *ctx, int which)
+{
+  return guarded([&]() {
+    if (which < 0 || which > 1)
+      throw HipError(RYUJIN_ERR_ARG, "which must be 0 or 1");
+    HIP_CHECK(hipEventRecord(ctx->ev_user[which], ctx->stream));
+    return RYUJIN_OK;
+  });
+}
+
+int ryujin_hip_event_elapsed_ms(ryujin_hip_ctx *ctx, double *ms)
+{
+  return guarded([&]() {
+    HIP_CHECK(hipEventSynchronize(ctx->ev_user[1]));
+    float f = 0.f;
+    HIP_CHECK(hipEventElapsedTime(&f, ctx->ev_user[0], ctx->ev_user[1]));
+    *ms = f;
+    return RYUJIN_OK;
+  });
+}
+
+} /* extern "C" */

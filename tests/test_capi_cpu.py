@@ -1,0 +1,150 @@
+"""CPU-side checks of the product library: it loads, exports every symbol include/ryujin_hip.h
+declares, and its host-side layout import (reference SparsityPatternSIMD storage -> SELL-64 ->
+logical view) reproduces the reference's layout golden tests/common/sparse_matrix_simd.output.*
+for SIMD widths 2 (sse2), 4 (avx2) and 8 (avx512). No compute calls (no GPU here)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from helpers_layout import OfflineView, data_pos, simd_layout_from_rows, to_simd_layout
+from ryujin_amd import _build, capi, offline
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "ryujin_hip.h")).read()
+    declared = set(re.findall(r"\b(ryujin_hip_[a-z_]+)\s*\(", header))
+    # struct/typedef names are not functions
+    declared -= {"ryujin_hip_params", "ryujin_hip_offline", "ryujin_hip_ctx", "ryujin_hip_comm"}
+    assert declared == set(capi.HIP_SYMBOLS), declared ^ set(capi.HIP_SYMBOLS)
+    lib = capi.load_hip()
+    for name in sorted(declared):
+        assert hasattr(lib, name), name
+    assert b"gfx950" in lib.ryujin_hip_version()
+
+
+def test_default_params_are_the_references():
+    lib = capi.load_hip()
+    p = capi.Params()
+    lib.ryujin_hip_default_params(C.byref(p), capi.EQ_EULER, 2)
+    assert p.gamma == 7.0 / 5.0 and p.cfl == 0.2                      # hyperbolic_module.template.h:45
+    assert p.limiter_iterations == 2 and p.limiter_newton_max_iterations == 2   # euler/limiter.h:26-49
+    assert p.limiter_newton_tolerance == 1e-10 and p.limiter_relaxation_factor == 1.0
+    assert p.riemann_newton_max_iterations == 0                      # euler/riemann_solver.h:34
+    assert p.indicator_evc_factor == 1.0                              # euler/indicator.h:28
+    assert p.vacuum_state_relaxation_small == 1e2 and p.vacuum_state_relaxation_large == 1e4
+
+
+def test_create_without_gpu_fails_loudly():
+    """No CPU fallback: on a machine without a GPU create() must return an error status."""
+    if os.path.exists("/dev/kfd"):
+        pytest.skip("a GPU is present")
+    from ryujin_amd import HyperbolicModule
+    off = offline.SyntheticOffline(offline.rectangle_2d(4))
+    with pytest.raises(RuntimeError, match="ryujin_hip_"):
+        HyperbolicModule(off, equation=capi.EQ_EULER, backend="hip")
+
+
+def _tridiag_pattern():
+    """tests/common/sparse_matrix_simd.cc:9-22: 14x14, tridiagonal + wrap-around (0,13),(13,0);
+    rows in deal.II order (diagonal first, then ascending)."""
+    rows = [[0, 1, 13]]
+    for i in range(1, 12):
+        rows.append([i, i - 1, i + 1])
+    rows.append([12, 11])
+    rows.append([13, 0])
+    return rows
+
+
+def _parse_golden(path):
+    text = open(path).read()
+    sec = re.split(r"Matrix entries[^\n]*\n", text)[1:]
+    parse = lambda s: [[float(x) for x in line.split()] for line in s.strip().split("\n")]  # noqa: E731
+    return [parse(s) for s in sec]  # row by row, simd rows, transposed row by row, transposed simd
+
+
+@pytest.mark.parametrize("sl,suffix", [(2, "sse2"), (4, "avx2"), (8, "avx512")])
+def test_layout_import_matches_reference_golden(golden_dir, oracle, sl, suffix):
+    rows = _tridiag_pattern()
+    n = 14
+    n_internal = (12 // sl) * sl
+    row_starts, columns = simd_layout_from_rows(rows, n_internal, sl)
+    # values as the reference test writes them (sparse_matrix_simd.cc:33-39)
+    data = np.zeros(len(columns))
+    for i in range(12):
+        for j in range(3):
+            data[data_pos(row_starts, n_internal, sl, i, j)] = i * 3 + j
+    data[data_pos(row_starts, n_internal, sl, 12, 0)] = 36.0
+    data[data_pos(row_starts, n_internal, sl, 12, 1)] = 37.0
+    data[data_pos(row_starts, n_internal, sl, 13, 0)] = 38.0
+    data[data_pos(row_starts, n_internal, sl, 13, 1)] = 39.0
+
+    g_rows, g_simd, g_trows, g_tsimd = _parse_golden(
+        os.path.join(golden_dir, f"common_sparse_matrix_simd.output.{suffix}"))
+
+    # raw storage order of the SIMD part = the golden's "by SIMD rows" section
+    # (the golden's last line lists only the first two entries of the non-SIMD rows)
+    flat_golden = [x for line in g_simd[: n_internal // sl] for x in line]
+    np.testing.assert_array_equal(data[: n_internal * 3], flat_golden)
+
+    dummy = np.ones(n)
+    view = OfflineView(1, 0, n_internal, n, n, sl, row_starts, columns, np.zeros(len(columns)), data, dummy,
+                       dummy, 1.0, [], np.zeros(0), [], [], [], [])
+    nnz = len(columns)
+    for name, fn in (("hip", capi.load_hip().ryujin_hip_debug_layout),
+                     ("oracle", oracle.load().ryujin_oracle_import_csr)):
+        ptr = np.zeros(n + 1, dtype=np.uint64)
+        col = np.zeros(nnz, dtype=np.uint32)
+        tr = np.zeros(nnz, dtype=np.uint64)
+        out = np.zeros(nnz)
+        rc = fn(view.c, capi.as_ptr(ptr, capi.c_u64_p), capi.as_ptr(col, capi.c_u32_p),
+                capi.as_ptr(tr, capi.c_u64_p), capi.as_ptr(data, capi.c_double_p), 1,
+                capi.as_ptr(out, capi.c_double_p))
+        assert rc == 0, name
+        got_rows = [out[ptr[i]:ptr[i + 1]].tolist() for i in range(n)]
+        assert got_rows == g_rows, name
+        assert [col[ptr[i]:ptr[i + 1]].tolist() for i in range(n)] == rows, name
+        got_t = [out[tr[ptr[i]:ptr[i + 1]].astype(np.int64)].tolist() for i in range(n)]
+        assert got_t == g_trows, name
+
+
+def test_layout_roundtrip_on_renumbered_mesh(oracle):
+    """SIMD-interleaved storage of a real stencil (2-D mesh, rows binned by stencil size) survives the
+    import bit for bit, multi-component matrices included."""
+    off = offline.SyntheticOffline(offline.rectangle_2d(9))
+    for sl in (4, 8):
+        v = to_simd_layout(off, sl)
+        assert v.n_internal >= sl
+        nnz = len(v._keep["columns"])
+        ptr = np.zeros(v.n_relevant + 1, dtype=np.uint64)
+        col = np.zeros(nnz, dtype=np.uint32)
+        out = np.zeros(nnz * 2)
+        rc = capi.load_hip().ryujin_hip_debug_layout(
+            v.c, capi.as_ptr(ptr, capi.c_u64_p), capi.as_ptr(col, capi.c_u32_p), None,
+            capi.as_ptr(v._keep["cij"], capi.c_double_p), 2, capi.as_ptr(out, capi.c_double_p))
+        assert rc == 0
+        out = out.reshape(-1, 2)
+        rs = off.row_starts.astype(np.int64)
+        for new in range(0, v.n_owned, 5):
+            old = v.order[new]
+            mine = {int(v.order[c]): tuple(out[e]) for e, c in
+                    zip(range(int(ptr[new]), int(ptr[new + 1])), col[int(ptr[new]):int(ptr[new + 1])])}
+            ref = {int(off.columns[e]): tuple(off.cij[e]) for e in range(rs[old], rs[old + 1])}
+            assert mine == ref
+
+
+def test_oracle_is_not_reachable_from_the_product():
+    """The product package must not import, link or load anything under oracle/."""
+    pkg = os.path.join(ROOT, "ryujin_amd")
+    for base, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hpp", ".h", ".hip", ".cc")):
+                text = open(os.path.join(base, f)).read()
+                if f == "_build.py":
+                    continue  # build recipe of the checker, not a use of it
+                assert "oracle_py" not in text and "libryujin_oracle" not in text and \
+                    "oracle/" not in text.replace("the CPU oracle", ""), f

@@ -1,0 +1,221 @@
+"""Parity of the HIP path (libryujin_hip.so through the C ABI) against the CPU oracle on the same
+seeded inputs, plus the reference's integration goldens run on the GPU.
+
+Stated tolerances (BASELINE.md / SURVEY.md Appendix E): d_ij, alpha 1e-12 relative;
+U_new 1e-11 relative (per component, scaled by max|U|); l_ij 1e-10 absolute; conservation
+defect 1e-13 relative; invariant-domain bounds preserved in sign.
+"""
+import numpy as np
+import pytest
+
+from ryujin_amd import HyperbolicModule, TimeIntegrator, capi, offline
+from ryujin_amd.initial_states import euler_radial_contrast, euler_uniform
+
+pytestmark = pytest.mark.gpu
+
+
+def _perturbed(U, seed=42, amp=1e-3):
+    """multiplicative 1 + 1e-3 U(-1,1) perturbation as initial_values.template.h:198-218"""
+    rng = np.random.default_rng(seed)
+    return U * (1.0 + amp * rng.uniform(-1.0, 1.0, size=U.shape))
+
+
+def _both(spec, U0, oracle, n_warm=0, dirichlet=None, params_edit=None):
+    off = offline.SyntheticOffline(spec)
+    mods = []
+    for backend in ("hip", oracle.backend()):
+        p = oracle.default_params(capi.EQ_EULER, off.dim)
+        p.cfl = 0.9
+        if params_edit:
+            params_edit(p)
+        m = HyperbolicModule(off, p, backend=backend)
+        old = m.new_state_vector(U0)
+        new = m.new_state_vector()
+        for _ in range(n_warm):
+            m.prepare_state_vector(old, 0.0, dirichlet)
+            m.step(old, [], [], new)
+            old, new = new, old
+        mods.append((m, old, new))
+    return off, mods
+
+
+def _compare_step(off, mods, dirichlet=None, tau=0.0, stages=(), weights=()):
+    out = []
+    for m, old, new in mods:
+        m.prepare_state_vector(old, 0.0, dirichlet)
+        tau_used = m.step(old, list(stages), list(weights), new, tau)
+        out.append(dict(tau=tau_used, U_old=old.download(), prec=old.download_precomputed(),
+                        U=new.download(), alpha=m.alpha(), dij=m.debug_fetch("dij"),
+                        lij=m.debug_fetch("lij"), pij=m.debug_fetch("pij"),
+                        bounds=m.debug_fetch("bounds"), r=m.debug_fetch("r"), status=m.last_status))
+    g, c = out
+    n = off.n_owned
+    scale = np.abs(c["U"][:n]).max(axis=0)
+    assert g["status"] == c["status"]
+    np.testing.assert_allclose(g["U_old"][:n], c["U_old"][:n], rtol=1e-14, atol=1e-14)  # BCs
+    np.testing.assert_allclose(g["prec"][:n], c["prec"][:n], rtol=1e-13)
+    np.testing.assert_allclose(g["alpha"][:n], c["alpha"][:n], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(g["dij"], c["dij"], rtol=1e-12, atol=1e-300)
+    assert abs(g["tau"] - c["tau"]) <= 1e-12 * c["tau"]
+    np.testing.assert_allclose(g["bounds"], c["bounds"], rtol=1e-12)
+    np.testing.assert_allclose(g["r"], c["r"], rtol=1e-9, atol=1e-11 * np.abs(c["r"]).max())
+    np.testing.assert_allclose(g["pij"], c["pij"], rtol=1e-8, atol=1e-12 * np.abs(c["pij"]).max())
+    assert np.abs(g["lij"] - c["lij"]).max() <= 1e-10
+    err = np.abs(g["U"][:n] - c["U"][:n]) / scale
+    assert err.max() <= 1e-11, err.max()
+    return g, c
+
+
+def test_step_parity_2d_step_geometry(oracle):
+    """C1-like: Mach-3 forward-facing step, Dirichlet/slip/do-nothing, after shocks formed."""
+    spec = offline.mach3_step_2d(40)
+    off0 = offline.SyntheticOffline(spec)
+    U0 = _perturbed(euler_uniform(off0.positions))
+    dirichlet = euler_uniform(off0.b_positions)
+    off, mods = _both(spec, U0, oracle, n_warm=12, dirichlet=dirichlet)
+    g, c = _compare_step(off, mods, dirichlet)
+    # conservation is exercised in test_conservation_closed_box; here: invariant domain in sign
+    rho, E = g["U"][: off.n_owned, 0], g["U"][: off.n_owned, 3]
+    m2 = (g["U"][: off.n_owned, 1:3] ** 2).sum(1)
+    assert (rho > 0).all() and (E - 0.5 * m2 / rho > 0).all()
+    assert (np.sign(rho) == np.sign(c["U"][: off.n_owned, 0])).all()
+
+
+def test_step_parity_3d_radial_contrast(oracle):
+    """C3-like: 3-D box, slip walls, strong radial pressure contrast (limiter active)."""
+    spec = offline.box_3d(12)
+    off0 = offline.SyntheticOffline(spec)
+    U0 = euler_radial_contrast(off0.positions, radius=0.4)
+    off, mods = _both(spec, U0, oracle, n_warm=4)
+    _compare_step(off, mods)
+
+
+def test_step_parity_1d(oracle):
+    spec = offline.MeshSpec(1, (200,), (0.0,), (1.0,), (capi.BC_DIRICHLET, capi.BC_DO_NOTHING))
+    off0 = offline.SyntheticOffline(spec)
+    x = off0.positions[:, 0]
+    from ryujin_amd.initial_states import euler_from_primitive
+    U0 = euler_from_primitive(np.where(x < 0.5, 1.0, 0.125), np.zeros((len(x), 1)), np.where(x < 0.5, 1.0, 0.1))
+    dirichlet = U0[off0.b_i]
+    off, mods = _both(spec, U0, oracle, n_warm=10, dirichlet=dirichlet)
+    _compare_step(off, mods, dirichlet)
+
+
+def test_multistage_parity_erk33(oracle):
+    """step<1>, step<2> with stage weights (time_integrator.template.h:373-403)."""
+    spec = offline.mach3_step_2d(20)
+    off = offline.SyntheticOffline(spec)
+    U0 = _perturbed(euler_uniform(off.positions))
+    dirichlet = euler_uniform(off.b_positions)
+    finals = []
+    for backend in ("hip", oracle.backend()):
+        m = HyperbolicModule(off, equation=capi.EQ_EULER, backend=backend)
+        sv = m.new_state_vector(U0)
+        ti = TimeIntegrator(m, "erk 33", dirichlet_fn=lambda t: dirichlet)
+        t = 0.0
+        for _ in range(4):
+            sv, tau = ti.step(sv, t)
+            t += tau
+        finals.append((t, sv.download()[: off.n_owned]))
+    assert abs(finals[0][0] - finals[1][0]) < 1e-12 * finals[1][0]
+    scale = np.abs(finals[1][1]).max(axis=0)
+    assert (np.abs(finals[0][1] - finals[1][1]) / scale).max() < 5e-11
+
+
+def test_conservation_closed_box(oracle):
+    """sum_i m_i U_i is conserved on a closed slip box for rho and E (c_ij = -c_ji, d_ij = d_ji,
+    symmetric l_ij): defect <= 1e-13 relative, as check-mass-conservation_01."""
+    spec = offline.rectangle_2d(48, (0.0, 0.0), (1.0, 1.0))
+    off = offline.SyntheticOffline(spec)
+    U0 = euler_radial_contrast(off.positions, inner=(1.0, 0.0, 10.0), outer=(0.125, 0.0, 0.1), radius=0.3,
+                               center=(0.5, 0.5))
+    m = HyperbolicModule(off, equation=capi.EQ_EULER, backend="hip")
+    sv = m.new_state_vector(U0)
+    ti = TimeIntegrator(m, "ssprk 33", cfl_min=0.9, cfl_max=0.9, cfl_recovery_strategy="none")
+    mi = off.mi[: off.n_owned]
+    m.prepare_state_vector(sv, 0.0)
+    before = (mi[:, None] * sv.download()[: off.n_owned]).sum(0)
+    t = 0.0
+    for _ in range(10):
+        sv, tau = ti.step(sv, t)
+        t += tau
+    after = (mi[:, None] * sv.download()[: off.n_owned]).sum(0)
+    for comp in (0, 3):
+        assert abs(after[comp] - before[comp]) <= 1e-13 * abs(before[comp])
+
+
+def test_mass_conservation_01_golden_on_gpu(golden_dir):
+    """The reference's own integration baseline, reproduced by the HIP path."""
+    from test_oracle_golden_integration import golden_mass_conservation, run_mass_conservation
+    gold = golden_mass_conservation(golden_dir)
+    got, m = run_mass_conservation("hip")
+    assert m.n_warnings() == 0
+    np.testing.assert_allclose(got[:, 0], gold[:, 0], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(got[:, [1, 2, 4]], gold[:, [1, 2, 4]], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(got[:, [5, 6, 8]], gold[:, [5, 6, 8]], rtol=1e-11, atol=0)
+    assert np.abs(got[:, 1] - 1.4).max() < 1e-13
+
+
+@pytest.mark.parametrize("scheme", ["ssprk 33", "erk 33"])
+def test_isentropic_vortex_golden_on_gpu(golden_dir, scheme):
+    from test_oracle_golden_integration import _golden_vortex, run_isentropic_vortex
+    dofs, t_ref, linf_ref, l1_ref, l2_ref = _golden_vortex(golden_dir, scheme, 5)
+    t, linf, l1, l2, n = run_isentropic_vortex("hip", scheme, 5)
+    assert n == dofs
+    assert abs(t - t_ref) < 1e-10
+    assert abs(linf - linf_ref) < 1e-8 * linf_ref
+    assert abs(l1 - l1_ref) < 1e-8 * l1_ref
+    assert abs(l2 - l2_ref) < 1e-8 * l2_ref
+
+
+def test_restart_signalling(oracle):
+    """An over-aggressive CFL violates the limiter bounds: RYUJIN_WARN / Restart exactly when the
+    oracle reports it, counters as hyperbolic_module.template.h:1198-1207."""
+    from ryujin_amd import Restart
+    spec = offline.rectangle_2d(24, (0.0, 0.0), (1.0, 1.0))
+    off = offline.SyntheticOffline(spec)
+    U0 = euler_radial_contrast(off.positions, inner=(1.0, 0.0, 1000.0), outer=(0.01, 0.0, 0.01), radius=0.3,
+                               center=(0.5, 0.5))
+    res = []
+    for backend in ("hip", oracle.backend()):
+        m = HyperbolicModule(off, equation=capi.EQ_EULER, backend=backend)
+        m.cfl = 3.0
+        old, new = m.new_state_vector(U0), m.new_state_vector()
+        m.prepare_state_vector(old, 0.0)
+        m.step(old, [], [], new)
+        w = m.n_warnings()
+        m.id_violation_strategy = capi.IDV_RAISE_EXCEPTION
+        raised = False
+        try:
+            m.step(old, [], [], new)
+        except Restart:
+            raised = True
+        res.append((w, raised, m.n_restarts()))
+    assert res[0] == res[1]
+    assert res[0][0] == 1 and res[0][1] and res[0][2] == 1
+
+
+def test_reference_simd_layout_import(oracle):
+    """The C ABI accepts the reference's SIMD-interleaved storage (simd_length 4 and 8): same
+    results as with the plain CSR input."""
+    import ctypes as C
+    spec = offline.rectangle_2d(20, (0.0, 0.0), (1.0, 1.0))
+    off = offline.SyntheticOffline(spec)
+    U0 = _perturbed(euler_uniform(off.positions))
+    m0 = HyperbolicModule(off, equation=capi.EQ_EULER, backend="hip")
+    a, b = m0.new_state_vector(U0), m0.new_state_vector()
+    m0.prepare_state_vector(a, 0.0)
+    m0.step(a, [], [], b)
+    ref = b.download()
+    from helpers_layout import to_simd_layout
+    scale = np.abs(ref).max(axis=0)
+    for sl in (4, 8):
+        off_simd = to_simd_layout(off, sl)   # renumbered: rows of equal stencil size first
+        assert off_simd.n_internal > 0
+        m1 = HyperbolicModule(off_simd, equation=capi.EQ_EULER, backend="hip")
+        a1, b1 = m1.new_state_vector(U0[off_simd.order]), m1.new_state_vector()
+        m1.prepare_state_vector(a1, 0.0)
+        m1.step(a1, [], [], b1)
+        got = b1.download()[off_simd.new_index]
+        # same mesh, different numbering: stencil summation order differs -> round-off only
+        assert (np.abs(got - ref) / scale).max() < 1e-12
