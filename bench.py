@@ -72,6 +72,26 @@ class Ssprk33Stages:
         self.stage = (self.stage + 1) % 3
 
 
+def usable_cores() -> int:
+    """Physical cores this process may use: affinity mask, cgroup CPU quota, SMT siblings folded."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:  # cgroup v2 quota
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    try:  # count one thread per physical core
+        sib = set()
+        for c in os.sched_getaffinity(0):
+            p = f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list"
+            sib.add(open(p).read().strip())
+        n = min(n, max(1, len(sib)))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(spec, U0, dirichlet, budget_s: float = 15.0) -> dict:
     """The CPU restatement of the reference path (oracle/, OpenMP over all host cores) timed on a
     bounded sample of the SAME workload: n forward-Euler updates of the same mesh."""
@@ -92,9 +112,14 @@ def cpu_baseline(spec, U0, dirichlet, budget_s: float = 15.0) -> dict:
         path = native
     except Exception:
         path = None  # fall back to the portable build shipped with the snapshot
+    cores = usable_cores()
+    # libgomp reads these when it is loaded: one thread per usable core, pinned
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_PLACES", "cores")
+    cores = int(os.environ["OMP_NUM_THREADS"])
     lib = oracle_py.load(path)
     lib.ryujin_oracle_set_flush_denormals(1)  # source/main.cc:26-36
-    cores = os.cpu_count() or 1
     off = offline.SyntheticOffline(spec)
     m = HyperbolicModule(off, equation=capi.EQ_EULER, backend=(lib, "ryujin_oracle_"))
     m.cfl = 0.9
