@@ -267,6 +267,9 @@ int ryujin_hip_event_elapsed_ms(ryujin_hip_ctx *ctx, double *ms);
  * device layout and gathered back into out [nnz*n_comp] (AoS per entry). Any pointer may be NULL. */
 int ryujin_hip_debug_layout(const ryujin_hip_offline *offline, uint64_t *ptr, uint32_t *col,
                             uint64_t *transposed, const double *data, uint32_t n_comp, double *out);
+/* Evaluate the device implementation of ryujin::pow (source/simd.template.h:196-272) on n pairs:
+ * out[i] = pow(x[i], y[i]). Needs a GPU; used by the parity tests only. */
+int ryujin_hip_debug_pow(int device, const double *x, const double *y, double *out, size_t n);
 const char *ryujin_hip_last_error(void);
 const char *ryujin_hip_version(void);
 

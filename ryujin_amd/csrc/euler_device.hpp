@@ -29,7 +29,76 @@ namespace ryujin_hip
 
 #define RYUJIN_DEV __device__ __forceinline__
 
-  RYUJIN_DEV double dev_pow(double x, double y) { return pow(x, y); }
+  /*
+   * ryujin::pow (source/simd.template.h:196-272) on the device.
+   *
+   * ocml's pow() costs ~230 VALU instructions (special cases + extended-precision log); the hot
+   * path only ever raises positive, finite, normal numbers to a real exponent, so we evaluate
+   * x^y = exp(y * log x) directly:
+   *   log x = e ln2 + 2 atanh(s),  s = (m-1)/(m+1),  x = m 2^e,  m in [sqrt(1/2), sqrt(2))
+   *           (odd series in s up to s^21: truncation 8e-18),
+   *   exp z = 2^n exp(r),  r = z - n ln2 (ln2 split hi/lo), |r| <= 0.35, Taylor to r^13 (2e-16
+   *           relative truncation at the interval ends, far below the y*log(x) rounding).
+   * Error: a few ulp for |y log x| <~ 10 (dominated by the rounding of the product y*log x), i.e.
+   * ~1e-15 relative -- two orders of magnitude inside the function-level parity tolerance
+   * (the reference's own pow variants already differ in the last digits).
+   * Everything else (x <= 0, subnormal, inf, nan) is forwarded to ocml's pow().
+   */
+  RYUJIN_DEV double dev_pow(double x, double y)
+  {
+    const long long bits = __double_as_longlong(x);
+    const int biased = (int)((bits >> 52) & 0x7ff);
+    if (__builtin_expect(bits <= 0 || biased == 0 || biased == 0x7ff, 0))
+      return pow(x, y);
+
+    /* x = m * 2^e, m in [sqrt(1/2), sqrt(2)) */
+    int e = biased - 1023;
+    double m = __longlong_as_double((bits & 0x000fffffffffffffLL) | 0x3ff0000000000000LL);
+    if (m > 1.4142135623730951) {
+      m *= 0.5;
+      e += 1;
+    }
+    const double s = (m - 1.) / (m + 1.);
+    const double s2 = s * s;
+    double p = 2. / 21.;
+    p = __builtin_fma(p, s2, 2. / 19.);
+    p = __builtin_fma(p, s2, 2. / 17.);
+    p = __builtin_fma(p, s2, 2. / 15.);
+    p = __builtin_fma(p, s2, 2. / 13.);
+    p = __builtin_fma(p, s2, 2. / 11.);
+    p = __builtin_fma(p, s2, 2. / 9.);
+    p = __builtin_fma(p, s2, 2. / 7.);
+    p = __builtin_fma(p, s2, 2. / 5.);
+    p = __builtin_fma(p, s2, 2. / 3.);
+    /* log m = 2s + s^3 p */
+    const double log_m = __builtin_fma(s * s2, p, 2. * s);
+    constexpr double ln2_hi = 6.93147180369123816490e-01; /* 0x3fe62e42fee00000 */
+    constexpr double ln2_lo = 1.90821492927058770002e-10; /* 0x3dea39ef35793c76 */
+    const double ed = (double)e;
+    const double log_x = __builtin_fma(ed, ln2_hi, __builtin_fma(ed, ln2_lo, log_m));
+
+    const double z = y * log_x;
+    if (__builtin_expect(!(fabs(z) < 700.), 0))
+      return pow(x, y);
+    const double n = __builtin_rint(z * 1.44269504088896338700e+00);
+    double r = __builtin_fma(-n, ln2_hi, z);
+    r = __builtin_fma(-n, ln2_lo, r);
+    double q = 1. / 6227020800.;               /* 1/13! */
+    q = __builtin_fma(q, r, 1. / 479001600.);  /* 1/12! */
+    q = __builtin_fma(q, r, 1. / 39916800.);
+    q = __builtin_fma(q, r, 1. / 3628800.);
+    q = __builtin_fma(q, r, 1. / 362880.);
+    q = __builtin_fma(q, r, 1. / 40320.);
+    q = __builtin_fma(q, r, 1. / 5040.);
+    q = __builtin_fma(q, r, 1. / 720.);
+    q = __builtin_fma(q, r, 1. / 120.);
+    q = __builtin_fma(q, r, 1. / 24.);
+    q = __builtin_fma(q, r, 1. / 6.);
+    q = __builtin_fma(q, r, 0.5);
+    q = __builtin_fma(q, r, 1.);
+    q = __builtin_fma(q, r, 1.);
+    return ldexp(q, (int)n);
+  }
   RYUJIN_DEV double positive_part(double x) { return fmax(0., x); }
   RYUJIN_DEV double negative_part(double x) { return -fmin(0., x); }
 
@@ -353,6 +422,55 @@ namespace ryujin_hip
     }
 
     /* ------------------------------------------------------------------ Limiter::limit */
+
+    /* The common case of limit() (limiter.template.h:40-108 + the first psi_r test :173-216):
+     * density clip, then "psi_r > 0 => return t_r". Only 1 in 25-50 (i,j) pairs needs the Newton
+     * iteration (reference comment :197-201); with 64 lanes per wave nearly every wave would drag
+     * the masked-off lanes through it. The kernels therefore run this wave-uniform fast part over
+     * all columns first and finish the few undecided (row, col) pairs with limit() afterwards.
+     * Returns the limiter value if decided, otherwise sets undecided = true. */
+    static RYUJIN_DEV double limit_fast(const EulerParams &P, const double rho_min,
+                                        const double rho_max, const double s_min,
+                                        const double (&U)[K], const double (&Pij)[K], bool &success,
+                                        bool &undecided)
+    {
+      constexpr double t_min = 0., t_max = 1.;
+      constexpr double eps = DBL_EPSILON;
+      success = true;
+      undecided = false;
+      const double relax_small = 1. + P.vacuum_small * eps;
+      const double relax = 1. + P.vacuum_large * eps;
+      double t_r = t_max;
+      {
+        const double rho_U = U[0];
+        const double rho_P = Pij[0];
+        const double test_min = filter_vacuum_density(P, fmax(0., rho_U - relax * rho_max));
+        const double test_max = filter_vacuum_density(P, fmax(0., rho_min - relax * rho_U));
+        if (!(test_min == 0. && test_max == 0.))
+          success = false;
+        const double denominator = 1. / (fabs(rho_P) + eps * rho_max);
+        t_r = rho_max < rho_U + t_r * rho_P ? (rho_max - rho_U) * denominator : t_r;
+        t_r = rho_U + t_r * rho_P < rho_min ? (rho_U - rho_min) * denominator : t_r;
+        t_r = fmin(t_r, t_max);
+        t_r = fmax(t_r, t_min);
+      }
+      if (P.lim_newton_max_iterations <= 0)
+        return t_min;
+      double U_r[K];
+#pragma unroll
+      for (int q = 0; q < K; ++q)
+        U_r[q] = U[q] + t_r * Pij[q];
+      const double rho_r = U_r[0];
+      const double rho_r_gamma = dev_pow(rho_r, P.gamma);
+      const double rho_e_r = internal_energy(U_r);
+      const double psi_r = relax_small * rho_r * rho_e_r - s_min * rho_r * rho_r_gamma;
+      if (psi_r > 0.)
+        return t_r; /* t_l = t_r, break */
+      if (t_r == t_min)
+        return t_min; /* t_l == t_r, break */
+      undecided = true;
+      return t_min;
+    }
 
     /* limiter.template.h:15-327, production control flow (no EXPENSIVE_BOUNDS_CHECK).
      * Per-thread early exits: a converged lane is a fixed point of quadratic_newton_step,

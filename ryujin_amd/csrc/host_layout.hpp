@@ -115,8 +115,8 @@ namespace ryujin_hip
       max_row_len = 0;
       for (uint32_t i = 0; i < n_owned; ++i) {
         const uint32_t len = ref.row_length(i);
-        if (len == 0 || len > 255)
-          throw std::invalid_argument("row length must be in [1,255]");
+        if (len == 0 || len > 64)
+          throw std::invalid_argument("row length must be in [1,64]");
         row_len[i] = (uint8_t)len;
         max_row_len = std::max(max_row_len, len);
         logical_ptr[i + 1] = logical_ptr[i] + len;

@@ -113,12 +113,27 @@ namespace ryujin_hip
       b[(NC / 2) * 128 + lane] = v[NC - 1];
   }
 
+
   RYUJIN_DEV double wave_min(double x)
   {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1)
       x = fmin(x, __shfl_xor(x, off, 64));
     return x;
+  }
+
+  /* tau_max: one device-scope atomicMin per wave would serialise ~40k atomics on one address
+   * (~12 ns each = the whole sweep); the running minimum only decreases, so a wave first peeks at
+   * it with a relaxed load and skips the atomic unless it can lower it. */
+  RYUJIN_DEV void publish_tau_min(DeviceScalars *scalars, const double tau, const uint32_t lane)
+  {
+    if (lane == 0 && tau < DBL_MAX) {
+      const unsigned long long bits = (unsigned long long)__double_as_longlong(tau);
+      const unsigned long long cur =
+          __hip_atomic_load(&scalars->tau_max_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (bits < cur)
+        atomicMin(&scalars->tau_max_bits, bits);
+    }
   }
 
   struct RowCtx {
@@ -351,9 +366,51 @@ namespace ryujin_hip
       dij[(uint64_t)r.base * 64 + r.lane] = d_sum;
       tau = cfl * M.mi[i] / (-2. * d_sum);
     }
-    tau = wave_min(tau);
-    if (r.lane == 0 && tau < DBL_MAX)
-      atomicMin(&scalars->tau_max_bits, (unsigned long long)__double_as_longlong(tau));
+    publish_tau_min(scalars, wave_min(tau), r.lane);
+  }
+
+  /* Same sweep with memory-level parallelism: the row's "lower triangle" columns are known at setup
+   * (bit c of lower_mask[row] <=> cols(row,c) < row), so neither the column indices nor a dependent
+   * load chain are needed: all d_ij / idx_t loads of a row are issued back to back (the generic
+   * kernel above spends 98 % of its wave cycles waiting on 3 dependent loads per column). */
+  template <int MAXW>
+  __global__ void __launch_bounds__(kBlock)
+  k_dij_diag_unrolled(const DeviceMesh M, const uint32_t *__restrict__ lower_mask, const double cfl,
+                      double *__restrict__ dij, DeviceScalars *__restrict__ scalars)
+  {
+    const RowCtx r = row_context(M);
+    if (!r.valid)
+      return;
+    const bool row_active = r.len > 1;
+    const uint32_t mask = row_active ? lower_mask[r.row] : 0u;
+    const uint32_t *__restrict__ idx_t = M.idx_t;
+    double d[MAXW];
+#pragma unroll
+    for (int c = 1; c < MAXW; ++c) {
+      d[c] = 0.;
+      if ((uint32_t)c < r.width) {
+        const uint32_t pos = (r.base + c) * 64 + r.lane;
+        const uint32_t src = ((mask >> c) & 1u) ? idx_t[pos] : pos;
+        d[c] = dij[src];
+      }
+    }
+    double d_sum = 0.;
+#pragma unroll
+    for (int c = 1; c < MAXW; ++c) {
+      if ((uint32_t)c < r.width) {
+        if ((mask >> c) & 1u)
+          dij[(r.base + c) * 64 + r.lane] = d[c];
+        if (row_active && (uint32_t)c < r.len)
+          d_sum -= d[c];
+      }
+    }
+    double tau = DBL_MAX;
+    if (row_active) {
+      d_sum = fmin(d_sum, -1.e6 * DBL_MIN);
+      dij[(uint64_t)r.base * 64 + r.lane] = d_sum;
+      tau = cfl * M.mi[r.row] / (-2. * d_sum);
+    }
+    publish_tau_min(scalars, wave_min(tau), r.lane);
   }
 
   /* tau = (tau_in == 0 ? tau_max : tau_in), validity check (:571-578) */
@@ -532,130 +589,7 @@ namespace ryujin_hip
     bounds[2 * stride + i] = s_min_r;
   }
 
-  /* ------------------------------------------------------------------ step 5 */
-
-  template <int DIM>
-  __global__ void __launch_bounds__(kBlock)
-  k_pij_lij(const EulerParams P, const DeviceMesh M, DeviceScalars *__restrict__ scalars,
-            const double *__restrict__ new_U, const double *__restrict__ r_in,
-            const double *__restrict__ bounds, double *__restrict__ pij, double *__restrict__ lij)
-  {
-    using E = Euler<DIM>;
-    constexpr int K = E::K;
-    const RowCtx r = row_context(M);
-    if (!r.valid)
-      return;
-    const bool row_active = r.len > 1;
-    const uint32_t i = row_active ? r.row : (r.row < M.n_owned ? r.row : M.n_owned - 1);
-    const double tau = scalars->tau;
-
-    const size_t stride = (size_t)M.n_slices * 64;
-    const double rho_min = bounds[i], rho_max = bounds[stride + i], s_min = bounds[2 * stride + i];
-    const double m_i_inv = M.mi_inv[i];
-    double U_i_new[K], F_iH[K];
-    load_state<K>(new_U, i, U_i_new);
-    load_state<K>(r_in, i, F_iH);
-    const double lambda_inv = (double)(r.len - 1);
-    const double factor = tau * m_i_inv * lambda_inv;
-    bool all_ok = true;
-
-    for (uint32_t c = 1; c < r.width; ++c) {
-      const uint64_t colbase = (uint64_t)r.base + c;
-      const uint64_t pos = colbase * 64 + r.lane;
-      const bool active = row_active && c < r.len;
-      const uint32_t j = M.cols[pos];
-      double P_ij[K];
-      load_entry<K>(pij, colbase, r.lane, P_ij);
-      double F_jH[K];
-      load_state<K>(r_in, j, F_jH);
-      const double m_j_inv = M.mi_inv[j];
-      const double m_ij = M.mij[pos];
-      if (!active)
-        continue;
-
-      const double b_ij = 0. - m_ij * m_j_inv;
-      const double b_ji = 0. - m_ij * m_i_inv;
-#pragma unroll
-      for (int q = 0; q < K; ++q) {
-        P_ij[q] += b_ij * F_jH[q] - b_ji * F_iH[q];
-        P_ij[q] *= factor;
-      }
-      store_entry<K>(pij, colbase, r.lane, P_ij);
-
-      bool success;
-      const double l_ij = E::limit(P, rho_min, rho_max, s_min, U_i_new, P_ij, success);
-      lij[pos] = l_ij;
-      all_ok = all_ok && success;
-    }
-    if (__any(!all_ok)) {
-      if (r.lane == 0)
-        atomicOr(&scalars->restart_needed, 1);
-    }
-  }
-
-  /* ------------------------------------------------------------------ steps 6, 7 */
-
-  template <int DIM, bool LAST_ROUND>
-  __global__ void __launch_bounds__(kBlock)
-  k_high_order(const EulerParams P, const DeviceMesh M, double *__restrict__ new_U,
-               const double *__restrict__ bounds, const double *__restrict__ pij,
-               const double *__restrict__ lij, double *__restrict__ lij_next)
-  {
-    using E = Euler<DIM>;
-    constexpr int K = E::K;
-    const RowCtx r = row_context(M);
-    if (!r.valid)
-      return;
-    const bool row_active = r.len > 1;
-    const uint32_t i = row_active ? r.row : (r.row < M.n_owned ? r.row : M.n_owned - 1);
-
-    double U_i_new[K];
-    load_state<K>(new_U, i, U_i_new);
-    const double lambda = 1. / (double)(r.len - 1);
-
-    for (uint32_t c = 1; c < r.width; ++c) {
-      const uint64_t colbase = (uint64_t)r.base + c;
-      const uint64_t pos = colbase * 64 + r.lane;
-      const bool active = row_active && c < r.len;
-      const double l_a = lij[pos];
-      const double l_b = lij[M.idx_t[pos]];
-      double p_ij[K];
-      load_entry<K>(pij, colbase, r.lane, p_ij);
-      if (!active)
-        continue;
-      const double l_ij = fmin(l_a, l_b);
-#pragma unroll
-      for (int q = 0; q < K; ++q)
-        U_i_new[q] += l_ij * lambda * p_ij[q];
-    }
-
-    if (row_active)
-      store_state<K>(new_U, i, U_i_new);
-
-    if constexpr (!LAST_ROUND) {
-      const size_t stride = (size_t)M.n_slices * 64;
-      const double rho_min = bounds[i], rho_max = bounds[stride + i], s_min = bounds[2 * stride + i];
-      for (uint32_t c = 1; c < r.width; ++c) {
-        const uint64_t colbase = (uint64_t)r.base + c;
-        const uint64_t pos = colbase * 64 + r.lane;
-        const bool active = row_active && c < r.len;
-        const double l_a = lij[pos];
-        const double l_b = lij[M.idx_t[pos]];
-        double p_ij[K];
-        load_entry<K>(pij, colbase, r.lane, p_ij);
-        if (!active)
-          continue;
-        const double old_l_ij = fmin(l_a, l_b);
-        double new_p_ij[K];
-#pragma unroll
-        for (int q = 0; q < K; ++q)
-          new_p_ij[q] = (1. - old_l_ij) * p_ij[q];
-        bool success;
-        const double new_l_ij = E::limit(P, rho_min, rho_max, s_min, U_i_new, new_p_ij, success);
-        lij_next[pos] = (1. - old_l_ij) * new_l_ij;
-      }
-    }
-  }
+  /* steps 5, 6, 7: kernels_limiter.hpp */
 
   /* ------------------------------------------------------------------ helpers */
 
@@ -672,6 +606,15 @@ namespace ryujin_hip
       d.y = s * d.y + b * v.y;
       reinterpret_cast<double2 *>(dst)[q] = d;
     }
+  }
+
+  __global__ void __launch_bounds__(kBlock)
+  k_debug_pow(const size_t n, const double *__restrict__ x, const double *__restrict__ y,
+              double *__restrict__ out)
+  {
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n)
+      out[q] = dev_pow(x[q], y[q]);
   }
 
   /* pack owned entries of an n_comp-strided AoS vector into a contiguous send buffer */

@@ -1,0 +1,279 @@
+// Steps 5, 6, 7 of HyperbolicModule::step (source/hyperbolic_module.template.h:892-1182):
+// mass-matrix correction of P_ij, convex limiter, high-order update.
+//
+// Wave-divergence strategy: Limiter::limit decides ~97 % of all (i,j) pairs with its first
+// psi_r test; the remaining pairs need the quadratic Newton iteration (second pow, derivatives,
+// two sqrt + three divisions per iteration). With one row per lane almost every 64-lane wave
+// contains such a pair in a shock region, so each sweep runs limit_fast() over all columns
+// (wave-uniform) and afterwards finishes the undecided (row, col) pairs -- collected in a per-lane
+// bit mask -- with the full limit(); the trip count of that tail is the maximum number of undecided
+// columns of any lane of the wave instead of "every column".
+
+#pragma once
+
+#include "kernels_euler.hpp"
+
+namespace ryujin_hip
+{
+  RYUJIN_DEV void flag_restart(DeviceScalars *scalars, const bool all_ok, const uint32_t lane)
+  {
+    if (__any(!all_ok)) {
+      if (lane == 0)
+        atomicOr(&scalars->restart_needed, 1);
+    }
+  }
+
+  /* ------------------------------------------------------------------ step 5 */
+
+  template <int DIM>
+  __global__ void __launch_bounds__(kBlock)
+  k_pij_lij(const EulerParams P, const DeviceMesh M, DeviceScalars *__restrict__ scalars,
+            const double *__restrict__ new_U, const double *__restrict__ r_in,
+            const double *__restrict__ bounds, double *pij, double *__restrict__ lij)
+  {
+    using E = Euler<DIM>;
+    constexpr int K = E::K;
+    const RowCtx r = row_context(M);
+    if (!r.valid)
+      return;
+    const bool row_active = r.len > 1;
+    const uint32_t i = row_active ? r.row : (r.row < M.n_owned ? r.row : M.n_owned - 1);
+    const double tau = scalars->tau;
+    const uint32_t *__restrict__ cols = M.cols;
+    const double *__restrict__ mij = M.mij;
+    const double *__restrict__ mi_inv = M.mi_inv;
+
+    const size_t stride = (size_t)M.n_slices * 64;
+    const double rho_min = bounds[i], rho_max = bounds[stride + i], s_min = bounds[2 * stride + i];
+    const double m_i_inv = mi_inv[i];
+    double U_i_new[K], F_iH[K];
+    load_state<K>(new_U, i, U_i_new);
+    load_state<K>(r_in, i, F_iH);
+    const double lambda_inv = (double)(r.len - 1);
+    const double factor = tau * m_i_inv * lambda_inv;
+    bool all_ok = true;
+    unsigned long long undecided_mask = 0;
+
+    for (uint32_t c = 1; c < r.width; ++c) {
+      const uint64_t colbase = (uint64_t)r.base + c;
+      const uint64_t pos = colbase * 64 + r.lane;
+      const bool active = row_active && c < r.len;
+      const uint32_t j = cols[pos];
+      double P_ij[K];
+      load_entry<K>(pij, colbase, r.lane, P_ij);
+      double F_jH[K];
+      load_state<K>(r_in, j, F_jH);
+      const double m_j_inv = mi_inv[j];
+      const double m_ij = mij[pos];
+      if (!active)
+        continue;
+
+      /* Neumann series: b_ij = delta_ij - m_ij/m_j, b_ji = delta_ij - m_ij/m_i (:987-996) */
+      const double b_ij = 0. - m_ij * m_j_inv;
+      const double b_ji = 0. - m_ij * m_i_inv;
+#pragma unroll
+      for (int q = 0; q < K; ++q) {
+        P_ij[q] += b_ij * F_jH[q] - b_ji * F_iH[q];
+        P_ij[q] *= factor;
+      }
+      store_entry<K>(pij, colbase, r.lane, P_ij);
+
+      bool success, undecided;
+      const double l_ij =
+          E::limit_fast(P, rho_min, rho_max, s_min, U_i_new, P_ij, success, undecided);
+      if (undecided) {
+        undecided_mask |= 1ull << c;
+      } else {
+        lij[pos] = l_ij;
+        all_ok = all_ok && success;
+      }
+    }
+
+    /* the few pairs that need the Newton iteration */
+    while (undecided_mask) {
+      const uint32_t c = (uint32_t)__builtin_ctzll(undecided_mask);
+      undecided_mask &= undecided_mask - 1;
+      const uint64_t colbase = (uint64_t)r.base + c;
+      double P_ij[K];
+      load_entry<K>(pij, colbase, r.lane, P_ij);
+      bool success;
+      const double l_ij = E::limit(P, rho_min, rho_max, s_min, U_i_new, P_ij, success);
+      lij[colbase * 64 + r.lane] = l_ij;
+      all_ok = all_ok && success;
+    }
+    flag_restart(scalars, all_ok, r.lane);
+  }
+
+  /* ------------------------------------------------------------------ steps 6, 7 */
+
+  /* Generic variant: two passes over the row's stencil (the second one re-reads l_ij, l_ji, P_ij). */
+  template <int DIM, bool LAST_ROUND>
+  __global__ void __launch_bounds__(kBlock)
+  k_high_order(const EulerParams P, const DeviceMesh M, double *__restrict__ new_U,
+               const double *__restrict__ bounds, const double *__restrict__ pij,
+               const double *__restrict__ lij, double *__restrict__ lij_next)
+  {
+    using E = Euler<DIM>;
+    constexpr int K = E::K;
+    const RowCtx r = row_context(M);
+    if (!r.valid)
+      return;
+    const bool row_active = r.len > 1;
+    const uint32_t i = row_active ? r.row : (r.row < M.n_owned ? r.row : M.n_owned - 1);
+    const uint32_t *__restrict__ idx_t = M.idx_t;
+
+    double U_i_new[K];
+    load_state<K>(new_U, i, U_i_new);
+    const double lambda = 1. / (double)(r.len - 1);
+
+    for (uint32_t c = 1; c < r.width; ++c) {
+      const uint64_t colbase = (uint64_t)r.base + c;
+      const uint64_t pos = colbase * 64 + r.lane;
+      const bool active = row_active && c < r.len;
+      const double l_a = lij[pos];
+      const double l_b = lij[idx_t[pos]];
+      double p_ij[K];
+      load_entry<K>(pij, colbase, r.lane, p_ij);
+      if (!active)
+        continue;
+      const double l_ij = fmin(l_a, l_b);
+#pragma unroll
+      for (int q = 0; q < K; ++q)
+        U_i_new[q] += l_ij * lambda * p_ij[q];
+    }
+
+    if (row_active)
+      store_state<K>(new_U, i, U_i_new);
+
+    if constexpr (!LAST_ROUND) {
+      const size_t stride = (size_t)M.n_slices * 64;
+      const double rho_min = bounds[i], rho_max = bounds[stride + i], s_min = bounds[2 * stride + i];
+      unsigned long long undecided_mask = 0;
+      for (uint32_t c = 1; c < r.width; ++c) {
+        const uint64_t colbase = (uint64_t)r.base + c;
+        const uint64_t pos = colbase * 64 + r.lane;
+        const bool active = row_active && c < r.len;
+        const double l_a = lij[pos];
+        const double l_b = lij[idx_t[pos]];
+        double p_ij[K];
+        load_entry<K>(pij, colbase, r.lane, p_ij);
+        if (!active)
+          continue;
+        const double old_l_ij = fmin(l_a, l_b);
+        double new_p_ij[K];
+#pragma unroll
+        for (int q = 0; q < K; ++q)
+          new_p_ij[q] = (1. - old_l_ij) * p_ij[q];
+        bool success, undecided;
+        const double new_l_ij =
+            E::limit_fast(P, rho_min, rho_max, s_min, U_i_new, new_p_ij, success, undecided);
+        if (undecided)
+          undecided_mask |= 1ull << c;
+        else
+          lij_next[pos] = (1. - old_l_ij) * new_l_ij;
+      }
+      while (undecided_mask) {
+        const uint32_t c = (uint32_t)__builtin_ctzll(undecided_mask);
+        undecided_mask &= undecided_mask - 1;
+        const uint64_t colbase = (uint64_t)r.base + c;
+        const uint64_t pos = colbase * 64 + r.lane;
+        const double old_l_ij = fmin(lij[pos], lij[idx_t[pos]]);
+        double p_ij[K], new_p_ij[K];
+        load_entry<K>(pij, colbase, r.lane, p_ij);
+#pragma unroll
+        for (int q = 0; q < K; ++q)
+          new_p_ij[q] = (1. - old_l_ij) * p_ij[q];
+        bool success;
+        const double new_l_ij = E::limit(P, rho_min, rho_max, s_min, U_i_new, new_p_ij, success);
+        lij_next[pos] = (1. - old_l_ij) * new_l_ij;
+      }
+    }
+  }
+
+  /* Register-cached variant for stencils of at most MAXW columns (2-D Q1: 9, 1-D: 3): the row's
+   * l_ij = min(l_ij, l_ji) and P_ij stay in registers between the update and the next limiter pass,
+   * so step 6 reads every array exactly once (the generic variant fetches ~2x the algorithmic bytes)
+   * and all loads of a row are independent and issued up front. */
+  template <int DIM, int MAXW>
+  __global__ void __launch_bounds__(kBlock)
+  k_high_order_next_cached(const EulerParams P, const DeviceMesh M, double *__restrict__ new_U,
+                           const double *__restrict__ bounds, const double *__restrict__ pij,
+                           const double *__restrict__ lij, double *__restrict__ lij_next)
+  {
+    using E = Euler<DIM>;
+    constexpr int K = E::K;
+    const RowCtx r = row_context(M);
+    if (!r.valid)
+      return;
+    const bool row_active = r.len > 1;
+    const uint32_t i = row_active ? r.row : (r.row < M.n_owned ? r.row : M.n_owned - 1);
+    const uint32_t *__restrict__ idx_t = M.idx_t;
+
+    double U_i_new[K];
+    load_state<K>(new_U, i, U_i_new);
+    const double lambda = 1. / (double)(r.len - 1);
+    const size_t stride = (size_t)M.n_slices * 64;
+    const double rho_min = bounds[i], rho_max = bounds[stride + i], s_min = bounds[2 * stride + i];
+
+    double l[MAXW];
+    double p[MAXW][K];
+#pragma unroll
+    for (int c = 1; c < MAXW; ++c) {
+      l[c] = 0.;
+#pragma unroll
+      for (int q = 0; q < K; ++q)
+        p[c][q] = 0.;
+      if ((uint32_t)c < r.width) {
+        const uint64_t colbase = (uint64_t)r.base + c;
+        const uint32_t pos = (uint32_t)(colbase * 64 + r.lane);
+        const double l_a = lij[pos];
+        const double l_b = lij[idx_t[pos]];
+        l[c] = fmin(l_a, l_b);
+        load_entry<K>(pij, colbase, r.lane, p[c]);
+      }
+    }
+#pragma unroll
+    for (int c = 1; c < MAXW; ++c) {
+      if (row_active && (uint32_t)c < r.len) {
+#pragma unroll
+        for (int q = 0; q < K; ++q)
+          U_i_new[q] += l[c] * lambda * p[c][q];
+      }
+    }
+    if (row_active)
+      store_state<K>(new_U, i, U_i_new);
+
+    unsigned long long undecided_mask = 0;
+#pragma unroll
+    for (int c = 1; c < MAXW; ++c) {
+      if (row_active && (uint32_t)c < r.len) {
+        double new_p_ij[K];
+#pragma unroll
+        for (int q = 0; q < K; ++q)
+          new_p_ij[q] = (1. - l[c]) * p[c][q];
+        bool success, undecided;
+        const double new_l_ij =
+            E::limit_fast(P, rho_min, rho_max, s_min, U_i_new, new_p_ij, success, undecided);
+        if (undecided)
+          undecided_mask |= 1ull << c;
+        else
+          lij_next[(r.base + c) * 64 + r.lane] = (1. - l[c]) * new_l_ij;
+      }
+    }
+    while (undecided_mask) {
+      const uint32_t c = (uint32_t)__builtin_ctzll(undecided_mask);
+      undecided_mask &= undecided_mask - 1;
+      const uint64_t colbase = (uint64_t)r.base + c;
+      const uint64_t pos = colbase * 64 + r.lane;
+      const double old_l_ij = fmin(lij[pos], lij[idx_t[pos]]);
+      double p_ij[K], new_p_ij[K];
+      load_entry<K>(pij, colbase, r.lane, p_ij);
+#pragma unroll
+      for (int q = 0; q < K; ++q)
+        new_p_ij[q] = (1. - old_l_ij) * p_ij[q];
+      bool success;
+      const double new_l_ij = E::limit(P, rho_min, rho_max, s_min, U_i_new, new_p_ij, success);
+      lij_next[pos] = (1. - old_l_ij) * new_l_ij;
+    }
+  }
+} // namespace ryujin_hip

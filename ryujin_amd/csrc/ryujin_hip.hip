@@ -23,6 +23,7 @@
 
 #include "host_layout.hpp"
 #include "kernels_euler.hpp"
+#include "kernels_limiter.hpp"
 
 using namespace ryujin_hip;
 
@@ -112,7 +113,7 @@ struct ryujin_hip_ctx {
   EulerParams eparams{};
 
   /* mesh arrays */
-  DeviceBuffer<uint32_t> d_slice_off, d_cols, d_idx_t;
+  DeviceBuffer<uint32_t> d_slice_off, d_cols, d_idx_t, d_lower_mask;
   DeviceBuffer<uint8_t> d_row_len;
   DeviceBuffer<double> d_cij, d_mij, d_mi, d_mi_inv;
 
@@ -238,6 +239,16 @@ void ryujin_hip_ctx::create(const ryujin_hip_offline &o, const ryujin_hip_params
   d_row_len.upload(L.row_len);
   d_cols.upload(L.cols);
   d_idx_t.upload(L.idx_t);
+  {
+    /* bit c of lower_mask[row] <=> column c of the row lies below the diagonal (cols < row) */
+    std::vector<uint32_t> lower_mask(L.rows_padded, 0u);
+    if (L.max_row_len <= 32)
+      for (uint32_t i = 0; i < L.n_owned; ++i)
+        for (uint32_t c = 1; c < L.row_len[i]; ++c)
+          if (L.cols[L.pos(i, c)] < i)
+            lower_mask[i] |= 1u << c;
+    d_lower_mask.upload(lower_mask);
+  }
   {
     const auto cij = L.scatter(o, o.cij, (uint32_t)dim);
     d_cij.upload(cij);
@@ -437,8 +448,18 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
     hipLaunchKernelGGL(k_dij_boundary<DIM>, dim3(grid_for(n_pairs)), block, 0, stream, eparams,
                        n_pairs, d_p_i.ptr, d_p_j.ptr, d_p_pos.ptr, (const uint32_t *)nullptr,
                        d_p_cji.ptr, old.U.ptr, d_dij.ptr);
-  hipLaunchKernelGGL(k_dij_diag, grid_rows, block, 0, stream, mesh, params.cfl, d_dij.ptr,
-                     d_scalars.ptr);
+  if (L.max_row_len <= 3)
+    hipLaunchKernelGGL(k_dij_diag_unrolled<3>, grid_rows, block, 0, stream, mesh, d_lower_mask.ptr,
+                       params.cfl, d_dij.ptr, d_scalars.ptr);
+  else if (L.max_row_len <= 9)
+    hipLaunchKernelGGL(k_dij_diag_unrolled<9>, grid_rows, block, 0, stream, mesh, d_lower_mask.ptr,
+                       params.cfl, d_dij.ptr, d_scalars.ptr);
+  else if (L.max_row_len <= 27)
+    hipLaunchKernelGGL(k_dij_diag_unrolled<27>, grid_rows, block, 0, stream, mesh, d_lower_mask.ptr,
+                       params.cfl, d_dij.ptr, d_scalars.ptr);
+  else
+    hipLaunchKernelGGL(k_dij_diag, grid_rows, block, 0, stream, mesh, params.cfl, d_dij.ptr,
+                       d_scalars.ptr);
   if (comm && comm->n_ranks > 1)
     NCCL_CHECK(ncclAllReduce(&d_scalars.ptr->tau_max_bits, &d_scalars.ptr->tau_max_bits, 1,
                              ncclDouble, ncclMin, comm->comm, stream));
@@ -488,8 +509,14 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
       hipLaunchKernelGGL((k_high_order<DIM, true>), grid_rows, block, 0, stream, eparams, mesh,
                          nw.U.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr, d_lij_next.ptr);
     } else {
-      hipLaunchKernelGGL((k_high_order<DIM, false>), grid_rows, block, 0, stream, eparams, mesh,
-                         nw.U.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr, d_lij_next.ptr);
+      constexpr int kCachedWidth = DIM == 1 ? 3 : 9;
+      if (DIM <= 2 && L.max_row_len <= (uint32_t)kCachedWidth)
+        hipLaunchKernelGGL((k_high_order_next_cached<DIM, kCachedWidth>), grid_rows, block, 0, stream,
+                           eparams, mesh, nw.U.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr,
+                           d_lij_next.ptr);
+      else
+        hipLaunchKernelGGL((k_high_order<DIM, false>), grid_rows, block, 0, stream, eparams, mesh,
+                           nw.U.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr, d_lij_next.ptr);
       exchange_matrix(d_lij_next.ptr);
     }
     mark(5 + pass);
@@ -889,6 +916,22 @@ int ryujin_hip_debug_layout(const ryujin_hip_offline *offline, uint64_t *ptr, ui
       }
     if (ptr)
       std::copy(lptr.begin(), lptr.end(), ptr);
+    return RYUJIN_OK;
+  });
+}
+
+int ryujin_hip_debug_pow(int device, const double *x, const double *y, double *out, size_t n)
+{
+  return guarded([&]() {
+    HIP_CHECK(hipSetDevice(device));
+    DeviceBuffer<double> dx, dy, dout;
+    dx.upload(x, n);
+    dy.upload(y, n);
+    dout.alloc(n);
+    hipLaunchKernelGGL(k_debug_pow, dim3(grid_for(n)), dim3(kBlock), 0, nullptr, n, dx.ptr, dy.ptr,
+                       dout.ptr);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpy(out, dout.ptr, n * sizeof(double), hipMemcpyDeviceToHost));
     return RYUJIN_OK;
   });
 }
