@@ -65,9 +65,18 @@ def hipcc_path() -> str | None:
     return None
 
 
-def build_hip(force: bool = False) -> str:
+def build_hip(force: bool = False, defines: tuple = (), out: str | None = None) -> str:
+    """defines/out: build an A/B variant (e.g. defines=("RYUJIN_OCC_DIJ=3",)) into another file;
+    select it at run time with RYUJIN_HIP_LIB=<path>."""
     src = [os.path.join(CSRC, "ryujin_hip.hip")]
     deps = src + _sources(CSRC, (".hpp", ".h", ".hip")) + _headers()
+    if out is not None:
+        hipcc = hipcc_path()
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        _run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+              "-ffp-contract=off", *["-D" + d for d in defines], "-I" + INCLUDE, "-I" + CSRC, *src,
+              "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib", "-o", out])
+        return out
     if force or not _newer(HIP_SO, deps):
         hipcc = hipcc_path()
         if hipcc is None:
@@ -76,7 +85,7 @@ def build_hip(force: bool = False) -> str:
             raise RuntimeError("hipcc not found and no prebuilt libryujin_hip.so")
         os.makedirs(LIBDIR, exist_ok=True)
         _run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-              "-ffp-contract=off", "-I" + INCLUDE, "-I" + CSRC, *src,
+              "-ffp-contract=" + os.environ.get("RYUJIN_FP_CONTRACT", "off"), "-I" + INCLUDE, "-I" + CSRC, *src,
               "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib", "-o", HIP_SO])
     return HIP_SO
 

@@ -161,7 +161,7 @@ def load_hip():
     """Load the HIP library. Fails loudly if it is missing: there is no CPU fallback."""
     global _hip
     if _hip is None:
-        path = _build.HIP_SO
+        path = os.environ.get("RYUJIN_HIP_LIB", _build.HIP_SO)  # A/B variants of the same library
         if not os.path.exists(path):
             raise RuntimeError(
                 f"{path} is missing: build it with `python -m ryujin_amd._build` "

@@ -45,6 +45,21 @@ namespace ryujin_hip
     int tau_invalid;
   };
 
+  /* minimum waves per SIMD requested from the register allocator for the heavy sweeps (second
+   * __launch_bounds__ argument): 512 registers / waves. Tuned on MI355X, see DESIGN.md. */
+#ifndef RYUJIN_OCC_DIJ
+#define RYUJIN_OCC_DIJ 2
+#endif
+#ifndef RYUJIN_OCC_LOW
+#define RYUJIN_OCC_LOW 2
+#endif
+#ifndef RYUJIN_OCC_PIJ
+#define RYUJIN_OCC_PIJ 2
+#endif
+#ifndef RYUJIN_OCC_HO
+#define RYUJIN_OCC_HO 2
+#endif
+
   constexpr int kBlock = 256;
   constexpr int kWavesPerBlock = kBlock / 64;
 
@@ -224,7 +239,7 @@ namespace ryujin_hip
   /* ------------------------------------------------------------------ step 2 */
 
   template <int DIM>
-  __global__ void __launch_bounds__(kBlock)
+  __global__ void __launch_bounds__(kBlock, RYUJIN_OCC_DIJ)
   k_dij_alpha(const EulerParams P, const DeviceMesh M, const double *__restrict__ U,
               const double *__restrict__ prec, double *__restrict__ dij, double *__restrict__ alpha)
   {
@@ -253,16 +268,37 @@ namespace ryujin_hip
     for (int q = 0; q < K; ++q)
       right[q] = 0.;
 
+    /* software pipeline: the loads of column c+1 (and the column index of c+2) are in flight while
+     * column c is processed, so the gather latency hides behind the Riemann solve */
+    const uint32_t *__restrict__ cols = M.cols;
+    const double *__restrict__ cij = M.cij;
+    uint32_t j_n = cols[(uint64_t)r.base * 64 + r.lane];
+    uint32_t j_nn = r.width > 1 ? cols[((uint64_t)r.base + 1) * 64 + r.lane] : i;
+    double c_n[DIM], U_n[K];
+    load_entry<DIM>(cij, r.base, r.lane, c_n);
+    load_state<K>(U, j_n, U_n);
+    double eta_n = prec[(size_t)j_n * 2 + 1];
+
     for (uint32_t c = 0; c < r.width; ++c) {
       const uint64_t colbase = (uint64_t)r.base + c;
       const uint64_t pos = colbase * 64 + r.lane;
       const bool active = row_active && c < r.len;
-      const uint32_t j = M.cols[pos];
-      double c_ij[DIM];
-      load_entry<DIM>(M.cij, colbase, r.lane, c_ij);
-      double U_j[K];
-      load_state<K>(U, j, U_j);
-      const double eta_j = prec[(size_t)j * 2 + 1];
+      const uint32_t j = j_n;
+      double c_ij[DIM], U_j[K];
+#pragma unroll
+      for (int d = 0; d < DIM; ++d)
+        c_ij[d] = c_n[d];
+#pragma unroll
+      for (int q = 0; q < K; ++q)
+        U_j[q] = U_n[q];
+      const double eta_j = eta_n;
+      if (c + 1 < r.width) {
+        j_n = j_nn;
+        load_entry<DIM>(cij, colbase + 1, r.lane, c_n);
+        load_state<K>(U, j_n, U_n);
+        eta_n = prec[(size_t)j_n * 2 + 1];
+        j_nn = (c + 2 < r.width) ? cols[(colbase + 2) * 64 + r.lane] : i;
+      }
 
       if (active) {
         /* Indicator::accumulate (indicator.h:211-238) */
@@ -431,7 +467,7 @@ namespace ryujin_hip
   };
 
   template <int DIM, bool HAS_STAGES>
-  __global__ void __launch_bounds__(kBlock)
+  __global__ void __launch_bounds__(kBlock, RYUJIN_OCC_LOW)
   k_low_order(const EulerParams P, const DeviceMesh M, const DeviceScalars *__restrict__ scalars,
               const double weight, const StageArgs<DIM> S, const double *__restrict__ U,
               const double *__restrict__ prec, const double *__restrict__ alpha,
@@ -464,18 +500,39 @@ namespace ryujin_hip
     double rho_min = DBL_MAX, rho_max = 0., s_min = DBL_MAX;
     double rho_relaxation_numerator = 0., rho_relaxation_denominator = 0., s_interp_max = 0.;
 
+    /* software pipeline (see k_dij_alpha) */
+    const uint32_t *__restrict__ cols = M.cols;
+    const double *__restrict__ cij = M.cij;
+    uint32_t j_n = cols[(uint64_t)r.base * 64 + r.lane];
+    uint32_t j_nn = r.width > 1 ? cols[((uint64_t)r.base + 1) * 64 + r.lane] : i;
+    double c_n[DIM], U_n[K];
+    load_entry<DIM>(cij, r.base, r.lane, c_n);
+    double d_n = dij[(uint64_t)r.base * 64 + r.lane];
+    load_state<K>(U, j_n, U_n);
+    double alpha_n = alpha[j_n];
+    double s_n = prec[(size_t)j_n * 2 + 0];
+
     for (uint32_t c = 0; c < r.width; ++c) {
       const uint64_t colbase = (uint64_t)r.base + c;
-      const uint64_t pos = colbase * 64 + r.lane;
       const bool active = row_active && c < r.len;
-      const uint32_t j = M.cols[pos];
-      double c_ij[DIM];
-      load_entry<DIM>(M.cij, colbase, r.lane, c_ij);
-      const double d_ij = dij[pos];
-      double U_j[K];
-      load_state<K>(U, j, U_j);
-      const double alpha_j = alpha[j];
-      const double s_j = prec[(size_t)j * 2 + 0];
+      const uint32_t j = j_n;
+      double c_ij[DIM], U_j[K];
+#pragma unroll
+      for (int d = 0; d < DIM; ++d)
+        c_ij[d] = c_n[d];
+#pragma unroll
+      for (int q = 0; q < K; ++q)
+        U_j[q] = U_n[q];
+      const double d_ij = d_n, alpha_j = alpha_n, s_j = s_n;
+      if (c + 1 < r.width) {
+        j_n = j_nn;
+        load_entry<DIM>(cij, colbase + 1, r.lane, c_n);
+        d_n = dij[(colbase + 1) * 64 + r.lane];
+        load_state<K>(U, j_n, U_n);
+        alpha_n = alpha[j_n];
+        s_n = prec[(size_t)j_n * 2 + 0];
+        j_nn = (c + 2 < r.width) ? cols[(colbase + 2) * 64 + r.lane] : i;
+      }
 
       if (!active)
         continue;

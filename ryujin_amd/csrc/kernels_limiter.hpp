@@ -26,7 +26,7 @@ namespace ryujin_hip
   /* ------------------------------------------------------------------ step 5 */
 
   template <int DIM>
-  __global__ void __launch_bounds__(kBlock)
+  __global__ void __launch_bounds__(kBlock, RYUJIN_OCC_PIJ)
   k_pij_lij(const EulerParams P, const DeviceMesh M, DeviceScalars *__restrict__ scalars,
             const double *__restrict__ new_U, const double *__restrict__ r_in,
             const double *__restrict__ bounds, double *pij, double *__restrict__ lij)
@@ -54,17 +54,37 @@ namespace ryujin_hip
     bool all_ok = true;
     unsigned long long undecided_mask = 0;
 
+    /* software pipeline: loads of column c+1 are in flight while column c is limited */
+    uint32_t j_n = r.width > 1 ? cols[((uint64_t)r.base + 1) * 64 + r.lane] : i;
+    uint32_t j_nn = r.width > 2 ? cols[((uint64_t)r.base + 2) * 64 + r.lane] : i;
+    double P_n[K], F_n[K];
+    double mjinv_n = 0., mij_n = 0.;
+    if (r.width > 1) {
+      load_entry<K>(pij, (uint64_t)r.base + 1, r.lane, P_n);
+      load_state<K>(r_in, j_n, F_n);
+      mjinv_n = mi_inv[j_n];
+      mij_n = mij[((uint64_t)r.base + 1) * 64 + r.lane];
+    }
+
     for (uint32_t c = 1; c < r.width; ++c) {
       const uint64_t colbase = (uint64_t)r.base + c;
       const uint64_t pos = colbase * 64 + r.lane;
       const bool active = row_active && c < r.len;
-      const uint32_t j = cols[pos];
-      double P_ij[K];
-      load_entry<K>(pij, colbase, r.lane, P_ij);
-      double F_jH[K];
-      load_state<K>(r_in, j, F_jH);
-      const double m_j_inv = mi_inv[j];
-      const double m_ij = mij[pos];
+      double P_ij[K], F_jH[K];
+#pragma unroll
+      for (int q = 0; q < K; ++q) {
+        P_ij[q] = P_n[q];
+        F_jH[q] = F_n[q];
+      }
+      const double m_j_inv = mjinv_n, m_ij = mij_n;
+      if (c + 1 < r.width) {
+        j_n = j_nn;
+        load_entry<K>(pij, colbase + 1, r.lane, P_n);
+        load_state<K>(r_in, j_n, F_n);
+        mjinv_n = mi_inv[j_n];
+        mij_n = mij[(colbase + 1) * 64 + r.lane];
+        j_nn = (c + 2 < r.width) ? cols[(colbase + 2) * 64 + r.lane] : i;
+      }
       if (!active)
         continue;
 
@@ -108,7 +128,7 @@ namespace ryujin_hip
 
   /* Generic variant: two passes over the row's stencil (the second one re-reads l_ij, l_ji, P_ij). */
   template <int DIM, bool LAST_ROUND>
-  __global__ void __launch_bounds__(kBlock)
+  __global__ void __launch_bounds__(kBlock, RYUJIN_OCC_HO)
   k_high_order(const EulerParams P, const DeviceMesh M, double *__restrict__ new_U,
                const double *__restrict__ bounds, const double *__restrict__ pij,
                const double *__restrict__ lij, double *__restrict__ lij_next)
@@ -195,7 +215,7 @@ namespace ryujin_hip
    * so step 6 reads every array exactly once (the generic variant fetches ~2x the algorithmic bytes)
    * and all loads of a row are independent and issued up front. */
   template <int DIM, int MAXW>
-  __global__ void __launch_bounds__(kBlock)
+  __global__ void __launch_bounds__(kBlock, RYUJIN_OCC_HO)
   k_high_order_next_cached(const EulerParams P, const DeviceMesh M, double *__restrict__ new_U,
                            const double *__restrict__ bounds, const double *__restrict__ pij,
                            const double *__restrict__ lij, double *__restrict__ lij_next)

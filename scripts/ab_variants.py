@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Within-process A/B of library build variants (ryujin_amd/lib/variants/*.so): same mesh, same
+developed state, interleaved rounds; prints the mean per-sweep device time of each variant.
+usage: ab_variants.py [--cells-per-unit N] [--develop D] [--steps K] [--rounds R] name=path ..."""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import Ssprk33Stages  # noqa: E402
+from ryujin_amd import HyperbolicModule, capi, offline  # noqa: E402
+from ryujin_amd.initial_states import euler_uniform  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--cells-per-unit", type=int, default=995)
+ap.add_argument("--develop", type=int, default=300)
+ap.add_argument("--steps", type=int, default=15)
+ap.add_argument("--rounds", type=int, default=3)
+ap.add_argument("--dim", type=int, default=2)
+ap.add_argument("variants", nargs="+")
+args = ap.parse_args()
+
+if args.dim == 2:
+    spec = offline.mach3_step_2d(args.cells_per_unit)
+else:
+    spec = offline.cylinder_channel_3d(args.cells_per_unit, length_units=2)
+off = offline.SyntheticOffline(spec)
+U0 = euler_uniform(off.positions)
+dirichlet = euler_uniform(off.b_positions)
+print(f"n_q={off.n_owned}", flush=True)
+
+mods = {}
+U_dev = None
+for v in args.variants:
+    name, path = v.split("=")
+    lib = C.CDLL(path)
+    capi._declare_module_api(lib, "ryujin_hip_")
+    lib.ryujin_hip_set_timers.argtypes = [C.c_void_p, C.c_int]
+    lib.ryujin_hip_get_timers.argtypes = [C.c_void_p, capi.c_double_p]
+    lib.ryujin_hip_synchronize.argtypes = [C.c_void_p]
+    m = HyperbolicModule(off, equation=capi.EQ_EULER, backend=(lib, "ryujin_hip_"))
+    m.cfl = 0.9
+    if U_dev is None:
+        d = Ssprk33Stages(m, U0, dirichlet)
+        for _ in range(args.develop):
+            d.update()
+        U_dev = d.U.download()
+    drv = Ssprk33Stages(m, U_dev, dirichlet)
+    for _ in range(3):
+        drv.update()
+    lib.ryujin_hip_set_timers(m._ctx, 1)
+    mods[name] = (lib, m, drv, np.zeros(8), [0])
+
+tmp = (C.c_double * 8)()
+for r in range(args.rounds):
+    for name, (lib, m, drv, acc, cnt) in mods.items():
+        for _ in range(args.steps):
+            drv.update()
+            lib.ryujin_hip_get_timers(m._ctx, tmp)
+            acc += np.array(tmp[:])
+            cnt[0] += 1
+names = ["dij_alpha", "diag", "low_order", "pij_lij", "ho_next", "ho_last"]
+print("%-8s " % "variant" + " ".join("%9s" % n for n in names) + "     total(2-7)")
+for name, (lib, m, drv, acc, cnt) in mods.items():
+    ms = acc[1:7] / cnt[0]
+    print("%-8s " % name + " ".join("%9.4f" % x for x in ms) + "  %9.4f" % ms.sum(), flush=True)

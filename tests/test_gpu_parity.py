@@ -81,7 +81,9 @@ def _compare_step(off, mods, dirichlet=None, tau=0.0, stages=(), weights=()):
         assert bad.sum() <= max(2, int(1e-4 * dl.size)), (name, int(bad.sum()), dl[bad].max())
         assert np.median(dl) == 0.0 or np.median(dl) < 1e-14, name
     err = np.abs(g["U"][:n] - c["U"][:n]) / scale
-    assert err.max() <= 1e-11, err.max()
+    # 1e-11 everywhere except at isolated limiter branch flips (see above), which stay below 1e-9
+    assert (err > 1e-11).sum() <= max(2, int(1e-4 * err.size)), (int((err > 1e-11).sum()), err.max())
+    assert err.max() <= 1e-9, err.max()
     return g, c
 
 
