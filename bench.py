@@ -153,9 +153,16 @@ def main():
                          "reflections exist (a uniform state would never enter the limiter's Newton branch)")
     ap.add_argument("--perturbation", type=float, default=0.0,
                     help="multiplicative random perturbation of the initial state (initial_values.template.h:198-218)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="take the multi-process code path (torch.distributed + RCCL communicator) even for one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     args = ap.parse_args()
+
+    # Library banners (gloo, RCCL) go to fd 1; keep stdout clean for the ONE JSON line.
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -165,11 +172,13 @@ def main():
     n_gpus = max(1, world)
 
     dist = None
-    if n_gpus > 1:
+    use_dist = n_gpus > 1 or args.force_dist
+    if use_dist:
         # torch must be imported BEFORE libryujin_hip.so so that one copy of the ROCm runtime is used
         import torch  # noqa: F401
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
     import ctypes as C
@@ -190,7 +199,7 @@ def main():
 
     lib = capi.load_hip()
     comm = None
-    if n_gpus > 1:
+    if use_dist:
         import torch
         uid = C.create_string_buffer(capi.UNIQUE_ID_BYTES)
         if rank == 0:
@@ -293,6 +302,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(spec, U_developed, dirichlet, args.cpu_budget)
         except Exception as e:  # the baseline must never take the GPU number down with it
             out["cpu_baseline"] = {"value": None, "error": repr(e)}
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)
     print(json.dumps(out), flush=True)
 
 

@@ -192,6 +192,9 @@ typedef struct ryujin_hip_comm ryujin_hip_comm;
 int ryujin_hip_comm_unique_id(char id[RYUJIN_HIP_UNIQUE_ID_BYTES]);
 int ryujin_hip_comm_init(ryujin_hip_comm **comm, const char id[RYUJIN_HIP_UNIQUE_ID_BYTES],
                          int rank, int n_ranks, int device);
+/* Test facility: n_ranks communicators of ONE process (one host thread per rank, all on `device`)
+ * that exchange ghost data with device-to-device copies instead of RCCL. comms: [n_ranks]. */
+int ryujin_hip_comm_init_local(ryujin_hip_comm **comms, int n_ranks, int device);
 void ryujin_hip_comm_destroy(ryujin_hip_comm *comm);
 
 /* ---- lifecycle ----------------------------------------------------------- */

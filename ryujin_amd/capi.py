@@ -113,7 +113,8 @@ def load_synth():
 # --------------------------------------------------------------------------- hip
 
 HIP_SYMBOLS = [
-    "ryujin_hip_comm_unique_id", "ryujin_hip_comm_init", "ryujin_hip_comm_destroy",
+    "ryujin_hip_comm_unique_id", "ryujin_hip_comm_init", "ryujin_hip_comm_init_local",
+    "ryujin_hip_comm_destroy",
     "ryujin_hip_default_params", "ryujin_hip_create", "ryujin_hip_destroy",
     "ryujin_hip_state_alloc", "ryujin_hip_state_free", "ryujin_hip_state_upload",
     "ryujin_hip_state_download", "ryujin_hip_state_download_precomputed",
@@ -171,6 +172,7 @@ def load_hip():
         vp = C.c_void_p
         lib.ryujin_hip_comm_unique_id.argtypes = [C.c_char_p]
         lib.ryujin_hip_comm_init.argtypes = [C.POINTER(vp), C.c_char_p, C.c_int, C.c_int, C.c_int]
+        lib.ryujin_hip_comm_init_local.argtypes = [C.POINTER(vp), C.c_int, C.c_int]
         lib.ryujin_hip_comm_destroy.argtypes = [vp]
         lib.ryujin_hip_comm_destroy.restype = None
         lib.ryujin_hip_set_timers.argtypes = [vp, C.c_int]

@@ -14,7 +14,9 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <condition_variable>
 #include <memory>
+#include <mutex>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -96,9 +98,45 @@ namespace
   int grid_for(size_t n, int block = kBlock) { return (int)std::max<size_t>(1, (n + block - 1) / block); }
 } // namespace
 
+/* In-process transport (test facility): several contexts of ONE process, each driven by its own
+ * host thread, exchange ghost data with device-to-device copies and rendezvous on a barrier. It
+ * exercises exactly the pack kernels, send/receive offsets and ghost-row layout of the RCCL path
+ * on a single GPU (RCCL itself refuses two ranks on one device). */
+struct LocalGroup {
+  int n_ranks;
+  std::mutex mtx;
+  std::condition_variable cv;
+  int arrived = 0;
+  unsigned long generation = 0;
+  std::vector<std::vector<const double *>> mail; /* [src][dst] -> segment in src's send buffer */
+  std::vector<double> scratch;                    /* all-reduce */
+  int refs = 0;
+
+  explicit LocalGroup(int n)
+      : n_ranks(n)
+      , mail(n, std::vector<const double *>(n, nullptr))
+      , scratch(n, 0.)
+  {
+  }
+
+  void barrier()
+  {
+    std::unique_lock<std::mutex> lock(mtx);
+    const unsigned long gen = generation;
+    if (++arrived == n_ranks) {
+      arrived = 0;
+      ++generation;
+      cv.notify_all();
+    } else {
+      cv.wait(lock, [&] { return generation != gen; });
+    }
+  }
+};
+
 struct ryujin_hip_comm {
   ncclComm_t comm = nullptr;
   int rank = 0, n_ranks = 1, device = 0;
+  LocalGroup *local = nullptr;
 };
 
 struct ryujin_hip_ctx {
@@ -183,6 +221,9 @@ struct ryujin_hip_ctx {
   void create(const ryujin_hip_offline &o, const ryujin_hip_params &p, ryujin_hip_comm *c, int dev);
   void exchange_vector(double *v, int stride);
   void exchange_matrix(double *m);
+  void local_exchange(double *base, const std::vector<size_t> &send_offset,
+                      const std::vector<size_t> &recv_offset, const std::vector<size_t> &recv_count);
+  void allreduce_scalar(void *dev_ptr, int op);
   template <int DIM>
   void prepare_state_vector(int h, const double *dirichlet);
   template <int DIM>
@@ -352,6 +393,61 @@ void ryujin_hip_ctx::create(const ryujin_hip_offline &o, const ryujin_hip_params
   HIP_CHECK(hipStreamSynchronize(stream));
 }
 
+/* in-process transport: publish the per-neighbour segments of the send buffer, rendezvous, pull */
+void ryujin_hip_ctx::local_exchange(double *base, const std::vector<size_t> &send_offset,
+                                    const std::vector<size_t> &recv_offset,
+                                    const std::vector<size_t> &recv_count)
+{
+  LocalGroup &g = *comm->local;
+  HIP_CHECK(hipStreamSynchronize(stream)); /* packed data is complete */
+  for (int q = 0; q < n_nbr; ++q)
+    g.mail[comm->rank][nbr_rank[q]] = d_send_buf.ptr + send_offset[q];
+  g.barrier();
+  for (int q = 0; q < n_nbr; ++q)
+    HIP_CHECK(hipMemcpyAsync(base + recv_offset[q], g.mail[nbr_rank[q]][comm->rank],
+                             recv_count[q] * sizeof(double), hipMemcpyDeviceToDevice, stream));
+  HIP_CHECK(hipStreamSynchronize(stream));
+  g.barrier(); /* send buffers may be reused */
+}
+
+/* 1-element all-reduce on a device scalar; op: 0 = min (double), 1 = max (int) */
+void ryujin_hip_ctx::allreduce_scalar(void *dev_ptr, int op)
+{
+  if (!comm || comm->n_ranks <= 1)
+    return;
+  if (!comm->local) {
+    if (op == 0)
+      NCCL_CHECK(ncclAllReduce(dev_ptr, dev_ptr, 1, ncclDouble, ncclMin, comm->comm, stream));
+    else
+      NCCL_CHECK(ncclAllReduce(dev_ptr, dev_ptr, 1, ncclInt, ncclMax, comm->comm, stream));
+    return;
+  }
+  LocalGroup &g = *comm->local;
+  double mine = 0.;
+  if (op == 0) {
+    HIP_CHECK(hipMemcpyAsync(&mine, dev_ptr, sizeof(double), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+  } else {
+    int v = 0;
+    HIP_CHECK(hipMemcpyAsync(&v, dev_ptr, sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    mine = v;
+  }
+  g.scratch[comm->rank] = mine;
+  g.barrier();
+  double r = g.scratch[0];
+  for (int q = 1; q < g.n_ranks; ++q)
+    r = op == 0 ? std::min(r, g.scratch[q]) : std::max(r, g.scratch[q]);
+  g.barrier();
+  if (op == 0) {
+    HIP_CHECK(hipMemcpyAsync(dev_ptr, &r, sizeof(double), hipMemcpyHostToDevice, stream));
+  } else {
+    const int v = (int)r;
+    HIP_CHECK(hipMemcpyAsync(dev_ptr, &v, sizeof(int), hipMemcpyHostToDevice, stream));
+  }
+  HIP_CHECK(hipStreamSynchronize(stream));
+}
+
 void ryujin_hip_ctx::exchange_vector(double *v, int stride)
 {
   if (n_nbr == 0)
@@ -359,6 +455,16 @@ void ryujin_hip_ctx::exchange_vector(double *v, int stride)
   const uint32_t n_send = send_off[n_nbr];
   hipLaunchKernelGGL(k_pack_vector, dim3(grid_for((size_t)n_send * stride)), dim3(kBlock), 0, stream,
                      n_send, d_send_idx.ptr, stride, v, d_send_buf.ptr);
+  if (comm->local) {
+    std::vector<size_t> off(n_nbr), cnt(n_nbr), dst(n_nbr), rcnt(n_nbr);
+    for (int q = 0; q < n_nbr; ++q) {
+      off[q] = (size_t)send_off[q] * stride;
+      dst[q] = (size_t)recv_off[q] * stride;
+      rcnt[q] = (size_t)(recv_off[q + 1] - recv_off[q]) * stride;
+    }
+    local_exchange(v, off, dst, rcnt);
+    return;
+  }
   NCCL_CHECK(ncclGroupStart());
   for (int q = 0; q < n_nbr; ++q) {
     NCCL_CHECK(ncclSend(d_send_buf.ptr + (size_t)send_off[q] * stride,
@@ -378,6 +484,16 @@ void ryujin_hip_ctx::exchange_matrix(double *m)
   const uint32_t n_send = row_send_off[n_nbr];
   hipLaunchKernelGGL(k_pack_matrix, dim3(grid_for(n_send)), dim3(kBlock), 0, stream, n_send,
                      d_row_send_pos.ptr, m, d_send_buf.ptr);
+  if (comm->local) {
+    std::vector<size_t> off(n_nbr), dst(n_nbr), rcnt(n_nbr);
+    for (int q = 0; q < n_nbr; ++q) {
+      off[q] = row_send_off[q];
+      dst[q] = L.nnz_sell + row_recv_off[q];
+      rcnt[q] = row_recv_off[q + 1] - row_recv_off[q];
+    }
+    local_exchange(m, off, dst, rcnt);
+    return;
+  }
   NCCL_CHECK(ncclGroupStart());
   for (int q = 0; q < n_nbr; ++q) {
     NCCL_CHECK(ncclSend(d_send_buf.ptr + row_send_off[q], row_send_off[q + 1] - row_send_off[q],
@@ -460,9 +576,7 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
   else
     hipLaunchKernelGGL(k_dij_diag, grid_rows, block, 0, stream, mesh, params.cfl, d_dij.ptr,
                        d_scalars.ptr);
-  if (comm && comm->n_ranks > 1)
-    NCCL_CHECK(ncclAllReduce(&d_scalars.ptr->tau_max_bits, &d_scalars.ptr->tau_max_bits, 1,
-                             ncclDouble, ncclMin, comm->comm, stream));
+  allreduce_scalar(&d_scalars.ptr->tau_max_bits, 0); /* Utilities::MPI::min(tau_max), :571 */
   hipLaunchKernelGGL(k_finalize_tau, dim3(1), dim3(1), 0, stream, tau_in, d_scalars.ptr);
   mark(2);
 
@@ -524,9 +638,7 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
   for (int k = 5 + n_iterations; k <= 7; ++k)
     mark(k);
 
-  if (comm && comm->n_ranks > 1)
-    NCCL_CHECK(ncclAllReduce(&d_scalars.ptr->restart_needed, &d_scalars.ptr->restart_needed, 1,
-                             ncclInt, ncclMax, comm->comm, stream));
+  allreduce_scalar(&d_scalars.ptr->restart_needed, 1); /* MPI::logical_or(restart_needed), :1194 */
 
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipMemcpyAsync(h_scalars, d_scalars.ptr, sizeof(DeviceScalars), hipMemcpyDeviceToHost,
@@ -657,10 +769,38 @@ int ryujin_hip_comm_init(ryujin_hip_comm **comm, const char id[RYUJIN_HIP_UNIQUE
   });
 }
 
+int ryujin_hip_comm_init_local(ryujin_hip_comm **comms, int n_ranks, int device)
+{
+  return guarded([&]() {
+    if (n_ranks < 1)
+      throw HipError(RYUJIN_ERR_ARG, "n_ranks must be positive");
+    auto *group = new LocalGroup(n_ranks);
+    group->refs = n_ranks;
+    for (int r = 0; r < n_ranks; ++r) {
+      auto *c = new ryujin_hip_comm;
+      c->rank = r;
+      c->n_ranks = n_ranks;
+      c->device = device;
+      c->local = group;
+      comms[r] = c;
+    }
+    return RYUJIN_OK;
+  });
+}
+
 void ryujin_hip_comm_destroy(ryujin_hip_comm *comm)
 {
   if (!comm)
     return;
+  if (comm->local) {
+    bool last;
+    {
+      std::lock_guard<std::mutex> lock(comm->local->mtx);
+      last = --comm->local->refs == 0;
+    }
+    if (last)
+      delete comm->local;
+  }
   if (comm->comm)
     (void)ncclCommDestroy(comm->comm);
   delete comm;
