@@ -75,3 +75,13 @@ def euler_isentropic_vortex(positions, t, mach=1.0, beta=5.0, gamma=1.4, directi
     U[:, 2] = ny * mx + nx * my
     U[:, -1] = E
     return U
+
+
+def sw_circular_dam_break(positions, h_inner=2.5, h_outer=0.5, radius=2.5):
+    """source/shallow_water/initial_state_circular_dam_break.h:48-54 (compares |x|^2 with `radius`,
+    sic): h = h_inner where |x|^2 <= radius, else h_outer; zero momentum. Returns (h, q) states."""
+    n, dim = positions.shape
+    r2 = np.sum(positions * positions, axis=1)
+    U = np.zeros((n, dim + 1))
+    U[:, 0] = np.where(r2 <= radius, h_inner, h_outer)
+    return U

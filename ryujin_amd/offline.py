@@ -69,6 +69,14 @@ class SyntheticOffline:
         self.measure_of_omega = o.measure_of_omega
         self.n_bdry, self.n_pairs = o.n_bdry, o.n_pairs
 
+    def set_initial_precomputed(self, values: np.ndarray) -> None:
+        """Attach initial_precomputed (shallow water: bathymetry Z_i per local index, ghosts included),
+        hyperbolic_module.template.h:84-85."""
+        v = np.ascontiguousarray(values, dtype=np.float64).reshape(-1)
+        assert v.size == self.n_relevant
+        self._initial_precomputed = v  # keep alive
+        self.c.contents.initial_precomputed = capi.as_ptr(v, capi.c_double_p)
+
     def close(self):
         if self._h:
             self._lib.ryujin_synth_free(self._h)
