@@ -138,8 +138,10 @@ namespace ryujin_hip
 
   template <int DIM>
   struct Euler {
+    static constexpr int DIMENSION = DIM;
     static constexpr int K = DIM + 2;
     static constexpr int NB = 3;
+    using Params = EulerParams;
 
     /* hyperbolic_system.h:783-792 */
     static RYUJIN_DEV double internal_energy(const double (&U)[K])
@@ -234,6 +236,70 @@ namespace ryujin_hip
       const double rho_cutoff_large = P.reference_density * P.vacuum_large * DBL_EPSILON;
       return fabs(rho) < rho_cutoff_large ? 0. : rho;
     }
+
+    /* precomputed values (s_i, eta_i): hyperbolic_system.h:702-737 */
+    static RYUJIN_DEV double2 precompute(const EulerParams &P, const double (&U)[K])
+    {
+      double2 out;
+      out.x = specific_entropy(P, U);
+      out.y = harten_entropy(P, U);
+      return out;
+    }
+
+    /* Indicator (entropy-viscosity commutator): indicator.h:187-258 */
+    struct Indicator {
+      double rho_i_inverse, eta_i, left;
+      double d_eta_i[K], f_i[K][DIM], right[K];
+
+      RYUJIN_DEV void reset(const EulerParams &P, const double (&U_i)[K], const double2 prec_i)
+      {
+        rho_i_inverse = 1. / U_i[0];
+        eta_i = prec_i.y;
+        harten_entropy_derivative(P, U_i, d_eta_i);
+        d_eta_i[0] -= eta_i * rho_i_inverse;
+        flux(P, U_i, f_i);
+        left = 0.;
+#pragma unroll
+        for (int q = 0; q < K; ++q)
+          right[q] = 0.;
+      }
+
+      RYUJIN_DEV void accumulate(const EulerParams &P, const double (&U_j)[K], const double2 prec_j,
+                                 const double (&c_ij)[DIM])
+      {
+        const double eta_j = prec_j.y;
+        const double rho_j_inverse = 1. / U_j[0];
+        double f_j[K][DIM];
+        flux(P, U_j, f_j);
+        double m_j_c = U_j[1] * c_ij[0];
+#pragma unroll
+        for (int d = 1; d < DIM; ++d)
+          m_j_c += U_j[1 + d] * c_ij[d];
+        const double entropy_flux = (eta_j * rho_j_inverse - eta_i * rho_i_inverse) * m_j_c;
+        left += entropy_flux;
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+          double component = (f_j[q][0] - f_i[q][0]) * c_ij[0];
+#pragma unroll
+          for (int d = 1; d < DIM; ++d)
+            component += (f_j[q][d] - f_i[q][d]) * c_ij[d];
+          right[q] += component;
+        }
+      }
+
+      RYUJIN_DEV double alpha(const EulerParams &P, const double hd_i) const
+      {
+        double numerator = left;
+        double denominator = fabs(left);
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+          numerator -= d_eta_i[q] * right[q];
+          denominator += fabs(d_eta_i[q] * right[q]);
+        }
+        const double quotient = fabs(numerator) / (denominator + hd_i * fabs(eta_i));
+        return fmin(1., P.evc_factor * quotient);
+      }
+    };
 
     /* ------------------------------------------------------------------ Riemann solver */
 
@@ -429,11 +495,11 @@ namespace ryujin_hip
      * the masked-off lanes through it. The kernels therefore run this wave-uniform fast part over
      * all columns first and finish the few undecided (row, col) pairs with limit() afterwards.
      * Returns the limiter value if decided, otherwise sets undecided = true. */
-    static RYUJIN_DEV double limit_fast(const EulerParams &P, const double rho_min,
-                                        const double rho_max, const double s_min,
+    static RYUJIN_DEV double limit_fast(const EulerParams &P, const double (&bnd)[NB],
                                         const double (&U)[K], const double (&Pij)[K], bool &success,
                                         bool &undecided)
     {
+      const double rho_min = bnd[0], rho_max = bnd[1], s_min = bnd[2];
       constexpr double t_min = 0., t_max = 1.;
       constexpr double eps = DBL_EPSILON;
       success = true;
@@ -475,10 +541,10 @@ namespace ryujin_hip
     /* limiter.template.h:15-327, production control flow (no EXPENSIVE_BOUNDS_CHECK).
      * Per-thread early exits: a converged lane is a fixed point of quadratic_newton_step,
      * see SURVEY.md Appendix E-3. */
-    static RYUJIN_DEV double limit(const EulerParams &P, const double rho_min, const double rho_max,
-                                   const double s_min, const double (&U)[K], const double (&Pij)[K],
-                                   bool &success)
+    static RYUJIN_DEV double limit(const EulerParams &P, const double (&bnd)[NB],
+                                   const double (&U)[K], const double (&Pij)[K], bool &success)
     {
+      const double rho_min = bnd[0], rho_max = bnd[1], s_min = bnd[2];
       constexpr double t_min = 0., t_max = 1.;
       success = true;
       double t_r = t_max;

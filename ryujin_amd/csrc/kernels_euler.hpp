@@ -177,15 +177,15 @@ namespace ryujin_hip
 
   /* One thread per boundary DoF; its boundary_map entries are applied in the reference's
    * (serial) order. grp_start[g]..grp_start[g+1] index the entry arrays sorted by DoF. */
-  template <int DIM>
+  template <typename E>
   __global__ void __launch_bounds__(kBlock)
-  k_apply_bc(const EulerParams P, const uint32_t n_groups, const uint32_t *__restrict__ grp_start,
+  k_apply_bc(const typename E::Params P, const uint32_t n_groups, const uint32_t *__restrict__ grp_start,
              const uint32_t *__restrict__ b_i, const double *__restrict__ b_normal,
              const uint8_t *__restrict__ b_id, const double *__restrict__ dirichlet,
              double *__restrict__ U)
   {
-    using E = Euler<DIM>;
     constexpr int K = E::K;
+    constexpr int DIM = E::DIMENSION;
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n_groups)
       return;
@@ -216,13 +216,13 @@ namespace ryujin_hip
   }
 
   /* precomputation_loop: source/euler/hyperbolic_system.h:702-737 */
-  template <int DIM>
+  template <typename E>
   __global__ void __launch_bounds__(kBlock)
-  k_precompute(const EulerParams P, const DeviceMesh M, const double *__restrict__ U,
+  k_precompute(const typename E::Params P, const DeviceMesh M, const double *__restrict__ U,
                double *__restrict__ prec)
   {
-    using E = Euler<DIM>;
     constexpr int K = E::K;
+    constexpr int DIM = E::DIMENSION;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M.n_owned)
       return;
@@ -230,43 +230,29 @@ namespace ryujin_hip
       return;
     double U_i[K];
     load_state<K>(U, i, U_i);
-    double2 out;
-    out.x = E::specific_entropy(P, U_i);
-    out.y = E::harten_entropy(P, U_i);
-    reinterpret_cast<double2 *>(prec)[i] = out;
+    reinterpret_cast<double2 *>(prec)[i] = E::precompute(P, U_i);
   }
 
   /* ------------------------------------------------------------------ step 2 */
 
-  template <int DIM>
+  template <typename E>
   __global__ void __launch_bounds__(kBlock, RYUJIN_OCC_DIJ)
-  k_dij_alpha(const EulerParams P, const DeviceMesh M, const double *__restrict__ U,
+  k_dij_alpha(const typename E::Params P, const DeviceMesh M, const double *__restrict__ U,
               const double *__restrict__ prec, double *__restrict__ dij, double *__restrict__ alpha)
   {
-    using E = Euler<DIM>;
     constexpr int K = E::K;
+    constexpr int DIM = E::DIMENSION;
     const RowCtx r = row_context(M);
     if (!r.valid)
       return;
     const bool row_active = r.len > 1;
     const uint32_t i = row_active ? r.row : (r.row < M.n_owned ? r.row : M.n_owned - 1);
+    const double2 *__restrict__ prec2 = reinterpret_cast<const double2 *>(prec);
 
     double U_i[K];
     load_state<K>(U, i, U_i);
-    const double eta_i = prec[(size_t)i * 2 + 1];
-
-    /* Indicator::reset (indicator.h:187-208) */
-    const double rho_i_inverse = 1. / U_i[0];
-    double d_eta_i[K];
-    E::harten_entropy_derivative(P, U_i, d_eta_i);
-    d_eta_i[0] -= eta_i * rho_i_inverse;
-    double f_i[K][DIM];
-    E::flux(P, U_i, f_i);
-    double left = 0.;
-    double right[K];
-#pragma unroll
-    for (int q = 0; q < K; ++q)
-      right[q] = 0.;
+    typename E::Indicator indicator;
+    indicator.reset(P, U_i, prec2[i]);
 
     /* software pipeline: the loads of column c+1 (and the column index of c+2) are in flight while
      * column c is processed, so the gather latency hides behind the Riemann solve */
@@ -277,7 +263,7 @@ namespace ryujin_hip
     double c_n[DIM], U_n[K];
     load_entry<DIM>(cij, r.base, r.lane, c_n);
     load_state<K>(U, j_n, U_n);
-    double eta_n = prec[(size_t)j_n * 2 + 1];
+    double2 prec_n = prec2[j_n];
 
     for (uint32_t c = 0; c < r.width; ++c) {
       const uint64_t colbase = (uint64_t)r.base + c;
@@ -291,68 +277,39 @@ namespace ryujin_hip
 #pragma unroll
       for (int q = 0; q < K; ++q)
         U_j[q] = U_n[q];
-      const double eta_j = eta_n;
+      const double2 prec_j = prec_n;
       if (c + 1 < r.width) {
         j_n = j_nn;
         load_entry<DIM>(cij, colbase + 1, r.lane, c_n);
         load_state<K>(U, j_n, U_n);
-        eta_n = prec[(size_t)j_n * 2 + 1];
+        prec_n = prec2[j_n];
         j_nn = (c + 2 < r.width) ? cols[(colbase + 2) * 64 + r.lane] : i;
       }
 
       if (active) {
-        /* Indicator::accumulate (indicator.h:211-238) */
-        const double rho_j_inverse = 1. / U_j[0];
-        double f_j[K][DIM];
-        E::flux(P, U_j, f_j);
-        double m_j_c = U_j[1] * c_ij[0];
-#pragma unroll
-        for (int d = 1; d < DIM; ++d)
-          m_j_c += U_j[1 + d] * c_ij[d];
-        const double entropy_flux = (eta_j * rho_j_inverse - eta_i * rho_i_inverse) * m_j_c;
-        left += entropy_flux;
-#pragma unroll
-        for (int q = 0; q < K; ++q) {
-          double component = (f_j[q][0] - f_i[q][0]) * c_ij[0];
-#pragma unroll
-          for (int d = 1; d < DIM; ++d)
-            component += (f_j[q][d] - f_i[q][d]) * c_ij[d];
-          right[q] += component;
-        }
-
+        indicator.accumulate(P, U_j, prec_j, c_ij);
         /* upper triangle only (:394-408) */
         if (c > 0 && j > i)
           dij[pos] = E::dij_from_states(P, U_i, U_j, c_ij);
       }
     }
 
-    if (row_active) {
-      /* Indicator::alpha (indicator.h:241-258) */
-      const double hd_i = M.mi[i] * M.measure_of_omega_inverse;
-      double numerator = left;
-      double denominator = fabs(left);
-#pragma unroll
-      for (int q = 0; q < K; ++q) {
-        numerator -= d_eta_i[q] * right[q];
-        denominator += fabs(d_eta_i[q] * right[q]);
-      }
-      const double quotient = fabs(numerator) / (denominator + hd_i * fabs(eta_i));
-      alpha[i] = fmin(1., P.evc_factor * quotient);
-    }
+    if (row_active)
+      alpha[i] = indicator.alpha(P, M.mi[i] * M.measure_of_omega_inverse);
   }
 
   /* ------------------------------------------------------------------ step 3 */
 
   /* boundary pairs (:462-490): d_ij = max(d_ij, |c_ji| lambda_max(U_j, U_i, n_ji)) for j >= i */
-  template <int DIM>
+  template <typename E>
   __global__ void __launch_bounds__(kBlock)
-  k_dij_boundary(const EulerParams P, const uint32_t n_pairs, const uint32_t *__restrict__ p_i,
+  k_dij_boundary(const typename E::Params P, const uint32_t n_pairs, const uint32_t *__restrict__ p_i,
                  const uint32_t *__restrict__ p_j, const uint32_t *__restrict__ p_pos,
                  const uint32_t *__restrict__ p_pos_t, const double *__restrict__ cji,
                  const double *__restrict__ U, double *__restrict__ dij)
   {
-    using E = Euler<DIM>;
     constexpr int K = E::K;
+    constexpr int DIM = E::DIMENSION;
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n_pairs)
       return;
@@ -463,6 +420,7 @@ namespace ryujin_hip
   struct StageArgs {
     int stages;
     const double *U[4];
+    const double *prec[4]; /* precomputed block of the stage vectors (shallow-water sources) */
     double w[4];
   };
 

@@ -25,14 +25,14 @@ namespace ryujin_hip
 
   /* ------------------------------------------------------------------ step 5 */
 
-  template <int DIM>
+  template <typename E>
   __global__ void __launch_bounds__(kBlock, RYUJIN_OCC_PIJ)
-  k_pij_lij(const EulerParams P, const DeviceMesh M, DeviceScalars *__restrict__ scalars,
+  k_pij_lij(const typename E::Params P, const DeviceMesh M, DeviceScalars *__restrict__ scalars,
             const double *__restrict__ new_U, const double *__restrict__ r_in,
             const double *__restrict__ bounds, double *pij, double *__restrict__ lij)
   {
-    using E = Euler<DIM>;
     constexpr int K = E::K;
+    constexpr int NB = E::NB;
     const RowCtx r = row_context(M);
     if (!r.valid)
       return;
@@ -44,7 +44,10 @@ namespace ryujin_hip
     const double *__restrict__ mi_inv = M.mi_inv;
 
     const size_t stride = (size_t)M.n_slices * 64;
-    const double rho_min = bounds[i], rho_max = bounds[stride + i], s_min = bounds[2 * stride + i];
+    double bnd[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+      bnd[b] = bounds[(size_t)b * stride + i];
     const double m_i_inv = mi_inv[i];
     double U_i_new[K], F_iH[K];
     load_state<K>(new_U, i, U_i_new);
@@ -100,7 +103,7 @@ namespace ryujin_hip
 
       bool success, undecided;
       const double l_ij =
-          E::limit_fast(P, rho_min, rho_max, s_min, U_i_new, P_ij, success, undecided);
+          E::limit_fast(P, bnd, U_i_new, P_ij, success, undecided);
       if (undecided) {
         undecided_mask |= 1ull << c;
       } else {
@@ -117,7 +120,7 @@ namespace ryujin_hip
       double P_ij[K];
       load_entry<K>(pij, colbase, r.lane, P_ij);
       bool success;
-      const double l_ij = E::limit(P, rho_min, rho_max, s_min, U_i_new, P_ij, success);
+      const double l_ij = E::limit(P, bnd, U_i_new, P_ij, success);
       lij[colbase * 64 + r.lane] = l_ij;
       all_ok = all_ok && success;
     }
@@ -127,14 +130,14 @@ namespace ryujin_hip
   /* ------------------------------------------------------------------ steps 6, 7 */
 
   /* Generic variant: two passes over the row's stencil (the second one re-reads l_ij, l_ji, P_ij). */
-  template <int DIM, bool LAST_ROUND>
+  template <typename E, bool LAST_ROUND>
   __global__ void __launch_bounds__(kBlock, RYUJIN_OCC_HO)
-  k_high_order(const EulerParams P, const DeviceMesh M, double *__restrict__ new_U,
+  k_high_order(const typename E::Params P, const DeviceMesh M, double *__restrict__ new_U,
                const double *__restrict__ bounds, const double *__restrict__ pij,
                const double *__restrict__ lij, double *__restrict__ lij_next)
   {
-    using E = Euler<DIM>;
     constexpr int K = E::K;
+    constexpr int NB = E::NB;
     const RowCtx r = row_context(M);
     if (!r.valid)
       return;
@@ -167,7 +170,10 @@ namespace ryujin_hip
 
     if constexpr (!LAST_ROUND) {
       const size_t stride = (size_t)M.n_slices * 64;
-      const double rho_min = bounds[i], rho_max = bounds[stride + i], s_min = bounds[2 * stride + i];
+      double bnd[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+      bnd[b] = bounds[(size_t)b * stride + i];
       unsigned long long undecided_mask = 0;
       for (uint32_t c = 1; c < r.width; ++c) {
         const uint64_t colbase = (uint64_t)r.base + c;
@@ -186,7 +192,7 @@ namespace ryujin_hip
           new_p_ij[q] = (1. - old_l_ij) * p_ij[q];
         bool success, undecided;
         const double new_l_ij =
-            E::limit_fast(P, rho_min, rho_max, s_min, U_i_new, new_p_ij, success, undecided);
+            E::limit_fast(P, bnd, U_i_new, new_p_ij, success, undecided);
         if (undecided)
           undecided_mask |= 1ull << c;
         else
@@ -204,7 +210,7 @@ namespace ryujin_hip
         for (int q = 0; q < K; ++q)
           new_p_ij[q] = (1. - old_l_ij) * p_ij[q];
         bool success;
-        const double new_l_ij = E::limit(P, rho_min, rho_max, s_min, U_i_new, new_p_ij, success);
+        const double new_l_ij = E::limit(P, bnd, U_i_new, new_p_ij, success);
         lij_next[pos] = (1. - old_l_ij) * new_l_ij;
       }
     }
@@ -214,14 +220,14 @@ namespace ryujin_hip
    * l_ij = min(l_ij, l_ji) and P_ij stay in registers between the update and the next limiter pass,
    * so step 6 reads every array exactly once (the generic variant fetches ~2x the algorithmic bytes)
    * and all loads of a row are independent and issued up front. */
-  template <int DIM, int MAXW>
+  template <typename E, int MAXW>
   __global__ void __launch_bounds__(kBlock, RYUJIN_OCC_HO)
-  k_high_order_next_cached(const EulerParams P, const DeviceMesh M, double *__restrict__ new_U,
+  k_high_order_next_cached(const typename E::Params P, const DeviceMesh M, double *__restrict__ new_U,
                            const double *__restrict__ bounds, const double *__restrict__ pij,
                            const double *__restrict__ lij, double *__restrict__ lij_next)
   {
-    using E = Euler<DIM>;
     constexpr int K = E::K;
+    constexpr int NB = E::NB;
     const RowCtx r = row_context(M);
     if (!r.valid)
       return;
@@ -233,7 +239,10 @@ namespace ryujin_hip
     load_state<K>(new_U, i, U_i_new);
     const double lambda = 1. / (double)(r.len - 1);
     const size_t stride = (size_t)M.n_slices * 64;
-    const double rho_min = bounds[i], rho_max = bounds[stride + i], s_min = bounds[2 * stride + i];
+    double bnd[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+      bnd[b] = bounds[(size_t)b * stride + i];
 
     double l[MAXW];
     double p[MAXW][K];
@@ -273,7 +282,7 @@ namespace ryujin_hip
           new_p_ij[q] = (1. - l[c]) * p[c][q];
         bool success, undecided;
         const double new_l_ij =
-            E::limit_fast(P, rho_min, rho_max, s_min, U_i_new, new_p_ij, success, undecided);
+            E::limit_fast(P, bnd, U_i_new, new_p_ij, success, undecided);
         if (undecided)
           undecided_mask |= 1ull << c;
         else
@@ -292,7 +301,7 @@ namespace ryujin_hip
       for (int q = 0; q < K; ++q)
         new_p_ij[q] = (1. - old_l_ij) * p_ij[q];
       bool success;
-      const double new_l_ij = E::limit(P, rho_min, rho_max, s_min, U_i_new, new_p_ij, success);
+      const double new_l_ij = E::limit(P, bnd, U_i_new, new_p_ij, success);
       lij_next[pos] = (1. - old_l_ij) * new_l_ij;
     }
   }

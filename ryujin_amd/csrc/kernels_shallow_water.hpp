@@ -1,0 +1,292 @@
+// Step 4 of HyperbolicModule::step for the shallow-water equations: the module-level special
+// cases of source/hyperbolic_module.template.h (:270-271 shallow_water flag, :660-720 sources and
+// affine-shift pre-loop, :773-787 equilibrated states, :797-846 source terms / high-order flux).
+// Steps 1-3 and 5-7 are the generic kernels instantiated with the ShallowWater<DIM> policy.
+
+#pragma once
+
+#include "kernels_euler.hpp"
+#include "shallow_water_device.hpp"
+
+namespace ryujin_hip
+{
+  template <int DIM, bool HAS_STAGES>
+  __global__ void __launch_bounds__(kBlock, RYUJIN_OCC_LOW)
+  k_low_order_sw(const ShallowWaterParams P, const DeviceMesh M,
+                 const DeviceScalars *__restrict__ scalars, const double weight,
+                 const StageArgs<DIM> S, const double *__restrict__ U,
+                 const double *__restrict__ prec, const double *__restrict__ Z,
+                 const double *__restrict__ alpha, const double *__restrict__ dij,
+                 double *__restrict__ new_U, double *__restrict__ r_out,
+                 double *__restrict__ bounds, double *__restrict__ pij)
+  {
+    using E = ShallowWater<DIM>;
+    constexpr int K = E::K;
+    const RowCtx r = row_context(M);
+    if (!r.valid)
+      return;
+    const bool row_active = r.len > 1;
+    const uint32_t i = row_active ? r.row : (r.row < M.n_owned ? r.row : M.n_owned - 1);
+    const double tau = scalars->tau;
+    const uint32_t *__restrict__ cols = M.cols;
+    const double *__restrict__ cij = M.cij;
+    const double *__restrict__ mij = M.mij;
+
+    double U_i[K], U_i_new[K], F_iH[K], S_iH[K], S_i[K];
+    load_state<K>(U, i, U_i);
+    const double alpha_i = alpha[i];
+    const double m_i = M.mi[i];
+    const double m_i_inv = M.mi_inv[i];
+    const double Z_i = Z[i];
+
+#pragma unroll
+    for (int q = 0; q < K; ++q)
+      S_iH[q] = 0.;
+    if constexpr (HAS_STAGES) {
+      for (int s = 0; s < S.stages; ++s) {
+        double U_iHs[K], Ss[K];
+        load_state<K>(S.U[s], i, U_iHs);
+        E::manning_friction(P, U_iHs, S.prec[s][(size_t)i * 2 + 1], tau, Ss);
+#pragma unroll
+        for (int q = 0; q < K; ++q)
+          S_iH[q] += S.w[s] * Ss[q];
+      }
+    }
+    E::manning_friction(P, U_i, prec[(size_t)i * 2 + 1], tau, S_i);
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+      S_iH[q] += weight * S_i[q];
+      U_i_new[q] = U_i[q];
+      U_i_new[q] += tau * S_i[q];
+      F_iH[q] = 0.;
+      F_iH[q] += m_i * S_iH[q];
+    }
+
+    /* affine shift pre-loop (:700-720, shallow_water/hyperbolic_system.h:1176-1191) */
+    double affine_shift[K];
+#pragma unroll
+    for (int q = 0; q < K; ++q)
+      affine_shift[q] = 0.;
+    {
+      const double h_inverse = E::inverse_water_depth_sharp(P, U_i);
+      for (uint32_t c = 0; c < r.width; ++c) {
+        const uint64_t colbase = (uint64_t)r.base + c;
+        const uint64_t pos = colbase * 64 + r.lane;
+        const uint32_t j = cols[pos];
+        double c_ij[DIM];
+        load_entry<DIM>(cij, colbase, r.lane, c_ij);
+        const double d_ij = dij[pos];
+        const double Z_j = Z[j];
+        if (!(row_active && c < r.len))
+          continue;
+        double U_star_ij[K];
+        E::star_state(P, U_i, Z_i, Z_j, U_star_ij);
+        double m_c = U_i[1] * c_ij[0];
+#pragma unroll
+        for (int d = 1; d < DIM; ++d)
+          m_c += U_i[1 + d] * c_ij[d];
+        const double factor = 2. * (d_ij + h_inverse * m_c);
+#pragma unroll
+        for (int q = 0; q < K; ++q)
+          affine_shift[q] += -factor * (U_star_ij[q] - U_i[q]);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+      affine_shift[q] *= tau * m_i_inv;
+      affine_shift[q] += tau * S_i[q];
+    }
+
+    /* Limiter::reset (shallow_water/limiter.h:247-268) */
+    double h_min = DBL_MAX, h_max = 0., kin_max = 0., v2_max = 0.;
+    double h_relaxation_numerator = 0., kin_relaxation_numerator = 0., v2_relaxation_numerator = 0.,
+           relaxation_denominator = 0.;
+    const double kin_i = E::kinetic_energy(P, U_i);
+    double v2_i;
+    {
+      const double ihm_i = E::inverse_water_depth_mollified(P, U_i);
+      const double v = U_i[1] * ihm_i;
+      v2_i = v * v;
+#pragma unroll
+      for (int d = 1; d < DIM; ++d) {
+        const double vd = U_i[1 + d] * ihm_i;
+        v2_i += vd * vd;
+      }
+    }
+
+    for (uint32_t c = 0; c < r.width; ++c) {
+      const uint64_t colbase = (uint64_t)r.base + c;
+      const uint64_t pos = colbase * 64 + r.lane;
+      const bool active = row_active && c < r.len;
+      const uint32_t j = cols[pos];
+      double c_ij[DIM];
+      load_entry<DIM>(cij, colbase, r.lane, c_ij);
+      const double d_ij = dij[pos];
+      const double m_ij = mij[pos];
+      double U_j[K];
+      load_state<K>(U, j, U_j);
+      const double alpha_j = alpha[j];
+      const double Z_j = Z[j];
+      const double h_star_j = prec[(size_t)j * 2 + 1];
+      if (!active)
+        continue;
+
+      const double factor = (alpha_i + alpha_j) * .5;
+      const double d_ijH = d_ij * factor;
+      const double denom = fmax(d_ij, 100. * DBL_MIN);
+      double scaled_c_ij[DIM];
+#pragma unroll
+      for (int d = 0; d < DIM; ++d)
+        scaled_c_ij[d] = c_ij[d] / denom;
+
+      double U_star_ij[K], U_star_ji[K];
+      E::star_state(P, U_i, Z_i, Z_j, U_star_ij);
+      E::star_state(P, U_j, Z_j, Z_i, U_star_ji);
+
+      double flux_ij[K];
+      E::flux_divergence(P, U_i, U_star_ij, U_star_ji, c_ij, flux_ij);
+
+      double P_ij[K];
+#pragma unroll
+      for (int q = 0; q < K; ++q) {
+        U_i_new[q] += tau * m_i_inv * flux_ij[q];
+        P_ij[q] = -flux_ij[q];
+      }
+#pragma unroll
+      for (int q = 0; q < K; ++q) {
+        const double dU = U_star_ji[q] - U_star_ij[q];
+        U_i_new[q] += tau * m_i_inv * d_ij * dU;
+        F_iH[q] += d_ijH * dU;
+        P_ij[q] += (d_ijH - d_ij) * dU;
+      }
+
+      /* Limiter::accumulate (shallow_water/limiter.h:271-330) */
+      {
+        double f_star_ij[K][DIM], f_star_ji[K][DIM], U_ij_bar[K];
+        E::f(P, U_star_ij, f_star_ij);
+        E::f(P, U_star_ji, f_star_ji);
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+          double s = (f_star_ij[q][0] + (-f_star_ji[q][0])) * scaled_c_ij[0];
+#pragma unroll
+          for (int d = 1; d < DIM; ++d)
+            s += (f_star_ij[q][d] + (-f_star_ji[q][d])) * scaled_c_ij[d];
+          U_ij_bar[q] = 0.5 * (U_star_ij[q] + U_star_ji[q] + s) + affine_shift[q];
+        }
+        const double h_bar_ij = U_ij_bar[0];
+        h_min = fmin(h_min, h_bar_ij);
+        h_max = fmax(h_max, h_bar_ij);
+        kin_max = fmax(kin_max, E::kinetic_energy(P, U_ij_bar));
+        {
+          const double ihm = E::inverse_water_depth_mollified(P, U_ij_bar);
+          const double v = U_ij_bar[1] * ihm;
+          double v2 = v * v;
+#pragma unroll
+          for (int d = 1; d < DIM; ++d) {
+            const double vd = U_ij_bar[1 + d] * ihm;
+            v2 += vd * vd;
+          }
+          v2_max = fmax(v2_max, v2);
+        }
+        relaxation_denominator += 1.;
+        h_relaxation_numerator += 1. * (U_i[0] + U_j[0]);
+        kin_relaxation_numerator += 1. * (kin_i + E::kinetic_energy(P, U_j));
+        double v2_j;
+        {
+          const double ihm_j = E::inverse_water_depth_mollified(P, U_j);
+          const double v = U_j[1] * ihm_j;
+          v2_j = v * v;
+#pragma unroll
+          for (int d = 1; d < DIM; ++d) {
+            const double vd = U_j[1 + d] * ihm_j;
+            v2_j += vd * vd;
+          }
+        }
+        v2_relaxation_numerator += 1. * (-v2_i + v2_j);
+      }
+
+#pragma unroll
+      for (int q = 0; q < K; ++q) {
+        F_iH[q] -= m_ij * S_iH[q];
+        P_ij[q] -= m_ij * /*sic!*/ S_i[q];
+      }
+      {
+        double hof[K];
+        E::high_order_flux_divergence(P, U_i, Z_i, U_j, Z_j, c_ij, hof);
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+          F_iH[q] += weight * hof[q];
+          P_ij[q] += weight * hof[q];
+        }
+      }
+      {
+        double S_j[K];
+        E::manning_friction(P, U_j, h_star_j, tau, S_j);
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+          F_iH[q] += weight * m_ij * S_j[q];
+          P_ij[q] += weight * m_ij * S_j[q];
+        }
+      }
+      if constexpr (HAS_STAGES) {
+        for (int s = 0; s < S.stages; ++s) {
+          double U_iHs[K], U_jHs[K], hof_s[K], S_js[K];
+          load_state<K>(S.U[s], i, U_iHs);
+          load_state<K>(S.U[s], j, U_jHs);
+          E::high_order_flux_divergence(P, U_iHs, Z_i, U_jHs, Z_j, c_ij, hof_s);
+          E::manning_friction(P, U_jHs, S.prec[s][(size_t)j * 2 + 1], tau, S_js);
+          const double w = S.w[s];
+#pragma unroll
+          for (int q = 0; q < K; ++q) {
+            F_iH[q] += w * hof_s[q];
+            P_ij[q] += w * hof_s[q];
+          }
+#pragma unroll
+          for (int q = 0; q < K; ++q) {
+            F_iH[q] += w * m_ij * S_js[q];
+            P_ij[q] += w * m_ij * S_js[q];
+          }
+        }
+      }
+      store_entry<K>(pij, colbase, r.lane, P_ij);
+    }
+
+    if (!row_active)
+      return;
+
+    store_state<K>(new_U, i, U_i_new);
+    store_state<K>(r_out, i, F_iH);
+
+    /* Limiter::bounds (shallow_water/limiter.h:333-377) */
+    const double hd_i = m_i * M.measure_of_omega_inverse;
+    double r_i = sqrt(hd_i);
+    if constexpr (DIM == 2) {
+      const double t = sqrt(r_i);
+      r_i = t * t * t;
+    } else if constexpr (DIM == 1) {
+      r_i = r_i * r_i * r_i;
+    }
+    r_i *= P.lim_relaxation_factor;
+    const double h_relaxed = 2. * fabs(h_relaxation_numerator) / (relaxation_denominator + DBL_EPSILON);
+    const double h_min_r = fmax((1. - r_i) * h_min, h_min - h_relaxed);
+    const double h_max_r = fmin((1. + r_i) * h_max, h_max + h_relaxed);
+    const double kin_relaxed =
+        2. * fabs(kin_relaxation_numerator) / (relaxation_denominator + DBL_EPSILON);
+    const double kin_max_r = fmin((1. + r_i) * kin_max, kin_max + kin_relaxed);
+    const double v2_relaxed =
+        2. * fabs(v2_relaxation_numerator) / (relaxation_denominator + DBL_EPSILON);
+    const double v2_max_r = fmin((1. + r_i) * v2_max, v2_max + v2_relaxed);
+    double r2 = hd_i;
+    if constexpr (DIM == 2)
+      r2 = sqrt(hd_i);
+    r2 *= P.dry_state_relaxation_factor;
+    const double h_small = P.reference_water_depth * r2;
+
+    const size_t stride = (size_t)M.n_slices * 64;
+    bounds[i] = h_min_r;
+    bounds[stride + i] = h_max_r;
+    bounds[2 * stride + i] = h_small;
+    bounds[3 * stride + i] = kin_max_r;
+    bounds[4 * stride + i] = v2_max_r;
+  }
+} // namespace ryujin_hip

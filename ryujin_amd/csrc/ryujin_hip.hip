@@ -19,6 +19,7 @@
 #include <mutex>
 #include <numeric>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "ryujin_hip.h"
@@ -26,6 +27,7 @@
 #include "host_layout.hpp"
 #include "kernels_euler.hpp"
 #include "kernels_limiter.hpp"
+#include "kernels_shallow_water.hpp"
 
 using namespace ryujin_hip;
 
@@ -149,6 +151,17 @@ struct ryujin_hip_ctx {
   SellLayout L;
   DeviceMesh mesh{};
   EulerParams eparams{};
+  ShallowWaterParams swparams{};
+  DeviceBuffer<double> d_Z; /* initial_precomputed (bathymetry), shallow water only */
+
+  template <typename E>
+  const typename E::Params &eq_params() const
+  {
+    if constexpr (std::is_same<typename E::Params, EulerParams>::value)
+      return eparams;
+    else
+      return swparams;
+  }
 
   /* mesh arrays */
   DeviceBuffer<uint32_t> d_slice_off, d_cols, d_idx_t, d_lower_mask;
@@ -224,9 +237,9 @@ struct ryujin_hip_ctx {
   void local_exchange(double *base, const std::vector<size_t> &send_offset,
                       const std::vector<size_t> &recv_offset, const std::vector<size_t> &recv_count);
   void allreduce_scalar(void *dev_ptr, int op);
-  template <int DIM>
+  template <typename E>
   void prepare_state_vector(int h, const double *dirichlet);
-  template <int DIM>
+  template <typename E>
   int step(int h_old, int stages, const int *h_stage, const double *w, int h_new, double tau_in,
            double tau_max_in, double *tau_out);
   void mark(int k)
@@ -243,13 +256,16 @@ void ryujin_hip_ctx::create(const ryujin_hip_offline &o, const ryujin_hip_params
   comm = c;
   device = dev;
   dim = p.dim;
-  if (p.equation != RYUJIN_EQ_EULER)
-    throw HipError(RYUJIN_ERR_UNSUPPORTED, "only the Euler equations are implemented on the device");
+  if (p.equation != RYUJIN_EQ_EULER && p.equation != RYUJIN_EQ_SHALLOW_WATER)
+    throw HipError(RYUJIN_ERR_UNSUPPORTED, "unknown equation");
+  if (p.equation == RYUJIN_EQ_SHALLOW_WATER && p.dim == 3)
+    throw HipError(RYUJIN_ERR_UNSUPPORTED, "the shallow water equations are defined for dim 1 and 2");
   if (dim < 1 || dim > 3)
     throw HipError(RYUJIN_ERR_ARG, "dim must be 1, 2 or 3");
   if (p.limiter_iterations < 0 || p.limiter_iterations > 2)
     throw HipError(RYUJIN_ERR_ARG, "The number of limiter iterations must be between [0,2]");
-  K = dim + 2;
+  K = p.equation == RYUJIN_EQ_EULER ? dim + 2 : dim + 1;
+  NB = p.equation == RYUJIN_EQ_EULER ? 3 : 5;
   KP = (K + 1) / 2 * 2;
 
   HIP_CHECK(hipSetDevice(device));
@@ -273,6 +289,24 @@ void ryujin_hip_ctx::create(const ryujin_hip_offline &o, const ryujin_hip_params
   eparams.lim_newton_max_iterations = p.limiter_newton_max_iterations;
   eparams.riemann_newton_max_iterations = p.riemann_newton_max_iterations;
   eparams.riemann_newton_tolerance = p.riemann_newton_tolerance;
+
+  swparams.gravity = p.gravity;
+  swparams.manning = p.manning_friction_coefficient;
+  swparams.reference_water_depth = p.reference_water_depth;
+  swparams.dry_state_relaxation_factor = p.dry_state_relaxation_factor;
+  swparams.dry_small = p.dry_state_relaxation_small;
+  swparams.dry_large = p.dry_state_relaxation_large;
+  swparams.evc_factor = p.indicator_evc_factor;
+  swparams.lim_newton_tolerance = p.limiter_newton_tolerance;
+  swparams.lim_relaxation_factor = p.limiter_relaxation_factor;
+  swparams.limit_on_kinetic_energy = p.limiter_limit_on_kinetic_energy;
+  swparams.limit_on_square_velocity = p.limiter_limit_on_square_velocity;
+  if (p.equation == RYUJIN_EQ_SHALLOW_WATER) {
+    if (o.initial_precomputed)
+      d_Z.upload(o.initial_precomputed, o.n_relevant);
+    else
+      d_Z.alloc(o.n_relevant); /* flat bed */
+  }
 
   /* ---- stencil ------------------------------------------------------------- */
   L.build(o);
@@ -504,9 +538,10 @@ void ryujin_hip_ctx::exchange_matrix(double *m)
   NCCL_CHECK(ncclGroupEnd());
 }
 
-template <int DIM>
+template <typename E>
 void ryujin_hip_ctx::prepare_state_vector(int h, const double *dirichlet)
 {
+  const auto &eparams = eq_params<E>(); /* shadows the member: the equation's parameter block */
   State &s = state(h);
   if (dirichlet && n_bdry) {
     /* permute into the grouped order, then upload */
@@ -519,20 +554,23 @@ void ryujin_hip_ctx::prepare_state_vector(int h, const double *dirichlet)
     have_dirichlet = true;
   }
   if (n_groups)
-    hipLaunchKernelGGL(k_apply_bc<DIM>, dim3(grid_for(n_groups)), dim3(kBlock), 0, stream, eparams,
+    hipLaunchKernelGGL(k_apply_bc<E>, dim3(grid_for(n_groups)), dim3(kBlock), 0, stream, eparams,
                        n_groups, d_grp_start.ptr, d_b_i.ptr, d_b_normal.ptr, d_b_id.ptr,
                        d_dirichlet.ptr, s.U.ptr);
   exchange_vector(s.U.ptr, KP);
-  hipLaunchKernelGGL(k_precompute<DIM>, dim3(grid_for(L.n_owned)), dim3(kBlock), 0, stream, eparams,
+  hipLaunchKernelGGL(k_precompute<E>, dim3(grid_for(L.n_owned)), dim3(kBlock), 0, stream, eparams,
                      mesh, s.U.ptr, s.prec.ptr);
   exchange_vector(s.prec.ptr, 2);
   HIP_CHECK(hipGetLastError());
 }
 
-template <int DIM>
+template <typename E>
 int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double *w, int h_new,
                          double tau_in, double tau_max_in, double *tau_out)
 {
+  constexpr int DIM = E::DIMENSION;
+  constexpr bool is_euler = std::is_same<typename E::Params, EulerParams>::value;
+  const auto &eparams = eq_params<E>(); /* shadows the member: the equation's parameter block */
   State &old = state(h_old);
   State &nw = state(h_new);
   if (h_old == h_new)
@@ -554,14 +592,14 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
 
   mark(0);
   /* Step 2 */
-  hipLaunchKernelGGL(k_dij_alpha<DIM>, grid_rows, block, 0, stream, eparams, mesh, old.U.ptr,
+  hipLaunchKernelGGL(k_dij_alpha<E>, grid_rows, block, 0, stream, eparams, mesh, old.U.ptr,
                      old.prec.ptr, d_dij.ptr, d_alpha.ptr);
   exchange_vector(d_alpha.ptr, 1);
   mark(1);
 
   /* Step 3 */
   if (n_pairs)
-    hipLaunchKernelGGL(k_dij_boundary<DIM>, dim3(grid_for(n_pairs)), block, 0, stream, eparams,
+    hipLaunchKernelGGL(k_dij_boundary<E>, dim3(grid_for(n_pairs)), block, 0, stream, eparams,
                        n_pairs, d_p_i.ptr, d_p_j.ptr, d_p_pos.ptr, (const uint32_t *)nullptr,
                        d_p_cji.ptr, old.U.ptr, d_dij.ptr);
   if (L.max_row_len <= 3)
@@ -592,23 +630,35 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
   S.stages = stages;
   for (int s = 0; s < stages; ++s) {
     S.U[s] = state(h_stage[s]).U.ptr;
+    S.prec[s] = state(h_stage[s]).prec.ptr;
     S.w[s] = w[s];
   }
-  if (stages == 0)
-    hipLaunchKernelGGL((k_low_order<DIM, false>), grid_rows, block, 0, stream, eparams, mesh,
-                       d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_alpha.ptr, d_dij.ptr,
-                       nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
-  else
-    hipLaunchKernelGGL((k_low_order<DIM, true>), grid_rows, block, 0, stream, eparams, mesh,
-                       d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_alpha.ptr, d_dij.ptr,
-                       nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
+  if constexpr (is_euler) {
+    if (stages == 0)
+      hipLaunchKernelGGL((k_low_order<DIM, false>), grid_rows, block, 0, stream, eparams, mesh,
+                         d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_alpha.ptr, d_dij.ptr,
+                         nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
+    else
+      hipLaunchKernelGGL((k_low_order<DIM, true>), grid_rows, block, 0, stream, eparams, mesh,
+                         d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_alpha.ptr, d_dij.ptr,
+                         nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
+  } else {
+    if (stages == 0)
+      hipLaunchKernelGGL((k_low_order_sw<DIM, false>), grid_rows, block, 0, stream, eparams, mesh,
+                         d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_Z.ptr, d_alpha.ptr,
+                         d_dij.ptr, nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
+    else
+      hipLaunchKernelGGL((k_low_order_sw<DIM, true>), grid_rows, block, 0, stream, eparams, mesh,
+                         d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_Z.ptr, d_alpha.ptr,
+                         d_dij.ptr, nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
+  }
   exchange_vector(d_r.ptr, KP);
   mark(3);
 
   /* Step 5 */
   const int n_iterations = params.limiter_iterations;
   if (n_iterations != 0) {
-    hipLaunchKernelGGL(k_pij_lij<DIM>, grid_rows, block, 0, stream, eparams, mesh, d_scalars.ptr,
+    hipLaunchKernelGGL(k_pij_lij<E>, grid_rows, block, 0, stream, eparams, mesh, d_scalars.ptr,
                        nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr);
     exchange_matrix(d_lij.ptr);
   }
@@ -620,16 +670,16 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
     if (n_iterations == 2 && last_round)
       std::swap(d_lij.ptr, d_lij_next.ptr);
     if (last_round) {
-      hipLaunchKernelGGL((k_high_order<DIM, true>), grid_rows, block, 0, stream, eparams, mesh,
+      hipLaunchKernelGGL((k_high_order<E, true>), grid_rows, block, 0, stream, eparams, mesh,
                          nw.U.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr, d_lij_next.ptr);
     } else {
       constexpr int kCachedWidth = DIM == 1 ? 3 : 9;
       if (DIM <= 2 && L.max_row_len <= (uint32_t)kCachedWidth)
-        hipLaunchKernelGGL((k_high_order_next_cached<DIM, kCachedWidth>), grid_rows, block, 0, stream,
+        hipLaunchKernelGGL((k_high_order_next_cached<E, kCachedWidth>), grid_rows, block, 0, stream,
                            eparams, mesh, nw.U.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr,
                            d_lij_next.ptr);
       else
-        hipLaunchKernelGGL((k_high_order<DIM, false>), grid_rows, block, 0, stream, eparams, mesh,
+        hipLaunchKernelGGL((k_high_order<E, false>), grid_rows, block, 0, stream, eparams, mesh,
                            nw.U.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr, d_lij_next.ptr);
       exchange_matrix(d_lij_next.ptr);
     }
@@ -689,13 +739,23 @@ namespace
     }
   }
 
+  template <typename E>
+  struct EqTag {
+    using type = E;
+  };
+
   template <typename F>
-  auto dispatch_dim(int dim, F &&f)
+  auto dispatch_equation(int equation, int dim, F &&f)
   {
+    if (equation == RYUJIN_EQ_SHALLOW_WATER) {
+      if (dim == 1)
+        return f(EqTag<ShallowWater<1>>{});
+      return f(EqTag<ShallowWater<2>>{});
+    }
     switch (dim) {
-    case 1: return f(std::integral_constant<int, 1>{});
-    case 2: return f(std::integral_constant<int, 2>{});
-    default: return f(std::integral_constant<int, 3>{});
+    case 1: return f(EqTag<Euler<1>>{});
+    case 2: return f(EqTag<Euler<2>>{});
+    default: return f(EqTag<Euler<3>>{});
     }
   }
 } // namespace
@@ -709,7 +769,7 @@ const char *ryujin_hip_last_error(void)
 
 const char *ryujin_hip_version(void)
 {
-  return "ryujin_hip 0.1 (gfx950; Euler; SELL-64)";
+  return "ryujin_hip 0.2 (gfx950; Euler + shallow water; SELL-64)";
 }
 
 void ryujin_hip_default_params(ryujin_hip_params *p, int equation, int dim)
@@ -908,8 +968,8 @@ int ryujin_hip_prepare_state_vector(ryujin_hip_ctx *ctx, int handle, double /*t*
 {
   return guarded([&]() {
     HIP_CHECK(hipSetDevice(ctx->device));
-    dispatch_dim(ctx->dim, [&](auto d) {
-      ctx->template prepare_state_vector<decltype(d)::value>(handle, dirichlet_aos);
+    dispatch_equation(ctx->params.equation, ctx->dim, [&](auto tag) {
+      ctx->template prepare_state_vector<typename decltype(tag)::type>(handle, dirichlet_aos);
       return 0;
     });
     return RYUJIN_OK;
@@ -924,9 +984,9 @@ int ryujin_hip_step(ryujin_hip_ctx *ctx, int h_old, int stages, const int *h_sta
     if (stages < 0 || stages > 4 || !tau_out)
       throw HipError(RYUJIN_ERR_ARG, "stages must be in [0,4]");
     HIP_CHECK(hipSetDevice(ctx->device));
-    return dispatch_dim(ctx->dim, [&](auto d) {
-      return ctx->template step<decltype(d)::value>(h_old, stages, h_stage, stage_weights, h_new,
-                                                    tau_in, tau_max_in, tau_out);
+    return dispatch_equation(ctx->params.equation, ctx->dim, [&](auto tag) {
+      return ctx->template step<typename decltype(tag)::type>(h_old, stages, h_stage, stage_weights,
+                                                              h_new, tau_in, tau_max_in, tau_out);
     });
   });
 }

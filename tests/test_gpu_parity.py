@@ -20,14 +20,16 @@ def _perturbed(U, seed=42, amp=1e-3):
     return U * (1.0 + amp * rng.uniform(-1.0, 1.0, size=U.shape))
 
 
-def _both(spec, U0, oracle, n_warm=0, dirichlet=None, params_edit=None):
+def _both(spec, U0, oracle, n_warm=0, dirichlet=None, params_edit=None, equation=capi.EQ_EULER, bathymetry=None):
     """Warm up on the GPU (lets shocks form so that the limiter branches are exercised), then hand the
     SAME state to both backends so that one update is compared on identical inputs."""
     off = offline.SyntheticOffline(spec)
+    if bathymetry is not None:
+        off.set_initial_precomputed(bathymetry(off.positions))
     mods = []
     U_start = U0
     for backend in ("hip", oracle.backend()):
-        p = oracle.default_params(capi.EQ_EULER, off.dim)
+        p = oracle.default_params(equation, off.dim)
         p.cfl = 0.9
         if params_edit:
             params_edit(p)
@@ -57,7 +59,7 @@ def _compare_step(off, mods, dirichlet=None, tau=0.0, stages=(), weights=()):
     g, c = out
     m_fetch = out
     n = off.n_owned
-    scale = np.abs(c["U"][:n]).max(axis=0)
+    scale = np.maximum(np.abs(c["U"][:n]).max(axis=0), 1e-3 * np.abs(c["U"][:n]).max())
     assert g["status"] == c["status"]
     np.testing.assert_allclose(g["U_old"][:n], c["U_old"][:n], rtol=1e-14, atol=1e-14)  # BCs
     np.testing.assert_allclose(g["prec"][:n], c["prec"][:n], rtol=1e-13)
@@ -328,3 +330,77 @@ def test_partitioned_hip_matches_single_rank(n_ranks):
     assert np.abs(ap[o2] - alpha[o1]).max() < 1e-10
     for r in range(n_ranks):
         lib.ryujin_hip_comm_destroy(C.c_void_p(comms[r]))
+
+
+# ----------------------------------------------------------------------------- shallow water
+
+def _bump(pos):
+    return 0.8 * np.exp(-1.5 * ((pos[:, 0] - 1.5) ** 2 + (pos[:, 1] + 1.0) ** 2)) + 0.02 * pos[:, 0]
+
+
+def test_sw_step_parity_2d_dam_break_over_bathymetry(oracle):
+    """BASELINE configs[4]-like: circular dam break (initial_state_circular_dam_break.h) over an uneven,
+    partly dry bed; slip walls; Manning friction on. Every sweep of the shallow-water path vs the oracle."""
+    from ryujin_amd.initial_states import sw_circular_dam_break
+    spec = offline.rectangle_2d(48, (-5.0, -5.0), (5.0, 5.0))
+    off0 = offline.SyntheticOffline(spec)
+    Z = _bump(off0.positions)
+    U0 = sw_circular_dam_break(off0.positions, h_outer=0.5)
+    U0[:, 0] = np.maximum(U0[:, 0] - Z, 0.0)      # free surface at h+Z, dry where the bump pierces it
+
+    def edit(p):
+        p.manning_friction_coefficient = 0.03
+    off, mods = _both(spec, U0, oracle, n_warm=8, equation=capi.EQ_SHALLOW_WATER, bathymetry=_bump,
+                      params_edit=edit)
+    g, c = _compare_step(off, mods)
+    assert (g["U"][: off.n_owned, 0] >= 0.0).all()
+    assert (np.sign(g["U"][: off.n_owned, 0]) == np.sign(c["U"][: off.n_owned, 0])).all()
+
+
+def test_sw_step_parity_1d(oracle):
+    spec = offline.MeshSpec(1, (160,), (-1.0,), (1.0,), (capi.BC_SLIP, capi.BC_SLIP))
+    off0 = offline.SyntheticOffline(spec)
+    x = off0.positions[:, 0]
+    U0 = np.zeros((len(x), 2))
+    U0[:, 0] = np.where(x < 0.0, 1.0, 0.2)
+    off, mods = _both(spec, U0, oracle, n_warm=6, equation=capi.EQ_SHALLOW_WATER)
+    _compare_step(off, mods)
+
+
+def test_sw_multistage_and_lake_at_rest(oracle):
+    """ERK33 (step<1>, step<2> incl. the stage source terms) on the GPU vs the oracle, and the
+    well-balancedness invariant: a lake at rest over an uneven bed stays at rest."""
+    from ryujin_amd.initial_states import sw_circular_dam_break
+    spec = offline.rectangle_2d(32, (-5.0, -5.0), (5.0, 5.0))
+    off = offline.SyntheticOffline(spec)
+    off.set_initial_precomputed(_bump(off.positions))
+    Z = _bump(off.positions)
+    U0 = sw_circular_dam_break(off.positions)
+    finals = []
+    for backend in ("hip", oracle.backend()):
+        p = oracle.default_params(capi.EQ_SHALLOW_WATER, 2)
+        p.manning_friction_coefficient = 0.02
+        m = HyperbolicModule(off, p, backend=backend)
+        sv = m.new_state_vector(U0)
+        ti = TimeIntegrator(m, "erk 33", cfl_recovery_strategy="none")
+        t = 0.0
+        for _ in range(4):
+            sv, tau = ti.step(sv, t)
+            t += tau
+        finals.append((t, sv.download()[: off.n_owned]))
+    assert abs(finals[0][0] - finals[1][0]) < 1e-12 * finals[1][0]
+    assert np.abs(finals[0][1] - finals[1][1]).max() < 5e-11 * np.abs(finals[1][1]).max()
+
+    m = HyperbolicModule(off, oracle.default_params(capi.EQ_SHALLOW_WATER, 2), backend="hip")
+    U_rest = np.zeros((off.n_relevant, 3))
+    U_rest[:, 0] = np.maximum(1.0 - Z, 0.0)
+    wet = 1.0 - Z > 0
+    sv = m.new_state_vector(U_rest)
+    ti = TimeIntegrator(m, "ssprk 33", cfl_recovery_strategy="none")
+    t = 0.0
+    for _ in range(5):
+        sv, tau = ti.step(sv, t)
+        t += tau
+    U = sv.download()
+    assert np.abs(U[wet, 0] + Z[wet] - 1.0).max() < 1e-13
+    assert np.abs(U[:, 1:]).max() < 1e-13
