@@ -92,7 +92,7 @@ def usable_cores() -> int:
     return max(1, n)
 
 
-def cpu_baseline(spec, U0, dirichlet, budget_s: float = 15.0) -> dict:
+def cpu_baseline(spec, U0, dirichlet, budget_s: float = 15.0, equation: int = 0) -> dict:
     """The CPU restatement of the reference path (oracle/, OpenMP over all host cores) timed on a
     bounded sample of the SAME workload: n forward-Euler updates of the same mesh."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -121,7 +121,7 @@ def cpu_baseline(spec, U0, dirichlet, budget_s: float = 15.0) -> dict:
     lib = oracle_py.load(path)
     lib.ryujin_oracle_set_flush_denormals(1)  # source/main.cc:26-36
     off = offline.SyntheticOffline(spec)
-    m = HyperbolicModule(off, equation=capi.EQ_EULER, backend=(lib, "ryujin_oracle_"))
+    m = HyperbolicModule(off, equation=equation, backend=(lib, "ryujin_oracle_"))
     m.cfl = 0.9
     drv = Ssprk33Stages(m, U0, dirichlet)
     t0 = time.perf_counter()
@@ -132,7 +132,7 @@ def cpu_baseline(spec, U0, dirichlet, budget_s: float = 15.0) -> dict:
     for _ in range(n):
         drv.update()
     dt = time.perf_counter() - t0
-    k = off.dim + 2
+    k = m.k
     return {"value": k * off.n_owned * n / dt / 1e6, "unit": "MDoF-updates/s", "cores": cores,
             "kind": "port",
             "sample": f"{n} forward-Euler updates (SSPRK33 stages) of the same mesh "
@@ -148,6 +148,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=12)
     ap.add_argument("--cells-per-unit", type=int, default=995,
                     help="mesh resolution h=1/N of the step geometry (995 -> ~2.5M gridpoints, ~10M DoFs per GPU)")
+    ap.add_argument("--workload", default="step2d", choices=["step2d", "sedov3d", "sw2d"],
+                    help="step2d = BASELINE configs[1] (the bench line); sedov3d = configs[2] (3-D radial "
+                         "contrast box, --size cells per direction, default 200 -> 8.1M gridpoints); "
+                         "sw2d = configs[4] (shallow-water circular dam break, default 1825^2 gridpoints)")
+    ap.add_argument("--size", type=int, default=0)
     ap.add_argument("--develop", type=int, default=900,
                     help="untimed forward-Euler updates run before the warm-up so that the bow shock and its "
                          "reflections exist (a uniform state would never enter the limiter's Newton branch)")
@@ -189,13 +194,35 @@ def main():
     from ryujin_amd.initial_states import euler_uniform
 
     # ---- workload: BASELINE.json configs[1] per GPU, lengthened channel for N GPUs (weak scaling)
-    spec = offline.mach3_step_2d(args.cells_per_unit, length_units=3 * n_gpus, n_ranks=n_gpus, rank=rank)
-    off = offline.SyntheticOffline(spec)
+    equation = capi.EQ_EULER
     rng = np.random.default_rng(42 + rank)
-    U0 = euler_uniform(off.positions)  # prm/benchmarks/euler-mach3-forward-facing-step.prm:55-66
+    if args.workload == "step2d":
+        spec = offline.mach3_step_2d(args.cells_per_unit, length_units=3 * n_gpus, n_ranks=n_gpus, rank=rank)
+        off = offline.SyntheticOffline(spec)
+        U0 = euler_uniform(off.positions)  # prm/benchmarks/euler-mach3-forward-facing-step.prm:55-66
+        dirichlet = euler_uniform(off.b_positions) if off.n_bdry else None
+        workload_name = ("2D Euler Mach-3 forward-facing step, Q1, SSPRK33 stage sequence "
+                         "(BASELINE.json configs[1])")
+    elif args.workload == "sedov3d":
+        from ryujin_amd.initial_states import euler_radial_contrast
+        n = args.size or 200
+        spec = offline.box_3d(n, nx=n * n_gpus, upper=(2.0 * n_gpus - 1.0, 1.0, 1.0), n_ranks=n_gpus, rank=rank)
+        off = offline.SyntheticOffline(spec)
+        U0 = euler_radial_contrast(off.positions, inner=(1.0, 0.0, 100.0), outer=(1.0, 0.0, 0.1), radius=0.1)
+        dirichlet = None
+        workload_name = "3D Euler Sedov-like radial contrast, rectangular domain, Q1 (BASELINE.json configs[2])"
+    else:
+        from ryujin_amd.initial_states import sw_circular_dam_break
+        equation = capi.EQ_SHALLOW_WATER
+        n = args.size or 1824
+        spec = offline.rectangle_2d(n * n_gpus, (-5.0, -5.0), (10.0 * n_gpus - 5.0, 5.0), ny=n, n_ranks=n_gpus,
+                                    rank=rank)
+        off = offline.SyntheticOffline(spec)
+        U0 = sw_circular_dam_break(off.positions)
+        dirichlet = None
+        workload_name = "2D shallow-water circular dam break, Q1 (BASELINE.json configs[4])"
     if args.perturbation != 0.0:
         U0 *= 1.0 + args.perturbation * rng.uniform(-1.0, 1.0, size=U0.shape)
-    dirichlet = euler_uniform(off.b_positions) if off.n_bdry else None
 
     lib = capi.load_hip()
     comm = None
@@ -211,7 +238,7 @@ def main():
         rc = lib.ryujin_hip_comm_init(C.byref(comm), uid, rank, world, local_rank)
         assert rc == 0, lib.ryujin_hip_last_error()
 
-    m = HyperbolicModule(off, equation=capi.EQ_EULER, backend="hip", comm=comm, device=local_rank)
+    m = HyperbolicModule(off, equation=equation, backend="hip", comm=comm, device=local_rank)
     m.cfl = 0.9
     drv = Ssprk33Stages(m, U0, dirichlet)
     ctx = m._ctx
@@ -258,10 +285,12 @@ def main():
     if rank != 0:
         return
 
-    k = off.dim + 2
+    k = m.k
     rs = off.row_starts
     S = float(rs[off.n_owned]) / off.n_owned
-    alg = algorithmic_bytes(off.dim, k, S)
+    alg = algorithmic_bytes(off.dim, k, S, n_bounds=m.n_bounds)
+    if equation == capi.EQ_SHALLOW_WATER:  # + bathymetry (8 B) and m_ij (8S) in step 4, SURVEY 8d
+        alg["4 low_order"] += 8 + 8 * S
     b_alg = sum(alg.values())
     # per-sweep mean kernel durations of rank 0 (hipEvent pairs on the library's stream); sweep 1
     # (prepare_state_vector) is not bracketed separately: it is the remainder of the event time
@@ -279,8 +308,7 @@ def main():
         "ms_per_step": wall / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "2D Euler Mach-3 forward-facing step, Q1, SSPRK33 stage sequence "
-                               "(BASELINE.json configs[1])",
+        "config": {"workload": workload_name,
                    "gridpoints_per_gpu": n_q_local, "gridpoints_total": n_q_total,
                    "dofs_total": k * n_q_total, "nnz_per_row": round(S, 3),
                    "cells_per_unit": args.cells_per_unit, "partition": f"x-slabs x{n_gpus}",
@@ -299,7 +327,7 @@ def main():
     }
     if not args.no_cpu_baseline and n_gpus == 1:
         try:
-            out["cpu_baseline"] = cpu_baseline(spec, U_developed, dirichlet, args.cpu_budget)
+            out["cpu_baseline"] = cpu_baseline(spec, U_developed, dirichlet, args.cpu_budget, equation)
         except Exception as e:  # the baseline must never take the GPU number down with it
             out["cpu_baseline"] = {"value": None, "error": repr(e)}
     sys.stdout.flush()
