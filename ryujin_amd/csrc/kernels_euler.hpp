@@ -47,6 +47,12 @@ namespace ryujin_hip
 
   /* minimum waves per SIMD requested from the register allocator for the heavy sweeps (second
    * __launch_bounds__ argument): 512 registers / waves. Tuned on MI355X, see DESIGN.md. */
+#ifndef RYUJIN_XCD_REMAP
+#define RYUJIN_XCD_REMAP 0 /* A/B on MI355X: no gain in 2-D (1.80 vs 1.77 ms), +0.4 % in 3-D: the 256 MiB Infinity Cache already serves the cross-XCD reuse */
+#endif
+#ifndef RYUJIN_RECOMPUTE_P
+#define RYUJIN_RECOMPUTE_P 1
+#endif
 #ifndef RYUJIN_OCC_DIJ
 #define RYUJIN_OCC_DIJ 2
 #endif
@@ -160,7 +166,16 @@ namespace ryujin_hip
   {
     RowCtx r;
     r.lane = threadIdx.x & 63;
-    r.slice = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+#if RYUJIN_XCD_REMAP
+    /* Workgroups are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8, observed, not a
+     * contract; speed only). Give every XCD a contiguous range of slices so that the U_j / r_j /
+     * alpha_j gathers of neighbouring grid lines hit the same 4 MiB L2. gridDim.x is a multiple of 8. */
+    const uint32_t blocks_per_xcd = gridDim.x >> 3;
+    const uint32_t block = (blockIdx.x & 7u) * blocks_per_xcd + (blockIdx.x >> 3);
+#else
+    const uint32_t block = blockIdx.x;
+#endif
+    r.slice = block * kWavesPerBlock + (threadIdx.x >> 6);
     r.valid = r.slice < M.n_slices;
     if (!r.valid) {
       r.row = r.len = r.base = r.width = 0;
@@ -424,7 +439,10 @@ namespace ryujin_hip
     double w[4];
   };
 
-  template <int DIM, bool HAS_STAGES>
+  /* STORE_P = false: the first part of P_ij is not written here but recomputed -- with the identical
+   * operation sequence, hence bit-identical -- by k_pij_lij_recompute (saves the 8kS B/row store of
+   * this sweep and the 8kS B/row load of step 5 for 8dS+8S B/row of c_ij, d_ij loads there). */
+  template <int DIM, bool HAS_STAGES, bool STORE_P = true>
   __global__ void __launch_bounds__(kBlock, RYUJIN_OCC_LOW)
   k_low_order(const EulerParams P, const DeviceMesh M, const DeviceScalars *__restrict__ scalars,
               const double weight, const StageArgs<DIM> S, const double *__restrict__ U,
@@ -570,7 +588,8 @@ namespace ryujin_hip
         }
       }
 
-      store_entry<K>(pij, colbase, r.lane, P_ij);
+      if constexpr (STORE_P)
+        store_entry<K>(pij, colbase, r.lane, P_ij);
     }
 
     if (!row_active)

@@ -127,6 +127,144 @@ namespace ryujin_hip
     flag_restart(scalars, all_ok, r.lane);
   }
 
+  /* Step 5 for Euler, stages == 0, fused with the first part of P_ij of step 4 (:769-813): instead of
+   * loading P_ij it is recomputed from U_i, U_j, alpha, d_ij, c_ij in exactly the operation order of
+   * k_low_order, then the mass-matrix correction and the limiter follow as in k_pij_lij. */
+  template <int DIM>
+  __global__ void __launch_bounds__(kBlock, RYUJIN_OCC_PIJ)
+  k_pij_lij_recompute(const EulerParams P, const DeviceMesh M, DeviceScalars *__restrict__ scalars,
+                      const double weight, const double *__restrict__ old_U,
+                      const double *__restrict__ alpha, const double *__restrict__ dij,
+                      const double *__restrict__ new_U, const double *__restrict__ r_in,
+                      const double *__restrict__ bounds, double *__restrict__ pij,
+                      double *__restrict__ lij)
+  {
+    using E = Euler<DIM>;
+    constexpr int K = E::K;
+    constexpr int NB = E::NB;
+    const RowCtx r = row_context(M);
+    if (!r.valid)
+      return;
+    const bool row_active = r.len > 1;
+    const uint32_t i = row_active ? r.row : (r.row < M.n_owned ? r.row : M.n_owned - 1);
+    const double tau = scalars->tau;
+    const uint32_t *__restrict__ cols = M.cols;
+    const double *__restrict__ cij = M.cij;
+    const double *__restrict__ mij = M.mij;
+    const double *__restrict__ mi_inv = M.mi_inv;
+
+    const size_t stride = (size_t)M.n_slices * 64;
+    double bnd[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+      bnd[b] = bounds[(size_t)b * stride + i];
+    const double m_i_inv = mi_inv[i];
+    const double alpha_i = alpha[i];
+    double U_i[K], U_i_new[K], F_iH[K];
+    load_state<K>(old_U, i, U_i);
+    load_state<K>(new_U, i, U_i_new);
+    load_state<K>(r_in, i, F_iH);
+    double f_i[K][DIM];
+    E::flux(P, U_i, f_i);
+    const double lambda_inv = (double)(r.len - 1);
+    const double factor = tau * m_i_inv * lambda_inv;
+    bool all_ok = true;
+    unsigned long long undecided_mask = 0;
+
+    /* software pipeline: loads of column c+1 are in flight while column c is processed */
+    uint32_t j_n = r.width > 1 ? cols[((uint64_t)r.base + 1) * 64 + r.lane] : i;
+    uint32_t j_nn = r.width > 2 ? cols[((uint64_t)r.base + 2) * 64 + r.lane] : i;
+    double c_n[DIM], U_n[K], F_n[K];
+    double mjinv_n = 0., mij_n = 0., d_n = 0., alpha_n = 0.;
+    if (r.width > 1) {
+      load_entry<DIM>(cij, (uint64_t)r.base + 1, r.lane, c_n);
+      d_n = dij[((uint64_t)r.base + 1) * 64 + r.lane];
+      mij_n = mij[((uint64_t)r.base + 1) * 64 + r.lane];
+      load_state<K>(old_U, j_n, U_n);
+      load_state<K>(r_in, j_n, F_n);
+      mjinv_n = mi_inv[j_n];
+      alpha_n = alpha[j_n];
+    }
+
+    for (uint32_t c = 1; c < r.width; ++c) {
+      const uint64_t colbase = (uint64_t)r.base + c;
+      const uint64_t pos = colbase * 64 + r.lane;
+      const bool active = row_active && c < r.len;
+      double c_ij[DIM], U_j[K], F_jH[K];
+#pragma unroll
+      for (int d = 0; d < DIM; ++d)
+        c_ij[d] = c_n[d];
+#pragma unroll
+      for (int q = 0; q < K; ++q) {
+        U_j[q] = U_n[q];
+        F_jH[q] = F_n[q];
+      }
+      const double m_j_inv = mjinv_n, m_ij = mij_n, d_ij = d_n, alpha_j = alpha_n;
+      if (c + 1 < r.width) {
+        j_n = j_nn;
+        load_entry<DIM>(cij, colbase + 1, r.lane, c_n);
+        d_n = dij[(colbase + 1) * 64 + r.lane];
+        mij_n = mij[(colbase + 1) * 64 + r.lane];
+        load_state<K>(old_U, j_n, U_n);
+        load_state<K>(r_in, j_n, F_n);
+        mjinv_n = mi_inv[j_n];
+        alpha_n = alpha[j_n];
+        j_nn = (c + 2 < r.width) ? cols[(colbase + 2) * 64 + r.lane] : i;
+      }
+      if (!active)
+        continue;
+
+      /* first part of P_ij: identical operation sequence to k_low_order (:769-813) */
+      const double d_ijH = d_ij * ((alpha_i + alpha_j) * .5);
+      double f_j[K][DIM], flux_ij[K], P_ij[K];
+      E::flux(P, U_j, f_j);
+      E::flux_divergence(f_i, f_j, c_ij, flux_ij);
+#pragma unroll
+      for (int q = 0; q < K; ++q)
+        P_ij[q] = -flux_ij[q];
+#pragma unroll
+      for (int q = 0; q < K; ++q) {
+        const double dU = U_j[q] - U_i[q];
+        P_ij[q] += (d_ijH - d_ij) * dU;
+      }
+#pragma unroll
+      for (int q = 0; q < K; ++q)
+        P_ij[q] += weight * flux_ij[q];
+
+      /* Neumann series: b_ij = delta_ij - m_ij/m_j, b_ji = delta_ij - m_ij/m_i (:987-996) */
+      const double b_ij = 0. - m_ij * m_j_inv;
+      const double b_ji = 0. - m_ij * m_i_inv;
+#pragma unroll
+      for (int q = 0; q < K; ++q) {
+        P_ij[q] += b_ij * F_jH[q] - b_ji * F_iH[q];
+        P_ij[q] *= factor;
+      }
+      store_entry<K>(pij, colbase, r.lane, P_ij);
+
+      bool success, undecided;
+      const double l_ij = E::limit_fast(P, bnd, U_i_new, P_ij, success, undecided);
+      if (undecided) {
+        undecided_mask |= 1ull << c;
+      } else {
+        lij[pos] = l_ij;
+        all_ok = all_ok && success;
+      }
+    }
+
+    while (undecided_mask) {
+      const uint32_t c = (uint32_t)__builtin_ctzll(undecided_mask);
+      undecided_mask &= undecided_mask - 1;
+      const uint64_t colbase = (uint64_t)r.base + c;
+      double P_ij[K];
+      load_entry<K>(pij, colbase, r.lane, P_ij);
+      bool success;
+      const double l_ij = E::limit(P, bnd, U_i_new, P_ij, success);
+      lij[colbase * 64 + r.lane] = l_ij;
+      all_ok = all_ok && success;
+    }
+    flag_restart(scalars, all_ok, r.lane);
+  }
+
   /* ------------------------------------------------------------------ steps 6, 7 */
 
   /* Generic variant: two passes over the row's stencil (the second one re-reads l_ij, l_ji, P_ij). */

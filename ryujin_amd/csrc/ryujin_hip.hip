@@ -577,7 +577,8 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
     throw HipError(RYUJIN_ERR_ARG, "old and new state vector must differ");
 
   const dim3 block(kBlock);
-  const dim3 grid_rows((L.n_slices + kWavesPerBlock - 1) / kWavesPerBlock);
+  /* one wave per slice, 4 slices per block; rounded up to a multiple of 8 for the XCD remap */
+  const dim3 grid_rows(((L.n_slices + kWavesPerBlock - 1) / kWavesPerBlock + 7) / 8 * 8);
 
   /* scalars: tau_max := tau_max_in, flags := 0 */
   DeviceScalars init{};
@@ -633,8 +634,17 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
     S.prec[s] = state(h_stage[s]).prec.ptr;
     S.w[s] = w[s];
   }
+  /* Euler, stages == 0, limiter on: P_ij (part 1) is recomputed in step 5 instead of stored here */
+  /* A/B on MI355X: -7 % per update in 2-D (k=4, 9 columns); +1 % in 3-D where step 5 turns
+   * register/VALU bound (k=5, 27 columns), so only for dim <= 2. */
+  const bool recompute_p = is_euler && DIM <= 2 && stages == 0 && params.limiter_iterations != 0 &&
+                           RYUJIN_RECOMPUTE_P;
   if constexpr (is_euler) {
-    if (stages == 0)
+    if (recompute_p)
+      hipLaunchKernelGGL((k_low_order<DIM, false, false>), grid_rows, block, 0, stream, eparams, mesh,
+                         d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_alpha.ptr, d_dij.ptr,
+                         nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
+    else if (stages == 0)
       hipLaunchKernelGGL((k_low_order<DIM, false>), grid_rows, block, 0, stream, eparams, mesh,
                          d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_alpha.ptr, d_dij.ptr,
                          nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
@@ -658,8 +668,18 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
   /* Step 5 */
   const int n_iterations = params.limiter_iterations;
   if (n_iterations != 0) {
-    hipLaunchKernelGGL(k_pij_lij<E>, grid_rows, block, 0, stream, eparams, mesh, d_scalars.ptr,
-                       nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr);
+    if constexpr (is_euler) {
+      if (recompute_p)
+        hipLaunchKernelGGL(k_pij_lij_recompute<DIM>, grid_rows, block, 0, stream, eparams, mesh,
+                           d_scalars.ptr, weight, old.U.ptr, d_alpha.ptr, d_dij.ptr, nw.U.ptr,
+                           d_r.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr);
+      else
+        hipLaunchKernelGGL(k_pij_lij<E>, grid_rows, block, 0, stream, eparams, mesh, d_scalars.ptr,
+                           nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr);
+    } else {
+      hipLaunchKernelGGL(k_pij_lij<E>, grid_rows, block, 0, stream, eparams, mesh, d_scalars.ptr,
+                         nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr);
+    }
     exchange_matrix(d_lij.ptr);
   }
   mark(4);
