@@ -39,6 +39,42 @@ def algorithmic_bytes(dim: int, k: int, S: float, n_prec: int = 2, n_bounds: int
     }
 
 
+KERNEL_OF_SWEEP = {  # sweep name -> kernel-name prefixes in the rocprof summaries
+    "2 dij_alpha": ("k_dij_alpha",), "3 dij_diag_tau": ("k_dij_diag",), "4 low_order": ("k_low_order",),
+    "5 pij_lij": ("k_pij_lij",), "6 high_order_next_lij": ("k_high_order_next_cached", "k_high_order<"),
+    "7 high_order": ("k_high_order<",),
+}
+
+
+def pmc_traffic_bytes(sweep: str, workload: str):
+    """HBM bytes per launch of the sweep's kernel from the committed rocprofv3 --pmc passes of this same
+    command (profiles/r*_pmc.md: (2*FETCH_SIZE + WRITE_SIZE)*1024, the gfx950 correction of
+    MI355X_MICROARCH.md). PMC cannot be collected inside this process; None if no profile matches."""
+    import glob
+    import re
+    if workload != "step2d":
+        return None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.md")))
+    if not files:
+        return None
+    rows = {}
+    for line in open(files[-1]):
+        if line.startswith("| k_"):
+            cells = [c.strip() for c in line.strip().strip("|").split("|")]
+            try:
+                rows[cells[0]] = float(cells[-1]) * 1e6
+            except ValueError:
+                pass
+    last = sweep.startswith("7")
+    for name, val in rows.items():
+        for prefix in KERNEL_OF_SWEEP.get(sweep, ()):
+            if name.startswith(prefix):
+                if prefix == "k_high_order<" and (("true" in name) != last):
+                    continue
+                return val
+    return None
+
+
 class Ssprk33Stages:
     """SSPRK33 (time_integrator.template.h:302-328) unrolled into single forward-Euler updates."""
 
@@ -316,7 +352,9 @@ def main():
                    "simulated_time_at_start": drv.t, "perturbation": args.perturbation},
         "mq_per_s": n_q_total * args.steps / wall / 1e6,
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": dom_gbs, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": dom_gbs / HBM_PEAK_GBS, "traffic": None,
+                     "unit": "GB/s", "frac": dom_gbs / HBM_PEAK_GBS,
+                     "traffic": pmc_traffic_bytes(dom, args.workload),
+                     "traffic_source": "profiles/r*_pmc.md (separate rocprofv3 --pmc passes, bytes per launch)",
                      "algorithmic_bytes_per_gridpoint": alg[dom],
                      "mean_launch_ms": per_sweep[dom]},
         "roofline_update": {"bound": "hbm", "achieved": upd_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -50,6 +50,9 @@ namespace ryujin_hip
 #ifndef RYUJIN_XCD_REMAP
 #define RYUJIN_XCD_REMAP 0 /* A/B on MI355X: no gain in 2-D (1.80 vs 1.77 ms), +0.4 % in 3-D: the 256 MiB Infinity Cache already serves the cross-XCD reuse */
 #endif
+#ifndef RYUJIN_PIPE_DIJ
+#define RYUJIN_PIPE_DIJ 0 /* A/B: the pipelined variant spills (60 B scratch per lane) and is 6 % slower */
+#endif
 #ifndef RYUJIN_RECOMPUTE_P
 #define RYUJIN_RECOMPUTE_P 1
 #endif
@@ -269,23 +272,26 @@ namespace ryujin_hip
     typename E::Indicator indicator;
     indicator.reset(P, U_i, prec2[i]);
 
-    /* software pipeline: the loads of column c+1 (and the column index of c+2) are in flight while
-     * column c is processed, so the gather latency hides behind the Riemann solve */
     const uint32_t *__restrict__ cols = M.cols;
     const double *__restrict__ cij = M.cij;
+#if RYUJIN_PIPE_DIJ
+    /* software pipeline: the loads of column c+1 (and the column index of c+2) are in flight while
+     * column c is processed, so the gather latency hides behind the Riemann solve */
     uint32_t j_n = cols[(uint64_t)r.base * 64 + r.lane];
     uint32_t j_nn = r.width > 1 ? cols[((uint64_t)r.base + 1) * 64 + r.lane] : i;
     double c_n[DIM], U_n[K];
     load_entry<DIM>(cij, r.base, r.lane, c_n);
     load_state<K>(U, j_n, U_n);
     double2 prec_n = prec2[j_n];
+#endif
 
     for (uint32_t c = 0; c < r.width; ++c) {
       const uint64_t colbase = (uint64_t)r.base + c;
       const uint64_t pos = colbase * 64 + r.lane;
       const bool active = row_active && c < r.len;
-      const uint32_t j = j_n;
       double c_ij[DIM], U_j[K];
+#if RYUJIN_PIPE_DIJ
+      const uint32_t j = j_n;
 #pragma unroll
       for (int d = 0; d < DIM; ++d)
         c_ij[d] = c_n[d];
@@ -300,6 +306,12 @@ namespace ryujin_hip
         prec_n = prec2[j_n];
         j_nn = (c + 2 < r.width) ? cols[(colbase + 2) * 64 + r.lane] : i;
       }
+#else
+      const uint32_t j = cols[pos];
+      load_entry<DIM>(cij, colbase, r.lane, c_ij);
+      load_state<K>(U, j, U_j);
+      const double2 prec_j = prec2[j];
+#endif
 
       if (active) {
         indicator.accumulate(P, U_j, prec_j, c_ij);
