@@ -27,6 +27,7 @@ namespace ryujin_hip
 {
   struct DeviceMesh {
     uint32_t n_owned, n_relevant, n_slices;
+    uint32_t slice_begin, slice_end; /* slice range of this launch (export rows first, then interior) */
     const uint32_t *slice_off; /* [n_slices+1] */
     const uint8_t *row_len;    /* [n_slices*64] */
     const uint32_t *cols;      /* [nnz_total] */
@@ -178,8 +179,8 @@ namespace ryujin_hip
 #else
     const uint32_t block = blockIdx.x;
 #endif
-    r.slice = block * kWavesPerBlock + (threadIdx.x >> 6);
-    r.valid = r.slice < M.n_slices;
+    r.slice = M.slice_begin + block * kWavesPerBlock + (threadIdx.x >> 6);
+    r.valid = r.slice < M.slice_end;
     if (!r.valid) {
       r.row = r.len = r.base = r.width = 0;
       return r;
@@ -241,8 +242,8 @@ namespace ryujin_hip
   {
     constexpr int K = E::K;
     constexpr int DIM = E::DIMENSION;
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= M.n_owned)
+    const uint32_t i = M.slice_begin * 64 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M.n_owned || i >= M.slice_end * 64)
       return;
     if (M.row_len[i] == 1)
       return;

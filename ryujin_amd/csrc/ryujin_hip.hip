@@ -146,7 +146,11 @@ struct ryujin_hip_ctx {
   int dim = 0, K = 0, KP = 0, NB = 3;
   int device = 0;
   ryujin_hip_comm *comm = nullptr;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;      /* compute */
+  hipStream_t comm_stream = nullptr; /* ghost exchange, overlapped with the interior rows */
+  hipEvent_t ev_export = nullptr, ev_comm = nullptr;
+  bool comm_pending = false;
+  uint32_t n_export_slices = 0;
 
   SellLayout L;
   DeviceMesh mesh{};
@@ -212,6 +216,14 @@ struct ryujin_hip_ctx {
   {
     if (stream)
       (void)hipStreamSynchronize(stream);
+    if (comm_stream) {
+      (void)hipStreamSynchronize(comm_stream);
+      (void)hipStreamDestroy(comm_stream);
+    }
+    if (ev_export)
+      (void)hipEventDestroy(ev_export);
+    if (ev_comm)
+      (void)hipEventDestroy(ev_comm);
     for (auto &e : ev)
       if (e)
         (void)hipEventDestroy(e);
@@ -232,11 +244,17 @@ struct ryujin_hip_ctx {
   }
 
   void create(const ryujin_hip_offline &o, const ryujin_hip_params &p, ryujin_hip_comm *c, int dev);
-  void exchange_vector(double *v, int stride);
-  void exchange_matrix(double *m);
+  void exchange_vector(double *v, int stride, bool after_split_sweep);
+  void exchange_matrix(double *m, bool after_split_sweep);
   void local_exchange(double *base, const std::vector<size_t> &send_offset,
                       const std::vector<size_t> &recv_offset, const std::vector<size_t> &recv_count);
   void allreduce_scalar(void *dev_ptr, int op);
+  void wait_comm();
+  void finish();
+  void begin_exchange(bool after_split_sweep);
+  void end_exchange();
+  template <typename F>
+  void sweep(F &&launch, bool followed_by_exchange);
   template <typename E>
   void prepare_state_vector(int h, const double *dirichlet);
   template <typename E>
@@ -270,6 +288,9 @@ void ryujin_hip_ctx::create(const ryujin_hip_offline &o, const ryujin_hip_params
 
   HIP_CHECK(hipSetDevice(device));
   HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+  HIP_CHECK(hipStreamCreateWithFlags(&comm_stream, hipStreamNonBlocking));
+  HIP_CHECK(hipEventCreateWithFlags(&ev_export, hipEventDisableTiming));
+  HIP_CHECK(hipEventCreateWithFlags(&ev_comm, hipEventDisableTiming));
   for (auto &e : ev)
     HIP_CHECK(hipEventCreate(&e));
   for (auto &e : ev_user)
@@ -354,6 +375,10 @@ void ryujin_hip_ctx::create(const ryujin_hip_offline &o, const ryujin_hip_params
   mesh.n_owned = L.n_owned;
   mesh.n_relevant = L.n_relevant;
   mesh.n_slices = L.n_slices;
+  mesh.slice_begin = 0;
+  mesh.slice_end = L.n_slices;
+  /* rows [0, n_export) are the ones other ranks hold as ghosts (offline_data.template.h:213-249) */
+  n_export_slices = std::min<uint32_t>(L.n_slices, (o.n_export + kWave - 1) / kWave);
   mesh.slice_off = d_slice_off.ptr;
   mesh.row_len = d_row_len.ptr;
   mesh.cols = d_cols.ptr;
@@ -427,20 +452,77 @@ void ryujin_hip_ctx::create(const ryujin_hip_offline &o, const ryujin_hip_params
   HIP_CHECK(hipStreamSynchronize(stream));
 }
 
+/* ---- stream choreography of the ghost exchange ------------------------------------------------
+ * A sweep that is followed by an exchange runs in two launches: the export slices first, then the
+ * interior slices. The exchange (pack + RCCL send/recv) is enqueued on comm_stream behind the export
+ * launch (ev_export) and therefore overlaps with the interior launch on the compute stream -- the
+ * reference's SynchronizationDispatch idea (source/openmp.h:141-183). The compute stream joins the
+ * communication (ev_comm) right before the next kernel: interior rows never touch ghost data, but the
+ * exchange is two orders of magnitude shorter than the interior launch, so the join is free. */
+void ryujin_hip_ctx::wait_comm()
+{
+  if (comm_pending) {
+    HIP_CHECK(hipStreamWaitEvent(stream, ev_comm, 0));
+    comm_pending = false;
+  }
+}
+
+void ryujin_hip_ctx::finish()
+{
+  wait_comm();
+  HIP_CHECK(hipStreamSynchronize(stream));
+}
+
+void ryujin_hip_ctx::begin_exchange(bool after_split_sweep)
+{
+  if (!after_split_sweep)
+    HIP_CHECK(hipEventRecord(ev_export, stream)); /* everything enqueued so far */
+  HIP_CHECK(hipStreamWaitEvent(comm_stream, ev_export, 0));
+}
+
+void ryujin_hip_ctx::end_exchange()
+{
+  HIP_CHECK(hipEventRecord(ev_comm, comm_stream));
+  comm_pending = true;
+}
+
+template <typename F>
+void ryujin_hip_ctx::sweep(F &&launch, bool followed_by_exchange)
+{
+  auto run = [&](uint32_t s0, uint32_t s1) {
+    if (s1 <= s0)
+      return;
+    DeviceMesh mm = mesh;
+    mm.slice_begin = s0;
+    mm.slice_end = s1;
+    /* one wave per slice, 4 slices per block; rounded up to a multiple of 8 for the XCD remap */
+    const dim3 grid(((s1 - s0 + kWavesPerBlock - 1) / kWavesPerBlock + 7) / 8 * 8);
+    launch(mm, grid);
+  };
+  wait_comm();
+  if (n_nbr == 0 || !followed_by_exchange) {
+    run(0, L.n_slices);
+    return;
+  }
+  run(0, n_export_slices);
+  HIP_CHECK(hipEventRecord(ev_export, stream));
+  run(n_export_slices, L.n_slices);
+}
+
 /* in-process transport: publish the per-neighbour segments of the send buffer, rendezvous, pull */
 void ryujin_hip_ctx::local_exchange(double *base, const std::vector<size_t> &send_offset,
                                     const std::vector<size_t> &recv_offset,
                                     const std::vector<size_t> &recv_count)
 {
   LocalGroup &g = *comm->local;
-  HIP_CHECK(hipStreamSynchronize(stream)); /* packed data is complete */
+  HIP_CHECK(hipStreamSynchronize(comm_stream)); /* packed data is complete */
   for (int q = 0; q < n_nbr; ++q)
     g.mail[comm->rank][nbr_rank[q]] = d_send_buf.ptr + send_offset[q];
   g.barrier();
   for (int q = 0; q < n_nbr; ++q)
     HIP_CHECK(hipMemcpyAsync(base + recv_offset[q], g.mail[nbr_rank[q]][comm->rank],
-                             recv_count[q] * sizeof(double), hipMemcpyDeviceToDevice, stream));
-  HIP_CHECK(hipStreamSynchronize(stream));
+                             recv_count[q] * sizeof(double), hipMemcpyDeviceToDevice, comm_stream));
+  HIP_CHECK(hipStreamSynchronize(comm_stream));
   g.barrier(); /* send buffers may be reused */
 }
 
@@ -482,12 +564,13 @@ void ryujin_hip_ctx::allreduce_scalar(void *dev_ptr, int op)
   HIP_CHECK(hipStreamSynchronize(stream));
 }
 
-void ryujin_hip_ctx::exchange_vector(double *v, int stride)
+void ryujin_hip_ctx::exchange_vector(double *v, int stride, bool after_split_sweep)
 {
   if (n_nbr == 0)
     return;
+  begin_exchange(after_split_sweep);
   const uint32_t n_send = send_off[n_nbr];
-  hipLaunchKernelGGL(k_pack_vector, dim3(grid_for((size_t)n_send * stride)), dim3(kBlock), 0, stream,
+  hipLaunchKernelGGL(k_pack_vector, dim3(grid_for((size_t)n_send * stride)), dim3(kBlock), 0, comm_stream,
                      n_send, d_send_idx.ptr, stride, v, d_send_buf.ptr);
   if (comm->local) {
     std::vector<size_t> off(n_nbr), cnt(n_nbr), dst(n_nbr), rcnt(n_nbr);
@@ -497,26 +580,29 @@ void ryujin_hip_ctx::exchange_vector(double *v, int stride)
       rcnt[q] = (size_t)(recv_off[q + 1] - recv_off[q]) * stride;
     }
     local_exchange(v, off, dst, rcnt);
+    end_exchange();
     return;
   }
   NCCL_CHECK(ncclGroupStart());
   for (int q = 0; q < n_nbr; ++q) {
     NCCL_CHECK(ncclSend(d_send_buf.ptr + (size_t)send_off[q] * stride,
                         (size_t)(send_off[q + 1] - send_off[q]) * stride, ncclDouble, nbr_rank[q],
-                        comm->comm, stream));
+                        comm->comm, comm_stream));
     NCCL_CHECK(ncclRecv(v + (size_t)recv_off[q] * stride,
                         (size_t)(recv_off[q + 1] - recv_off[q]) * stride, ncclDouble, nbr_rank[q],
-                        comm->comm, stream));
+                        comm->comm, comm_stream));
   }
   NCCL_CHECK(ncclGroupEnd());
+  end_exchange();
 }
 
-void ryujin_hip_ctx::exchange_matrix(double *m)
+void ryujin_hip_ctx::exchange_matrix(double *m, bool after_split_sweep)
 {
   if (n_nbr == 0)
     return;
+  begin_exchange(after_split_sweep);
   const uint32_t n_send = row_send_off[n_nbr];
-  hipLaunchKernelGGL(k_pack_matrix, dim3(grid_for(n_send)), dim3(kBlock), 0, stream, n_send,
+  hipLaunchKernelGGL(k_pack_matrix, dim3(grid_for(n_send)), dim3(kBlock), 0, comm_stream, n_send,
                      d_row_send_pos.ptr, m, d_send_buf.ptr);
   if (comm->local) {
     std::vector<size_t> off(n_nbr), dst(n_nbr), rcnt(n_nbr);
@@ -526,16 +612,18 @@ void ryujin_hip_ctx::exchange_matrix(double *m)
       rcnt[q] = row_recv_off[q + 1] - row_recv_off[q];
     }
     local_exchange(m, off, dst, rcnt);
+    end_exchange();
     return;
   }
   NCCL_CHECK(ncclGroupStart());
   for (int q = 0; q < n_nbr; ++q) {
     NCCL_CHECK(ncclSend(d_send_buf.ptr + row_send_off[q], row_send_off[q + 1] - row_send_off[q],
-                        ncclDouble, nbr_rank[q], comm->comm, stream));
+                        ncclDouble, nbr_rank[q], comm->comm, comm_stream));
     NCCL_CHECK(ncclRecv(m + L.nnz_sell + row_recv_off[q], row_recv_off[q + 1] - row_recv_off[q],
-                        ncclDouble, nbr_rank[q], comm->comm, stream));
+                        ncclDouble, nbr_rank[q], comm->comm, comm_stream));
   }
   NCCL_CHECK(ncclGroupEnd());
+  end_exchange();
 }
 
 template <typename E>
@@ -543,6 +631,7 @@ void ryujin_hip_ctx::prepare_state_vector(int h, const double *dirichlet)
 {
   const auto &eparams = eq_params<E>(); /* shadows the member: the equation's parameter block */
   State &s = state(h);
+  const dim3 block(kBlock);
   if (dirichlet && n_bdry) {
     /* permute into the grouped order, then upload */
     std::vector<double> tmp((size_t)n_bdry * K);
@@ -553,14 +642,16 @@ void ryujin_hip_ctx::prepare_state_vector(int h, const double *dirichlet)
     HIP_CHECK(hipStreamSynchronize(stream)); /* tmp goes out of scope */
     have_dirichlet = true;
   }
+  wait_comm();
   if (n_groups)
-    hipLaunchKernelGGL(k_apply_bc<E>, dim3(grid_for(n_groups)), dim3(kBlock), 0, stream, eparams,
-                       n_groups, d_grp_start.ptr, d_b_i.ptr, d_b_normal.ptr, d_b_id.ptr,
-                       d_dirichlet.ptr, s.U.ptr);
-  exchange_vector(s.U.ptr, KP);
-  hipLaunchKernelGGL(k_precompute<E>, dim3(grid_for(L.n_owned)), dim3(kBlock), 0, stream, eparams,
-                     mesh, s.U.ptr, s.prec.ptr);
-  exchange_vector(s.prec.ptr, 2);
+    hipLaunchKernelGGL(k_apply_bc<E>, dim3(grid_for(n_groups)), block, 0, stream, eparams, n_groups,
+                       d_grp_start.ptr, d_b_i.ptr, d_b_normal.ptr, d_b_id.ptr, d_dirichlet.ptr,
+                       s.U.ptr);
+  exchange_vector(s.U.ptr, KP, false); /* U.update_ghost_values(), :148 */
+  sweep([&](const DeviceMesh &mm, dim3 grid) {
+    hipLaunchKernelGGL(k_precompute<E>, grid, block, 0, stream, eparams, mm, s.U.ptr, s.prec.ptr);
+  }, true);
+  exchange_vector(s.prec.ptr, 2, true); /* :157-160 */
   HIP_CHECK(hipGetLastError());
 }
 
@@ -577,8 +668,6 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
     throw HipError(RYUJIN_ERR_ARG, "old and new state vector must differ");
 
   const dim3 block(kBlock);
-  /* one wave per slice, 4 slices per block; rounded up to a multiple of 8 for the XCD remap */
-  const dim3 grid_rows(((L.n_slices + kWavesPerBlock - 1) / kWavesPerBlock + 7) / 8 * 8);
 
   /* scalars: tau_max := tau_max_in, flags := 0 */
   DeviceScalars init{};
@@ -592,34 +681,38 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
                            stream));
 
   mark(0);
-  /* Step 2 */
-  hipLaunchKernelGGL(k_dij_alpha<E>, grid_rows, block, 0, stream, eparams, mesh, old.U.ptr,
-                     old.prec.ptr, d_dij.ptr, d_alpha.ptr);
-  exchange_vector(d_alpha.ptr, 1);
+  /* Step 2: d_ij (upper triangle), alpha_i; ghost alpha (:341-424) */
+  sweep([&](const DeviceMesh &mm, dim3 grid) {
+    hipLaunchKernelGGL(k_dij_alpha<E>, grid, block, 0, stream, eparams, mm, old.U.ptr, old.prec.ptr,
+                       d_dij.ptr, d_alpha.ptr);
+  }, true);
+  exchange_vector(d_alpha.ptr, 1, true);
   mark(1);
 
-  /* Step 3 */
+  /* Step 3: boundary d_ij, symmetrise, diagonal, tau_max (:432-578) */
   if (n_pairs)
     hipLaunchKernelGGL(k_dij_boundary<E>, dim3(grid_for(n_pairs)), block, 0, stream, eparams,
                        n_pairs, d_p_i.ptr, d_p_j.ptr, d_p_pos.ptr, (const uint32_t *)nullptr,
                        d_p_cji.ptr, old.U.ptr, d_dij.ptr);
-  if (L.max_row_len <= 3)
-    hipLaunchKernelGGL(k_dij_diag_unrolled<3>, grid_rows, block, 0, stream, mesh, d_lower_mask.ptr,
-                       params.cfl, d_dij.ptr, d_scalars.ptr);
-  else if (L.max_row_len <= 9)
-    hipLaunchKernelGGL(k_dij_diag_unrolled<9>, grid_rows, block, 0, stream, mesh, d_lower_mask.ptr,
-                       params.cfl, d_dij.ptr, d_scalars.ptr);
-  else if (L.max_row_len <= 27)
-    hipLaunchKernelGGL(k_dij_diag_unrolled<27>, grid_rows, block, 0, stream, mesh, d_lower_mask.ptr,
-                       params.cfl, d_dij.ptr, d_scalars.ptr);
-  else
-    hipLaunchKernelGGL(k_dij_diag, grid_rows, block, 0, stream, mesh, params.cfl, d_dij.ptr,
-                       d_scalars.ptr);
+  sweep([&](const DeviceMesh &mm, dim3 grid) {
+    if (L.max_row_len <= 3)
+      hipLaunchKernelGGL(k_dij_diag_unrolled<3>, grid, block, 0, stream, mm, d_lower_mask.ptr,
+                         params.cfl, d_dij.ptr, d_scalars.ptr);
+    else if (L.max_row_len <= 9)
+      hipLaunchKernelGGL(k_dij_diag_unrolled<9>, grid, block, 0, stream, mm, d_lower_mask.ptr,
+                         params.cfl, d_dij.ptr, d_scalars.ptr);
+    else if (L.max_row_len <= 27)
+      hipLaunchKernelGGL(k_dij_diag_unrolled<27>, grid, block, 0, stream, mm, d_lower_mask.ptr,
+                         params.cfl, d_dij.ptr, d_scalars.ptr);
+    else
+      hipLaunchKernelGGL(k_dij_diag, grid, block, 0, stream, mm, params.cfl, d_dij.ptr,
+                         d_scalars.ptr);
+  }, false);
   allreduce_scalar(&d_scalars.ptr->tau_max_bits, 0); /* Utilities::MPI::min(tau_max), :571 */
   hipLaunchKernelGGL(k_finalize_tau, dim3(1), dim3(1), 0, stream, tau_in, d_scalars.ptr);
   mark(2);
 
-  /* Step 4 */
+  /* Step 4: low-order update, bounds, r_i, p_ij; ghost r (:597-884) */
   double weight;
   {
     double acc = -1.;
@@ -634,80 +727,87 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
     S.prec[s] = state(h_stage[s]).prec.ptr;
     S.w[s] = w[s];
   }
-  /* Euler, stages == 0, limiter on: P_ij (part 1) is recomputed in step 5 instead of stored here */
-  /* A/B on MI355X: -7 % per update in 2-D (k=4, 9 columns); +1 % in 3-D where step 5 turns
+  /* Euler, stages == 0, limiter on: P_ij (part 1) is recomputed in step 5 instead of stored here.
+   * A/B on MI355X: -7 % per update in 2-D (k=4, 9 columns); +1 % in 3-D where step 5 turns
    * register/VALU bound (k=5, 27 columns), so only for dim <= 2. */
   const bool recompute_p = is_euler && DIM <= 2 && stages == 0 && params.limiter_iterations != 0 &&
                            RYUJIN_RECOMPUTE_P;
-  if constexpr (is_euler) {
-    if (recompute_p)
-      hipLaunchKernelGGL((k_low_order<DIM, false, false>), grid_rows, block, 0, stream, eparams, mesh,
-                         d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_alpha.ptr, d_dij.ptr,
-                         nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
-    else if (stages == 0)
-      hipLaunchKernelGGL((k_low_order<DIM, false>), grid_rows, block, 0, stream, eparams, mesh,
-                         d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_alpha.ptr, d_dij.ptr,
-                         nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
-    else
-      hipLaunchKernelGGL((k_low_order<DIM, true>), grid_rows, block, 0, stream, eparams, mesh,
-                         d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_alpha.ptr, d_dij.ptr,
-                         nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
-  } else {
-    if (stages == 0)
-      hipLaunchKernelGGL((k_low_order_sw<DIM, false>), grid_rows, block, 0, stream, eparams, mesh,
-                         d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_Z.ptr, d_alpha.ptr,
-                         d_dij.ptr, nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
-    else
-      hipLaunchKernelGGL((k_low_order_sw<DIM, true>), grid_rows, block, 0, stream, eparams, mesh,
-                         d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_Z.ptr, d_alpha.ptr,
-                         d_dij.ptr, nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
-  }
-  exchange_vector(d_r.ptr, KP);
-  mark(3);
-
-  /* Step 5 */
-  const int n_iterations = params.limiter_iterations;
-  if (n_iterations != 0) {
+  sweep([&](const DeviceMesh &mm, dim3 grid) {
     if constexpr (is_euler) {
       if (recompute_p)
-        hipLaunchKernelGGL(k_pij_lij_recompute<DIM>, grid_rows, block, 0, stream, eparams, mesh,
-                           d_scalars.ptr, weight, old.U.ptr, d_alpha.ptr, d_dij.ptr, nw.U.ptr,
-                           d_r.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr);
+        hipLaunchKernelGGL((k_low_order<DIM, false, false>), grid, block, 0, stream, eparams, mm,
+                           d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_alpha.ptr, d_dij.ptr,
+                           nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
+      else if (stages == 0)
+        hipLaunchKernelGGL((k_low_order<DIM, false>), grid, block, 0, stream, eparams, mm,
+                           d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_alpha.ptr, d_dij.ptr,
+                           nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
       else
-        hipLaunchKernelGGL(k_pij_lij<E>, grid_rows, block, 0, stream, eparams, mesh, d_scalars.ptr,
-                           nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr);
+        hipLaunchKernelGGL((k_low_order<DIM, true>), grid, block, 0, stream, eparams, mm,
+                           d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_alpha.ptr, d_dij.ptr,
+                           nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
     } else {
-      hipLaunchKernelGGL(k_pij_lij<E>, grid_rows, block, 0, stream, eparams, mesh, d_scalars.ptr,
-                         nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr);
+      if (stages == 0)
+        hipLaunchKernelGGL((k_low_order_sw<DIM, false>), grid, block, 0, stream, eparams, mm,
+                           d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_Z.ptr, d_alpha.ptr,
+                           d_dij.ptr, nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
+      else
+        hipLaunchKernelGGL((k_low_order_sw<DIM, true>), grid, block, 0, stream, eparams, mm,
+                           d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_Z.ptr, d_alpha.ptr,
+                           d_dij.ptr, nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
     }
-    exchange_matrix(d_lij.ptr);
+  }, true);
+  exchange_vector(d_r.ptr, KP, true);
+  mark(3);
+
+  /* Step 5: second part of p_ij, first l_ij; ghost rows of l_ij (:892-1041) */
+  const int n_iterations = params.limiter_iterations;
+  if (n_iterations != 0) {
+    sweep([&](const DeviceMesh &mm, dim3 grid) {
+      if constexpr (is_euler) {
+        if (recompute_p) {
+          hipLaunchKernelGGL(k_pij_lij_recompute<DIM>, grid, block, 0, stream, eparams, mm,
+                             d_scalars.ptr, weight, old.U.ptr, d_alpha.ptr, d_dij.ptr, nw.U.ptr,
+                             d_r.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr);
+          return;
+        }
+      }
+      hipLaunchKernelGGL(k_pij_lij<E>, grid, block, 0, stream, eparams, mm, d_scalars.ptr, nw.U.ptr,
+                         d_r.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr);
+    }, true);
+    exchange_matrix(d_lij.ptr, true);
   }
   mark(4);
 
-  /* Steps 6, 7 */
+  /* Steps 6, 7: symmetrise l_ij, high-order update, next l_ij (:1053-1182) */
   for (int pass = 0; pass < n_iterations; ++pass) {
     const bool last_round = (pass + 1 == n_iterations);
     if (n_iterations == 2 && last_round)
       std::swap(d_lij.ptr, d_lij_next.ptr);
     if (last_round) {
-      hipLaunchKernelGGL((k_high_order<E, true>), grid_rows, block, 0, stream, eparams, mesh,
-                         nw.U.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr, d_lij_next.ptr);
+      sweep([&](const DeviceMesh &mm, dim3 grid) {
+        hipLaunchKernelGGL((k_high_order<E, true>), grid, block, 0, stream, eparams, mm, nw.U.ptr,
+                           d_bounds.ptr, d_pij.ptr, d_lij.ptr, d_lij_next.ptr);
+      }, false);
     } else {
       constexpr int kCachedWidth = DIM == 1 ? 3 : 9;
-      if (DIM <= 2 && L.max_row_len <= (uint32_t)kCachedWidth)
-        hipLaunchKernelGGL((k_high_order_next_cached<E, kCachedWidth>), grid_rows, block, 0, stream,
-                           eparams, mesh, nw.U.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr,
-                           d_lij_next.ptr);
-      else
-        hipLaunchKernelGGL((k_high_order<E, false>), grid_rows, block, 0, stream, eparams, mesh,
-                           nw.U.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr, d_lij_next.ptr);
-      exchange_matrix(d_lij_next.ptr);
+      sweep([&](const DeviceMesh &mm, dim3 grid) {
+        if (DIM <= 2 && L.max_row_len <= (uint32_t)kCachedWidth)
+          hipLaunchKernelGGL((k_high_order_next_cached<E, kCachedWidth>), grid, block, 0, stream,
+                             eparams, mm, nw.U.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr,
+                             d_lij_next.ptr);
+        else
+          hipLaunchKernelGGL((k_high_order<E, false>), grid, block, 0, stream, eparams, mm, nw.U.ptr,
+                             d_bounds.ptr, d_pij.ptr, d_lij.ptr, d_lij_next.ptr);
+      }, true);
+      exchange_matrix(d_lij_next.ptr, true);
     }
     mark(5 + pass);
   }
   for (int k = 5 + n_iterations; k <= 7; ++k)
     mark(k);
 
+  wait_comm();
   allreduce_scalar(&d_scalars.ptr->restart_needed, 1); /* MPI::logical_or(restart_needed), :1194 */
 
   HIP_CHECK(hipGetLastError());
@@ -940,7 +1040,7 @@ int ryujin_hip_state_upload(ryujin_hip_ctx *ctx, int handle, const double *U_aos
     auto &s = ctx->state(handle);
     const size_t n = ctx->L.n_relevant;
     const int K = ctx->K, KP = ctx->KP;
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->finish();
     if (K == KP) {
       HIP_CHECK(hipMemcpy(s.U.ptr, U_aos, n * K * sizeof(double), hipMemcpyHostToDevice));
     } else {
@@ -959,7 +1059,7 @@ int ryujin_hip_state_download(ryujin_hip_ctx *ctx, int handle, double *U_aos)
     auto &s = ctx->state(handle);
     const size_t n = ctx->L.n_relevant;
     const int K = ctx->K, KP = ctx->KP;
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->finish();
     if (K == KP) {
       HIP_CHECK(hipMemcpy(U_aos, s.U.ptr, n * K * sizeof(double), hipMemcpyDeviceToHost));
     } else {
@@ -976,7 +1076,7 @@ int ryujin_hip_state_download_precomputed(ryujin_hip_ctx *ctx, int handle, doubl
 {
   return guarded([&]() {
     auto &s = ctx->state(handle);
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->finish();
     HIP_CHECK(hipMemcpy(prec_aos, s.prec.ptr, (size_t)ctx->L.n_relevant * 2 * sizeof(double),
                         hipMemcpyDeviceToHost));
     return RYUJIN_OK;
@@ -1017,6 +1117,7 @@ int ryujin_hip_sadd(ryujin_hip_ctx *ctx, int h_dst, double s, double b, int h_sr
     auto &dst = ctx->state(h_dst);
     auto &src = ctx->state(h_src);
     const size_t n = (size_t)ctx->L.n_relevant * ctx->KP;
+    ctx->wait_comm();
     const int grid = (int)std::min<size_t>(2048, (n / 2 + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(k_sadd, dim3(std::max(1, grid)), dim3(kBlock), 0, ctx->stream, n, s, b,
                        dst.U.ptr, src.U.ptr);
@@ -1046,7 +1147,7 @@ int ryujin_hip_set_id_violation_strategy(ryujin_hip_ctx *ctx, int strategy)
 int ryujin_hip_get_alpha(ryujin_hip_ctx *ctx, double *alpha)
 {
   return guarded([&]() {
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->finish();
     HIP_CHECK(hipMemcpy(alpha, ctx->d_alpha.ptr, (size_t)ctx->L.n_relevant * sizeof(double),
                         hipMemcpyDeviceToHost));
     return RYUJIN_OK;
@@ -1064,7 +1165,7 @@ int ryujin_hip_debug_fetch(ryujin_hip_ctx *ctx, int what, double *out, size_t n_
 {
   return guarded([&]() {
     const auto &L = ctx->L;
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->finish();
     auto fetch_matrix = [&](const double *dev, uint32_t n_comp) {
       if (n_doubles < L.nnz_owned_logical * n_comp)
         throw HipError(RYUJIN_ERR_ARG, "output buffer too small");
@@ -1172,7 +1273,7 @@ int ryujin_hip_get_timers(ryujin_hip_ctx *ctx, double ms[8])
 int ryujin_hip_synchronize(ryujin_hip_ctx *ctx)
 {
   return guarded([&]() {
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->finish();
     return RYUJIN_OK;
   });
 }
