@@ -253,9 +253,9 @@ int ryujin_hip_get_counters(ryujin_hip_ctx *ctx, unsigned *n_restarts, unsigned 
  * what: 0 d_ij, 1 l_ij (after the last pass = lij_matrix_), 2 p_ij (k comps),
  *       3 bounds (n_bounds per row), 4 r_i (k per row), 5 lij_next */
 int ryujin_hip_debug_fetch(ryujin_hip_ctx *ctx, int what, double *out, size_t n_doubles);
-/* wall time [ms] of each of the 7 sweeps of the last step (hipEvent pairs; names as
- * the reference's Scope timers "time step [H] 1..7"); enable = nonzero switches the
- * event recording on (off by default). */
+/* device time [ms] of the sweeps of the last step (hipEvent pairs; ms[n] = the reference's Scope timer
+ * "time step [H] n", n = 2..7; ms[1] unused (step 1 is a separate call); ms[0] = the indicator kernel
+ * alone when step 2 runs as two kernels, else 0); enable = nonzero switches the event recording on. */
 int ryujin_hip_set_timers(ryujin_hip_ctx *ctx, int enable);
 int ryujin_hip_get_timers(ryujin_hip_ctx *ctx, double ms[8]);
 /* Block until all device work of this context has finished. */

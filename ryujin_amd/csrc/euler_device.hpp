@@ -15,6 +15,10 @@
 
 #include <cfloat>
 
+#ifndef RYUJIN_SCHED_FENCE
+#define RYUJIN_SCHED_FENCE 0
+#endif
+
 namespace ryujin_hip
 {
   struct EulerParams {
@@ -28,6 +32,15 @@ namespace ryujin_hip
   };
 
 #define RYUJIN_DEV __device__ __forceinline__
+
+/* Scheduling fence between independent blocks of the Riemann solver: keeps the compiler from
+ * interleaving the expansions of several pow/sqrt/div at once (which needs >250 registers) so that the
+ * sweep fits a higher occupancy without spilling. Purely a scheduling hint: no effect on results. */
+#if RYUJIN_SCHED_FENCE
+#define RYUJIN_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define RYUJIN_FENCE() ((void)0)
+#endif
 
   /*
    * ryujin::pow (source/simd.template.h:196-272) on the device.
@@ -407,9 +420,11 @@ namespace ryujin_hip
         const double numerator = positive_part(rd_i.a + rd_j.a - factor * (rd_j.u - rd_i.u));
         const double denominator =
             rd_i.a * dev_pow(rd_i.p * inv_p_j, -factor * P.gamma_inverse) + rd_j.a;
+        RYUJIN_FENCE();
         const double exponent = 2.0 * P.gamma * P.gamma_minus_one_inverse;
         rarefaction = rd_j.p * dev_pow(numerator / denominator, exponent);
       }
+      RYUJIN_FENCE();
 
       /* p_star_failsafe :330-374 */
       double failsafe;
@@ -426,6 +441,7 @@ namespace ryujin_hip
         const double base = (-b + sqrt(b * b - 4. * a * c)) / (2. * a);
         failsafe = base * base;
       }
+      RYUJIN_FENCE();
       const double p_star_tilde = fmin(rarefaction, failsafe);
 
       /* phi_of_p_max :122-149 */
@@ -439,6 +455,7 @@ namespace ryujin_hip
         const double value_j = (p_max - rd_j.p) / sqrt(radicand_inverse_j);
         phi_p_max = value_i + value_j + rd_j.u - rd_i.u;
       }
+      RYUJIN_FENCE();
 
       double p_2 = phi_p_max < 0. ? p_star_tilde : fmin(p_max, p_star_tilde);
 
@@ -483,7 +500,9 @@ namespace ryujin_hip
       for (int d = 0; d < DIM; ++d)
         n[d] = c[d] / norm;
       const RiemannData rd_i = riemann_data_from_state(P, U_i, n);
+      RYUJIN_FENCE();
       const RiemannData rd_j = riemann_data_from_state(P, U_j, n);
+      RYUJIN_FENCE();
       return norm * riemann_compute(P, rd_i, rd_j);
     }
 

@@ -51,6 +51,9 @@ namespace ryujin_hip
 #ifndef RYUJIN_XCD_REMAP
 #define RYUJIN_XCD_REMAP 0 /* A/B on MI355X: no gain in 2-D (1.80 vs 1.77 ms), +0.4 % in 3-D: the 256 MiB Infinity Cache already serves the cross-XCD reuse */
 #endif
+#ifndef RYUJIN_SPLIT_DIJ
+#define RYUJIN_SPLIT_DIJ 1
+#endif
 #ifndef RYUJIN_PIPE_DIJ
 #define RYUJIN_PIPE_DIJ 0 /* A/B: the pipelined variant spills (60 B scratch per lane) and is 6 % slower */
 #endif
@@ -324,6 +327,96 @@ namespace ryujin_hip
 
     if (row_active)
       alpha[i] = indicator.alpha(P, M.mi[i] * M.measure_of_omega_inverse);
+  }
+
+  /* Step 2 as two kernels (RYUJIN_SPLIT_DIJ): the streaming indicator sweep and the compute-bound
+   * Riemann sweep have very different register needs; split, the Riemann kernel only touches the
+   * upper-triangle columns (known from the per-row bitmask, no loads for the others) and runs at a
+   * higher occupancy. */
+  template <typename E>
+  __global__ void __launch_bounds__(kBlock)
+  k_alpha(const typename E::Params P, const DeviceMesh M, const double *__restrict__ U,
+          const double *__restrict__ prec, double *__restrict__ alpha)
+  {
+    constexpr int K = E::K;
+    constexpr int DIM = E::DIMENSION;
+    const RowCtx r = row_context(M);
+    if (!r.valid)
+      return;
+    const bool row_active = r.len > 1;
+    const uint32_t i = row_active ? r.row : (r.row < M.n_owned ? r.row : M.n_owned - 1);
+    const double2 *__restrict__ prec2 = reinterpret_cast<const double2 *>(prec);
+    const uint32_t *__restrict__ cols = M.cols;
+    const double *__restrict__ cij = M.cij;
+
+    double U_i[K];
+    load_state<K>(U, i, U_i);
+    typename E::Indicator indicator;
+    indicator.reset(P, U_i, prec2[i]);
+
+    uint32_t j_n = cols[(uint64_t)r.base * 64 + r.lane];
+    uint32_t j_nn = r.width > 1 ? cols[((uint64_t)r.base + 1) * 64 + r.lane] : i;
+    double c_n[DIM], U_n[K];
+    load_entry<DIM>(cij, r.base, r.lane, c_n);
+    load_state<K>(U, j_n, U_n);
+    double2 prec_n = prec2[j_n];
+    for (uint32_t c = 0; c < r.width; ++c) {
+      const uint64_t colbase = (uint64_t)r.base + c;
+      double c_ij[DIM], U_j[K];
+#pragma unroll
+      for (int d = 0; d < DIM; ++d)
+        c_ij[d] = c_n[d];
+#pragma unroll
+      for (int q = 0; q < K; ++q)
+        U_j[q] = U_n[q];
+      const double2 prec_j = prec_n;
+      if (c + 1 < r.width) {
+        j_n = j_nn;
+        load_entry<DIM>(cij, colbase + 1, r.lane, c_n);
+        load_state<K>(U, j_n, U_n);
+        prec_n = prec2[j_n];
+        j_nn = (c + 2 < r.width) ? cols[(colbase + 2) * 64 + r.lane] : i;
+      }
+      if (row_active && c < r.len)
+        indicator.accumulate(P, U_j, prec_j, c_ij);
+    }
+    if (row_active)
+      alpha[i] = indicator.alpha(P, M.mi[i] * M.measure_of_omega_inverse);
+  }
+
+  template <typename E>
+  __global__ void __launch_bounds__(kBlock, RYUJIN_OCC_DIJ)
+  k_dij(const typename E::Params P, const DeviceMesh M, const uint32_t *__restrict__ lower_mask,
+        const double *__restrict__ U, double *__restrict__ dij)
+  {
+    constexpr int K = E::K;
+    constexpr int DIM = E::DIMENSION;
+    const RowCtx r = row_context(M);
+    if (!r.valid)
+      return;
+    const bool row_active = r.len > 1;
+    const uint32_t i = row_active ? r.row : (r.row < M.n_owned ? r.row : M.n_owned - 1);
+    const uint32_t *__restrict__ cols = M.cols;
+    const double *__restrict__ cij = M.cij;
+    /* columns 1..len-1 that lie above the diagonal */
+    const uint32_t upper =
+        row_active ? (~lower_mask[r.row] & (r.len >= 32 ? 0xFFFFFFFFu : ((1u << r.len) - 1u)) & ~1u) : 0u;
+
+    double U_i[K];
+    load_state<K>(U, i, U_i);
+    for (uint32_t c = 1; c < r.width; ++c) {
+      const bool mine = (upper >> c) & 1u;
+      if (!__any(mine))
+        continue; /* wave-uniform: no loads at all for lower-triangle columns */
+      const uint64_t colbase = (uint64_t)r.base + c;
+      const uint64_t pos = colbase * 64 + r.lane;
+      const uint32_t j = cols[pos];
+      double c_ij[DIM], U_j[K];
+      load_entry<DIM>(cij, colbase, r.lane, c_ij);
+      load_state<K>(U, j, U_j);
+      if (mine)
+        dij[pos] = E::dij_from_states(P, U_i, U_j, c_ij);
+    }
   }
 
   /* ------------------------------------------------------------------ step 3 */

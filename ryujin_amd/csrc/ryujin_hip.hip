@@ -682,11 +682,27 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
 
   mark(0);
   /* Step 2: d_ij (upper triangle), alpha_i; ghost alpha (:341-424) */
-  sweep([&](const DeviceMesh &mm, dim3 grid) {
-    hipLaunchKernelGGL(k_dij_alpha<E>, grid, block, 0, stream, eparams, mm, old.U.ptr, old.prec.ptr,
-                       d_dij.ptr, d_alpha.ptr);
-  }, true);
-  exchange_vector(d_alpha.ptr, 1, true);
+  if (RYUJIN_SPLIT_DIJ && L.max_row_len <= 32) {
+    sweep([&](const DeviceMesh &mm, dim3 grid) {
+      hipLaunchKernelGGL(k_alpha<E>, grid, block, 0, stream, eparams, mm, old.U.ptr, old.prec.ptr,
+                         d_alpha.ptr);
+    }, true);
+    mark(8); /* end of the indicator kernel: sweep_ms[0] = k_alpha alone */
+    exchange_vector(d_alpha.ptr, 1, true); /* overlaps with the Riemann sweep as well */
+    const bool pending = comm_pending;
+    comm_pending = false; /* k_dij does not read alpha: do not join the exchange yet */
+    sweep([&](const DeviceMesh &mm, dim3 grid) {
+      hipLaunchKernelGGL(k_dij<E>, grid, block, 0, stream, eparams, mm, d_lower_mask.ptr, old.U.ptr,
+                         d_dij.ptr);
+    }, false);
+    comm_pending = pending;
+  } else {
+    sweep([&](const DeviceMesh &mm, dim3 grid) {
+      hipLaunchKernelGGL(k_dij_alpha<E>, grid, block, 0, stream, eparams, mm, old.U.ptr,
+                         old.prec.ptr, d_dij.ptr, d_alpha.ptr);
+    }, true);
+    exchange_vector(d_alpha.ptr, 1, true);
+  }
   mark(1);
 
   /* Step 3: boundary d_ij, symmetrise, diagonal, tau_max (:432-578) */
@@ -820,6 +836,12 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
       float ms = 0.f;
       HIP_CHECK(hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
       sweep_ms[k + 1] = ms;
+    }
+    sweep_ms[0] = 0.;
+    if (RYUJIN_SPLIT_DIJ && L.max_row_len <= 32) {
+      float ms = 0.f;
+      HIP_CHECK(hipEventElapsedTime(&ms, ev[0], ev[8]));
+      sweep_ms[0] = ms;
     }
   }
 
