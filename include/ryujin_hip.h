@@ -240,6 +240,26 @@ int ryujin_hip_step(ryujin_hip_ctx *ctx, int h_old, int stages, const int *h_sta
  * sadd(dst,s,b,src): dst.U = s*dst.U + b*src.U (time_integrator.template.h:18-25) */
 int ryujin_hip_sadd(ryujin_hip_ctx *ctx, int h_dst, double s, double b, int h_src);
 
+/* Device-resident TimeIntegrator::step (source/time_integrator.template.h:207-403) for the explicit
+ * schemes built from prepare_state_vector + step<s> + sadd. One host synchronisation per RK step: the
+ * tau of the first stage and the restart flags of all stages stay on the device. h_state names the
+ * solution before and after the call (state_vector.swap(temp) is done on the handles); h_tmp are three
+ * scratch state vectors (temp_[0..2]). dirichlet_aos as in prepare_state_vector (time independent; use
+ * the per-stage API for time-dependent Dirichlet data). tau_max = t_final - t. With
+ * RYUJIN_CFL_RECOVERY_BANG_BANG the reference's bang-bang control (:250-274) is applied internally.
+ * *tau_out = the time increment of the whole RK step (3 tau for ERK33). */
+enum {
+  RYUJIN_SCHEME_SSPRK_22 = 0,
+  RYUJIN_SCHEME_SSPRK_33 = 1,
+  RYUJIN_SCHEME_ERK_11 = 2,
+  RYUJIN_SCHEME_ERK_22 = 3,
+  RYUJIN_SCHEME_ERK_33 = 4
+};
+enum { RYUJIN_CFL_RECOVERY_NONE = 0, RYUJIN_CFL_RECOVERY_BANG_BANG = 1 };
+int ryujin_hip_time_step(ryujin_hip_ctx *ctx, int scheme, int h_state, const int h_tmp[3],
+                         const double *dirichlet_aos, double tau_max, int cfl_recovery, double cfl_min,
+                         double cfl_max, double *tau_out);
+
 /* ---- accessors of HyperbolicModule (hyperbolic_module.h:225-278) --------- */
 int ryujin_hip_set_cfl(ryujin_hip_ctx *ctx, double cfl);
 int ryujin_hip_get_cfl(ryujin_hip_ctx *ctx, double *cfl);
@@ -258,6 +278,8 @@ int ryujin_hip_debug_fetch(ryujin_hip_ctx *ctx, int what, double *out, size_t n_
  * alone when step 2 runs as two kernels, else 0); enable = nonzero switches the event recording on. */
 int ryujin_hip_set_timers(ryujin_hip_ctx *ctx, int enable);
 int ryujin_hip_get_timers(ryujin_hip_ctx *ctx, double ms[8]);
+/* sums over all updates since the last reset (also filled by ryujin_hip_time_step) */
+int ryujin_hip_get_timers_accum(ryujin_hip_ctx *ctx, double ms[8], unsigned *n_updates, int reset);
 /* Block until all device work of this context has finished. */
 int ryujin_hip_synchronize(ryujin_hip_ctx *ctx);
 /* Record start/stop HIP events on the context's compute stream and read the elapsed ms. */

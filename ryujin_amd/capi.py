@@ -23,6 +23,8 @@ EQ_EULER, EQ_SHALLOW_WATER = 0, 1
 BC_DO_NOTHING, BC_PERIODIC, BC_SLIP, BC_NO_SLIP, BC_DIRICHLET, BC_DYNAMIC, BC_DIRICHLET_MOMENTUM = range(7)
 IDV_WARN, IDV_RAISE_EXCEPTION = 0, 1
 CUT_NONE, CUT_BOX, CUT_CYLINDER = 0, 1, 2
+SCHEME_SSPRK_22, SCHEME_SSPRK_33, SCHEME_ERK_11, SCHEME_ERK_22, SCHEME_ERK_33 = range(5)
+CFL_RECOVERY_NONE, CFL_RECOVERY_BANG_BANG = 0, 1
 UNIQUE_ID_BYTES = 128
 
 
@@ -118,7 +120,8 @@ HIP_SYMBOLS = [
     "ryujin_hip_default_params", "ryujin_hip_create", "ryujin_hip_destroy",
     "ryujin_hip_state_alloc", "ryujin_hip_state_free", "ryujin_hip_state_upload",
     "ryujin_hip_state_download", "ryujin_hip_state_download_precomputed",
-    "ryujin_hip_prepare_state_vector", "ryujin_hip_step", "ryujin_hip_sadd",
+    "ryujin_hip_prepare_state_vector", "ryujin_hip_step", "ryujin_hip_sadd", "ryujin_hip_time_step",
+    "ryujin_hip_get_timers_accum",
     "ryujin_hip_set_cfl", "ryujin_hip_get_cfl", "ryujin_hip_set_id_violation_strategy",
     "ryujin_hip_get_alpha", "ryujin_hip_get_counters", "ryujin_hip_debug_fetch",
     "ryujin_hip_set_timers", "ryujin_hip_get_timers", "ryujin_hip_synchronize",
@@ -177,6 +180,9 @@ def load_hip():
         lib.ryujin_hip_comm_destroy.restype = None
         lib.ryujin_hip_set_timers.argtypes = [vp, C.c_int]
         lib.ryujin_hip_get_timers.argtypes = [vp, c_double_p]
+        lib.ryujin_hip_get_timers_accum.argtypes = [vp, c_double_p, C.POINTER(C.c_uint), C.c_int]
+        lib.ryujin_hip_time_step.argtypes = [vp, C.c_int, C.c_int, c_int_p, c_double_p, C.c_double, C.c_int,
+                                             C.c_double, C.c_double, c_double_p]
         lib.ryujin_hip_synchronize.argtypes = [vp]
         lib.ryujin_hip_event_record.argtypes = [vp, C.c_int]
         lib.ryujin_hip_event_elapsed_ms.argtypes = [vp, c_double_p]

@@ -44,6 +44,11 @@ namespace ryujin_hip
     double tau;                      /* the tau used by steps 4,5 */
     int restart_needed;
     int tau_invalid;
+    /* device-resident Runge-Kutta driver (ryujin_hip_time_step): the tau of the first stage and the
+     * flags of all stages stay on the device until the end of the RK step */
+    double tau_rk;
+    int restart_accum;
+    int tau_invalid_accum;
   };
 
   /* minimum waves per SIMD requested from the register allocator for the heavy sweeps (second
@@ -527,12 +532,41 @@ namespace ryujin_hip
     publish_tau_min(scalars, wave_min(tau), r.lane);
   }
 
-  /* tau = (tau_in == 0 ? tau_max : tau_in), validity check (:571-578) */
-  __global__ void k_finalize_tau(const double tau_in, DeviceScalars *__restrict__ scalars)
+  /* start of a step: tau_max := tau_max_in, per-step flags := 0 (accumulators untouched) */
+  __global__ void k_reset_scalars(const double tau_max_in, const int reset_accumulators,
+                                  DeviceScalars *__restrict__ scalars)
+  {
+    scalars->tau_max_bits = (unsigned long long)__double_as_longlong(tau_max_in);
+    scalars->restart_needed = 0;
+    scalars->tau_invalid = 0;
+    if (reset_accumulators) {
+      scalars->restart_accum = 0;
+      scalars->tau_invalid_accum = 0;
+    }
+  }
+
+  /* tau = (tau_in == 0 ? tau_max : tau_in), validity check (:571-578); use_device_tau: later stages of
+   * a device-resident RK step reuse the tau of the first stage without a host round trip */
+  __global__ void k_finalize_tau(const double tau_in, const int use_device_tau,
+                                 DeviceScalars *__restrict__ scalars)
   {
     const double tau_max = __longlong_as_double((long long)scalars->tau_max_bits);
-    scalars->tau_invalid = (isnan(tau_max) || isinf(tau_max) || !(tau_max > 0.)) ? 1 : 0;
-    scalars->tau = (tau_in == 0. ? tau_max : tau_in);
+    const int invalid = (isnan(tau_max) || isinf(tau_max) || !(tau_max > 0.)) ? 1 : 0;
+    scalars->tau_invalid = invalid;
+    scalars->tau_invalid_accum |= invalid;
+    if (use_device_tau) {
+      scalars->tau = scalars->tau_rk;
+    } else {
+      const double tau = (tau_in == 0. ? tau_max : tau_in);
+      scalars->tau = tau;
+      scalars->tau_rk = tau;
+    }
+  }
+
+  /* end of a step: fold the (all-reduced) restart flag into the accumulator */
+  __global__ void k_accumulate_flags(DeviceScalars *__restrict__ scalars)
+  {
+    scalars->restart_accum |= scalars->restart_needed;
   }
 
   /* ------------------------------------------------------------------ step 4 */

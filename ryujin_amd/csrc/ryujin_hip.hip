@@ -15,6 +15,7 @@
 #include <cmath>
 #include <cstring>
 #include <condition_variable>
+#include <limits>
 #include <memory>
 #include <mutex>
 #include <numeric>
@@ -208,6 +209,12 @@ struct ryujin_hip_ctx {
 
   /* profiling */
   bool timers_enabled = false;
+  /* device-resident RK driver: per-step host synchronisation is deferred to the end of the RK step */
+  bool deferred = false;
+  int rk_stage = 0; /* selects the event set while deferred */
+  double sweep_ms_accum[8] = {};
+  unsigned sweep_updates_accum = 0;
+  hipEvent_t ev_rk[4][9] = {};
   hipEvent_t ev[9] = {};
   hipEvent_t ev_user[2] = {};
   double sweep_ms[8] = {};
@@ -227,6 +234,10 @@ struct ryujin_hip_ctx {
     for (auto &e : ev)
       if (e)
         (void)hipEventDestroy(e);
+    for (auto &set : ev_rk)
+      for (auto &e : set)
+        if (e)
+          (void)hipEventDestroy(e);
     for (auto &e : ev_user)
       if (e)
         (void)hipEventDestroy(e);
@@ -260,10 +271,13 @@ struct ryujin_hip_ctx {
   template <typename E>
   int step(int h_old, int stages, const int *h_stage, const double *w, int h_new, double tau_in,
            double tau_max_in, double *tau_out);
+  template <typename E>
+  int time_step(int scheme, int h_state, const int *h_tmp, const double *dirichlet, double tau_max,
+                int cfl_recovery, double cfl_min, double cfl_max, double *tau_out);
   void mark(int k)
   {
     if (timers_enabled)
-      HIP_CHECK(hipEventRecord(ev[k], stream));
+      HIP_CHECK(hipEventRecord(deferred ? ev_rk[rk_stage][k] : ev[k], stream));
   }
 };
 
@@ -293,6 +307,9 @@ void ryujin_hip_ctx::create(const ryujin_hip_offline &o, const ryujin_hip_params
   HIP_CHECK(hipEventCreateWithFlags(&ev_comm, hipEventDisableTiming));
   for (auto &e : ev)
     HIP_CHECK(hipEventCreate(&e));
+  for (auto &set : ev_rk)
+    for (auto &e : set)
+      HIP_CHECK(hipEventCreate(&e));
   for (auto &e : ev_user)
     HIP_CHECK(hipEventCreate(&e));
   HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&h_scalars), sizeof(DeviceScalars)));
@@ -670,15 +687,9 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
   const dim3 block(kBlock);
 
   /* scalars: tau_max := tau_max_in, flags := 0 */
-  DeviceScalars init{};
-  {
-    long long bits;
-    std::memcpy(&bits, &tau_max_in, sizeof(bits));
-    init.tau_max_bits = (unsigned long long)bits;
-  }
-  *h_scalars = init;
-  HIP_CHECK(hipMemcpyAsync(d_scalars.ptr, h_scalars, sizeof(DeviceScalars), hipMemcpyHostToDevice,
-                           stream));
+  const bool use_device_tau = deferred && rk_stage > 0;
+  hipLaunchKernelGGL(k_reset_scalars, dim3(1), dim3(1), 0, stream, tau_max_in,
+                     (!deferred || rk_stage == 0) ? 1 : 0, d_scalars.ptr);
 
   mark(0);
   /* Step 2: d_ij (upper triangle), alpha_i; ghost alpha (:341-424) */
@@ -725,7 +736,8 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
                          d_scalars.ptr);
   }, false);
   allreduce_scalar(&d_scalars.ptr->tau_max_bits, 0); /* Utilities::MPI::min(tau_max), :571 */
-  hipLaunchKernelGGL(k_finalize_tau, dim3(1), dim3(1), 0, stream, tau_in, d_scalars.ptr);
+  hipLaunchKernelGGL(k_finalize_tau, dim3(1), dim3(1), 0, stream, tau_in, use_device_tau ? 1 : 0,
+                     d_scalars.ptr);
   mark(2);
 
   /* Step 4: low-order update, bounds, r_i, p_ij; ghost r (:597-884) */
@@ -825,8 +837,13 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
 
   wait_comm();
   allreduce_scalar(&d_scalars.ptr->restart_needed, 1); /* MPI::logical_or(restart_needed), :1194 */
+  hipLaunchKernelGGL(k_accumulate_flags, dim3(1), dim3(1), 0, stream, d_scalars.ptr);
 
   HIP_CHECK(hipGetLastError());
+  if (deferred) {
+    *tau_out = std::numeric_limits<double>::quiet_NaN(); /* known at the end of the RK step */
+    return RYUJIN_OK;
+  }
   HIP_CHECK(hipMemcpyAsync(h_scalars, d_scalars.ptr, sizeof(DeviceScalars), hipMemcpyDeviceToHost,
                            stream));
   HIP_CHECK(hipStreamSynchronize(stream));
@@ -843,6 +860,9 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
       HIP_CHECK(hipEventElapsedTime(&ms, ev[0], ev[8]));
       sweep_ms[0] = ms;
     }
+    for (int k = 0; k < 8; ++k)
+      sweep_ms_accum[k] += sweep_ms[k];
+    ++sweep_updates_accum;
   }
 
   if (h_scalars->tau_invalid)
@@ -858,6 +878,135 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
     return RYUJIN_RESTART;
   }
   return RYUJIN_OK;
+}
+
+/* Device-resident Runge-Kutta driver: ryujin::TimeIntegrator::step for the
+ * schemes that consist solely of prepare_state_vector + step<s> + sadd
+ * (source/time_integrator.template.h:207-403), including the bang-bang CFL recovery (:250-274).
+ * All stages are enqueued back to back: the tau of the first stage stays on the device, the restart /
+ * tau-validity flags of all stages are accumulated there, and the host synchronises ONCE per RK step.
+ * A Restart is therefore detected at the end of the RK step instead of inside it; the reference repeats
+ * the whole RK step from the untouched state vector anyway, so the outcome is the same. */
+template <typename E>
+int ryujin_hip_ctx::time_step(int scheme, int h_state, const int *h_tmp, const double *dirichlet,
+                              double tau_max, int cfl_recovery, double cfl_min, double cfl_max,
+                              double *tau_out)
+{
+  const int U = h_state, T0 = h_tmp[0], T1 = h_tmp[1], T2 = h_tmp[2];
+  int n_stages = 0;
+  double tau_factor = 1.;
+  switch (scheme) {
+  case RYUJIN_SCHEME_ERK_11: n_stages = 1; break;
+  case RYUJIN_SCHEME_SSPRK_22: n_stages = 2; break;
+  case RYUJIN_SCHEME_ERK_22: n_stages = 2; tau_factor = 2.; break;
+  case RYUJIN_SCHEME_SSPRK_33: n_stages = 3; break;
+  case RYUJIN_SCHEME_ERK_33: n_stages = 3; tau_factor = 3.; break;
+  default: throw HipError(RYUJIN_ERR_ARG, "unknown time stepping scheme");
+  }
+  const bool erk = scheme == RYUJIN_SCHEME_ERK_11 || scheme == RYUJIN_SCHEME_ERK_22 ||
+                   scheme == RYUJIN_SCHEME_ERK_33;
+  const double first_tau_max = erk ? tau_max / n_stages : tau_max;
+
+  auto single_step = [&]() -> int {
+    double dummy = 0.;
+    deferred = true;
+    struct Guard {
+      bool &flag;
+      ~Guard() { flag = false; }
+    } guard{deferred};
+    int result = -1; /* handle that holds the new solution */
+    const double no_limit = std::numeric_limits<double>::max();
+    const int none[1] = {0};
+    const double no_w[1] = {0.};
+
+    rk_stage = 0;
+    prepare_state_vector<E>(U, dirichlet);
+    step<E>(U, 0, none, no_w, T0, 0., first_tau_max, &dummy);
+    result = T0;
+    if (n_stages >= 2) {
+      rk_stage = 1;
+      prepare_state_vector<E>(T0, nullptr);
+      if (erk) {
+        const int hs[1] = {U};
+        const double ws[1] = {-1.};
+        step<E>(T0, 1, hs, ws, T1, 1. /*device tau*/, no_limit, &dummy);
+      } else {
+        step<E>(T0, 0, none, no_w, T1, 1., no_limit, &dummy);
+        if (scheme == RYUJIN_SCHEME_SSPRK_22)
+          ryujin_hip_sadd(this, T1, 1. / 2., 1. / 2., U);
+        else
+          ryujin_hip_sadd(this, T1, 1. / 4., 3. / 4., U);
+      }
+      result = T1;
+    }
+    if (n_stages >= 3) {
+      rk_stage = 2;
+      prepare_state_vector<E>(T1, nullptr);
+      if (erk) {
+        const int hs[2] = {U, T0};
+        const double ws[2] = {0.75, -2.};
+        step<E>(T1, 2, hs, ws, T2, 1., no_limit, &dummy);
+        result = T2;
+      } else {
+        step<E>(T1, 0, none, no_w, T0, 1., no_limit, &dummy);
+        ryujin_hip_sadd(this, T0, 2. / 3., 1. / 3., U);
+        result = T0;
+      }
+    }
+    /* the only host synchronisation of the RK step */
+    wait_comm();
+    HIP_CHECK(hipMemcpyAsync(h_scalars, d_scalars.ptr, sizeof(DeviceScalars), hipMemcpyDeviceToHost,
+                             stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    if (timers_enabled) {
+      for (int st = 0; st < n_stages; ++st) {
+        for (int k = 0; k < 7; ++k) {
+          float ms = 0.f;
+          HIP_CHECK(hipEventElapsedTime(&ms, ev_rk[st][k], ev_rk[st][k + 1]));
+          sweep_ms_accum[k + 1] += ms;
+        }
+        if (RYUJIN_SPLIT_DIJ && L.max_row_len <= 32) {
+          float ms = 0.f;
+          HIP_CHECK(hipEventElapsedTime(&ms, ev_rk[st][0], ev_rk[st][8]));
+          sweep_ms_accum[0] += ms;
+        }
+        ++sweep_updates_accum;
+      }
+    }
+    return result;
+  };
+
+  if (cfl_recovery == RYUJIN_CFL_RECOVERY_BANG_BANG) {
+    params.id_violation_strategy = RYUJIN_IDV_RAISE_EXCEPTION;
+    params.cfl = cfl_max;
+  }
+  int result = single_step();
+  if (h_scalars->tau_invalid_accum)
+    return RYUJIN_ERR_TAU;
+  int status = RYUJIN_OK;
+  if (h_scalars->restart_accum) {
+    if (params.id_violation_strategy == RYUJIN_IDV_RAISE_EXCEPTION) {
+      n_restarts++;
+      if (cfl_recovery != RYUJIN_CFL_RECOVERY_BANG_BANG)
+        return RYUJIN_RESTART; /* the caller owns the recovery: state vector untouched */
+      params.id_violation_strategy = RYUJIN_IDV_WARN;
+      params.cfl = cfl_min;
+      result = single_step();
+      if (h_scalars->tau_invalid_accum)
+        return RYUJIN_ERR_TAU;
+      if (h_scalars->restart_accum) {
+        n_warnings++;
+        status = RYUJIN_WARN;
+      }
+    } else {
+      n_warnings++;
+      status = RYUJIN_WARN;
+    }
+  }
+  /* state_vector.swap(temp_[..]): the caller's handle keeps naming the solution */
+  std::swap(states[U], states[result]);
+  *tau_out = tau_factor * h_scalars->tau_rk;
+  return status;
 }
 
 /* ============================================================================ C ABI */
@@ -1131,6 +1280,37 @@ int ryujin_hip_step(ryujin_hip_ctx *ctx, int h_old, int stages, const int *h_sta
                                                               h_new, tau_in, tau_max_in, tau_out);
     });
   });
+}
+
+int ryujin_hip_time_step(ryujin_hip_ctx *ctx, int scheme, int h_state, const int h_tmp[3],
+                         const double *dirichlet_aos, double tau_max, int cfl_recovery, double cfl_min,
+                         double cfl_max, double *tau_out)
+{
+  return guarded([&]() {
+    if (!h_tmp || !tau_out)
+      throw HipError(RYUJIN_ERR_ARG, "null argument");
+    HIP_CHECK(hipSetDevice(ctx->device));
+    ctx->state(h_state);
+    for (int q = 0; q < 3; ++q)
+      ctx->state(h_tmp[q]);
+    return dispatch_equation(ctx->params.equation, ctx->dim, [&](auto tag) {
+      return ctx->template time_step<typename decltype(tag)::type>(
+          scheme, h_state, h_tmp, dirichlet_aos, tau_max, cfl_recovery, cfl_min, cfl_max, tau_out);
+    });
+  });
+}
+
+int ryujin_hip_get_timers_accum(ryujin_hip_ctx *ctx, double ms[8], unsigned *n_updates, int reset)
+{
+  for (int k = 0; k < 8; ++k)
+    ms[k] = ctx->sweep_ms_accum[k];
+  *n_updates = ctx->sweep_updates_accum;
+  if (reset) {
+    for (auto &v : ctx->sweep_ms_accum)
+      v = 0.;
+    ctx->sweep_updates_accum = 0;
+  }
+  return RYUJIN_OK;
 }
 
 int ryujin_hip_sadd(ryujin_hip_ctx *ctx, int h_dst, double s, double b, int h_src)

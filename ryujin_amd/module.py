@@ -141,6 +141,30 @@ class HyperbolicModule:
             raise Restart()
         return tau_out.value
 
+    def time_step(self, scheme: str, state: StateVector, temps, dirichlet=None, tau_max=None,
+                  cfl_recovery="none", cfl_min=0.45, cfl_max=0.90) -> float:
+        """Device-resident TimeIntegrator::step (ryujin_hip_time_step): one host synchronisation per
+        RK step. `state` names the solution before and after the call."""
+        schemes = {"ssprk 22": capi.SCHEME_SSPRK_22, "ssprk 33": capi.SCHEME_SSPRK_33,
+                   "erk 11": capi.SCHEME_ERK_11, "erk 22": capi.SCHEME_ERK_22, "erk 33": capi.SCHEME_ERK_33}
+        ptr = None
+        if dirichlet is not None:
+            dirichlet = np.ascontiguousarray(dirichlet, dtype=np.float64)
+            ptr = capi.as_ptr(dirichlet, capi.c_double_p)
+        hs = (C.c_int * 3)(*[t.handle for t in temps])
+        tau = C.c_double(0.0)
+        rc = self._f("time_step")(self._ctx, schemes[scheme], state.handle, hs, ptr,
+                                  float(np.finfo(np.float64).max if tau_max is None else tau_max),
+                                  capi.CFL_RECOVERY_BANG_BANG if cfl_recovery == "bang bang control"
+                                  else capi.CFL_RECOVERY_NONE, float(cfl_min), float(cfl_max), C.byref(tau))
+        if rc == capi.RYUJIN_ERR_TAU:
+            raise TauError("I'm sorry, Dave. I'm afraid I can't do that. We crashed.")
+        self._check(rc)
+        self.last_status = rc
+        if rc == capi.RYUJIN_RESTART:
+            raise Restart()
+        return tau.value
+
     def sadd(self, dst: StateVector, s: float, b: float, src: StateVector):
         self._check(self._f("sadd")(self._ctx, dst.handle, float(s), float(b), src.handle))
 

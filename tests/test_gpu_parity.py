@@ -404,3 +404,54 @@ def test_sw_multistage_and_lake_at_rest(oracle):
     U = sv.download()
     assert np.abs(U[wet, 0] + Z[wet] - 1.0).max() < 1e-13
     assert np.abs(U[:, 1:]).max() < 1e-13
+
+
+@pytest.mark.parametrize("scheme", ["ssprk 33", "erk 33", "ssprk 22", "erk 22", "erk 11"])
+def test_device_resident_time_step_equals_stagewise_driver(scheme):
+    """ryujin_hip_time_step (one host synchronisation per RK step, tau kept on the device) must give
+    bit-identical results to the stage-by-stage driver that mirrors TimeIntegrator::step_*."""
+    spec = offline.mach3_step_2d(30)
+    off = offline.SyntheticOffline(spec)
+    U0 = _perturbed(euler_uniform(off.positions))
+    dirichlet = euler_uniform(off.b_positions)
+    m = HyperbolicModule(off, equation=capi.EQ_EULER, backend="hip")
+    sv = m.new_state_vector(U0)
+    ti = TimeIntegrator(m, scheme, cfl_min=0.9, cfl_max=0.9, cfl_recovery_strategy="none",
+                        dirichlet_fn=lambda t: dirichlet)
+    t_a = 0.0
+    for _ in range(5):
+        sv, tau = ti.step(sv, t_a)
+        t_a += tau
+    ref = sv.download()
+
+    m2 = HyperbolicModule(off, equation=capi.EQ_EULER, backend="hip")
+    m2.cfl = 0.9
+    state = m2.new_state_vector(U0)
+    temps = [m2.new_state_vector() for _ in range(3)]
+    t_b = 0.0
+    for n in range(5):
+        t_b += m2.time_step(scheme, state, temps, dirichlet if n == 0 else None)
+    assert t_a == t_b
+    np.testing.assert_array_equal(state.download()[: off.n_owned], ref[: off.n_owned])
+
+
+def test_device_resident_time_step_bang_bang_recovery(oracle):
+    """Restart is detected at the end of the RK step and the step is repeated with cfl_min, as
+    TimeIntegrator::step does (time_integrator.template.h:250-274)."""
+    spec = offline.rectangle_2d(24, (0.0, 0.0), (1.0, 1.0))
+    off = offline.SyntheticOffline(spec)
+    U0 = euler_radial_contrast(off.positions, inner=(1.0, 0.0, 1000.0), outer=(0.01, 0.0, 0.01), radius=0.3,
+                               center=(0.5, 0.5))
+    m = HyperbolicModule(off, equation=capi.EQ_EULER, backend="hip")
+    state = m.new_state_vector(U0)
+    temps = [m.new_state_vector() for _ in range(3)]
+    tau = m.time_step("ssprk 33", state, temps, None, cfl_recovery="bang bang control", cfl_min=0.45, cfl_max=3.0)
+    assert m.n_restarts() == 1 and tau > 0.0
+    assert abs(m.cfl - 0.45) < 1e-15
+    # same as the stage-wise driver with the reference's try/catch
+    m2 = HyperbolicModule(off, equation=capi.EQ_EULER, backend="hip")
+    sv = m2.new_state_vector(U0)
+    ti = TimeIntegrator(m2, "ssprk 33", cfl_min=0.45, cfl_max=3.0)
+    sv, tau2 = ti.step(sv, 0.0)
+    assert tau == tau2
+    np.testing.assert_array_equal(state.download()[: off.n_owned], sv.download()[: off.n_owned])
