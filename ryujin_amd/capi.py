@@ -108,6 +108,24 @@ def load_synth():
         lib.ryujin_synth_global_ids.argtypes = [C.c_void_p]
         lib.ryujin_synth_bdry_positions.restype = c_double_p
         lib.ryujin_synth_bdry_positions.argtypes = [C.c_void_p]
+        # OfflineData dumps (include/ryujin_offline_io.h)
+        lib.ryujin_offline_write.restype = C.c_int
+        lib.ryujin_offline_write.argtypes = [C.c_char_p, C.POINTER(Offline), C.c_int, C.c_int, c_double_p,
+                                             c_double_p]
+        lib.ryujin_offline_read.restype = C.c_void_p
+        lib.ryujin_offline_read.argtypes = [C.c_char_p]
+        lib.ryujin_offline_file_free.argtypes = [C.c_void_p]
+        lib.ryujin_offline_io_last_error.restype = C.c_char_p
+        lib.ryujin_offline_file_view.restype = C.POINTER(Offline)
+        lib.ryujin_offline_file_view.argtypes = [C.c_void_p]
+        lib.ryujin_offline_file_dim.argtypes = [C.c_void_p]
+        lib.ryujin_offline_file_n_initial_precomputed.argtypes = [C.c_void_p]
+        lib.ryujin_offline_file_nnz.restype = C.c_uint64
+        lib.ryujin_offline_file_nnz.argtypes = [C.c_void_p]
+        lib.ryujin_offline_file_positions.restype = c_double_p
+        lib.ryujin_offline_file_positions.argtypes = [C.c_void_p]
+        lib.ryujin_offline_file_b_positions.restype = c_double_p
+        lib.ryujin_offline_file_b_positions.argtypes = [C.c_void_p]
         _synth = lib
     return _synth
 

@@ -56,6 +56,9 @@ namespace ryujin_hip
 #ifndef RYUJIN_XCD_REMAP
 #define RYUJIN_XCD_REMAP 0 /* A/B on MI355X: no gain in 2-D (1.80 vs 1.77 ms), +0.4 % in 3-D: the 256 MiB Infinity Cache already serves the cross-XCD reuse */
 #endif
+#ifndef RYUJIN_HO_CACHED_3D
+#define RYUJIN_HO_CACHED_3D 0
+#endif
 #ifndef RYUJIN_SPLIT_DIJ
 #define RYUJIN_SPLIT_DIJ 1
 #endif

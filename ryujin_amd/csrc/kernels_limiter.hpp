@@ -359,7 +359,7 @@ namespace ryujin_hip
    * so step 6 reads every array exactly once (the generic variant fetches ~2x the algorithmic bytes)
    * and all loads of a row are independent and issued up front. */
   template <typename E, int MAXW>
-  __global__ void __launch_bounds__(kBlock, RYUJIN_OCC_HO)
+  __global__ void __launch_bounds__(kBlock, (MAXW > 9 ? 1 : RYUJIN_OCC_HO))
   k_high_order_next_cached(const typename E::Params P, const DeviceMesh M, double *__restrict__ new_U,
                            const double *__restrict__ bounds, const double *__restrict__ pij,
                            const double *__restrict__ lij, double *__restrict__ lij_next)

@@ -818,9 +818,9 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
                            d_bounds.ptr, d_pij.ptr, d_lij.ptr, d_lij_next.ptr);
       }, false);
     } else {
-      constexpr int kCachedWidth = DIM == 1 ? 3 : 9;
+      constexpr int kCachedWidth = DIM == 1 ? 3 : (DIM == 2 ? 9 : 27);
       sweep([&](const DeviceMesh &mm, dim3 grid) {
-        if (DIM <= 2 && L.max_row_len <= (uint32_t)kCachedWidth)
+        if ((DIM <= 2 || RYUJIN_HO_CACHED_3D) && L.max_row_len <= (uint32_t)kCachedWidth)
           hipLaunchKernelGGL((k_high_order_next_cached<E, kCachedWidth>), grid, block, 0, stream,
                              eparams, mm, nw.U.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr,
                              d_lij_next.ptr);

@@ -49,23 +49,13 @@ class MeshSpec:
         return s
 
 
-class SyntheticOffline:
-    """Owns a ryujin_synth handle; `.c` is the ryujin_hip_offline view passed to create()."""
+class _OfflineArrays:
+    """numpy accessors over a ryujin_hip_offline view (`self.c`); shared by the generator and the importer."""
 
-    def __init__(self, spec: MeshSpec):
-        self.spec = spec
-        self._lib = capi.load_synth()
-        cs = spec.to_c()
-        self._h = self._lib.ryujin_synth_build(C.byref(cs))
-        if not self._h:
-            raise RuntimeError("ryujin_synth_build: " + self._lib.ryujin_synth_last_error().decode())
-        self.c = self._lib.ryujin_synth_offline(self._h)  # POINTER(Offline)
+    def _init_counts(self):
         o = self.c.contents
-        self.dim = spec.dim
         self.n_export, self.n_internal = o.n_export, o.n_internal
         self.n_owned, self.n_relevant = o.n_owned, o.n_relevant
-        self.nnz = int(self._lib.ryujin_synth_nnz(self._h))
-        self.n_global = int(self._lib.ryujin_synth_n_global(self._h))
         self.measure_of_omega = o.measure_of_omega
         self.n_bdry, self.n_pairs = o.n_bdry, o.n_pairs
 
@@ -77,10 +67,18 @@ class SyntheticOffline:
         self._initial_precomputed = v  # keep alive
         self.c.contents.initial_precomputed = capi.as_ptr(v, capi.c_double_p)
 
-    def close(self):
-        if self._h:
-            self._lib.ryujin_synth_free(self._h)
-            self._h = None
+    def save(self, path: str, n_initial_precomputed: int | None = None) -> None:
+        """Write the arrays as an OfflineData dump (include/ryujin_offline_io.h)."""
+        nip = n_initial_precomputed
+        if nip is None:
+            nip = 1 if self.c.contents.initial_precomputed else 0
+        pos = np.ascontiguousarray(self.positions)
+        bpos = np.ascontiguousarray(self.b_positions)
+        rc = self._lib.ryujin_offline_write(path.encode(), self.c, self.dim, nip,
+                                            capi.as_ptr(pos, capi.c_double_p),
+                                            capi.as_ptr(bpos, capi.c_double_p))
+        if rc != 0:
+            raise RuntimeError(self._lib.ryujin_offline_io_last_error().decode())
 
     def __del__(self):
         try:
@@ -113,15 +111,6 @@ class SyntheticOffline:
         return self._arr(self.c.contents.mi, self.n_relevant, np.float64)
 
     @property
-    def positions(self):
-        return self._arr(self._lib.ryujin_synth_positions(self._h), self.n_relevant * self.dim,
-                         np.float64).reshape(-1, self.dim)
-
-    @property
-    def global_ids(self):
-        return self._arr(self._lib.ryujin_synth_global_ids(self._h), self.n_relevant, np.uint64)
-
-    @property
     def b_i(self):
         return self._arr(self.c.contents.b_i, self.n_bdry, np.uint32)
 
@@ -134,15 +123,83 @@ class SyntheticOffline:
         return self._arr(self.c.contents.b_normal, self.n_bdry * self.dim, np.float64).reshape(-1, self.dim)
 
     @property
-    def b_positions(self):
-        return self._arr(self._lib.ryujin_synth_bdry_positions(self._h), self.n_bdry * self.dim,
-                         np.float64).reshape(-1, self.dim)
-
-    @property
     def pairs(self):
         o = self.c.contents
         return (self._arr(o.p_i, self.n_pairs, np.uint32), self._arr(o.p_col, self.n_pairs, np.uint32),
                 self._arr(o.p_j, self.n_pairs, np.uint32))
+
+
+class SyntheticOffline(_OfflineArrays):
+    """Owns a ryujin_synth handle; `.c` is the ryujin_hip_offline view passed to create()."""
+
+    def __init__(self, spec: MeshSpec):
+        self.spec = spec
+        self._lib = capi.load_synth()
+        cs = spec.to_c()
+        self._h = self._lib.ryujin_synth_build(C.byref(cs))
+        if not self._h:
+            raise RuntimeError("ryujin_synth_build: " + self._lib.ryujin_synth_last_error().decode())
+        self.c = self._lib.ryujin_synth_offline(self._h)  # POINTER(Offline)
+        self.dim = spec.dim
+        self._init_counts()
+        self.nnz = int(self._lib.ryujin_synth_nnz(self._h))
+        self.n_global = int(self._lib.ryujin_synth_n_global(self._h))
+
+    def close(self):
+        if self._h:
+            self._lib.ryujin_synth_free(self._h)
+            self._h = None
+
+    @property
+    def positions(self):
+        return self._arr(self._lib.ryujin_synth_positions(self._h), self.n_relevant * self.dim,
+                         np.float64).reshape(-1, self.dim)
+
+    @property
+    def global_ids(self):
+        return self._arr(self._lib.ryujin_synth_global_ids(self._h), self.n_relevant, np.uint64)
+
+    @property
+    def b_positions(self):
+        return self._arr(self._lib.ryujin_synth_bdry_positions(self._h), self.n_bdry * self.dim,
+                         np.float64).reshape(-1, self.dim)
+
+
+class ImportedOffline(_OfflineArrays):
+    """An OfflineData dump read from disk: the same object as SyntheticOffline as far
+    as HyperbolicModule is concerned. `spec` is None (there is no recipe to rebuild the mesh from)."""
+
+    def __init__(self, path: str):
+        self.spec = None
+        self._lib = capi.load_synth()
+        self._h = self._lib.ryujin_offline_read(path.encode())
+        if not self._h:
+            raise RuntimeError(self._lib.ryujin_offline_io_last_error().decode())
+        self.c = self._lib.ryujin_offline_file_view(self._h)
+        self.dim = int(self._lib.ryujin_offline_file_dim(self._h))
+        self.n_initial_precomputed = int(self._lib.ryujin_offline_file_n_initial_precomputed(self._h))
+        self._init_counts()
+        self.nnz = int(self._lib.ryujin_offline_file_nnz(self._h))
+        self.n_global = None
+
+    def close(self):
+        if self._h:
+            self._lib.ryujin_offline_file_free(self._h)
+            self._h = None
+
+    @property
+    def positions(self):
+        p = self._lib.ryujin_offline_file_positions(self._h)
+        if not p:
+            raise ValueError("the dump holds no support point positions")
+        return self._arr(p, self.n_relevant * self.dim, np.float64).reshape(-1, self.dim)
+
+    @property
+    def b_positions(self):
+        p = self._lib.ryujin_offline_file_b_positions(self._h)
+        if not p:
+            raise ValueError("the dump holds no boundary positions")
+        return self._arr(p, self.n_bdry * self.dim, np.float64).reshape(-1, self.dim)
 
 
 # ------------------------------------------------------------------ mesh recipes (SURVEY 8d)

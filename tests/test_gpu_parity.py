@@ -455,3 +455,33 @@ def test_device_resident_time_step_bang_bang_recovery(oracle):
     sv, tau2 = ti.step(sv, 0.0)
     assert tau == tau2
     np.testing.assert_array_equal(state.download()[: off.n_owned], sv.download()[: off.n_owned])
+
+
+def test_imported_offline_dump_is_bit_identical_on_the_gpu(tmp_path):
+    """a context created from an OfflineData dump (include/ryujin_offline_io.h) computes
+    exactly what the context created from the in-memory arrays computes (Euler step mesh with
+    Dirichlet/slip/do-nothing boundaries and coupling pairs; shallow water with bathymetry)."""
+    from ryujin_amd.initial_states import sw_circular_dam_break
+    cases = []
+    off = offline.SyntheticOffline(offline.mach3_step_2d(20))
+    cases.append((off, capi.EQ_EULER, _perturbed(euler_uniform(off.positions)), euler_uniform(off.b_positions)))
+    off = offline.SyntheticOffline(offline.rectangle_2d(40, (-5.0, -5.0), (5.0, 5.0)))
+    off.set_initial_precomputed(0.2 * np.cos(off.positions[:, 0]) * np.sin(0.7 * off.positions[:, 1]))
+    cases.append((off, capi.EQ_SHALLOW_WATER, sw_circular_dam_break(off.positions), None))
+    for n, (off, equation, U0, dirichlet) in enumerate(cases):
+        path = str(tmp_path / f"case{n}.ryjoffl")
+        off.save(path)
+        imp = offline.ImportedOffline(path)
+        res = []
+        for o in (off, imp):
+            m = HyperbolicModule(o, equation=equation, backend="hip")
+            m.cfl = 0.9
+            a, b = m.new_state_vector(U0), m.new_state_vector()
+            taus = []
+            for _ in range(4):
+                m.prepare_state_vector(a, 0.0, dirichlet)
+                taus.append(m.step(a, [], [], b))
+                a, b = b, a
+            res.append((taus, a.download()))
+        assert res[0][0] == res[1][0]
+        assert np.array_equal(res[0][1], res[1][1])
