@@ -157,6 +157,35 @@ namespace ryujin_hip_shim
       return tau_out;
     }
 
+    /* TimeIntegrator::step(state_vector, t, t_final) (time_integrator.template.h:207-277) for the
+     * explicit schemes, executed device-resident with one host synchronisation per Runge-Kutta step
+     * (ryujin_hip_time_step). `scheme` is a RYUJIN_SCHEME_* id, `temp` the integrator's temp_[0..2].
+     * With cfl_recovery == RYUJIN_CFL_RECOVERY_BANG_BANG the reference's retry loop (:250-274) runs
+     * inside the library; otherwise a Restart propagates as in step(). Dirichlet data is evaluated at
+     * time t (time independent during the step, as in the benchmark configurations). */
+    double time_step(int scheme, StateVector &state_vector, std::array<StateVector, 3> &temp, double t,
+                     double t_final = std::numeric_limits<double>::max(),
+                     int cfl_recovery = RYUJIN_CFL_RECOVERY_NONE, double cfl_min = 0.45,
+                     double cfl_max = 0.9) const
+    {
+      const double *ptr = nullptr;
+      if (dirichlet_) {
+        dirichlet_values_.resize((size_t)offline_.n_bdry * k_);
+        dirichlet_(t, dirichlet_values_);
+        ptr = dirichlet_values_.data();
+      }
+      const int h_tmp[3] = {temp[0].handle_, temp[1].handle_, temp[2].handle_};
+      double tau_out = 0.;
+      const int status = ryujin_hip_time_step(ctx_, scheme, state_vector.handle_, h_tmp, ptr, t_final - t,
+                                              cfl_recovery, cfl_min, cfl_max, &tau_out);
+      if (status == RYUJIN_ERR_TAU)
+        throw std::runtime_error("I'm sorry, Dave. I'm afraid I can't do that.\nWe crashed.");
+      check(status);
+      if (status == RYUJIN_RESTART)
+        throw Restart();
+      return tau_out;
+    }
+
     /* accessors: hyperbolic_module.h:225-278 */
     void cfl(double new_cfl) const { check(ryujin_hip_set_cfl(ctx_, new_cfl)); }
     double cfl() const

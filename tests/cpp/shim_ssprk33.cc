@@ -1,7 +1,9 @@
 // Drives the C++ shim the way ryujin's TimeIntegrator::step_ssprk_33 drives HyperbolicModule
 // (source/time_integrator.template.h:302-328) on the check-mass-conservation_01 configuration and
 // prints "t mean_rho" after every step. Built and run by tests/test_shim_cpp.py.
+#include <array>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "hyperbolic_module_shim.hpp"
@@ -12,6 +14,7 @@ using namespace ryujin_hip_shim;
 int main(int argc, char **argv)
 {
   const int n_steps = argc > 1 ? std::atoi(argv[1]) : 3;
+  const bool device_resident = argc > 2 && std::atoi(argv[2]) != 0; /* 1: HyperbolicModule::time_step */
   ryujin_synth_spec spec{};
   spec.dim = 2;
   spec.n_cells[0] = spec.n_cells[1] = 64;
@@ -45,23 +48,29 @@ int main(int argc, char **argv)
       U[4 * i + 3] = 1. / 0.4 + 0.5 * 1.4 * 9.;
     }
     StateVector state_vector = hyperbolic_module.create_state_vector();
-    StateVector temp_[2] = {hyperbolic_module.create_state_vector(),
-                            hyperbolic_module.create_state_vector()};
+    std::array<StateVector, 3> temp_ = {hyperbolic_module.create_state_vector(),
+                                        hyperbolic_module.create_state_vector(),
+                                        hyperbolic_module.create_state_vector()};
     hyperbolic_module.upload(state_vector, U.data());
 
     double t = 0.;
     for (int cycle = 0; cycle < n_steps; ++cycle) {
-      /* step_ssprk_33 */
-      hyperbolic_module.prepare_state_vector(state_vector, t);
-      const double tau = hyperbolic_module.step<0>(state_vector, {}, {}, temp_[0], 0.);
-      hyperbolic_module.prepare_state_vector(temp_[0], t + 1.0 * tau);
-      hyperbolic_module.step<0>(temp_[0], {}, {}, temp_[1], tau);
-      sadd(hyperbolic_module, temp_[1], 1.0 / 4.0, 3.0 / 4.0, state_vector);
-      hyperbolic_module.prepare_state_vector(temp_[1], t + 0.5 * tau);
-      hyperbolic_module.step<0>(temp_[1], {}, {}, temp_[0], tau);
-      sadd(hyperbolic_module, temp_[0], 2.0 / 3.0, 1.0 / 3.0, state_vector);
-      state_vector.swap(temp_[0]);
-      t += tau;
+      if (device_resident) {
+        /* the whole Runge-Kutta step inside the library: one host synchronisation */
+        t += hyperbolic_module.time_step(RYUJIN_SCHEME_SSPRK_33, state_vector, temp_, t);
+      } else {
+        /* step_ssprk_33 */
+        hyperbolic_module.prepare_state_vector(state_vector, t);
+        const double tau = hyperbolic_module.step<0>(state_vector, {}, {}, temp_[0], 0.);
+        hyperbolic_module.prepare_state_vector(temp_[0], t + 1.0 * tau);
+        hyperbolic_module.step<0>(temp_[0], {}, {}, temp_[1], tau);
+        sadd(hyperbolic_module, temp_[1], 1.0 / 4.0, 3.0 / 4.0, state_vector);
+        hyperbolic_module.prepare_state_vector(temp_[1], t + 0.5 * tau);
+        hyperbolic_module.step<0>(temp_[1], {}, {}, temp_[0], tau);
+        sadd(hyperbolic_module, temp_[0], 2.0 / 3.0, 1.0 / 3.0, state_vector);
+        state_vector.swap(temp_[0]);
+        t += tau;
+      }
 
       hyperbolic_module.download(state_vector, U.data());
       double mass = 0., rho = 0.;

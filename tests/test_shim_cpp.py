@@ -33,8 +33,13 @@ def test_shim_reproduces_mass_conservation_golden(golden_dir):
     from test_oracle_golden_integration import golden_mass_conservation
     if not os.path.exists(EXE):
         _build_exe()
-    out = subprocess.run([EXE, "6"], check=True, capture_output=True, text=True, timeout=300).stdout
-    got = np.array([[float(x) for x in line.split()] for line in out.strip().splitlines()])
     gold = golden_mass_conservation(golden_dir)
-    np.testing.assert_allclose(got[:, 0], gold[1:7, 0], rtol=0, atol=1e-12)
-    np.testing.assert_allclose(got[:, 1], gold[1:7, 1], rtol=0, atol=1e-12)
+    outs = []
+    for device_resident in ("0", "1"):  # stage-wise like step_ssprk_33 / the library's time_step
+        out = subprocess.run([EXE, "6", device_resident], check=True, capture_output=True, text=True,
+                             timeout=300).stdout
+        got = np.array([[float(x) for x in line.split()] for line in out.strip().splitlines()])
+        np.testing.assert_allclose(got[:, 0], gold[1:7, 0], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(got[:, 1], gold[1:7, 1], rtol=0, atol=1e-12)
+        outs.append(out)
+    assert outs[0] == outs[1]
