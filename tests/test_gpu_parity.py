@@ -485,3 +485,62 @@ def test_imported_offline_dump_is_bit_identical_on_the_gpu(tmp_path):
             res.append((taus, a.download()))
         assert res[0][0] == res[1][0]
         assert np.array_equal(res[0][1], res[1][1])
+
+
+def test_partitioned_3d_cylinder_erk33_matches_single_rank():
+    """BASELINE.json configs[3] in miniature: 3-D Mach-3 cylinder channel (staircase cylinder, Dirichlet
+    inflow, do-nothing outflow, slip walls), ERK33 through the device-resident driver, x-slab partition
+    over 2 and 4 ranks with the in-process transport: identical tau sequence, U to round-off."""
+    import ctypes as C
+    import threading
+
+    lib = capi.load_hip()
+    cpu, n_steps = 6, 3
+
+    def prim(pos):
+        return euler_uniform(pos, rho=1.4, u=3.0, p=1.0)
+
+    def run(off, comm, out, key):
+        try:
+            m = HyperbolicModule(off, equation=capi.EQ_EULER, backend="hip", comm=comm)
+            m.cfl = 0.9
+            U0 = prim(off.positions)
+            U0 *= 1.0 + 1e-3 * np.sin(5.0 * off.positions[:, :1] + 3.0 * off.positions[:, 1:2] +
+                                      2.0 * off.positions[:, 2:3])
+            dirichlet = prim(off.b_positions) if off.n_bdry else None
+            state = m.new_state_vector(U0)
+            temps = [m.new_state_vector() for _ in range(3)]
+            taus = [m.time_step("erk 33", state, temps, dirichlet) for _ in range(n_steps)]
+            out[key] = (off.global_ids[: off.n_owned].astype(np.int64), state.download()[: off.n_owned], taus)
+        except Exception as e:
+            out[key] = e
+
+    ref = {}
+    run(offline.SyntheticOffline(offline.cylinder_channel_3d(cpu)), None, ref, 0)
+    assert not isinstance(ref[0], Exception), ref[0]
+    gid, U, taus = ref[0]
+    assert np.all(np.isfinite(U)) and U[:, 0].min() > 0
+    scale = np.abs(U).max(axis=0)
+    for n_ranks in (2, 4):
+        comms = (C.c_void_p * n_ranks)()
+        assert lib.ryujin_hip_comm_init_local(comms, n_ranks, 0) == 0
+        parts = [offline.SyntheticOffline(offline.cylinder_channel_3d(cpu, n_ranks=n_ranks, rank=r))
+                 for r in range(n_ranks)]
+        out = {}
+        threads = [threading.Thread(target=run, args=(parts[r], C.c_void_p(comms[r]), out, r))
+                   for r in range(n_ranks)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=300)
+            assert not t.is_alive(), "rank thread hung"
+        for r in range(n_ranks):
+            assert not isinstance(out[r], Exception), out[r]
+            assert np.allclose(out[r][2], taus, rtol=1e-13, atol=0)
+        g = np.concatenate([out[r][0] for r in range(n_ranks)])
+        Up = np.concatenate([out[r][1] for r in range(n_ranks)])
+        o1, o2 = np.argsort(gid), np.argsort(g)
+        assert np.array_equal(gid[o1], g[o2])
+        assert (np.abs(Up[o2] - U[o1]) / scale).max() < 1e-11
+        for r in range(n_ranks):
+            lib.ryujin_hip_comm_destroy(C.c_void_p(comms[r]))
