@@ -117,6 +117,33 @@ namespace ryujin_hip
     }
   }
 
+#ifndef RYUJIN_NT
+#define RYUJIN_NT 3 /* non-temporal hints on the single-use multi-component matrix streams (c_ij, P_ij):
+                       bit 0 loads, bit 1 stores. A/B on MI355X: -2..3 % per update (the streams no longer
+                       evict the gathered U_j / l_ji lines from L2) */
+#endif
+  typedef double v2d_t __attribute__((ext_vector_type(2)));
+
+  /* single-use scalar streams (column indices, m_ij, l'_ij): bits 2 (loads) and 3 (stores) */
+  template <typename T>
+  RYUJIN_DEV T ld_stream(const T *p)
+  {
+#if RYUJIN_NT & 4
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+  }
+  template <typename T, typename V>
+  RYUJIN_DEV void st_stream(T *p, const V v)
+  {
+#if RYUJIN_NT & 8
+    __builtin_nontemporal_store((T)v, p);
+#else
+    *p = (T)v;
+#endif
+  }
+
   /* entry of an NC-component matrix in the paired SELL layout; colbase = slice_off + col_idx */
   template <int NC>
   RYUJIN_DEV void load_entry(const double *__restrict__ m, const uint64_t colbase,
@@ -125,7 +152,11 @@ namespace ryujin_hip
     const double *b = m + colbase * 64 * NC;
 #pragma unroll
     for (int g = 0; g < NC / 2; ++g) {
+#if RYUJIN_NT & 1
+      const v2d_t t = __builtin_nontemporal_load(reinterpret_cast<const v2d_t *>(b + g * 128 + lane * 2));
+#else
       const double2 t = *reinterpret_cast<const double2 *>(b + g * 128 + lane * 2);
+#endif
       v[2 * g] = t.x;
       v[2 * g + 1] = t.y;
     }
@@ -140,10 +171,17 @@ namespace ryujin_hip
     double *b = m + colbase * 64 * NC;
 #pragma unroll
     for (int g = 0; g < NC / 2; ++g) {
+#if RYUJIN_NT & 2
+      v2d_t t;
+      t.x = v[2 * g];
+      t.y = v[2 * g + 1];
+      __builtin_nontemporal_store(t, reinterpret_cast<v2d_t *>(b + g * 128 + lane * 2));
+#else
       double2 t;
       t.x = v[2 * g];
       t.y = v[2 * g + 1];
       *reinterpret_cast<double2 *>(b + g * 128 + lane * 2) = t;
+#endif
     }
     if (NC & 1)
       b[(NC / 2) * 128 + lane] = v[NC - 1];
@@ -289,8 +327,8 @@ namespace ryujin_hip
 #if RYUJIN_PIPE_DIJ
     /* software pipeline: the loads of column c+1 (and the column index of c+2) are in flight while
      * column c is processed, so the gather latency hides behind the Riemann solve */
-    uint32_t j_n = cols[(uint64_t)r.base * 64 + r.lane];
-    uint32_t j_nn = r.width > 1 ? cols[((uint64_t)r.base + 1) * 64 + r.lane] : i;
+    uint32_t j_n = ld_stream(cols + ((uint64_t)r.base * 64 + r.lane));
+    uint32_t j_nn = r.width > 1 ? ld_stream(cols + (((uint64_t)r.base + 1) * 64 + r.lane)) : i;
     double c_n[DIM], U_n[K];
     load_entry<DIM>(cij, r.base, r.lane, c_n);
     load_state<K>(U, j_n, U_n);
@@ -316,10 +354,10 @@ namespace ryujin_hip
         load_entry<DIM>(cij, colbase + 1, r.lane, c_n);
         load_state<K>(U, j_n, U_n);
         prec_n = prec2[j_n];
-        j_nn = (c + 2 < r.width) ? cols[(colbase + 2) * 64 + r.lane] : i;
+        j_nn = (c + 2 < r.width) ? ld_stream(cols + ((colbase + 2) * 64 + r.lane)) : i;
       }
 #else
-      const uint32_t j = cols[pos];
+      const uint32_t j = ld_stream(cols + (pos));
       load_entry<DIM>(cij, colbase, r.lane, c_ij);
       load_state<K>(U, j, U_j);
       const double2 prec_j = prec2[j];
@@ -362,8 +400,8 @@ namespace ryujin_hip
     typename E::Indicator indicator;
     indicator.reset(P, U_i, prec2[i]);
 
-    uint32_t j_n = cols[(uint64_t)r.base * 64 + r.lane];
-    uint32_t j_nn = r.width > 1 ? cols[((uint64_t)r.base + 1) * 64 + r.lane] : i;
+    uint32_t j_n = ld_stream(cols + ((uint64_t)r.base * 64 + r.lane));
+    uint32_t j_nn = r.width > 1 ? ld_stream(cols + (((uint64_t)r.base + 1) * 64 + r.lane)) : i;
     double c_n[DIM], U_n[K];
     load_entry<DIM>(cij, r.base, r.lane, c_n);
     load_state<K>(U, j_n, U_n);
@@ -383,7 +421,7 @@ namespace ryujin_hip
         load_entry<DIM>(cij, colbase + 1, r.lane, c_n);
         load_state<K>(U, j_n, U_n);
         prec_n = prec2[j_n];
-        j_nn = (c + 2 < r.width) ? cols[(colbase + 2) * 64 + r.lane] : i;
+        j_nn = (c + 2 < r.width) ? ld_stream(cols + ((colbase + 2) * 64 + r.lane)) : i;
       }
       if (row_active && c < r.len)
         indicator.accumulate(P, U_j, prec_j, c_ij);
@@ -418,7 +456,7 @@ namespace ryujin_hip
         continue; /* wave-uniform: no loads at all for lower-triangle columns */
       const uint64_t colbase = (uint64_t)r.base + c;
       const uint64_t pos = colbase * 64 + r.lane;
-      const uint32_t j = cols[pos];
+      const uint32_t j = ld_stream(cols + (pos));
       double c_ij[DIM], U_j[K];
       load_entry<DIM>(cij, colbase, r.lane, c_ij);
       load_state<K>(U, j, U_j);
@@ -471,7 +509,7 @@ namespace ryujin_hip
     for (uint32_t c = 1; c < r.width; ++c) {
       const uint64_t pos = ((uint64_t)r.base + c) * 64 + r.lane;
       if (row_active && c < r.len) {
-        const uint32_t j = M.cols[pos];
+        const uint32_t j = ld_stream(M.cols + (pos));
         double d;
         if (j < i) {
           d = dij[M.idx_t[pos]];
@@ -622,8 +660,8 @@ namespace ryujin_hip
     /* software pipeline (see k_dij_alpha) */
     const uint32_t *__restrict__ cols = M.cols;
     const double *__restrict__ cij = M.cij;
-    uint32_t j_n = cols[(uint64_t)r.base * 64 + r.lane];
-    uint32_t j_nn = r.width > 1 ? cols[((uint64_t)r.base + 1) * 64 + r.lane] : i;
+    uint32_t j_n = ld_stream(cols + ((uint64_t)r.base * 64 + r.lane));
+    uint32_t j_nn = r.width > 1 ? ld_stream(cols + (((uint64_t)r.base + 1) * 64 + r.lane)) : i;
     double c_n[DIM], U_n[K];
     load_entry<DIM>(cij, r.base, r.lane, c_n);
     double d_n = dij[(uint64_t)r.base * 64 + r.lane];
@@ -650,7 +688,7 @@ namespace ryujin_hip
         load_state<K>(U, j_n, U_n);
         alpha_n = alpha[j_n];
         s_n = prec[(size_t)j_n * 2 + 0];
-        j_nn = (c + 2 < r.width) ? cols[(colbase + 2) * 64 + r.lane] : i;
+        j_nn = (c + 2 < r.width) ? ld_stream(cols + ((colbase + 2) * 64 + r.lane)) : i;
       }
 
       if (!active)

@@ -58,15 +58,15 @@ namespace ryujin_hip
     unsigned long long undecided_mask = 0;
 
     /* software pipeline: loads of column c+1 are in flight while column c is limited */
-    uint32_t j_n = r.width > 1 ? cols[((uint64_t)r.base + 1) * 64 + r.lane] : i;
-    uint32_t j_nn = r.width > 2 ? cols[((uint64_t)r.base + 2) * 64 + r.lane] : i;
+    uint32_t j_n = r.width > 1 ? ld_stream(cols + (((uint64_t)r.base + 1) * 64 + r.lane)) : i;
+    uint32_t j_nn = r.width > 2 ? ld_stream(cols + (((uint64_t)r.base + 2) * 64 + r.lane)) : i;
     double P_n[K], F_n[K];
     double mjinv_n = 0., mij_n = 0.;
     if (r.width > 1) {
       load_entry<K>(pij, (uint64_t)r.base + 1, r.lane, P_n);
       load_state<K>(r_in, j_n, F_n);
       mjinv_n = mi_inv[j_n];
-      mij_n = mij[((uint64_t)r.base + 1) * 64 + r.lane];
+      mij_n = ld_stream(mij + (((uint64_t)r.base + 1) * 64 + r.lane));
     }
 
     for (uint32_t c = 1; c < r.width; ++c) {
@@ -85,8 +85,8 @@ namespace ryujin_hip
         load_entry<K>(pij, colbase + 1, r.lane, P_n);
         load_state<K>(r_in, j_n, F_n);
         mjinv_n = mi_inv[j_n];
-        mij_n = mij[(colbase + 1) * 64 + r.lane];
-        j_nn = (c + 2 < r.width) ? cols[(colbase + 2) * 64 + r.lane] : i;
+        mij_n = ld_stream(mij + ((colbase + 1) * 64 + r.lane));
+        j_nn = (c + 2 < r.width) ? ld_stream(cols + ((colbase + 2) * 64 + r.lane)) : i;
       }
       if (!active)
         continue;
@@ -172,14 +172,14 @@ namespace ryujin_hip
     unsigned long long undecided_mask = 0;
 
     /* software pipeline: loads of column c+1 are in flight while column c is processed */
-    uint32_t j_n = r.width > 1 ? cols[((uint64_t)r.base + 1) * 64 + r.lane] : i;
-    uint32_t j_nn = r.width > 2 ? cols[((uint64_t)r.base + 2) * 64 + r.lane] : i;
+    uint32_t j_n = r.width > 1 ? ld_stream(cols + (((uint64_t)r.base + 1) * 64 + r.lane)) : i;
+    uint32_t j_nn = r.width > 2 ? ld_stream(cols + (((uint64_t)r.base + 2) * 64 + r.lane)) : i;
     double c_n[DIM], U_n[K], F_n[K];
     double mjinv_n = 0., mij_n = 0., d_n = 0., alpha_n = 0.;
     if (r.width > 1) {
       load_entry<DIM>(cij, (uint64_t)r.base + 1, r.lane, c_n);
       d_n = dij[((uint64_t)r.base + 1) * 64 + r.lane];
-      mij_n = mij[((uint64_t)r.base + 1) * 64 + r.lane];
+      mij_n = ld_stream(mij + (((uint64_t)r.base + 1) * 64 + r.lane));
       load_state<K>(old_U, j_n, U_n);
       load_state<K>(r_in, j_n, F_n);
       mjinv_n = mi_inv[j_n];
@@ -204,12 +204,12 @@ namespace ryujin_hip
         j_n = j_nn;
         load_entry<DIM>(cij, colbase + 1, r.lane, c_n);
         d_n = dij[(colbase + 1) * 64 + r.lane];
-        mij_n = mij[(colbase + 1) * 64 + r.lane];
+        mij_n = ld_stream(mij + ((colbase + 1) * 64 + r.lane));
         load_state<K>(old_U, j_n, U_n);
         load_state<K>(r_in, j_n, F_n);
         mjinv_n = mi_inv[j_n];
         alpha_n = alpha[j_n];
-        j_nn = (c + 2 < r.width) ? cols[(colbase + 2) * 64 + r.lane] : i;
+        j_nn = (c + 2 < r.width) ? ld_stream(cols + ((colbase + 2) * 64 + r.lane)) : i;
       }
       if (!active)
         continue;
@@ -334,7 +334,7 @@ namespace ryujin_hip
         if (undecided)
           undecided_mask |= 1ull << c;
         else
-          lij_next[pos] = (1. - old_l_ij) * new_l_ij;
+          st_stream(lij_next + (pos), (1. - old_l_ij) * new_l_ij);
       }
       while (undecided_mask) {
         const uint32_t c = (uint32_t)__builtin_ctzll(undecided_mask);
@@ -349,7 +349,7 @@ namespace ryujin_hip
           new_p_ij[q] = (1. - old_l_ij) * p_ij[q];
         bool success;
         const double new_l_ij = E::limit(P, bnd, U_i_new, new_p_ij, success);
-        lij_next[pos] = (1. - old_l_ij) * new_l_ij;
+        st_stream(lij_next + (pos), (1. - old_l_ij) * new_l_ij);
       }
     }
   }
@@ -424,7 +424,7 @@ namespace ryujin_hip
         if (undecided)
           undecided_mask |= 1ull << c;
         else
-          lij_next[(r.base + c) * 64 + r.lane] = (1. - l[c]) * new_l_ij;
+          st_stream(lij_next + ((r.base + c) * 64 + r.lane), (1. - l[c]) * new_l_ij);
       }
     }
     while (undecided_mask) {
@@ -440,7 +440,7 @@ namespace ryujin_hip
         new_p_ij[q] = (1. - old_l_ij) * p_ij[q];
       bool success;
       const double new_l_ij = E::limit(P, bnd, U_i_new, new_p_ij, success);
-      lij_next[pos] = (1. - old_l_ij) * new_l_ij;
+      st_stream(lij_next + (pos), (1. - old_l_ij) * new_l_ij);
     }
   }
 } // namespace ryujin_hip
