@@ -46,7 +46,16 @@ extern "C" {
 
 /* ---- enums -------------------------------------------------------------- */
 /* Description (source/<eq>/description.h) */
-enum { RYUJIN_EQ_EULER = 0, RYUJIN_EQ_SHALLOW_WATER = 1 };
+enum { RYUJIN_EQ_EULER = 0, RYUJIN_EQ_SHALLOW_WATER = 1, RYUJIN_EQ_EULER_AEOS = 2 };
+
+/* EquationOfStateLibrary (source/euler_aeos/equation_of_state_library.h): the closed-form members.
+ * "sesame" (tabulated, needs EOSPAC) and "function" (muparser) are host-library bound and not offered. */
+enum {
+  RYUJIN_EOS_POLYTROPIC_GAS = 0,             /* equation_of_state_polytropic_gas.h */
+  RYUJIN_EOS_NOBLE_ABEL_STIFFENED_GAS = 1,   /* equation_of_state_noble_abel_stiffened_gas.h */
+  RYUJIN_EOS_VAN_DER_WAALS = 2,              /* equation_of_state_van_der_waals.h */
+  RYUJIN_EOS_JONES_WILKINS_LEE = 3           /* equation_of_state_jones_wilkins_lee.h */
+};
 
 /* ryujin::Boundary (source/discretization.h:28-112) */
 enum {
@@ -103,6 +112,19 @@ typedef struct ryujin_hip_params {
   /* "/riemann solver": source/euler/riemann_solver.h:27-38 */
   int riemann_newton_max_iterations; /* 0 */
   double riemann_newton_tolerance;   /* 1e-10 */
+
+  /* "B - Equation" Euler with arbitrary equation of state (RYUJIN_EQ_EULER_AEOS):
+   * source/euler_aeos/hyperbolic_system.h:766-812; `gamma`, `reference_density`,
+   * `vacuum_state_relaxation_*` above are shared with Euler */
+  int eos;                    /* RYUJIN_EOS_*: "equation of state", polytropic gas */
+  int compute_strict_bounds;  /* 1 */
+  double eos_covolume_b;      /* NASG, van der Waals: "covolume b", 0 */
+  double eos_q;               /* NASG: "reference specific internal energy", 0 */
+  double eos_pinf;            /* NASG: "reference pressure", 0 */
+  double eos_vdw_a;           /* van der Waals: "vdw a", 0 */
+  double eos_gas_constant_R;  /* 287.052874 (van der Waals: 0.4); only temperature() uses it */
+  /* Jones-Wilkins-Lee (equation_of_state_jones_wilkins_lee.h:38-66) */
+  double jwl_A, jwl_B, jwl_R1, jwl_R2, jwl_omega, jwl_rho_0, jwl_q_0, jwl_cv;
 } ryujin_hip_params;
 
 /* ---- offline data (input contract) ------------------------------------- */

@@ -13,6 +13,7 @@
 #include <xmmintrin.h>
 #include <pmmintrin.h>
 
+#include "aeos_module.hpp"
 #include "hyperbolic_module.hpp"
 #include "shallow_water.hpp"
 
@@ -68,6 +69,21 @@ void ryujin_oracle_default_params(ryujin_hip_params *p, int equation, int dim)
   p->limiter_limit_on_square_velocity = 1;
   p->riemann_newton_max_iterations = 0;
   p->riemann_newton_tolerance = 1.e-10;
+  p->eos = RYUJIN_EOS_POLYTROPIC_GAS;
+  p->compute_strict_bounds = 1;
+  p->eos_covolume_b = 0.;
+  p->eos_q = 0.;
+  p->eos_pinf = 0.;
+  p->eos_vdw_a = 0.;
+  p->eos_gas_constant_R = 287.052874;
+  p->jwl_A = 6.3207e13;
+  p->jwl_B = -4.472e9;
+  p->jwl_R1 = 11.3;
+  p->jwl_R2 = 1.13;
+  p->jwl_omega = 0.8938;
+  p->jwl_rho_0 = 1895.;
+  p->jwl_q_0 = 0.;
+  p->jwl_cv = 2487. / 1895.;
 }
 
 /* FTZ/DAZ as the reference sets in main (source/main.cc:26-36) */
@@ -90,6 +106,13 @@ int ryujin_oracle_create(void **ctx, const ryujin_hip_offline *offline,
         c->m = std::make_unique<EulerModule<2>>(*offline, *params);
       else if (dim == 3)
         c->m = std::make_unique<EulerModule<3>>(*offline, *params);
+    } else if (params->equation == RYUJIN_EQ_EULER_AEOS) {
+      if (dim == 1)
+        c->m = std::make_unique<EulerAeosModule<1>>(*offline, *params);
+      else if (dim == 2)
+        c->m = std::make_unique<EulerAeosModule<2>>(*offline, *params);
+      else if (dim == 3)
+        c->m = std::make_unique<EulerAeosModule<3>>(*offline, *params);
     } else if (params->equation == RYUJIN_EQ_SHALLOW_WATER) {
       if (dim == 1)
         c->m = std::make_unique<ShallowWaterModule<1>>(*offline, *params);
@@ -439,6 +462,164 @@ int ryujin_oracle_import_csr(const ryujin_hip_offline *o, uint64_t *ptr, uint32_
       const auto g = csr.gather(*o, data, n_comp);
       std::copy(g.begin(), g.end(), out);
     }
+    return RYUJIN_OK;
+  });
+}
+
+/* ---- EulerAEOS function-level entry points (tests/euler_aeos/*.cc of the reference) ---------- */
+
+/* RiemannSolver::compute(riemann_data_i, riemann_data_j): rd = (rho, u, p, gamma, a).
+ * trace[7] = RS p_1, RS p_2, SS p_1, SS p_2, interpolated p, p_star, phi(p_star) */
+int ryujin_oracle_aeos_riemann(const ryujin_hip_params *p, const double rd_i[5], const double rd_j[5],
+                               double *lambda_max, double *trace)
+{
+  return guarded([&]() {
+    const aeos::EquationOfState eos(*p);
+    aeos::RiemannSolver rs(eos.interpolation_b, eos.interpolation_pinfty, p->compute_strict_bounds != 0);
+    aeos::RiemannTrace t;
+    if (trace)
+      rs.trace = &t;
+    aeos::RiemannSolver::primitive_type a, b;
+    for (int q = 0; q < 5; ++q) {
+      a[q] = rd_i[q];
+      b[q] = rd_j[q];
+    }
+    *lambda_max = rs.compute(a, b);
+    if (trace) {
+      const double v[7] = {t.rs_p_1, t.rs_p_2, t.ss_p_1, t.ss_p_2, t.interpolated, t.p_star, t.phi_p_star};
+      std::copy(v, v + 7, trace);
+    }
+    return RYUJIN_OK;
+  });
+}
+
+/* the whole pipeline from states: precomputed pressures -> riemann data -> lambda_max */
+double ryujin_oracle_aeos_lambda_max(const ryujin_hip_params *p, const double *U_i, const double *U_j,
+                                     const double *n_ij)
+{
+  auto run = [&](auto tag) {
+    constexpr int dim = decltype(tag)::value;
+    const aeos::View<dim> view(*p);
+    const aeos::RiemannSolver rs(view.b(), view.pinf(), view.compute_strict_bounds);
+    typename aeos::View<dim>::state_type a, b;
+    std::array<double, dim> n;
+    for (int q = 0; q < dim + 2; ++q) {
+      a[q] = U_i[q];
+      b[q] = U_j[q];
+    }
+    for (int d = 0; d < dim; ++d)
+      n[d] = n_ij[d];
+    return rs.template compute<dim>(view, a, view.eos_pressure_of_state(a), b,
+                                    view.eos_pressure_of_state(b), n);
+  };
+  switch (p->dim) {
+  case 1: return run(std::integral_constant<int, 1>{});
+  case 2: return run(std::integral_constant<int, 2>{});
+  default: return run(std::integral_constant<int, 3>{});
+  }
+}
+
+/* Limiter<1>::limit(bounds[4], U[3], P[3]); trace_out: t_l_start, t_r_start, n_iter, then per
+ * iteration (psi_l, psi_r, dpsi_l, dpsi_r, t_l, t_r, newton?) */
+int ryujin_oracle_aeos_limit(const ryujin_hip_params *p, int expensive_bounds_check,
+                             const double *bounds, const double *U, const double *P, double *l,
+                             int *success, double *trace_out, int trace_cap)
+{
+  return guarded([&]() {
+    auto run = [&](auto tag) {
+      constexpr int dim = decltype(tag)::value;
+      const aeos::View<dim> view(*p);
+      aeos::Limiter<dim> limiter(view, *p);
+      limiter.expensive_bounds_check = expensive_bounds_check != 0;
+      aeos::LimiterTrace t;
+      limiter.trace = &t;
+      typename aeos::Limiter<dim>::Bounds bnd;
+      typename aeos::View<dim>::state_type u, pp;
+      for (int q = 0; q < 4; ++q)
+        bnd[q] = bounds[q];
+      for (int q = 0; q < dim + 2; ++q) {
+        u[q] = U[q];
+        pp[q] = P[q];
+      }
+      const auto [t_l, ok] = limiter.limit(bnd, u, pp);
+      *l = t_l;
+      *success = ok ? 1 : 0;
+      if (trace_out && trace_cap >= 3) {
+        trace_out[0] = t.t_l_start;
+        trace_out[1] = t.t_r_start;
+        int n = 0;
+        for (const auto &it : t.iters) {
+          if (3 + 7 * (n + 1) > trace_cap)
+            break;
+          double *o = trace_out + 3 + 7 * n;
+          o[0] = it.psi_l; o[1] = it.psi_r; o[2] = it.dpsi_l; o[3] = it.dpsi_r;
+          o[4] = it.t_l; o[5] = it.t_r; o[6] = it.newton ? 1. : 0.;
+          ++n;
+        }
+        trace_out[2] = n;
+      }
+      return RYUJIN_OK;
+    };
+    switch (p->dim) {
+    case 1: return run(std::integral_constant<int, 1>{});
+    case 2: return run(std::integral_constant<int, 2>{});
+    default: return run(std::integral_constant<int, 3>{});
+    }
+  });
+}
+
+/* tests/euler_aeos/hyperbolic_system.cc: out = internal_energy, internal_energy_derivative[k],
+ * surrogate_specific_entropy, surrogate_harten_entropy, its derivative[k], surrogate_pressure,
+ * surrogate_gamma(U, that pressure), f(U, p)[k*dim] -- all with gamma_min = gamma_in */
+int ryujin_oracle_aeos_view(const ryujin_hip_params *p, const double *U, double gamma_in, double *out)
+{
+  return guarded([&]() {
+    auto run = [&](auto tag) {
+      constexpr int dim = decltype(tag)::value;
+      constexpr int k = dim + 2;
+      const aeos::View<dim> view(*p);
+      typename aeos::View<dim>::state_type u;
+      for (int q = 0; q < k; ++q)
+        u[q] = U[q];
+      int n = 0;
+      out[n++] = view.internal_energy(u);
+      for (double v : view.internal_energy_derivative(u))
+        out[n++] = v;
+      out[n++] = view.surrogate_specific_entropy(u, gamma_in);
+      const double eta = view.surrogate_harten_entropy(u, gamma_in);
+      out[n++] = eta;
+      for (double v : view.surrogate_harten_entropy_derivative(u, eta, gamma_in))
+        out[n++] = v;
+      const double ps = view.surrogate_pressure(u, gamma_in);
+      out[n++] = ps;
+      out[n++] = view.surrogate_gamma(u, ps);
+      const auto f = view.f(u, ps);
+      for (int q = 0; q < k; ++q)
+        for (int d = 0; d < dim; ++d)
+          out[n++] = f[q][d];
+      return RYUJIN_OK;
+    };
+    switch (p->dim) {
+    case 1: return run(std::integral_constant<int, 1>{});
+    case 2: return run(std::integral_constant<int, 2>{});
+    default: return run(std::integral_constant<int, 3>{});
+    }
+  });
+}
+
+/* EquationOfState: out = pressure(rho,e), specific_internal_energy(rho,p_in), temperature(rho,e),
+ * speed_of_sound(rho,e), interpolation b, pinfty, q */
+int ryujin_oracle_aeos_eos(const ryujin_hip_params *p, double rho, double e, double p_in, double *out)
+{
+  return guarded([&]() {
+    const aeos::EquationOfState eos(*p);
+    out[0] = eos.pressure(rho, e);
+    out[1] = eos.specific_internal_energy(rho, p_in);
+    out[2] = eos.temperature(rho, e);
+    out[3] = eos.speed_of_sound(rho, e);
+    out[4] = eos.interpolation_b;
+    out[5] = eos.interpolation_pinfty;
+    out[6] = eos.interpolation_q;
     return RYUJIN_OK;
   });
 }

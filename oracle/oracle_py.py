@@ -44,9 +44,20 @@ def load(path: str | None = None):
     lib.ryujin_oracle_sw_riemann.argtypes = [C.POINTER(capi.Params), dp, dp, dp]
     lib.ryujin_oracle_import_csr.argtypes = [C.POINTER(capi.Offline), capi.c_u64_p, capi.c_u32_p,
                                              capi.c_u64_p, dp, C.c_uint32, dp]
+    pp = C.POINTER(capi.Params)
+    lib.ryujin_oracle_aeos_riemann.argtypes = [pp, dp, dp, dp, dp]
+    lib.ryujin_oracle_aeos_lambda_max.argtypes = [pp, dp, dp, dp]
+    lib.ryujin_oracle_aeos_lambda_max.restype = C.c_double
+    lib.ryujin_oracle_aeos_limit.argtypes = [pp, C.c_int, dp, dp, dp, dp, capi.c_int_p, dp, C.c_int]
+    lib.ryujin_oracle_aeos_view.argtypes = [pp, dp, C.c_double, dp]
+    lib.ryujin_oracle_aeos_eos.argtypes = [pp, C.c_double, C.c_double, C.c_double, dp]
     if path == _build.ORACLE_SO:
         _lib = lib
     return lib
+
+
+def lib():
+    return load()
 
 
 def backend(path: str | None = None):

@@ -19,7 +19,8 @@ c_int_p = C.POINTER(C.c_int)
 
 RYUJIN_OK, RYUJIN_WARN, RYUJIN_RESTART = 0, 1, 2
 RYUJIN_ERR_TAU, RYUJIN_ERR_ARG, RYUJIN_ERR_HIP, RYUJIN_ERR_COMM, RYUJIN_ERR_UNSUPPORTED = -1, -2, -3, -4, -5
-EQ_EULER, EQ_SHALLOW_WATER = 0, 1
+EQ_EULER, EQ_SHALLOW_WATER, EQ_EULER_AEOS = 0, 1, 2
+EOS_POLYTROPIC_GAS, EOS_NOBLE_ABEL_STIFFENED_GAS, EOS_VAN_DER_WAALS, EOS_JONES_WILKINS_LEE = 0, 1, 2, 3
 BC_DO_NOTHING, BC_PERIODIC, BC_SLIP, BC_NO_SLIP, BC_DIRICHLET, BC_DYNAMIC, BC_DIRICHLET_MOMENTUM = range(7)
 IDV_WARN, IDV_RAISE_EXCEPTION = 0, 1
 CUT_NONE, CUT_BOX, CUT_CYLINDER = 0, 1, 2
@@ -42,6 +43,12 @@ class Params(C.Structure):
         ("limiter_newton_max_iterations", C.c_int), ("limiter_relaxation_factor", C.c_double),
         ("limiter_limit_on_kinetic_energy", C.c_int), ("limiter_limit_on_square_velocity", C.c_int),
         ("riemann_newton_max_iterations", C.c_int), ("riemann_newton_tolerance", C.c_double),
+        ("eos", C.c_int), ("compute_strict_bounds", C.c_int),
+        ("eos_covolume_b", C.c_double), ("eos_q", C.c_double), ("eos_pinf", C.c_double),
+        ("eos_vdw_a", C.c_double), ("eos_gas_constant_R", C.c_double),
+        ("jwl_A", C.c_double), ("jwl_B", C.c_double), ("jwl_R1", C.c_double), ("jwl_R2", C.c_double),
+        ("jwl_omega", C.c_double), ("jwl_rho_0", C.c_double), ("jwl_q_0", C.c_double),
+        ("jwl_cv", C.c_double),
     ]
 
 

@@ -1089,6 +1089,21 @@ void ryujin_hip_default_params(ryujin_hip_params *p, int equation, int dim)
   p->limiter_limit_on_square_velocity = 1;
   p->riemann_newton_max_iterations = 0;
   p->riemann_newton_tolerance = 1.e-10;
+  p->eos = RYUJIN_EOS_POLYTROPIC_GAS;
+  p->compute_strict_bounds = 1;
+  p->eos_covolume_b = 0.;
+  p->eos_q = 0.;
+  p->eos_pinf = 0.;
+  p->eos_vdw_a = 0.;
+  p->eos_gas_constant_R = 287.052874;
+  p->jwl_A = 6.3207e13;
+  p->jwl_B = -4.472e9;
+  p->jwl_R1 = 11.3;
+  p->jwl_R2 = 1.13;
+  p->jwl_omega = 0.8938;
+  p->jwl_rho_0 = 1895.;
+  p->jwl_q_0 = 0.;
+  p->jwl_cv = 2487. / 1895.;
 }
 
 int ryujin_hip_comm_unique_id(char id[RYUJIN_HIP_UNIQUE_ID_BYTES])

@@ -72,9 +72,12 @@ class HyperbolicModule:
             params = self.default_params(equation, self.dim)
         self.params = params
         self.equation = params.equation
-        self.k = self.dim + 2 if self.equation == capi.EQ_EULER else self.dim + 1
-        self.n_prec = 2
-        self.n_bounds = 3 if self.equation == capi.EQ_EULER else 5
+        # problem_dimension, n_precomputed_values, Limiter::n_bounds of the Description
+        self.k, self.n_prec, self.n_bounds = {
+            capi.EQ_EULER: (self.dim + 2, 2, 3),            # source/euler/{hyperbolic_system,limiter}.h
+            capi.EQ_SHALLOW_WATER: (self.dim + 1, 2, 5),    # source/shallow_water/...
+            capi.EQ_EULER_AEOS: (self.dim + 2, 4, 4),       # source/euler_aeos/...
+        }[self.equation]
         self.n_owned, self.n_relevant = offline.n_owned, offline.n_relevant
         self._ctx = C.c_void_p()
         self._comm = comm

@@ -23,3 +23,12 @@ cp $R/common/sparse_matrix_simd.output.sse2    $D/common_sparse_matrix_simd.outp
 cp $R/common/sparse_matrix_simd.output.avx2    $D/common_sparse_matrix_simd.output.avx2
 cp $R/common/sparse_matrix_simd.output.avx512  $D/common_sparse_matrix_simd.output.avx512
 cp "$R/common/sparsity_pattern_simd_01.mpirun=4.output" $D/common_sparsity_pattern_simd_01.mpirun4.output
+# Euler with arbitrary equation of state
+for f in riemann_solver riemann_solver-strict riemann_solver-strict-NASG limiter limiter-NASG \
+         hyperbolic_system equation_of_state_library; do
+  cp $R/euler_aeos/$f.output $D/euler_aeos_$f.output
+done
+for l in 5 6; do
+  cp $R/euler_aeos/verification-isentropic_vortex-pge-2d-ssprk33-l$l.output $D/euler_aeos_verification-isentropic_vortex-pge-2d-ssprk33-l$l.output
+  cp $R/euler_aeos/verification-isentropic_vortex-pge-2d-erk33-l$l.output   $D/euler_aeos_verification-isentropic_vortex-pge-2d-erk33-l$l.output
+done

@@ -90,10 +90,10 @@ def _cell_norms(values_grid, h):
     return l1 * h * h, np.sqrt(l2 * h * h)
 
 
-def run_isentropic_vortex(backend, scheme, refinement=5, t_final=2.0):
+def run_isentropic_vortex(backend, scheme, refinement=5, t_final=2.0, equation=capi.EQ_EULER):
     n = 2 ** refinement
     off = offline.SyntheticOffline(offline.rectangle_2d(n, (-5.0, -5.0), (5.0, 5.0), bc=capi.BC_DIRICHLET))
-    m = HyperbolicModule(off, equation=capi.EQ_EULER, backend=backend)
+    m = HyperbolicModule(off, equation=equation, backend=backend)
     exact = lambda pos, t: euler_isentropic_vortex(pos, t, mach=1.0, beta=5.0)  # noqa: E731
     sv = m.new_state_vector(exact(off.positions, 0.0))
     bpos = off.b_positions
@@ -121,8 +121,8 @@ def run_isentropic_vortex(backend, scheme, refinement=5, t_final=2.0):
     return t, linf, l1, l2, off.n_owned
 
 
-def _golden_vortex(golden_dir, scheme, level):
-    name = f"euler_verification-isentropic_vortex-2d-{scheme.replace(' ', '')}-l{level}.output"
+def _golden_vortex(golden_dir, scheme, level, prefix="euler_verification-isentropic_vortex-2d"):
+    name = f"{prefix}-{scheme.replace(' ', '')}-l{level}.output"
     text = open(os.path.join(golden_dir, name)).read()
     g = lambda k: float(re.search(k + r"\s*=\s*([0-9.e+-]+)", text).group(1))  # noqa: E731
     return int(g("#dofs")), g("t    "), g("Linf "), g("L1   "), g("L2   ")
@@ -136,6 +136,22 @@ def test_isentropic_vortex_l5_golden(oracle, golden_dir, scheme):
     t, linf, l1, l2, n = run_isentropic_vortex(oracle.backend(), scheme, 5)
     assert n == dofs == 1089
     assert abs(t - t_ref) < 1e-11           # final time pins all time-step sizes
+    assert abs(linf - linf_ref) < 1e-9 * linf_ref + 1e-12
+    assert abs(l1 - l1_ref) < 1e-9 * l1_ref + 1e-12
+    assert abs(l2 - l2_ref) < 1e-9 * l2_ref + 1e-12
+
+
+@pytest.mark.parametrize("scheme", ["ssprk 33", "erk 33"])
+def test_aeos_isentropic_vortex_l5_golden(oracle, golden_dir, scheme):
+    """tests/euler_aeos/verification-isentropic_vortex-pge-2d-{ssprk33,erk33}-l5: the EulerAEOS
+    Description (polytropic gas EOS, compute strict bounds = true) on the same configuration: pins the
+    two precomputation cycles, the surrogate-gamma Riemann solver, indicator and limiter of
+    source/euler_aeos/ through a whole run."""
+    prefix = "euler_aeos_verification-isentropic_vortex-pge-2d"
+    dofs, t_ref, linf_ref, l1_ref, l2_ref = _golden_vortex(golden_dir, scheme, 5, prefix)
+    t, linf, l1, l2, n = run_isentropic_vortex(oracle.backend(), scheme, 5, equation=capi.EQ_EULER_AEOS)
+    assert n == dofs == 1089
+    assert abs(t - t_ref) < 1e-11
     assert abs(linf - linf_ref) < 1e-9 * linf_ref + 1e-12
     assert abs(l1 - l1_ref) < 1e-9 * l1_ref + 1e-12
     assert abs(l2 - l2_ref) < 1e-9 * l2_ref + 1e-12
