@@ -197,7 +197,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=12)
     ap.add_argument("--cells-per-unit", type=int, default=995,
                     help="mesh resolution h=1/N of the step geometry (995 -> ~2.5M gridpoints, ~10M DoFs per GPU)")
-    ap.add_argument("--workload", default="step2d", choices=["step2d", "sedov3d", "sw2d"],
+    ap.add_argument("--workload", default="step2d", choices=["step2d", "sedov3d", "sw2d", "step2d_aeos"],
                     help="step2d = BASELINE configs[1] (the bench line); sedov3d = configs[2] (3-D radial "
                          "contrast box, --size cells per direction, default 200 -> 8.1M gridpoints); "
                          "sw2d = configs[4] (shallow-water circular dam break, default 1825^2 gridpoints)")
@@ -248,13 +248,17 @@ def main():
     # ---- workload: BASELINE.json configs[1] per GPU, lengthened channel for N GPUs (weak scaling)
     equation = capi.EQ_EULER
     rng = np.random.default_rng(42 + rank)
-    if args.workload == "step2d":
+    if args.workload in ("step2d", "step2d_aeos"):
         spec = offline.mach3_step_2d(args.cells_per_unit, length_units=3 * n_gpus, n_ranks=n_gpus, rank=rank)
         off = offline.SyntheticOffline(spec)
         U0 = euler_uniform(off.positions)  # prm/benchmarks/euler-mach3-forward-facing-step.prm:55-66
         dirichlet = euler_uniform(off.b_positions) if off.n_bdry else None
         workload_name = ("2D Euler Mach-3 forward-facing step, Q1, SSPRK33 stage sequence "
                          "(BASELINE.json configs[1])")
+        if args.workload == "step2d_aeos":  # same problem through the EulerAEOS Description (f-3)
+            equation = capi.EQ_EULER_AEOS
+            workload_name = ("2D Euler-AEOS (polytropic gas EOS, strict bounds) Mach-3 forward-facing step, "
+                             "Q1, SSPRK33 stage sequence")
     elif args.workload == "sedov3d":
         from ryujin_amd.initial_states import euler_radial_contrast
         n = args.size or 200
@@ -349,7 +353,7 @@ def main():
     k = m.k
     rs = off.row_starts
     S = float(rs[off.n_owned]) / off.n_owned
-    alg = algorithmic_bytes(off.dim, k, S, n_bounds=m.n_bounds)
+    alg = algorithmic_bytes(off.dim, k, S, n_prec=m.n_prec, n_bounds=m.n_bounds)
     if equation == capi.EQ_SHALLOW_WATER:  # + bathymetry (8 B) and m_ij (8S) in step 4, SURVEY 8d
         alg["4 low_order"] += 8 + 8 * S
     b_alg = sum(alg.values())

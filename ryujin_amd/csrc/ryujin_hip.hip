@@ -28,6 +28,7 @@
 #include "host_layout.hpp"
 #include "kernels_euler.hpp"
 #include "kernels_limiter.hpp"
+#include "kernels_euler_aeos.hpp"
 #include "kernels_shallow_water.hpp"
 
 using namespace ryujin_hip;
@@ -144,7 +145,7 @@ struct ryujin_hip_comm {
 
 struct ryujin_hip_ctx {
   ryujin_hip_params params{};
-  int dim = 0, K = 0, KP = 0, NB = 3;
+  int dim = 0, K = 0, KP = 0, NB = 3, NPREC = 2;
   int device = 0;
   ryujin_hip_comm *comm = nullptr;
   hipStream_t stream = nullptr;      /* compute */
@@ -157,6 +158,7 @@ struct ryujin_hip_ctx {
   DeviceMesh mesh{};
   EulerParams eparams{};
   ShallowWaterParams swparams{};
+  EulerAeosParams aeosparams{};
   DeviceBuffer<double> d_Z; /* initial_precomputed (bathymetry), shallow water only */
 
   template <typename E>
@@ -164,6 +166,8 @@ struct ryujin_hip_ctx {
   {
     if constexpr (std::is_same<typename E::Params, EulerParams>::value)
       return eparams;
+    else if constexpr (std::is_same<typename E::Params, EulerAeosParams>::value)
+      return aeosparams;
     else
       return swparams;
   }
@@ -288,16 +292,26 @@ void ryujin_hip_ctx::create(const ryujin_hip_offline &o, const ryujin_hip_params
   comm = c;
   device = dev;
   dim = p.dim;
-  if (p.equation != RYUJIN_EQ_EULER && p.equation != RYUJIN_EQ_SHALLOW_WATER)
+  if (p.equation != RYUJIN_EQ_EULER && p.equation != RYUJIN_EQ_SHALLOW_WATER &&
+      p.equation != RYUJIN_EQ_EULER_AEOS)
     throw HipError(RYUJIN_ERR_UNSUPPORTED, "unknown equation");
+  if (p.equation == RYUJIN_EQ_EULER_AEOS) {
+    if (p.eos < RYUJIN_EOS_POLYTROPIC_GAS || p.eos > RYUJIN_EOS_JONES_WILKINS_LEE)
+      throw HipError(RYUJIN_ERR_UNSUPPORTED, "unknown equation of state");
+    for (uint32_t b = 0; b < o.n_bdry; ++b)
+      if (o.b_id[b] == RYUJIN_BC_DYNAMIC) /* __builtin_trap() in euler_aeos/hyperbolic_system.h:1337 */
+        throw HipError(RYUJIN_ERR_UNSUPPORTED,
+                       "euler aeos: dynamic boundary conditions are not implemented in the reference");
+  }
   if (p.equation == RYUJIN_EQ_SHALLOW_WATER && p.dim == 3)
     throw HipError(RYUJIN_ERR_UNSUPPORTED, "the shallow water equations are defined for dim 1 and 2");
   if (dim < 1 || dim > 3)
     throw HipError(RYUJIN_ERR_ARG, "dim must be 1, 2 or 3");
   if (p.limiter_iterations < 0 || p.limiter_iterations > 2)
     throw HipError(RYUJIN_ERR_ARG, "The number of limiter iterations must be between [0,2]");
-  K = p.equation == RYUJIN_EQ_EULER ? dim + 2 : dim + 1;
-  NB = p.equation == RYUJIN_EQ_EULER ? 3 : 5;
+  K = p.equation == RYUJIN_EQ_SHALLOW_WATER ? dim + 1 : dim + 2;
+  NB = p.equation == RYUJIN_EQ_EULER ? 3 : (p.equation == RYUJIN_EQ_EULER_AEOS ? 4 : 5);
+  NPREC = p.equation == RYUJIN_EQ_EULER_AEOS ? 4 : 2;
   KP = (K + 1) / 2 * 2;
 
   HIP_CHECK(hipSetDevice(device));
@@ -327,6 +341,40 @@ void ryujin_hip_ctx::create(const ryujin_hip_offline &o, const ryujin_hip_params
   eparams.lim_newton_max_iterations = p.limiter_newton_max_iterations;
   eparams.riemann_newton_max_iterations = p.riemann_newton_max_iterations;
   eparams.riemann_newton_tolerance = p.riemann_newton_tolerance;
+
+  aeosparams.eos = p.eos;
+  aeosparams.strict = p.compute_strict_bounds != 0;
+  aeosparams.gamma = p.gamma;
+  aeosparams.eos_b = p.eos_covolume_b;
+  aeosparams.eos_q = p.eos_q;
+  aeosparams.eos_pinf = p.eos_pinf;
+  aeosparams.vdw_a = p.eos_vdw_a;
+  aeosparams.jwl_A = p.jwl_A;
+  aeosparams.jwl_B = p.jwl_B;
+  aeosparams.jwl_R1 = p.jwl_R1;
+  aeosparams.jwl_R2 = p.jwl_R2;
+  aeosparams.jwl_omega = p.jwl_omega;
+  aeosparams.jwl_rho_0 = p.jwl_rho_0;
+  aeosparams.jwl_q_0 = p.jwl_q_0;
+  /* interpolation parameters of the surrogate (equation_of_state_noble_abel_stiffened_gas.h:52-56,
+   * equation_of_state_van_der_waals.h:46-52; zero for the other equations of state) */
+  aeosparams.b = aeosparams.pinf = aeosparams.q = 0.;
+  if (p.eos == RYUJIN_EOS_NOBLE_ABEL_STIFFENED_GAS) {
+    aeosparams.b = p.eos_covolume_b;
+    aeosparams.pinf = p.eos_pinf;
+    aeosparams.q = p.eos_q;
+  } else if (p.eos == RYUJIN_EOS_VAN_DER_WAALS) {
+    aeosparams.b = p.eos_covolume_b;
+    if (p.eos_covolume_b > 0.)
+      aeosparams.pinf = p.eos_vdw_a / (p.eos_covolume_b * p.eos_covolume_b);
+  }
+  aeosparams.reference_density = p.reference_density;
+  aeosparams.vacuum_small = p.vacuum_state_relaxation_small;
+  aeosparams.vacuum_large = p.vacuum_state_relaxation_large;
+  aeosparams.evc_factor = p.indicator_evc_factor;
+  aeosparams.lim_newton_tolerance = p.limiter_newton_tolerance;
+  aeosparams.lim_relaxation_factor = p.limiter_relaxation_factor;
+  aeosparams.lim_newton_max_iterations = p.limiter_newton_max_iterations;
 
   swparams.gravity = p.gravity;
   swparams.manning = p.manning_friction_coefficient;
@@ -665,10 +713,24 @@ void ryujin_hip_ctx::prepare_state_vector(int h, const double *dirichlet)
                        d_grp_start.ptr, d_b_i.ptr, d_b_normal.ptr, d_b_id.ptr, d_dirichlet.ptr,
                        s.U.ptr);
   exchange_vector(s.U.ptr, KP, false); /* U.update_ghost_values(), :148 */
-  sweep([&](const DeviceMesh &mm, dim3 grid) {
-    hipLaunchKernelGGL(k_precompute<E>, grid, block, 0, stream, eparams, mm, s.U.ptr, s.prec.ptr);
-  }, true);
-  exchange_vector(s.prec.ptr, 2, true); /* :157-160 */
+  if constexpr (std::is_same<typename E::Params, EulerAeosParams>::value) {
+    /* n_precomputation_cycles = 2 (euler_aeos/hyperbolic_system.h:433), ghost update after each */
+    sweep([&](const DeviceMesh &mm, dim3 grid) {
+      hipLaunchKernelGGL(k_precompute_aeos0<E::DIMENSION>, grid, block, 0, stream, eparams, mm, s.U.ptr,
+                         s.prec.ptr);
+    }, true);
+    exchange_vector(s.prec.ptr, 4, true);
+    sweep([&](const DeviceMesh &mm, dim3 grid) {
+      hipLaunchKernelGGL(k_precompute_aeos1<E::DIMENSION>, grid, block, 0, stream, eparams, mm, s.U.ptr,
+                         s.prec.ptr, s.prec.ptr);
+    }, true);
+    exchange_vector(s.prec.ptr, 4, true);
+  } else {
+    sweep([&](const DeviceMesh &mm, dim3 grid) {
+      hipLaunchKernelGGL(k_precompute<E>, grid, block, 0, stream, eparams, mm, s.U.ptr, s.prec.ptr);
+    }, true);
+    exchange_vector(s.prec.ptr, 2, true); /* :157-160 */
+  }
   HIP_CHECK(hipGetLastError());
 }
 
@@ -678,6 +740,7 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
 {
   constexpr int DIM = E::DIMENSION;
   constexpr bool is_euler = std::is_same<typename E::Params, EulerParams>::value;
+  constexpr bool is_aeos = std::is_same<typename E::Params, EulerAeosParams>::value;
   const auto &eparams = eq_params<E>(); /* shadows the member: the equation's parameter block */
   State &old = state(h_old);
   State &nw = state(h_new);
@@ -693,7 +756,23 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
 
   mark(0);
   /* Step 2: d_ij (upper triangle), alpha_i; ghost alpha (:341-424) */
-  if (RYUJIN_SPLIT_DIJ && L.max_row_len <= 32) {
+  if constexpr (is_aeos) {
+    if (L.max_row_len > 32)
+      throw HipError(RYUJIN_ERR_UNSUPPORTED, "euler aeos: stencils of more than 32 entries");
+    sweep([&](const DeviceMesh &mm, dim3 grid) {
+      hipLaunchKernelGGL(k_alpha_aeos<DIM>, grid, block, 0, stream, eparams, mm, old.U.ptr, old.prec.ptr,
+                         d_alpha.ptr);
+    }, true);
+    mark(8);
+    exchange_vector(d_alpha.ptr, 1, true);
+    const bool pending = comm_pending;
+    comm_pending = false; /* k_dij does not read alpha: do not join the exchange yet */
+    sweep([&](const DeviceMesh &mm, dim3 grid) {
+      hipLaunchKernelGGL(k_dij_aeos<DIM>, grid, block, 0, stream, eparams, mm, d_lower_mask.ptr,
+                         old.U.ptr, old.prec.ptr, d_dij.ptr);
+    }, false);
+    comm_pending = pending;
+  } else if (RYUJIN_SPLIT_DIJ && L.max_row_len <= 32) {
     sweep([&](const DeviceMesh &mm, dim3 grid) {
       hipLaunchKernelGGL(k_alpha<E>, grid, block, 0, stream, eparams, mm, old.U.ptr, old.prec.ptr,
                          d_alpha.ptr);
@@ -717,10 +796,16 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
   mark(1);
 
   /* Step 3: boundary d_ij, symmetrise, diagonal, tau_max (:432-578) */
-  if (n_pairs)
-    hipLaunchKernelGGL(k_dij_boundary<E>, dim3(grid_for(n_pairs)), block, 0, stream, eparams,
-                       n_pairs, d_p_i.ptr, d_p_j.ptr, d_p_pos.ptr, (const uint32_t *)nullptr,
-                       d_p_cji.ptr, old.U.ptr, d_dij.ptr);
+  if (n_pairs) {
+    if constexpr (is_aeos)
+      hipLaunchKernelGGL(k_dij_boundary_aeos<DIM>, dim3(grid_for(n_pairs)), block, 0, stream, eparams,
+                         n_pairs, d_p_i.ptr, d_p_j.ptr, d_p_pos.ptr, d_p_cji.ptr, old.U.ptr,
+                         old.prec.ptr, d_dij.ptr);
+    else
+      hipLaunchKernelGGL(k_dij_boundary<E>, dim3(grid_for(n_pairs)), block, 0, stream, eparams,
+                         n_pairs, d_p_i.ptr, d_p_j.ptr, d_p_pos.ptr, (const uint32_t *)nullptr,
+                         d_p_cji.ptr, old.U.ptr, d_dij.ptr);
+  }
   sweep([&](const DeviceMesh &mm, dim3 grid) {
     if (L.max_row_len <= 3)
       hipLaunchKernelGGL(k_dij_diag_unrolled<3>, grid, block, 0, stream, mm, d_lower_mask.ptr,
@@ -772,6 +857,15 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
                            nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
       else
         hipLaunchKernelGGL((k_low_order<DIM, true>), grid, block, 0, stream, eparams, mm,
+                           d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_alpha.ptr, d_dij.ptr,
+                           nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
+    } else if constexpr (is_aeos) {
+      if (stages == 0)
+        hipLaunchKernelGGL((k_low_order_aeos<DIM, false>), grid, block, 0, stream, eparams, mm,
+                           d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_alpha.ptr, d_dij.ptr,
+                           nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
+      else
+        hipLaunchKernelGGL((k_low_order_aeos<DIM, true>), grid, block, 0, stream, eparams, mm,
                            d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_alpha.ptr, d_dij.ptr,
                            nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
     } else {
@@ -1043,6 +1137,13 @@ namespace
         return f(EqTag<ShallowWater<1>>{});
       return f(EqTag<ShallowWater<2>>{});
     }
+    if (equation == RYUJIN_EQ_EULER_AEOS) {
+      switch (dim) {
+      case 1: return f(EqTag<EulerAeos<1>>{});
+      case 2: return f(EqTag<EulerAeos<2>>{});
+      default: return f(EqTag<EulerAeos<3>>{});
+      }
+    }
     switch (dim) {
     case 1: return f(EqTag<Euler<1>>{});
     case 2: return f(EqTag<Euler<2>>{});
@@ -1060,7 +1161,7 @@ const char *ryujin_hip_last_error(void)
 
 const char *ryujin_hip_version(void)
 {
-  return "ryujin_hip 0.2 (gfx950; Euler + shallow water; SELL-64)";
+  return "ryujin_hip 0.3 (gfx950; Euler, Euler AEOS, shallow water; SELL-64)";
 }
 
 void ryujin_hip_default_params(ryujin_hip_params *p, int equation, int dim)
@@ -1204,7 +1305,7 @@ int ryujin_hip_state_alloc(ryujin_hip_ctx *ctx, int *handle)
       ctx->states.push_back(std::make_unique<ryujin_hip_ctx::State>());
       h = (int)ctx->states.size() - 1;
       ctx->states[h]->U.alloc((size_t)ctx->L.n_relevant * ctx->KP);
-      ctx->states[h]->prec.alloc((size_t)ctx->L.n_relevant * 2);
+      ctx->states[h]->prec.alloc((size_t)ctx->L.n_relevant * ctx->NPREC);
     }
     ctx->states[h]->used = true;
     *handle = h;
@@ -1263,7 +1364,7 @@ int ryujin_hip_state_download_precomputed(ryujin_hip_ctx *ctx, int handle, doubl
   return guarded([&]() {
     auto &s = ctx->state(handle);
     ctx->finish();
-    HIP_CHECK(hipMemcpy(prec_aos, s.prec.ptr, (size_t)ctx->L.n_relevant * 2 * sizeof(double),
+    HIP_CHECK(hipMemcpy(prec_aos, s.prec.ptr, (size_t)ctx->L.n_relevant * ctx->NPREC * sizeof(double),
                         hipMemcpyDeviceToHost));
     return RYUJIN_OK;
   });

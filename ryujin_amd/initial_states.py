@@ -5,6 +5,8 @@ from __future__ import annotations
 
 import numpy as np
 
+from . import capi
+
 
 def euler_from_primitive(rho, vel, p, gamma=1.4):
     """vel: [..., dim]. Returns conserved [..., dim+2] = (rho, rho v, p/(gamma-1) + rho |v|^2/2)."""
@@ -84,4 +86,37 @@ def sw_circular_dam_break(positions, h_inner=2.5, h_outer=0.5, radius=2.5):
     r2 = np.sum(positions * positions, axis=1)
     U = np.zeros((n, dim + 1))
     U[:, 0] = np.where(r2 <= radius, h_inner, h_outer)
+    return U
+
+
+def aeos_specific_internal_energy(params, rho, p):
+    """EquationOfState::specific_internal_energy(rho, p) of the closed-form equations of state
+    (source/euler_aeos/equation_of_state_*.h), vectorised; `params` is a capi.Params."""
+    rho = np.asarray(rho, dtype=np.float64)
+    p = np.asarray(p, dtype=np.float64)
+    g = params.gamma
+    if params.eos == capi.EOS_POLYTROPIC_GAS:
+        return p / (rho * (g - 1.0))
+    if params.eos == capi.EOS_NOBLE_ABEL_STIFFENED_GAS:
+        b, q, pinf = params.eos_covolume_b, params.eos_q, params.eos_pinf
+        return q + (p + g * pinf) * (1.0 - b * rho) / (rho * (g - 1.0))
+    if params.eos == capi.EOS_VAN_DER_WAALS:
+        a, b = params.eos_vdw_a, params.eos_covolume_b
+        return (p + a * rho * rho) * (1.0 - b * rho) / (rho * (g - 1.0)) - a * rho
+    ratio = rho / params.jwl_rho_0
+    first = params.jwl_A * (1.0 - params.jwl_omega / params.jwl_R1 * ratio) * np.exp(-params.jwl_R1 / ratio)
+    second = params.jwl_B * (1.0 - params.jwl_omega / params.jwl_R2 * ratio) * np.exp(-params.jwl_R2 / ratio)
+    return (p - first - second) / (rho * params.jwl_omega)
+
+
+def aeos_from_primitive(params, rho, vel, p):
+    """HyperbolicSystemView::from_initial_state (source/euler_aeos/hyperbolic_system.h:1470-1512):
+    primitive (rho, v, p) -> conserved state with the selected equation of state."""
+    rho = np.asarray(rho, dtype=np.float64)
+    vel = np.asarray(vel, dtype=np.float64)
+    e = aeos_specific_internal_energy(params, rho, p)
+    U = np.empty(vel.shape[:-1] + (vel.shape[-1] + 2,), dtype=np.float64)
+    U[..., 0] = rho
+    U[..., 1:-1] = rho[..., None] * vel
+    U[..., -1] = rho * e + 0.5 * rho * np.sum(vel * vel, axis=-1)
     return U

@@ -544,3 +544,105 @@ def test_partitioned_3d_cylinder_erk33_matches_single_rank():
         assert (np.abs(Up[o2] - U[o1]) / scale).max() < 1e-11
         for r in range(n_ranks):
             lib.ryujin_hip_comm_destroy(C.c_void_p(comms[r]))
+
+
+# ------------------------------------------------------------------ Euler with arbitrary equation of state
+
+def _aeos_edit(eos=capi.EOS_POLYTROPIC_GAS, strict=True, **kw):
+    def edit(p):
+        p.eos = eos
+        p.compute_strict_bounds = 1 if strict else 0
+        for k, v in kw.items():
+            setattr(p, k, v)
+    return edit
+
+
+@pytest.mark.parametrize("strict", [True, False])
+def test_aeos_step_parity_2d_step_geometry(oracle, strict):
+    """EulerAEOS Description (source/euler_aeos/), polytropic gas EOS, Mach-3 forward-facing step with
+    developed shocks: four precomputed values after two cycles, surrogate-gamma Riemann solver,
+    indicator, four limiter bounds, both `compute strict bounds` settings."""
+    spec = offline.mach3_step_2d(40)
+    off0 = offline.SyntheticOffline(spec)
+    U0 = _perturbed(euler_uniform(off0.positions))
+    dirichlet = euler_uniform(off0.b_positions)
+    off, mods = _both(spec, U0, oracle, n_warm=12, dirichlet=dirichlet, equation=capi.EQ_EULER_AEOS,
+                      params_edit=_aeos_edit(strict=strict))
+    g, c = _compare_step(off, mods, dirichlet)
+    assert g["prec"].shape[1] == 4 and g["bounds"].size == off.n_owned * 4
+    n = off.n_owned
+    # polytropic gas: precomputed p equals (gamma-1) rho e; gamma_min == 1.4 up to round-off
+    rho_e = g["U_old"][:n, 3] - 0.5 * (g["U_old"][:n, 1:3] ** 2).sum(1) / g["U_old"][:n, 0]
+    np.testing.assert_allclose(g["prec"][:n, 0], 0.4 * rho_e, rtol=1e-13)
+    assert np.abs(g["prec"][:n, 1] - 1.4).max() < 1e-12
+    assert (g["U"][:n, 0] > 0).all()
+
+
+@pytest.mark.parametrize("eos_name", ["nasg", "vdw", "jwl"])
+def test_aeos_step_parity_equations_of_state(oracle, eos_name):
+    """Noble-Abel stiffened gas, van der Waals and Jones-Wilkins-Lee equations of state (non-trivial
+    interpolation b, pinf, q; varying surrogate gamma): radial pressure/density contrast in a slip box."""
+    from ryujin_amd.initial_states import aeos_from_primitive
+    eos_kw = {
+        "nasg": dict(eos=capi.EOS_NOBLE_ABEL_STIFFENED_GAS, eos_covolume_b=0.05, eos_pinf=0.5, eos_q=0.1),
+        "vdw": dict(eos=capi.EOS_VAN_DER_WAALS, eos_covolume_b=0.1, eos_vdw_a=0.01),
+        "jwl": dict(eos=capi.EOS_JONES_WILKINS_LEE, jwl_A=1.0, jwl_B=-0.1, jwl_R1=4.0, jwl_R2=1.0,
+                    jwl_omega=0.4, jwl_rho_0=1.0, jwl_q_0=0.0, jwl_cv=1.0),
+    }[eos_name]
+    edit = _aeos_edit(**eos_kw)
+    spec = offline.rectangle_2d(48, (-1.0, -1.0), (1.0, 1.0))
+    off0 = offline.SyntheticOffline(spec)
+    p = oracle.default_params(capi.EQ_EULER_AEOS, 2)
+    edit(p)
+    r = np.linalg.norm(off0.positions, axis=1)
+    rho = np.where(r < 0.4, 2.0, 1.0)
+    pr = np.where(r < 0.4, 10.0, 1.0)
+    U0 = _perturbed(aeos_from_primitive(p, rho, np.zeros((off0.n_relevant, 2)), pr))
+    off, mods = _both(spec, U0, oracle, n_warm=15, equation=capi.EQ_EULER_AEOS, params_edit=edit)
+    g, c = _compare_step(off, mods)
+    n = off.n_owned
+    assert np.ptp(g["prec"][:n, 1]) > 1e-3 or eos_name == "nasg"   # the surrogate gamma varies
+    assert (g["U"][:n, 0] > 0).all()
+
+
+def test_aeos_step_parity_1d_and_3d(oracle):
+    from ryujin_amd.initial_states import aeos_from_primitive
+    edit = _aeos_edit(eos=capi.EOS_NOBLE_ABEL_STIFFENED_GAS, eos_covolume_b=0.1, eos_pinf=0.2, eos_q=0.05)
+    for dim in (1, 3):
+        if dim == 1:
+            spec = offline.MeshSpec(1, (200,), (0.0,), (1.0,), (capi.BC_DIRICHLET, capi.BC_DO_NOTHING))
+        else:
+            spec = offline.box_3d(10)
+        off0 = offline.SyntheticOffline(spec)
+        p = oracle.default_params(capi.EQ_EULER_AEOS, dim)
+        edit(p)
+        x = off0.positions
+        inner = (x[:, 0] < 0.5) if dim == 1 else (np.linalg.norm(x, axis=1) < 0.4)
+        U0 = aeos_from_primitive(p, np.where(inner, 1.0, 0.125), np.zeros((len(x), dim)), np.where(inner, 1.0, 0.1))
+        dirichlet = U0[off0.b_i] if dim == 1 else None
+        off, mods = _both(spec, U0, oracle, n_warm=8, dirichlet=dirichlet, equation=capi.EQ_EULER_AEOS,
+                          params_edit=edit)
+        _compare_step(off, mods, dirichlet)
+
+
+@pytest.mark.parametrize("scheme", ["ssprk 33", "erk 33"])
+def test_aeos_isentropic_vortex_golden_on_gpu(golden_dir, scheme):
+    """tests/euler_aeos/verification-isentropic_vortex-pge-2d-*-l5 on the GPU (ERK33: multi-stage fluxes
+    from the stage vectors' precomputed pressures)."""
+    from test_oracle_golden_integration import _golden_vortex, run_isentropic_vortex
+    prefix = "euler_aeos_verification-isentropic_vortex-pge-2d"
+    dofs, t_ref, linf_ref, l1_ref, l2_ref = _golden_vortex(golden_dir, scheme, 5, prefix)
+    t, linf, l1, l2, n = run_isentropic_vortex("hip", scheme, 5, equation=capi.EQ_EULER_AEOS)
+    assert n == dofs
+    assert abs(t - t_ref) < 1e-10
+    assert abs(linf - linf_ref) < 1e-8 * linf_ref
+    assert abs(l1 - l1_ref) < 1e-8 * l1_ref
+    assert abs(l2 - l2_ref) < 1e-8 * l2_ref
+
+
+def test_aeos_rejects_what_the_reference_does_not_implement():
+    """`dynamic` boundary conditions are __builtin_trap() in euler_aeos/hyperbolic_system.h:1337."""
+    spec = offline.rectangle_2d(8, bc=(capi.BC_DYNAMIC, capi.BC_SLIP, capi.BC_SLIP, capi.BC_SLIP))
+    off = offline.SyntheticOffline(spec)
+    with pytest.raises(RuntimeError, match="dynamic"):
+        HyperbolicModule(off, equation=capi.EQ_EULER_AEOS, backend="hip")
