@@ -282,8 +282,12 @@ def main():
 
     lib = capi.load_hip()
     comm = None
+    device = local_rank
     if use_dist:
         import torch
+        n_visible = torch.cuda.device_count()  # a launcher may expose one GPU per rank
+        if n_visible > 0:
+            device = local_rank % n_visible
         uid = C.create_string_buffer(capi.UNIQUE_ID_BYTES)
         if rank == 0:
             assert lib.ryujin_hip_comm_unique_id(uid) == 0, lib.ryujin_hip_last_error()
@@ -291,10 +295,10 @@ def main():
         dist.broadcast(t, src=0)
         uid = C.create_string_buffer(bytes(t.tolist()), capi.UNIQUE_ID_BYTES)
         comm = C.c_void_p()
-        rc = lib.ryujin_hip_comm_init(C.byref(comm), uid, rank, world, local_rank)
+        rc = lib.ryujin_hip_comm_init(C.byref(comm), uid, rank, world, device)
         assert rc == 0, lib.ryujin_hip_last_error()
 
-    m = HyperbolicModule(off, equation=equation, backend="hip", comm=comm, device=local_rank)
+    m = HyperbolicModule(off, equation=equation, backend="hip", comm=comm, device=device)
     m.cfl = 0.9
     drv = Ssprk33Stages(m, U0, dirichlet)
     ctx = m._ctx

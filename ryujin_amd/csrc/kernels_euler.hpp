@@ -56,8 +56,8 @@ namespace ryujin_hip
 #ifndef RYUJIN_XCD_REMAP
 #define RYUJIN_XCD_REMAP 0 /* A/B on MI355X: no gain in 2-D (1.80 vs 1.77 ms), +0.4 % in 3-D: the 256 MiB Infinity Cache already serves the cross-XCD reuse */
 #endif
-#ifndef RYUJIN_HO_CACHED_3D
-#define RYUJIN_HO_CACHED_3D 0
+#ifndef RYUJIN_HO_CP_3D
+#define RYUJIN_HO_CP_3D 14 /* step 6 in 3-D: 0 = two-pass kernel, n = l_ij and the first n P_ij columns in registers. A/B on MI355X (3.98 M gridpoints): 3.07 ms (0), 2.64 (1), 2.43 (8), 2.24 (14), 2.36 (18) */
 #endif
 #ifndef RYUJIN_SPLIT_DIJ
 #define RYUJIN_SPLIT_DIJ 1

@@ -357,9 +357,11 @@ namespace ryujin_hip
   /* Register-cached variant for stencils of at most MAXW columns (2-D Q1: 9, 1-D: 3): the row's
    * l_ij = min(l_ij, l_ji) and P_ij stay in registers between the update and the next limiter pass,
    * so step 6 reads every array exactly once (the generic variant fetches ~2x the algorithmic bytes)
-   * and all loads of a row are independent and issued up front. */
-  template <typename E, int MAXW>
-  __global__ void __launch_bounds__(kBlock, (MAXW > 9 ? 1 : RYUJIN_OCC_HO))
+   * and all loads of a row are independent and issued up front.
+   * CP < MAXW (3-D Q1: 27 columns of 5 components do not fit the register file at a useful occupancy):
+   * all l_ij but only the P_ij of columns < CP are cached, the others are fetched a second time. */
+  template <typename E, int MAXW, int CP = MAXW>
+  __global__ void __launch_bounds__(kBlock, (MAXW > 9 ? (CP < MAXW ? 2 : 1) : RYUJIN_OCC_HO))
   k_high_order_next_cached(const typename E::Params P, const DeviceMesh M, double *__restrict__ new_U,
                            const double *__restrict__ bounds, const double *__restrict__ pij,
                            const double *__restrict__ lij, double *__restrict__ lij_next)
@@ -383,28 +385,41 @@ namespace ryujin_hip
       bnd[b] = bounds[(size_t)b * stride + i];
 
     double l[MAXW];
-    double p[MAXW][K];
+    double p[CP][K];
 #pragma unroll
     for (int c = 1; c < MAXW; ++c) {
       l[c] = 0.;
+      if (c < CP) {
 #pragma unroll
-      for (int q = 0; q < K; ++q)
-        p[c][q] = 0.;
+        for (int q = 0; q < K; ++q)
+          p[c < CP ? c : 0][q] = 0.;
+      }
       if ((uint32_t)c < r.width) {
         const uint64_t colbase = (uint64_t)r.base + c;
         const uint32_t pos = (uint32_t)(colbase * 64 + r.lane);
         const double l_a = lij[pos];
         const double l_b = lij[idx_t[pos]];
         l[c] = fmin(l_a, l_b);
-        load_entry<K>(pij, colbase, r.lane, p[c]);
+        if (c < CP)
+          load_entry<K>(pij, colbase, r.lane, p[c < CP ? c : 0]);
       }
     }
 #pragma unroll
     for (int c = 1; c < MAXW; ++c) {
-      if (row_active && (uint32_t)c < r.len) {
+      if (c < CP) {
+        if (row_active && (uint32_t)c < r.len) {
 #pragma unroll
-        for (int q = 0; q < K; ++q)
-          U_i_new[q] += l[c] * lambda * p[c][q];
+          for (int q = 0; q < K; ++q)
+            U_i_new[q] += l[c] * lambda * p[c < CP ? c : 0][q];
+        }
+      } else if ((uint32_t)c < r.width) {
+        double pt[K];
+        load_entry<K>(pij, (uint64_t)r.base + c, r.lane, pt);
+        if (row_active && (uint32_t)c < r.len) {
+#pragma unroll
+          for (int q = 0; q < K; ++q)
+            U_i_new[q] += l[c] * lambda * pt[q];
+        }
       }
     }
     if (row_active)
@@ -413,11 +428,21 @@ namespace ryujin_hip
     unsigned long long undecided_mask = 0;
 #pragma unroll
     for (int c = 1; c < MAXW; ++c) {
+      if ((uint32_t)c >= r.width)
+        continue;
+      double pc[K];
+      if (c < CP) {
+#pragma unroll
+        for (int q = 0; q < K; ++q)
+          pc[q] = p[c < CP ? c : 0][q];
+      } else {
+        load_entry<K>(pij, (uint64_t)r.base + c, r.lane, pc);
+      }
       if (row_active && (uint32_t)c < r.len) {
         double new_p_ij[K];
 #pragma unroll
         for (int q = 0; q < K; ++q)
-          new_p_ij[q] = (1. - l[c]) * p[c][q];
+          new_p_ij[q] = (1. - l[c]) * pc[q];
         bool success, undecided;
         const double new_l_ij =
             E::limit_fast(P, bnd, U_i_new, new_p_ij, success, undecided);

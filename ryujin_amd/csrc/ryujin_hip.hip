@@ -913,10 +913,12 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
       }, false);
     } else {
       constexpr int kCachedWidth = DIM == 1 ? 3 : (DIM == 2 ? 9 : 27);
+      /* 3-D: cache all l_ij and the P_ij of the first RYUJIN_HO_CP_3D columns (0: two-pass kernel) */
+      constexpr int kCachedP = DIM == 3 ? (RYUJIN_HO_CP_3D > 0 ? RYUJIN_HO_CP_3D : 27) : kCachedWidth;
       sweep([&](const DeviceMesh &mm, dim3 grid) {
-        if ((DIM <= 2 || RYUJIN_HO_CACHED_3D) && L.max_row_len <= (uint32_t)kCachedWidth)
-          hipLaunchKernelGGL((k_high_order_next_cached<E, kCachedWidth>), grid, block, 0, stream,
-                             eparams, mm, nw.U.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr,
+        if ((DIM <= 2 || RYUJIN_HO_CP_3D > 0) && L.max_row_len <= (uint32_t)kCachedWidth)
+          hipLaunchKernelGGL((k_high_order_next_cached<E, kCachedWidth, kCachedP>), grid, block, 0,
+                             stream, eparams, mm, nw.U.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr,
                              d_lij_next.ptr);
         else
           hipLaunchKernelGGL((k_high_order<E, false>), grid, block, 0, stream, eparams, mm, nw.U.ptr,
