@@ -412,8 +412,12 @@ def main():
         except Exception as e:  # the baseline must never take the GPU number down with it
             out["cpu_baseline"] = {"value": None, "error": repr(e)}
     sys.stdout.flush()
+    C.CDLL(None).fflush(None)  # C stdio of librccl (version banner) is block-buffered on a pipe: drain it to fd 2
     os.dup2(saved_stdout, 1)
     print(json.dumps(out), flush=True)
+    # anything a library prints at exit must not follow the JSON line on stdout
+    sys.stdout.flush()
+    os.dup2(2, 1)
 
 
 if __name__ == "__main__":
