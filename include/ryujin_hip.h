@@ -282,6 +282,12 @@ int ryujin_hip_time_step(ryujin_hip_ctx *ctx, int scheme, int h_state, const int
                          const double *dirichlet_aos, double tau_max, int cfl_recovery, double cfl_min,
                          double cfl_max, double *tau_out);
 
+/* Conservation monitor on the device (the interior integrals of ryujin::Quantities,
+ * source/quantities.template.h): out[q] = sum over ALL ranks of
+ * sum_{i < n_owned} m_i U_i[q], q < k. Fixed summation order: bitwise reproducible for a given
+ * partition. Collective when the context has a communicator. */
+int ryujin_hip_state_integrals(ryujin_hip_ctx *ctx, int handle, double *out /* [k] */);
+
 /* ---- accessors of HyperbolicModule (hyperbolic_module.h:225-278) --------- */
 int ryujin_hip_set_cfl(ryujin_hip_ctx *ctx, double cfl);
 int ryujin_hip_get_cfl(ryujin_hip_ctx *ctx, double *cfl);

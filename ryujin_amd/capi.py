@@ -144,7 +144,7 @@ HIP_SYMBOLS = [
     "ryujin_hip_comm_destroy",
     "ryujin_hip_default_params", "ryujin_hip_create", "ryujin_hip_destroy",
     "ryujin_hip_state_alloc", "ryujin_hip_state_free", "ryujin_hip_state_upload",
-    "ryujin_hip_state_download", "ryujin_hip_state_download_precomputed",
+    "ryujin_hip_state_download", "ryujin_hip_state_download_precomputed", "ryujin_hip_state_integrals",
     "ryujin_hip_prepare_state_vector", "ryujin_hip_step", "ryujin_hip_sadd", "ryujin_hip_time_step",
     "ryujin_hip_get_timers_accum",
     "ryujin_hip_set_cfl", "ryujin_hip_get_cfl", "ryujin_hip_set_id_violation_strategy",
@@ -170,6 +170,8 @@ def _declare_module_api(lib, prefix: str):
     p("state_upload").argtypes = [vp, C.c_int, c_double_p]
     p("state_download").argtypes = [vp, C.c_int, c_double_p]
     p("state_download_precomputed").argtypes = [vp, C.c_int, c_double_p]
+    if hasattr(lib, prefix + "state_integrals"):  # device library only
+        p("state_integrals").argtypes = [vp, C.c_int, c_double_p]
     p("prepare_state_vector").argtypes = [vp, C.c_int, C.c_double, c_double_p]
     p("step").argtypes = [vp, C.c_int, C.c_int, c_int_p, c_double_p, C.c_int, C.c_double,
                           C.c_double, c_double_p]

@@ -823,6 +823,56 @@ namespace ryujin_hip
     }
   }
 
+  /* Quantities-style conservation monitor (source/quantities.template.h: interior "mass" integrals):
+   * partial[b][q] = sum over the rows of block b of m_i U_i[q]; fixed summation tree (wave shuffles,
+   * then the 4 waves in order), second pass adds the blocks in order: bitwise reproducible. */
+  template <int K>
+  __global__ void __launch_bounds__(kBlock)
+  k_integrals_partial(const uint32_t n_owned, const double *__restrict__ mi, const double *__restrict__ U,
+                      double *__restrict__ partial)
+  {
+    __shared__ double lds[kWavesPerBlock][K];
+    double acc[K];
+#pragma unroll
+    for (int q = 0; q < K; ++q)
+      acc[q] = 0.;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_owned; i += gridDim.x * blockDim.x) {
+      double U_i[K];
+      load_state<K>(U, i, U_i);
+      const double m = mi[i];
+#pragma unroll
+      for (int q = 0; q < K; ++q)
+        acc[q] += m * U_i[q];
+    }
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+      double v = acc[q];
+      for (int off = 32; off > 0; off >>= 1)
+        v += __shfl_down(v, off, 64);
+      if ((threadIdx.x & 63) == 0)
+        lds[threadIdx.x >> 6][q] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < K) {
+      double v = 0.;
+      for (int w = 0; w < kWavesPerBlock; ++w)
+        v += lds[w][threadIdx.x];
+      partial[(size_t)blockIdx.x * K + threadIdx.x] = v;
+    }
+  }
+
+  template <int K>
+  __global__ void k_integrals_final(const uint32_t n_blocks, const double *__restrict__ partial,
+                                    double *__restrict__ out)
+  {
+    if (threadIdx.x < K) {
+      double v = 0.;
+      for (uint32_t b = 0; b < n_blocks; ++b)
+        v += partial[(size_t)b * K + threadIdx.x];
+      out[threadIdx.x] = v;
+    }
+  }
+
   __global__ void __launch_bounds__(kBlock)
   k_debug_pow(const size_t n, const double *__restrict__ x, const double *__restrict__ y,
               double *__restrict__ out)

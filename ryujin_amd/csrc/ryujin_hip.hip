@@ -114,12 +114,14 @@ struct LocalGroup {
   unsigned long generation = 0;
   std::vector<std::vector<const double *>> mail; /* [src][dst] -> segment in src's send buffer */
   std::vector<double> scratch;                    /* all-reduce */
+  std::vector<double> scratch_vec;                /* [n_ranks][8] vector sums */
   int refs = 0;
 
   explicit LocalGroup(int n)
       : n_ranks(n)
       , mail(n, std::vector<const double *>(n, nullptr))
       , scratch(n, 0.)
+      , scratch_vec((size_t)n * 8, 0.)
   {
   }
 
@@ -193,6 +195,7 @@ struct ryujin_hip_ctx {
   /* module-owned vectors and matrices */
   DeviceBuffer<double> d_alpha, d_bounds, d_r, d_dij, d_lij, d_lij_next, d_pij;
   DeviceBuffer<DeviceScalars> d_scalars;
+  DeviceBuffer<double> d_integrals; /* ryujin_hip_state_integrals: block partials + result */
   DeviceScalars *h_scalars = nullptr; /* pinned */
 
   struct State {
@@ -1470,6 +1473,58 @@ int ryujin_hip_get_alpha(ryujin_hip_ctx *ctx, double *alpha)
     ctx->finish();
     HIP_CHECK(hipMemcpy(alpha, ctx->d_alpha.ptr, (size_t)ctx->L.n_relevant * sizeof(double),
                         hipMemcpyDeviceToHost));
+    return RYUJIN_OK;
+  });
+}
+
+int ryujin_hip_state_integrals(ryujin_hip_ctx *ctx, int handle, double *out)
+{
+  return guarded([&]() {
+    if (!out)
+      throw HipError(RYUJIN_ERR_ARG, "null argument");
+    HIP_CHECK(hipSetDevice(ctx->device));
+    auto &st = ctx->state(handle);
+    ctx->wait_comm();
+    constexpr uint32_t n_blocks = 512;
+    const int K = ctx->K;
+    if (ctx->d_integrals.n < (size_t)(n_blocks + 1) * 8)
+      ctx->d_integrals.alloc((size_t)(n_blocks + 1) * 8);
+    double *partial = ctx->d_integrals.ptr, *result = ctx->d_integrals.ptr + (size_t)n_blocks * 8;
+    auto launch = [&](auto tag) {
+      constexpr int KK = decltype(tag)::value;
+      hipLaunchKernelGGL(k_integrals_partial<KK>, dim3(n_blocks), dim3(kBlock), 0, ctx->stream,
+                         ctx->L.n_owned, ctx->d_mi.ptr, st.U.ptr, partial);
+      hipLaunchKernelGGL(k_integrals_final<KK>, dim3(1), dim3(64), 0, ctx->stream, n_blocks, partial,
+                         result);
+    };
+    switch (K) {
+    case 2: launch(std::integral_constant<int, 2>{}); break;
+    case 3: launch(std::integral_constant<int, 3>{}); break;
+    case 4: launch(std::integral_constant<int, 4>{}); break;
+    default: launch(std::integral_constant<int, 5>{}); break;
+    }
+    HIP_CHECK(hipGetLastError());
+    const ryujin_hip_comm *cm = ctx->comm;
+    if (cm && cm->n_ranks > 1 && !cm->local)
+      NCCL_CHECK(ncclAllReduce(result, result, K, ncclDouble, ncclSum, cm->comm, ctx->stream));
+    double host[8] = {0.};
+    HIP_CHECK(hipMemcpyAsync(host, result, sizeof(double) * K, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (cm && cm->n_ranks > 1 && cm->local) {
+      LocalGroup &g = *cm->local;
+      for (int q = 0; q < K; ++q)
+        g.scratch_vec[(size_t)cm->rank * 8 + q] = host[q];
+      g.barrier();
+      for (int q = 0; q < K; ++q) {
+        double v = 0.;
+        for (int r = 0; r < g.n_ranks; ++r)
+          v += g.scratch_vec[(size_t)r * 8 + q];
+        host[q] = v;
+      }
+      g.barrier();
+    }
+    for (int q = 0; q < K; ++q)
+      out[q] = host[q];
     return RYUJIN_OK;
   });
 }

@@ -168,6 +168,13 @@ class HyperbolicModule:
             raise Restart()
         return tau.value
 
+    def integrals(self, state: StateVector) -> np.ndarray:
+        """sum_i m_i U_i over the owned DoFs of all ranks, computed on the device with a fixed
+        summation order (ryujin_hip_state_integrals; device backend only)."""
+        out = np.zeros(self.k, dtype=np.float64)
+        self._check(self._f("state_integrals")(self._ctx, state.handle, capi.as_ptr(out, capi.c_double_p)))
+        return out
+
     def sadd(self, dst: StateVector, s: float, b: float, src: StateVector):
         self._check(self._f("sadd")(self._ctx, dst.handle, float(s), float(b), src.handle))
 

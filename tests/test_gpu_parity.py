@@ -646,3 +646,60 @@ def test_aeos_rejects_what_the_reference_does_not_implement():
     off = offline.SyntheticOffline(spec)
     with pytest.raises(RuntimeError, match="dynamic"):
         HyperbolicModule(off, equation=capi.EQ_EULER_AEOS, backend="hip")
+
+
+def test_device_integrals_conservation_monitor():
+    """ryujin_hip_state_integrals (Quantities-style interior integrals): equals
+    sum_i m_i U_i computed on the host to round-off, is bitwise reproducible, stays constant to 1e-13 over
+    SSPRK33 steps in a closed box, and the partitioned run (collective sum over 3 in-process ranks)
+    agrees with the single-rank value."""
+    import ctypes as C
+    import threading
+    spec = offline.rectangle_2d(64, (0.0, 0.0), (1.0, 1.0))
+    off = offline.SyntheticOffline(spec)
+    U0 = euler_radial_contrast(off.positions, inner=(1.0, 0.0, 10.0), outer=(0.5, 0.0, 1.0), radius=0.3,
+                               center=(0.5, 0.5))
+    m = HyperbolicModule(off, equation=capi.EQ_EULER, backend="hip")
+    m.cfl = 0.9
+    state = m.new_state_vector(U0)
+    I0 = m.integrals(state)
+    ref = (off.mi[: off.n_owned, None] * U0[: off.n_owned]).sum(axis=0)
+    np.testing.assert_allclose(I0, ref, rtol=1e-13)
+    assert np.array_equal(I0, m.integrals(state))
+    temps = [m.new_state_vector() for _ in range(3)]
+    for _ in range(10):
+        m.time_step("ssprk 33", state, temps)
+    I1 = m.integrals(state)
+    assert np.abs(I1[[0, 3]] - I0[[0, 3]]).max() <= 1e-13 * np.abs(I0[[0, 3]]).max()   # mass, energy
+    # momentum is not conserved at slip walls, but symmetric data keep it at round-off of the mass scale
+    assert np.abs(I1[1:3]).max() <= 1e-10
+
+    n_ranks = 3
+    lib = capi.load_hip()
+    comms = (C.c_void_p * n_ranks)()
+    assert lib.ryujin_hip_comm_init_local(comms, n_ranks, 0) == 0
+    parts = [offline.SyntheticOffline(offline.rectangle_2d(64, (0.0, 0.0), (1.0, 1.0), n_ranks=n_ranks, rank=r))
+             for r in range(n_ranks)]
+    out = {}
+
+    def run(r):
+        try:
+            o = parts[r]
+            mm = HyperbolicModule(o, equation=capi.EQ_EULER, backend="hip", comm=C.c_void_p(comms[r]))
+            sv = mm.new_state_vector(euler_radial_contrast(o.positions, inner=(1.0, 0.0, 10.0),
+                                                           outer=(0.5, 0.0, 1.0), radius=0.3, center=(0.5, 0.5)))
+            out[r] = mm.integrals(sv)
+        except Exception as e:
+            out[r] = e
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(n_ranks)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+        assert not t.is_alive()
+    for r in range(n_ranks):
+        assert not isinstance(out[r], Exception), out[r]
+        np.testing.assert_allclose(out[r], I0, rtol=1e-13)
+        assert np.array_equal(out[r], out[0])
+    for r in range(n_ranks):
+        lib.ryujin_hip_comm_destroy(C.c_void_p(comms[r]))
