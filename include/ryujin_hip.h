@@ -275,12 +275,18 @@ enum {
   RYUJIN_SCHEME_SSPRK_33 = 1,
   RYUJIN_SCHEME_ERK_11 = 2,
   RYUJIN_SCHEME_ERK_22 = 3,
-  RYUJIN_SCHEME_ERK_33 = 4
+  RYUJIN_SCHEME_ERK_33 = 4,
+  RYUJIN_SCHEME_ERK_43 = 5, /* step_erk_43, :405-440: 4 temporaries */
+  RYUJIN_SCHEME_ERK_54 = 6  /* step_erk_54, :443-510: 5 temporaries */
 };
 enum { RYUJIN_CFL_RECOVERY_NONE = 0, RYUJIN_CFL_RECOVERY_BANG_BANG = 1 };
 int ryujin_hip_time_step(ryujin_hip_ctx *ctx, int scheme, int h_state, const int h_tmp[3],
                          const double *dirichlet_aos, double tau_max, int cfl_recovery, double cfl_min,
                          double cfl_max, double *tau_out);
+/* the same with n_tmp temporaries (ERK43 needs 4, ERK54 needs 5; TimeIntegrator::prepare :163-205) */
+int ryujin_hip_time_step_n(ryujin_hip_ctx *ctx, int scheme, int h_state, int n_tmp, const int *h_tmp,
+                           const double *dirichlet_aos, double tau_max, int cfl_recovery,
+                           double cfl_min, double cfl_max, double *tau_out);
 
 /* Conservation monitor on the device (the interior integrals of ryujin::Quantities,
  * source/quantities.template.h): out[q] = sum over ALL ranks of

@@ -24,7 +24,7 @@ EOS_POLYTROPIC_GAS, EOS_NOBLE_ABEL_STIFFENED_GAS, EOS_VAN_DER_WAALS, EOS_JONES_W
 BC_DO_NOTHING, BC_PERIODIC, BC_SLIP, BC_NO_SLIP, BC_DIRICHLET, BC_DYNAMIC, BC_DIRICHLET_MOMENTUM = range(7)
 IDV_WARN, IDV_RAISE_EXCEPTION = 0, 1
 CUT_NONE, CUT_BOX, CUT_CYLINDER = 0, 1, 2
-SCHEME_SSPRK_22, SCHEME_SSPRK_33, SCHEME_ERK_11, SCHEME_ERK_22, SCHEME_ERK_33 = range(5)
+SCHEME_SSPRK_22, SCHEME_SSPRK_33, SCHEME_ERK_11, SCHEME_ERK_22, SCHEME_ERK_33, SCHEME_ERK_43, SCHEME_ERK_54 = range(7)
 CFL_RECOVERY_NONE, CFL_RECOVERY_BANG_BANG = 0, 1
 UNIQUE_ID_BYTES = 128
 
@@ -145,7 +145,7 @@ HIP_SYMBOLS = [
     "ryujin_hip_default_params", "ryujin_hip_create", "ryujin_hip_destroy",
     "ryujin_hip_state_alloc", "ryujin_hip_state_free", "ryujin_hip_state_upload",
     "ryujin_hip_state_download", "ryujin_hip_state_download_precomputed", "ryujin_hip_state_integrals",
-    "ryujin_hip_prepare_state_vector", "ryujin_hip_step", "ryujin_hip_sadd", "ryujin_hip_time_step",
+    "ryujin_hip_prepare_state_vector", "ryujin_hip_step", "ryujin_hip_sadd", "ryujin_hip_time_step", "ryujin_hip_time_step_n",
     "ryujin_hip_get_timers_accum",
     "ryujin_hip_set_cfl", "ryujin_hip_get_cfl", "ryujin_hip_set_id_violation_strategy",
     "ryujin_hip_get_alpha", "ryujin_hip_get_counters", "ryujin_hip_debug_fetch",
@@ -210,6 +210,8 @@ def load_hip():
         lib.ryujin_hip_get_timers_accum.argtypes = [vp, c_double_p, C.POINTER(C.c_uint), C.c_int]
         lib.ryujin_hip_time_step.argtypes = [vp, C.c_int, C.c_int, c_int_p, c_double_p, C.c_double, C.c_int,
                                              C.c_double, C.c_double, c_double_p]
+        lib.ryujin_hip_time_step_n.argtypes = [vp, C.c_int, C.c_int, C.c_int, c_int_p, c_double_p, C.c_double,
+                                               C.c_int, C.c_double, C.c_double, c_double_p]
         lib.ryujin_hip_synchronize.argtypes = [vp]
         lib.ryujin_hip_event_record.argtypes = [vp, C.c_int]
         lib.ryujin_hip_event_elapsed_ms.argtypes = [vp, c_double_p]

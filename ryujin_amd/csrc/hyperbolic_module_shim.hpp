@@ -163,7 +163,8 @@ namespace ryujin_hip_shim
      * With cfl_recovery == RYUJIN_CFL_RECOVERY_BANG_BANG the reference's retry loop (:250-274) runs
      * inside the library; otherwise a Restart propagates as in step(). Dirichlet data is evaluated at
      * time t (time independent during the step, as in the benchmark configurations). */
-    double time_step(int scheme, StateVector &state_vector, std::array<StateVector, 3> &temp, double t,
+    template <std::size_t n_temp>
+    double time_step(int scheme, StateVector &state_vector, std::array<StateVector, n_temp> &temp, double t,
                      double t_final = std::numeric_limits<double>::max(),
                      int cfl_recovery = RYUJIN_CFL_RECOVERY_NONE, double cfl_min = 0.45,
                      double cfl_max = 0.9) const
@@ -174,10 +175,13 @@ namespace ryujin_hip_shim
         dirichlet_(t, dirichlet_values_);
         ptr = dirichlet_values_.data();
       }
-      const int h_tmp[3] = {temp[0].handle_, temp[1].handle_, temp[2].handle_};
+      int h_tmp[n_temp]; /* temp_[0..n): 3 for SSPRK22/33 and ERK11/22/33, 4 for ERK43, 5 for ERK54 */
+      for (std::size_t q = 0; q < n_temp; ++q)
+        h_tmp[q] = temp[q].handle_;
       double tau_out = 0.;
-      const int status = ryujin_hip_time_step(ctx_, scheme, state_vector.handle_, h_tmp, ptr, t_final - t,
-                                              cfl_recovery, cfl_min, cfl_max, &tau_out);
+      const int status =
+          ryujin_hip_time_step_n(ctx_, scheme, state_vector.handle_, (int)n_temp, h_tmp, ptr, t_final - t,
+                                 cfl_recovery, cfl_min, cfl_max, &tau_out);
       if (status == RYUJIN_ERR_TAU)
         throw std::runtime_error("I'm sorry, Dave. I'm afraid I can't do that.\nWe crashed.");
       check(status);

@@ -221,7 +221,7 @@ struct ryujin_hip_ctx {
   int rk_stage = 0; /* selects the event set while deferred */
   double sweep_ms_accum[8] = {};
   unsigned sweep_updates_accum = 0;
-  hipEvent_t ev_rk[4][9] = {};
+  hipEvent_t ev_rk[5][9] = {};
   hipEvent_t ev[9] = {};
   hipEvent_t ev_user[2] = {};
   double sweep_ms[8] = {};
@@ -279,8 +279,8 @@ struct ryujin_hip_ctx {
   int step(int h_old, int stages, const int *h_stage, const double *w, int h_new, double tau_in,
            double tau_max_in, double *tau_out);
   template <typename E>
-  int time_step(int scheme, int h_state, const int *h_tmp, const double *dirichlet, double tau_max,
-                int cfl_recovery, double cfl_min, double cfl_max, double *tau_out);
+  int time_step(int scheme, int h_state, int n_tmp, const int *h_tmp, const double *dirichlet,
+                double tau_max, int cfl_recovery, double cfl_min, double cfl_max, double *tau_out);
   void mark(int k)
   {
     if (timers_enabled)
@@ -987,11 +987,11 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
  * A Restart is therefore detected at the end of the RK step instead of inside it; the reference repeats
  * the whole RK step from the untouched state vector anyway, so the outcome is the same. */
 template <typename E>
-int ryujin_hip_ctx::time_step(int scheme, int h_state, const int *h_tmp, const double *dirichlet,
+int ryujin_hip_ctx::time_step(int scheme, int h_state, int n_tmp, const int *h_tmp, const double *dirichlet,
                               double tau_max, int cfl_recovery, double cfl_min, double cfl_max,
                               double *tau_out)
 {
-  const int U = h_state, T0 = h_tmp[0], T1 = h_tmp[1], T2 = h_tmp[2];
+  const int U = h_state;
   int n_stages = 0;
   double tau_factor = 1.;
   switch (scheme) {
@@ -1000,11 +1000,50 @@ int ryujin_hip_ctx::time_step(int scheme, int h_state, const int *h_tmp, const d
   case RYUJIN_SCHEME_ERK_22: n_stages = 2; tau_factor = 2.; break;
   case RYUJIN_SCHEME_SSPRK_33: n_stages = 3; break;
   case RYUJIN_SCHEME_ERK_33: n_stages = 3; tau_factor = 3.; break;
+  case RYUJIN_SCHEME_ERK_43: n_stages = 4; tau_factor = 4.; break;
+  case RYUJIN_SCHEME_ERK_54: n_stages = 5; tau_factor = 5.; break;
   default: throw HipError(RYUJIN_ERR_ARG, "unknown time stepping scheme");
   }
-  const bool erk = scheme == RYUJIN_SCHEME_ERK_11 || scheme == RYUJIN_SCHEME_ERK_22 ||
-                   scheme == RYUJIN_SCHEME_ERK_33;
+  const bool erk = scheme != RYUJIN_SCHEME_SSPRK_22 && scheme != RYUJIN_SCHEME_SSPRK_33;
+  /* temp_ vectors: SSPRK22 2, SSPRK33 2, ERK s stages: s (time_integrator.template.h:163-205) */
+  const int n_needed = erk ? n_stages : 2;
+  if (n_tmp < n_needed)
+    throw HipError(RYUJIN_ERR_ARG, "time_step: not enough temporary state vectors for this scheme");
+  const int *T = h_tmp;
   const double first_tau_max = erk ? tau_max / n_stages : tau_max;
+
+  /* explicit Runge-Kutta stages 2.. as (number of stage vectors, their handles, weights):
+   * step_erk_22/33/43/54 (time_integrator.template.h:341-500) */
+  struct ErkStage {
+    int n;
+    int h[4];
+    double w[4];
+  };
+  ErkStage erk_stage[5] = {};
+  if (scheme == RYUJIN_SCHEME_ERK_22) {
+    erk_stage[1] = {1, {U}, {-1.}};
+  } else if (scheme == RYUJIN_SCHEME_ERK_33) {
+    erk_stage[1] = {1, {U}, {-1.}};
+    erk_stage[2] = {2, {U, T[0]}, {0.75, -2.}};
+  } else if (scheme == RYUJIN_SCHEME_ERK_43) {
+    erk_stage[1] = {1, {U}, {-1.}};
+    erk_stage[2] = {1, {T[0]}, {-1.}};
+    erk_stage[3] = {2, {T[0], T[1]}, {5. / 3., -10. / 3.}};
+  } else if (scheme == RYUJIN_SCHEME_ERK_54) {
+    constexpr double c = 0.2;
+    constexpr double a_21 = +0.2;
+    constexpr double a_31 = +0.26075582269554909, a_32 = +0.13924417730445096;
+    constexpr double a_41 = -0.25856517872570289, a_42 = +0.91136274166280729, a_43 = -0.05279756293710430;
+    constexpr double a_51 = +0.21623276431503774, a_52 = +0.51534223099602405, a_53 = -0.81662794199265554,
+                     a_54 = +0.88505294668159373;
+    constexpr double a_61 = -0.10511678454691901, a_62 = +0.87880047152100838, a_63 = -0.58903404061484477,
+                     a_64 = +0.46213380485434047;
+    erk_stage[1] = {1, {U}, {(a_31 - a_21) / c}};
+    erk_stage[2] = {2, {U, T[0]}, {(a_41 - a_31) / c, (a_42 - a_32) / c}};
+    erk_stage[3] = {3, {U, T[0], T[1]}, {(a_51 - a_41) / c, (a_52 - a_42) / c, (a_53 - a_43) / c}};
+    erk_stage[4] = {4, {U, T[0], T[1], T[2]},
+                    {(a_61 - a_51) / c, (a_62 - a_52) / c, (a_63 - a_53) / c, (a_64 - a_54) / c}};
+  }
 
   auto single_step = [&]() -> int {
     double dummy = 0.;
@@ -1020,36 +1059,31 @@ int ryujin_hip_ctx::time_step(int scheme, int h_state, const int *h_tmp, const d
 
     rk_stage = 0;
     prepare_state_vector<E>(U, dirichlet);
-    step<E>(U, 0, none, no_w, T0, 0., first_tau_max, &dummy);
-    result = T0;
-    if (n_stages >= 2) {
-      rk_stage = 1;
-      prepare_state_vector<E>(T0, nullptr);
-      if (erk) {
-        const int hs[1] = {U};
-        const double ws[1] = {-1.};
-        step<E>(T0, 1, hs, ws, T1, 1. /*device tau*/, no_limit, &dummy);
-      } else {
-        step<E>(T0, 0, none, no_w, T1, 1., no_limit, &dummy);
-        if (scheme == RYUJIN_SCHEME_SSPRK_22)
-          ryujin_hip_sadd(this, T1, 1. / 2., 1. / 2., U);
-        else
-          ryujin_hip_sadd(this, T1, 1. / 4., 3. / 4., U);
+    step<E>(U, 0, none, no_w, T[0], 0., first_tau_max, &dummy);
+    result = T[0];
+    if (erk) {
+      for (int st = 1; st < n_stages; ++st) {
+        rk_stage = st;
+        prepare_state_vector<E>(T[st - 1], nullptr);
+        step<E>(T[st - 1], erk_stage[st].n, erk_stage[st].h, erk_stage[st].w, T[st], 1. /*device tau*/,
+                no_limit, &dummy);
+        result = T[st];
       }
-      result = T1;
-    }
-    if (n_stages >= 3) {
-      rk_stage = 2;
-      prepare_state_vector<E>(T1, nullptr);
-      if (erk) {
-        const int hs[2] = {U, T0};
-        const double ws[2] = {0.75, -2.};
-        step<E>(T1, 2, hs, ws, T2, 1., no_limit, &dummy);
-        result = T2;
-      } else {
-        step<E>(T1, 0, none, no_w, T0, 1., no_limit, &dummy);
-        ryujin_hip_sadd(this, T0, 2. / 3., 1. / 3., U);
-        result = T0;
+    } else {
+      rk_stage = 1;
+      prepare_state_vector<E>(T[0], nullptr);
+      step<E>(T[0], 0, none, no_w, T[1], 1., no_limit, &dummy);
+      if (scheme == RYUJIN_SCHEME_SSPRK_22)
+        ryujin_hip_sadd(this, T[1], 1. / 2., 1. / 2., U);
+      else
+        ryujin_hip_sadd(this, T[1], 1. / 4., 3. / 4., U);
+      result = T[1];
+      if (n_stages >= 3) {
+        rk_stage = 2;
+        prepare_state_vector<E>(T[1], nullptr);
+        step<E>(T[1], 0, none, no_w, T[0], 1., no_limit, &dummy);
+        ryujin_hip_sadd(this, T[0], 2. / 3., 1. / 3., U);
+        result = T[0];
       }
     }
     /* the only host synchronisation of the RK step */
@@ -1403,22 +1437,37 @@ int ryujin_hip_step(ryujin_hip_ctx *ctx, int h_old, int stages, const int *h_sta
   });
 }
 
+int ryujin_hip_time_step_n(ryujin_hip_ctx *ctx, int scheme, int h_state, int n_tmp, const int *h_tmp,
+                           const double *dirichlet_aos, double tau_max, int cfl_recovery,
+                           double cfl_min, double cfl_max, double *tau_out)
+{
+  return guarded([&]() {
+    if (!h_tmp || !tau_out || n_tmp < 1 || n_tmp > 8)
+      throw HipError(RYUJIN_ERR_ARG, "time_step: bad argument");
+    HIP_CHECK(hipSetDevice(ctx->device));
+    ctx->state(h_state);
+    for (int q = 0; q < n_tmp; ++q) {
+      ctx->state(h_tmp[q]);
+      if (h_tmp[q] == h_state)
+        throw HipError(RYUJIN_ERR_ARG, "time_step: temporary vectors must differ from the state vector");
+      for (int r = 0; r < q; ++r)
+        if (h_tmp[r] == h_tmp[q])
+          throw HipError(RYUJIN_ERR_ARG, "time_step: temporary vectors must be distinct");
+    }
+    return dispatch_equation(ctx->params.equation, ctx->dim, [&](auto tag) {
+      return ctx->template time_step<typename decltype(tag)::type>(scheme, h_state, n_tmp, h_tmp,
+                                                                   dirichlet_aos, tau_max, cfl_recovery,
+                                                                   cfl_min, cfl_max, tau_out);
+    });
+  });
+}
+
 int ryujin_hip_time_step(ryujin_hip_ctx *ctx, int scheme, int h_state, const int h_tmp[3],
                          const double *dirichlet_aos, double tau_max, int cfl_recovery, double cfl_min,
                          double cfl_max, double *tau_out)
 {
-  return guarded([&]() {
-    if (!h_tmp || !tau_out)
-      throw HipError(RYUJIN_ERR_ARG, "null argument");
-    HIP_CHECK(hipSetDevice(ctx->device));
-    ctx->state(h_state);
-    for (int q = 0; q < 3; ++q)
-      ctx->state(h_tmp[q]);
-    return dispatch_equation(ctx->params.equation, ctx->dim, [&](auto tag) {
-      return ctx->template time_step<typename decltype(tag)::type>(
-          scheme, h_state, h_tmp, dirichlet_aos, tau_max, cfl_recovery, cfl_min, cfl_max, tau_out);
-    });
-  });
+  return ryujin_hip_time_step_n(ctx, scheme, h_state, 3, h_tmp, dirichlet_aos, tau_max, cfl_recovery,
+                                cfl_min, cfl_max, tau_out);
 }
 
 int ryujin_hip_get_timers_accum(ryujin_hip_ctx *ctx, double ms[8], unsigned *n_updates, int reset)

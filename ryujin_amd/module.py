@@ -149,14 +149,15 @@ class HyperbolicModule:
         """Device-resident TimeIntegrator::step (ryujin_hip_time_step): one host synchronisation per
         RK step. `state` names the solution before and after the call."""
         schemes = {"ssprk 22": capi.SCHEME_SSPRK_22, "ssprk 33": capi.SCHEME_SSPRK_33,
-                   "erk 11": capi.SCHEME_ERK_11, "erk 22": capi.SCHEME_ERK_22, "erk 33": capi.SCHEME_ERK_33}
+                   "erk 11": capi.SCHEME_ERK_11, "erk 22": capi.SCHEME_ERK_22, "erk 33": capi.SCHEME_ERK_33,
+                   "erk 43": capi.SCHEME_ERK_43, "erk 54": capi.SCHEME_ERK_54}
         ptr = None
         if dirichlet is not None:
             dirichlet = np.ascontiguousarray(dirichlet, dtype=np.float64)
             ptr = capi.as_ptr(dirichlet, capi.c_double_p)
-        hs = (C.c_int * 3)(*[t.handle for t in temps])
+        hs = (C.c_int * len(temps))(*[t.handle for t in temps])
         tau = C.c_double(0.0)
-        rc = self._f("time_step")(self._ctx, schemes[scheme], state.handle, hs, ptr,
+        rc = self._f("time_step_n")(self._ctx, schemes[scheme], state.handle, len(temps), hs, ptr,
                                   float(np.finfo(np.float64).max if tau_max is None else tau_max),
                                   capi.CFL_RECOVERY_BANG_BANG if cfl_recovery == "bang bang control"
                                   else capi.CFL_RECOVERY_NONE, float(cfl_min), float(cfl_max), C.byref(tau))
@@ -238,7 +239,9 @@ class TimeIntegrator:
         self.cfl_min, self.cfl_max = cfl_min, cfl_max
         self.cfl_recovery_strategy = cfl_recovery_strategy
         self.dirichlet_fn = dirichlet_fn  # t -> [n_bdry, k] array or None
-        self.temp = [module.new_state_vector() for _ in range(3)]
+        # temp_ vectors per scheme: TimeIntegrator::prepare() (:163-205)
+        n_temp = {"erk 43": 4, "erk 54": 5}.get(scheme, 3)
+        self.temp = [module.new_state_vector() for _ in range(n_temp)]
         # TimeIntegrator::prepare(): hyperbolic_module_->cfl(cfl_max_)  (:150)
         module.cfl = cfl_max
 
@@ -249,7 +252,8 @@ class TimeIntegrator:
         """Returns (new_state, tau). The handles are swapped like state_vector.swap(temp)."""
         tau_max = t_final - t
         single = {"ssprk 22": self._ssprk22, "ssprk 33": self._ssprk33, "erk 11": self._erk11,
-                  "erk 22": self._erk22, "erk 33": self._erk33}[self.scheme]
+                  "erk 22": self._erk22, "erk 33": self._erk33, "erk 43": self._erk43,
+                  "erk 54": self._erk54}[self.scheme]
         if self.cfl_recovery_strategy == "bang bang control":
             self.m.id_violation_strategy = capi.IDV_RAISE_EXCEPTION
             self.m.cfl = self.cfl_max
@@ -310,3 +314,43 @@ class TimeIntegrator:
         self._prepare(T[1], t + 2.0 * tau)
         self.m.step(T[1], [sv, T[0]], [0.75, -2.0], T[2], tau)
         return self._swap(sv, 2), 3.0 * tau
+
+    def _erk43(self, sv, t, tau_max):
+        """step_erk_43 (time_integrator.template.h:405-440)"""
+        T = self.temp
+        self._prepare(sv, t)
+        tau = self.m.step(sv, [], [], T[0], 0.0, tau_max / 4.0)
+        self._prepare(T[0], t + 1.0 * tau)
+        self.m.step(T[0], [sv], [-1.0], T[1], tau)
+        self._prepare(T[1], t + 2.0 * tau)
+        self.m.step(T[1], [T[0]], [-1.0], T[2], tau)
+        self._prepare(T[2], t + 3.0 * tau)
+        self.m.step(T[2], [T[0], T[1]], [5.0 / 3.0, -10.0 / 3.0], T[3], tau)
+        return self._swap(sv, 3), 4.0 * tau
+
+    ERK54 = dict(c=0.2, a_21=+0.2, a_31=+0.26075582269554909, a_32=+0.13924417730445096,
+                 a_41=-0.25856517872570289, a_42=+0.91136274166280729, a_43=-0.05279756293710430,
+                 a_51=+0.21623276431503774, a_52=+0.51534223099602405, a_53=-0.81662794199265554,
+                 a_54=+0.88505294668159373, a_61=-0.10511678454691901, a_62=+0.87880047152100838,
+                 a_63=-0.58903404061484477, a_64=+0.46213380485434047)
+
+    def _erk54(self, sv, t, tau_max):
+        """step_erk_54 (time_integrator.template.h:443-510)"""
+        T = self.temp
+        a = self.ERK54
+        c = a["c"]
+        self._prepare(sv, t)
+        tau = self.m.step(sv, [], [], T[0], 0.0, tau_max / 5.0)
+        self._prepare(T[0], t + 1.0 * tau)
+        self.m.step(T[0], [sv], [(a["a_31"] - a["a_21"]) / c], T[1], tau)
+        self._prepare(T[1], t + 2.0 * tau)
+        self.m.step(T[1], [sv, T[0]], [(a["a_41"] - a["a_31"]) / c, (a["a_42"] - a["a_32"]) / c], T[2], tau)
+        self._prepare(T[2], t + 3.0 * tau)
+        self.m.step(T[2], [sv, T[0], T[1]],
+                    [(a["a_51"] - a["a_41"]) / c, (a["a_52"] - a["a_42"]) / c, (a["a_53"] - a["a_43"]) / c],
+                    T[3], tau)
+        self._prepare(T[3], t + 4.0 * tau)
+        self.m.step(T[3], [sv, T[0], T[1], T[2]],
+                    [(a["a_61"] - a["a_51"]) / c, (a["a_62"] - a["a_52"]) / c, (a["a_63"] - a["a_53"]) / c,
+                     (a["a_64"] - a["a_54"]) / c], T[4], tau)
+        return self._swap(sv, 4), 5.0 * tau

@@ -406,7 +406,7 @@ def test_sw_multistage_and_lake_at_rest(oracle):
     assert np.abs(U[:, 1:]).max() < 1e-13
 
 
-@pytest.mark.parametrize("scheme", ["ssprk 33", "erk 33", "ssprk 22", "erk 22", "erk 11"])
+@pytest.mark.parametrize("scheme", ["ssprk 33", "erk 33", "ssprk 22", "erk 22", "erk 11", "erk 43", "erk 54"])
 def test_device_resident_time_step_equals_stagewise_driver(scheme):
     """ryujin_hip_time_step (one host synchronisation per RK step, tau kept on the device) must give
     bit-identical results to the stage-by-stage driver that mirrors TimeIntegrator::step_*."""
@@ -427,7 +427,7 @@ def test_device_resident_time_step_equals_stagewise_driver(scheme):
     m2 = HyperbolicModule(off, equation=capi.EQ_EULER, backend="hip")
     m2.cfl = 0.9
     state = m2.new_state_vector(U0)
-    temps = [m2.new_state_vector() for _ in range(3)]
+    temps = [m2.new_state_vector() for _ in range({"erk 43": 4, "erk 54": 5}.get(scheme, 3))]
     t_b = 0.0
     for n in range(5):
         t_b += m2.time_step(scheme, state, temps, dirichlet if n == 0 else None)
@@ -703,3 +703,28 @@ def test_device_integrals_conservation_monitor():
         assert np.array_equal(out[r], out[0])
     for r in range(n_ranks):
         lib.ryujin_hip_comm_destroy(C.c_void_p(comms[r]))
+
+
+@pytest.mark.parametrize("scheme", ["erk 43", "erk 54"])
+def test_erk43_erk54_parity_with_the_oracle(oracle, scheme):
+    """step<3> and step<4> (four stage vectors with the ERK54 weights, time_integrator.template.h:405-510):
+    three Runge-Kutta steps on the GPU and with the oracle from the same developed state."""
+    spec = offline.mach3_step_2d(20)
+    off = offline.SyntheticOffline(spec)
+    dirichlet = euler_uniform(off.b_positions)
+    U_start = _perturbed(euler_uniform(off.positions))
+    res = []
+    for backend in ("hip", oracle.backend()):
+        m = HyperbolicModule(off, equation=capi.EQ_EULER, backend=backend)
+        sv = m.new_state_vector(U_start)
+        ti = TimeIntegrator(m, scheme, cfl_min=0.9, cfl_max=0.9, cfl_recovery_strategy="none",
+                            dirichlet_fn=lambda t: dirichlet)
+        t = 0.0
+        for _ in range(3):
+            sv, tau = ti.step(sv, t)
+            t += tau
+        res.append((t, sv.download()[: off.n_owned]))
+    assert abs(res[0][0] - res[1][0]) <= 1e-12 * res[1][0]
+    scale = np.abs(res[1][1]).max(axis=0)
+    err = np.abs(res[0][1] - res[1][1]) / scale
+    assert (err > 1e-10).sum() <= max(2, int(1e-4 * err.size)) and err.max() < 1e-8
