@@ -97,7 +97,7 @@ namespace ryujin_hip_shim
         ctx_ = nullptr;
       }
       check(ryujin_hip_create(&ctx_, &offline_, &params_, comm_, device_));
-      k_ = params_.equation == RYUJIN_EQ_EULER ? params_.dim + 2 : params_.dim + 1;
+      k_ = params_.equation == RYUJIN_EQ_SHALLOW_WATER ? params_.dim + 1 : params_.dim + 2;
     }
 
     StateVector create_state_vector() const
