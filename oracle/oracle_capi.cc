@@ -466,7 +466,7 @@ int ryujin_oracle_import_csr(const ryujin_hip_offline *o, uint64_t *ptr, uint32_
   });
 }
 
-/* ---- EulerAEOS function-level entry points (tests/euler_aeos/*.cc of the reference) ---------- */
+/* ---- EulerAEOS function-level entry points (the tests under tests/euler_aeos of the reference) ---- */
 
 /* RiemannSolver::compute(riemann_data_i, riemann_data_j): rd = (rho, u, p, gamma, a).
  * trace[7] = RS p_1, RS p_2, SS p_1, SS p_2, interpolated p, p_star, phi(p_star) */
