@@ -46,7 +46,17 @@ extern "C" {
 
 /* ---- enums -------------------------------------------------------------- */
 /* Description (source/<eq>/description.h) */
-enum { RYUJIN_EQ_EULER = 0, RYUJIN_EQ_SHALLOW_WATER = 1, RYUJIN_EQ_EULER_AEOS = 2 };
+enum {
+  RYUJIN_EQ_EULER = 0,
+  RYUJIN_EQ_SHALLOW_WATER = 1,
+  RYUJIN_EQ_EULER_AEOS = 2,
+  RYUJIN_EQ_SCALAR_CONSERVATION = 3
+};
+
+/* FluxLibrary (source/scalar_conservation/flux_library.h). "function" takes a muparser expression in
+ * the reference; here its polynomial subset sum_n c_n u^n per direction (covers "u", "0.5*u*u", ...),
+ * with the same central-difference gradient (flux_function.h:80-84). */
+enum { RYUJIN_FLUX_BURGERS = 0, RYUJIN_FLUX_KPP = 1, RYUJIN_FLUX_POLYNOMIAL = 2 };
 
 /* EquationOfStateLibrary (source/euler_aeos/equation_of_state_library.h): the closed-form members.
  * "sesame" (tabulated, needs EOSPAC) and "function" (muparser) are host-library bound and not offered. */
@@ -125,6 +135,15 @@ typedef struct ryujin_hip_params {
   double eos_gas_constant_R;  /* 287.052874 (van der Waals: 0.4); only temperature() uses it */
   /* Jones-Wilkins-Lee (equation_of_state_jones_wilkins_lee.h:38-66) */
   double jwl_A, jwl_B, jwl_R1, jwl_R2, jwl_omega, jwl_rho_0, jwl_q_0, jwl_cv;
+
+  /* "B - Equation" scalar conservation (RYUJIN_EQ_SCALAR_CONSERVATION):
+   * source/scalar_conservation/hyperbolic_system.h:510-540 and "/riemann solver" riemann_solver.h:26-55 */
+  int sc_flux;                                /* RYUJIN_FLUX_*: burgers */
+  double sc_flux_polynomial[3][4];            /* RYUJIN_FLUX_POLYNOMIAL: c_0..c_3 per direction */
+  double sc_derivative_approximation_delta;   /* "function": 1e-10 */
+  int sc_use_greedy_wavespeed;                /* 0 */
+  int sc_use_averaged_entropy;                /* 0 */
+  int sc_random_entropies;                    /* 0; > 0 is not reproducible in the reference: rejected */
 } ryujin_hip_params;
 
 /* ---- offline data (input contract) ------------------------------------- */

@@ -14,6 +14,7 @@
 #include <pmmintrin.h>
 
 #include "aeos_module.hpp"
+#include "scalar_module.hpp"
 #include "hyperbolic_module.hpp"
 #include "shallow_water.hpp"
 
@@ -84,6 +85,12 @@ void ryujin_oracle_default_params(ryujin_hip_params *p, int equation, int dim)
   p->jwl_rho_0 = 1895.;
   p->jwl_q_0 = 0.;
   p->jwl_cv = 2487. / 1895.;
+  p->sc_flux = RYUJIN_FLUX_BURGERS;
+  p->sc_flux_polynomial[0][2] = 0.5; /* "0.5*u*u", the default expression of flux_function.h:32 */
+  p->sc_derivative_approximation_delta = 1.e-10;
+  p->sc_use_greedy_wavespeed = 0;
+  p->sc_use_averaged_entropy = 0;
+  p->sc_random_entropies = 0;
 }
 
 /* FTZ/DAZ as the reference sets in main (source/main.cc:26-36) */
@@ -113,6 +120,13 @@ int ryujin_oracle_create(void **ctx, const ryujin_hip_offline *offline,
         c->m = std::make_unique<EulerAeosModule<2>>(*offline, *params);
       else if (dim == 3)
         c->m = std::make_unique<EulerAeosModule<3>>(*offline, *params);
+    } else if (params->equation == RYUJIN_EQ_SCALAR_CONSERVATION) {
+      if (dim == 1)
+        c->m = std::make_unique<ScalarConservationModule<1>>(*offline, *params);
+      else if (dim == 2)
+        c->m = std::make_unique<ScalarConservationModule<2>>(*offline, *params);
+      else if (dim == 3)
+        c->m = std::make_unique<ScalarConservationModule<3>>(*offline, *params);
     } else if (params->equation == RYUJIN_EQ_SHALLOW_WATER) {
       if (dim == 1)
         c->m = std::make_unique<ShallowWaterModule<1>>(*offline, *params);
@@ -620,6 +634,65 @@ int ryujin_oracle_aeos_eos(const ryujin_hip_params *p, double rho, double e, dou
     out[4] = eos.interpolation_b;
     out[5] = eos.interpolation_pinfty;
     out[6] = eos.interpolation_q;
+    return RYUJIN_OK;
+  });
+}
+
+/* ---- scalar conservation function-level entry points ------------------------------------------ */
+
+/* RiemannSolver::compute(u_i, u_j, prec_i, prec_j, n_ij) with prec = (f, df) of the selected flux;
+ * trace[11] = f_i, f_j, df_i, df_j, Roe average, second, third, k, f_k, left, right wavespeed */
+int ryujin_oracle_scalar_riemann(const ryujin_hip_params *p, double u_i, double u_j, const double *n_ij,
+                                 double *lambda_max, double *trace)
+{
+  return guarded([&]() {
+    auto run = [&](auto tag) {
+      constexpr int dim = decltype(tag)::value;
+      const scalar::View<dim> view(*p);
+      scalar::RiemannSolver<dim> rs(view, *p);
+      scalar::RiemannTrace t{};
+      rs.trace = &t;
+      std::array<double, dim> n;
+      for (int d = 0; d < dim; ++d)
+        n[d] = n_ij[d];
+      *lambda_max = rs.compute(u_i, u_j, view.precompute(u_i), view.precompute(u_j), n);
+      if (trace) {
+        const double v[11] = {t.f_i, t.f_j, t.df_i, t.df_j, t.roe, t.second, t.third, t.k, t.f_k, t.left, t.right};
+        std::copy(v, v + 11, trace);
+      }
+      return RYUJIN_OK;
+    };
+    switch (p->dim) {
+    case 1: return run(std::integral_constant<int, 1>{});
+    case 2: return run(std::integral_constant<int, 2>{});
+    default: return run(std::integral_constant<int, 3>{});
+    }
+  });
+}
+
+/* flux_function(u)[dim], flux_gradient_function(u)[dim] */
+int ryujin_oracle_scalar_flux(const ryujin_hip_params *p, double u, double *out)
+{
+  return guarded([&]() {
+    const scalar::Flux flux(*p);
+    for (int d = 0; d < p->dim; ++d) {
+      out[d] = flux.value(u, d);
+      out[p->dim + d] = flux.gradient(u, d);
+    }
+    return RYUJIN_OK;
+  });
+}
+
+/* Limiter::limit(bounds[2], u, p) */
+int ryujin_oracle_scalar_limit(const ryujin_hip_params *p, int expensive_bounds_check, const double *bounds,
+                               double u, double pp, double *l, int *success)
+{
+  return guarded([&]() {
+    scalar::Limiter<1> limiter(*p);
+    limiter.expensive_bounds_check = expensive_bounds_check != 0;
+    const auto [t, ok] = limiter.limit({{bounds[0], bounds[1]}}, u, pp);
+    *l = t;
+    *success = ok ? 1 : 0;
     return RYUJIN_OK;
   });
 }

@@ -51,6 +51,9 @@ def load(path: str | None = None):
     lib.ryujin_oracle_aeos_limit.argtypes = [pp, C.c_int, dp, dp, dp, dp, capi.c_int_p, dp, C.c_int]
     lib.ryujin_oracle_aeos_view.argtypes = [pp, dp, C.c_double, dp]
     lib.ryujin_oracle_aeos_eos.argtypes = [pp, C.c_double, C.c_double, C.c_double, dp]
+    lib.ryujin_oracle_scalar_riemann.argtypes = [pp, C.c_double, C.c_double, dp, dp, dp]
+    lib.ryujin_oracle_scalar_flux.argtypes = [pp, C.c_double, dp]
+    lib.ryujin_oracle_scalar_limit.argtypes = [pp, C.c_int, dp, C.c_double, C.c_double, dp, capi.c_int_p]
     if path == _build.ORACLE_SO:
         _lib = lib
     return lib

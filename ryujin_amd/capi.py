@@ -19,7 +19,8 @@ c_int_p = C.POINTER(C.c_int)
 
 RYUJIN_OK, RYUJIN_WARN, RYUJIN_RESTART = 0, 1, 2
 RYUJIN_ERR_TAU, RYUJIN_ERR_ARG, RYUJIN_ERR_HIP, RYUJIN_ERR_COMM, RYUJIN_ERR_UNSUPPORTED = -1, -2, -3, -4, -5
-EQ_EULER, EQ_SHALLOW_WATER, EQ_EULER_AEOS = 0, 1, 2
+EQ_EULER, EQ_SHALLOW_WATER, EQ_EULER_AEOS, EQ_SCALAR_CONSERVATION = 0, 1, 2, 3
+FLUX_BURGERS, FLUX_KPP, FLUX_POLYNOMIAL = 0, 1, 2
 EOS_POLYTROPIC_GAS, EOS_NOBLE_ABEL_STIFFENED_GAS, EOS_VAN_DER_WAALS, EOS_JONES_WILKINS_LEE = 0, 1, 2, 3
 BC_DO_NOTHING, BC_PERIODIC, BC_SLIP, BC_NO_SLIP, BC_DIRICHLET, BC_DYNAMIC, BC_DIRICHLET_MOMENTUM = range(7)
 IDV_WARN, IDV_RAISE_EXCEPTION = 0, 1
@@ -49,6 +50,9 @@ class Params(C.Structure):
         ("jwl_A", C.c_double), ("jwl_B", C.c_double), ("jwl_R1", C.c_double), ("jwl_R2", C.c_double),
         ("jwl_omega", C.c_double), ("jwl_rho_0", C.c_double), ("jwl_q_0", C.c_double),
         ("jwl_cv", C.c_double),
+        ("sc_flux", C.c_int), ("sc_flux_polynomial", (C.c_double * 4) * 3),
+        ("sc_derivative_approximation_delta", C.c_double), ("sc_use_greedy_wavespeed", C.c_int),
+        ("sc_use_averaged_entropy", C.c_int), ("sc_random_entropies", C.c_int),
     ]
 
 

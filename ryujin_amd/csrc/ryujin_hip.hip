@@ -1244,6 +1244,12 @@ void ryujin_hip_default_params(ryujin_hip_params *p, int equation, int dim)
   p->jwl_rho_0 = 1895.;
   p->jwl_q_0 = 0.;
   p->jwl_cv = 2487. / 1895.;
+  p->sc_flux = RYUJIN_FLUX_BURGERS;
+  p->sc_flux_polynomial[0][2] = 0.5; /* "0.5*u*u", the default expression of flux_function.h:32 */
+  p->sc_derivative_approximation_delta = 1.e-10;
+  p->sc_use_greedy_wavespeed = 0;
+  p->sc_use_averaged_entropy = 0;
+  p->sc_random_entropies = 0;
 }
 
 int ryujin_hip_comm_unique_id(char id[RYUJIN_HIP_UNIQUE_ID_BYTES])

@@ -77,6 +77,7 @@ class HyperbolicModule:
             capi.EQ_EULER: (self.dim + 2, 2, 3),            # source/euler/{hyperbolic_system,limiter}.h
             capi.EQ_SHALLOW_WATER: (self.dim + 1, 2, 5),    # source/shallow_water/...
             capi.EQ_EULER_AEOS: (self.dim + 2, 4, 4),       # source/euler_aeos/...
+            capi.EQ_SCALAR_CONSERVATION: (1, 2 * self.dim, 2),  # source/scalar_conservation/...
         }[self.equation]
         self.n_owned, self.n_relevant = offline.n_owned, offline.n_relevant
         self._ctx = C.c_void_p()

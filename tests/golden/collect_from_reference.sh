@@ -32,3 +32,9 @@ for l in 5 6; do
   cp $R/euler_aeos/verification-isentropic_vortex-pge-2d-ssprk33-l$l.output $D/euler_aeos_verification-isentropic_vortex-pge-2d-ssprk33-l$l.output
   cp $R/euler_aeos/verification-isentropic_vortex-pge-2d-erk33-l$l.output   $D/euler_aeos_verification-isentropic_vortex-pge-2d-erk33-l$l.output
 done
+# scalar conservation
+cp $R/scalar_conservation/riemann_solver.output     $D/scalar_conservation_riemann_solver.output
+cp $R/scalar_conservation/hyperbolic_system.output  $D/scalar_conservation_hyperbolic_system.output
+for s in ssprk22 ssprk33 erk11 erk22 erk33 erk43 erk54; do
+  cp $R/scalar_conservation/verification-linear_transport-$s.output $D/scalar_conservation_verification-linear_transport-$s.output
+done
