@@ -30,6 +30,7 @@
 #include "kernels_limiter.hpp"
 #include "kernels_euler_aeos.hpp"
 #include "kernels_shallow_water.hpp"
+#include "scalar_conservation_device.hpp"
 
 using namespace ryujin_hip;
 
@@ -161,6 +162,7 @@ struct ryujin_hip_ctx {
   EulerParams eparams{};
   ShallowWaterParams swparams{};
   EulerAeosParams aeosparams{};
+  ScalarParams scparams{};
   DeviceBuffer<double> d_Z; /* initial_precomputed (bathymetry), shallow water only */
 
   template <typename E>
@@ -170,6 +172,8 @@ struct ryujin_hip_ctx {
       return eparams;
     else if constexpr (std::is_same<typename E::Params, EulerAeosParams>::value)
       return aeosparams;
+    else if constexpr (std::is_same<typename E::Params, ScalarParams>::value)
+      return scparams;
     else
       return swparams;
   }
@@ -296,8 +300,21 @@ void ryujin_hip_ctx::create(const ryujin_hip_offline &o, const ryujin_hip_params
   device = dev;
   dim = p.dim;
   if (p.equation != RYUJIN_EQ_EULER && p.equation != RYUJIN_EQ_SHALLOW_WATER &&
-      p.equation != RYUJIN_EQ_EULER_AEOS)
+      p.equation != RYUJIN_EQ_EULER_AEOS && p.equation != RYUJIN_EQ_SCALAR_CONSERVATION)
     throw HipError(RYUJIN_ERR_UNSUPPORTED, "unknown equation");
+  if (p.equation == RYUJIN_EQ_SCALAR_CONSERVATION) {
+    if (p.sc_flux < RYUJIN_FLUX_BURGERS || p.sc_flux > RYUJIN_FLUX_POLYNOMIAL)
+      throw HipError(RYUJIN_ERR_UNSUPPORTED, "unknown flux");
+    if (p.sc_flux == RYUJIN_FLUX_KPP && p.dim == 3)
+      throw HipError(RYUJIN_ERR_UNSUPPORTED, "KPP is only defined in (1 or) 2 space dimensions");
+    if (p.sc_random_entropies != 0) /* std::random_device in riemann_solver.template.h:93-107 */
+      throw HipError(RYUJIN_ERR_UNSUPPORTED,
+                     "scalar conservation: random entropies are not reproducible in the reference");
+    for (uint32_t b = 0; b < o.n_bdry; ++b)
+      if (o.b_id[b] == RYUJIN_BC_SLIP || o.b_id[b] == RYUJIN_BC_NO_SLIP || o.b_id[b] == RYUJIN_BC_DYNAMIC)
+        throw HipError(RYUJIN_ERR_UNSUPPORTED, "slip, no-slip and dynamic boundary conditions are "
+                                               "unavailable for scalar conservation equations");
+  }
   if (p.equation == RYUJIN_EQ_EULER_AEOS) {
     if (p.eos < RYUJIN_EOS_POLYTROPIC_GAS || p.eos > RYUJIN_EOS_JONES_WILKINS_LEE)
       throw HipError(RYUJIN_ERR_UNSUPPORTED, "unknown equation of state");
@@ -315,6 +332,11 @@ void ryujin_hip_ctx::create(const ryujin_hip_offline &o, const ryujin_hip_params
   K = p.equation == RYUJIN_EQ_SHALLOW_WATER ? dim + 1 : dim + 2;
   NB = p.equation == RYUJIN_EQ_EULER ? 3 : (p.equation == RYUJIN_EQ_EULER_AEOS ? 4 : 5);
   NPREC = p.equation == RYUJIN_EQ_EULER_AEOS ? 4 : 2;
+  if (p.equation == RYUJIN_EQ_SCALAR_CONSERVATION) {
+    K = 1;
+    NB = 2;
+    NPREC = 2 * dim;
+  }
   KP = (K + 1) / 2 * 2;
 
   HIP_CHECK(hipSetDevice(device));
@@ -378,6 +400,18 @@ void ryujin_hip_ctx::create(const ryujin_hip_offline &o, const ryujin_hip_params
   aeosparams.lim_newton_tolerance = p.limiter_newton_tolerance;
   aeosparams.lim_relaxation_factor = p.limiter_relaxation_factor;
   aeosparams.lim_newton_max_iterations = p.limiter_newton_max_iterations;
+
+  scparams.flux = p.sc_flux;
+  scparams.use_greedy_wavespeed = p.sc_use_greedy_wavespeed != 0;
+  scparams.use_averaged_entropy = p.sc_use_averaged_entropy != 0;
+  for (int d = 0; d < 3; ++d)
+    for (int n = 0; n < 4; ++n)
+      scparams.poly[d][n] = p.sc_flux_polynomial[d][n];
+  /* flux.h:33-34; the "function" flux reads its own parameter (flux_function.h:40-44) */
+  scparams.delta = p.sc_flux == RYUJIN_FLUX_POLYNOMIAL ? p.sc_derivative_approximation_delta
+                                                       : 1.e4 * std::numeric_limits<double>::epsilon();
+  scparams.evc_factor = p.indicator_evc_factor;
+  scparams.lim_relaxation_factor = p.limiter_relaxation_factor;
 
   swparams.gravity = p.gravity;
   swparams.manning = p.manning_friction_coefficient;
@@ -514,7 +548,8 @@ void ryujin_hip_ctx::create(const ryujin_hip_offline &o, const ryujin_hip_params
     row_recv_off.resize((size_t)n_nbr + 1);
     for (int q = 0; q <= n_nbr; ++q)
       row_recv_off[q] = L.ghost_ptr[recv_off[q] - L.n_owned];
-    const size_t buf = std::max<size_t>((size_t)send_off[n_nbr] * KP, row_send_off[n_nbr]);
+    const size_t buf =
+        std::max<size_t>((size_t)send_off[n_nbr] * std::max(KP, NPREC), row_send_off[n_nbr]);
     d_send_buf.alloc(buf);
   }
   HIP_CHECK(hipStreamSynchronize(stream));
@@ -728,6 +763,12 @@ void ryujin_hip_ctx::prepare_state_vector(int h, const double *dirichlet)
                          s.prec.ptr, s.prec.ptr);
     }, true);
     exchange_vector(s.prec.ptr, 4, true);
+  } else if constexpr (std::is_same<typename E::Params, ScalarParams>::value) {
+    sweep([&](const DeviceMesh &mm, dim3 grid) {
+      hipLaunchKernelGGL(k_precompute_sc<E::DIMENSION>, grid, block, 0, stream, eparams, mm, s.U.ptr,
+                         s.prec.ptr);
+    }, true);
+    exchange_vector(s.prec.ptr, E::NPREC, true);
   } else {
     sweep([&](const DeviceMesh &mm, dim3 grid) {
       hipLaunchKernelGGL(k_precompute<E>, grid, block, 0, stream, eparams, mm, s.U.ptr, s.prec.ptr);
@@ -744,6 +785,7 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
   constexpr int DIM = E::DIMENSION;
   constexpr bool is_euler = std::is_same<typename E::Params, EulerParams>::value;
   constexpr bool is_aeos = std::is_same<typename E::Params, EulerAeosParams>::value;
+  constexpr bool is_scalar = std::is_same<typename E::Params, ScalarParams>::value;
   const auto &eparams = eq_params<E>(); /* shadows the member: the equation's parameter block */
   State &old = state(h_old);
   State &nw = state(h_new);
@@ -775,6 +817,13 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
                          old.U.ptr, old.prec.ptr, d_dij.ptr);
     }, false);
     comm_pending = pending;
+  } else if constexpr (is_scalar) {
+    sweep([&](const DeviceMesh &mm, dim3 grid) {
+      hipLaunchKernelGGL(k_dij_alpha_sc<DIM>, grid, block, 0, stream, eparams, mm, old.U.ptr,
+                         old.prec.ptr, d_dij.ptr, d_alpha.ptr);
+    }, true);
+    mark(8);
+    exchange_vector(d_alpha.ptr, 1, true);
   } else if (RYUJIN_SPLIT_DIJ && L.max_row_len <= 32) {
     sweep([&](const DeviceMesh &mm, dim3 grid) {
       hipLaunchKernelGGL(k_alpha<E>, grid, block, 0, stream, eparams, mm, old.U.ptr, old.prec.ptr,
@@ -802,6 +851,10 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
   if (n_pairs) {
     if constexpr (is_aeos)
       hipLaunchKernelGGL(k_dij_boundary_aeos<DIM>, dim3(grid_for(n_pairs)), block, 0, stream, eparams,
+                         n_pairs, d_p_i.ptr, d_p_j.ptr, d_p_pos.ptr, d_p_cji.ptr, old.U.ptr,
+                         old.prec.ptr, d_dij.ptr);
+    else if constexpr (is_scalar)
+      hipLaunchKernelGGL(k_dij_boundary_sc<DIM>, dim3(grid_for(n_pairs)), block, 0, stream, eparams,
                          n_pairs, d_p_i.ptr, d_p_j.ptr, d_p_pos.ptr, d_p_cji.ptr, old.U.ptr,
                          old.prec.ptr, d_dij.ptr);
     else
@@ -860,6 +913,15 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
                            nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
       else
         hipLaunchKernelGGL((k_low_order<DIM, true>), grid, block, 0, stream, eparams, mm,
+                           d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_alpha.ptr, d_dij.ptr,
+                           nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
+    } else if constexpr (is_scalar) {
+      if (stages == 0)
+        hipLaunchKernelGGL((k_low_order_sc<DIM, false>), grid, block, 0, stream, eparams, mm,
+                           d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_alpha.ptr, d_dij.ptr,
+                           nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
+      else
+        hipLaunchKernelGGL((k_low_order_sc<DIM, true>), grid, block, 0, stream, eparams, mm,
                            d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_alpha.ptr, d_dij.ptr,
                            nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
     } else if constexpr (is_aeos) {
@@ -1176,6 +1238,13 @@ namespace
         return f(EqTag<ShallowWater<1>>{});
       return f(EqTag<ShallowWater<2>>{});
     }
+    if (equation == RYUJIN_EQ_SCALAR_CONSERVATION) {
+      switch (dim) {
+      case 1: return f(EqTag<ScalarConservation<1>>{});
+      case 2: return f(EqTag<ScalarConservation<2>>{});
+      default: return f(EqTag<ScalarConservation<3>>{});
+      }
+    }
     if (equation == RYUJIN_EQ_EULER_AEOS) {
       switch (dim) {
       case 1: return f(EqTag<EulerAeos<1>>{});
@@ -1200,7 +1269,7 @@ const char *ryujin_hip_last_error(void)
 
 const char *ryujin_hip_version(void)
 {
-  return "ryujin_hip 0.3 (gfx950; Euler, Euler AEOS, shallow water; SELL-64)";
+  return "ryujin_hip 0.4 (gfx950; Euler, Euler AEOS, shallow water, scalar conservation; SELL-64)";
 }
 
 void ryujin_hip_default_params(ryujin_hip_params *p, int equation, int dim)
@@ -1553,6 +1622,7 @@ int ryujin_hip_state_integrals(ryujin_hip_ctx *ctx, int handle, double *out)
                          result);
     };
     switch (K) {
+    case 1: launch(std::integral_constant<int, 1>{}); break;
     case 2: launch(std::integral_constant<int, 2>{}); break;
     case 3: launch(std::integral_constant<int, 3>{}); break;
     case 4: launch(std::integral_constant<int, 4>{}); break;
