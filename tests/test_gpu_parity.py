@@ -863,3 +863,56 @@ def test_scalar_rejects_what_the_reference_rejects():
     off = offline.SyntheticOffline(spec)
     with pytest.raises(RuntimeError, match="unavailable for scalar conservation"):
         HyperbolicModule(off, equation=capi.EQ_SCALAR_CONSERVATION, backend="hip")
+
+
+def test_wide_ragged_stencil_generic_kernels(oracle):
+    """Stencils wider than anything a Q1 mesh produces (up to 49 entries per row, strongly ragged near
+    the boundary): exercises the generic, non-unrolled sweeps (k_dij_alpha, k_dij_diag, the two-pass
+    k_high_order) and the 64-entry limit of a SELL-64 slice. The matrices are synthetic but consistent
+    (c_ij = -c_ji, m_ij = m_ji > 0, m_i = sum_j m_ij), which is all step() relies on."""
+    from helpers_layout import OfflineView
+    nx = ny = 24
+    R = 3                                   # (2R+1)^2 = 49 entries in the interior
+    h = 1.0 / nx
+    idx = lambda ix, iy: iy * nx + ix       # noqa: E731
+    rows, cij, mij = [], [], []
+    for iy in range(ny):
+        for ix in range(nx):
+            i = idx(ix, iy)
+            nb = []
+            for dy in range(-R, R + 1):
+                for dx in range(-R, R + 1):
+                    jx, jy = ix + dx, iy + dy
+                    if (dx, dy) != (0, 0) and 0 <= jx < nx and 0 <= jy < ny:
+                        w = h * h / (1.0 + dx * dx + dy * dy) ** 2
+                        nb.append((idx(jx, jy), (0.5 * h * w / (h * h) * dx, 0.5 * h * w / (h * h) * dy), w / 9.0))
+            nb.sort()
+            rows.append([i] + [j for j, _, _ in nb])
+            cij.extend([(0.0, 0.0)] + [c for _, c, _ in nb])
+            mij.extend([h * h * 0.5] + [m for _, _, m in nb])
+    n = nx * ny
+    row_starts = np.cumsum([0] + [len(r) for r in rows]).astype(np.uint64)
+    assert max(len(r) for r in rows) == 49 and min(len(r) for r in rows) == 16
+    columns = np.concatenate([np.array(r, dtype=np.uint32) for r in rows])
+    mij = np.array(mij)
+    mi = np.add.reduceat(mij, row_starts[:-1].astype(np.int64))
+    off = OfflineView(2, 0, 0, n, n, 1, row_starts, columns, np.array(cij), mij, mi, 1.0 / mi, mi.sum(),
+                      [], np.zeros((0, 2)), [], [], [], [])
+    pos = np.array([[(ix + 0.5) * h, (iy + 0.5) * h] for iy in range(ny) for ix in range(nx)])
+    U0 = _perturbed(euler_radial_contrast(pos, inner=(1.0, 0.0, 5.0), outer=(0.5, 0.0, 0.5), radius=0.25,
+                                          center=(0.5, 0.5)))
+    mods = []
+    U_start = U0
+    for backend in ("hip", oracle.backend()):
+        m = HyperbolicModule(off, equation=capi.EQ_EULER, backend=backend)
+        m.cfl = 0.5
+        old, new = m.new_state_vector(U_start), m.new_state_vector()
+        if backend == "hip":
+            for _ in range(5):
+                m.prepare_state_vector(old, 0.0)
+                m.step(old, [], [], new)
+                old, new = new, old
+            U_start = old.download()
+        mods.append((m, old, new))
+    off.row_starts = row_starts
+    _compare_step(off, mods)
