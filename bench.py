@@ -245,6 +245,13 @@ def main():
     from ryujin_amd import HyperbolicModule, capi, offline
     from ryujin_amd.initial_states import euler_uniform
 
+    if dist is not None:
+        # the in-tree libraries are (re)built on demand: let rank 0 do that alone, the others load after it
+        if rank == 0:
+            capi.load_synth()
+            capi.load_hip()
+        dist.barrier()
+
     # ---- workload: BASELINE.json configs[1] per GPU, lengthened channel for N GPUs (weak scaling)
     equation = capi.EQ_EULER
     rng = np.random.default_rng(42 + rank)
