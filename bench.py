@@ -221,6 +221,8 @@ def main():
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
 
+    # the host driver only supports dmabuf IPC: RCCL's cross-process buffers need this
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
