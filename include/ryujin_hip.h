@@ -217,6 +217,17 @@ typedef struct ryujin_hip_offline {
   const uint32_t *row_send_off; /* [n_nbr+1] */
   const uint32_t *row_send_row; /* [row_send_off[n_nbr]] */
   const uint32_t *row_send_col; /* [row_send_off[n_nbr]] */
+
+  /*
+   * Discontinuous finite element ansatz (Discretization::have_discontinuous_ansatz(), SURVEY.md
+   * section 8 f-4). When nonzero the step uses the incidence matrix in the high-order viscosity
+   * (hyperbolic_module.template.h:733-737), the full block-diagonal inverse mass matrix instead of the
+   * Neumann series (:976-986) and extends the limiter bounds over the stencil (:938-948).
+   * Both matrices in the storage scheme of mij. Single rank, Euler only, in this version.
+   */
+  int discontinuous_ansatz;
+  const double *incidence;           /* [nnz] OfflineData::incidence_matrix() */
+  const double *mass_matrix_inverse; /* [nnz] OfflineData::mass_matrix_inverse() */
 } ryujin_hip_offline;
 
 typedef struct ryujin_hip_ctx ryujin_hip_ctx; /* opaque; one per (rank, GPU) */

@@ -10,7 +10,8 @@
  *
  * Layout (little endian, every section 8-byte aligned):
  *   char     magic[8] = "RYJOFFL1"
- *   uint32   version (1), dim, n_initial_precomputed, flags (bit 0: positions, bit 1: boundary positions)
+ *   uint32   version (1), dim, n_initial_precomputed, flags (bit 0: positions, bit 1: boundary positions,
+ *            bit 2: discontinuous ansatz)
  *   uint32   n_export, n_internal, n_owned, n_relevant, simd_length, n_bdry, n_pairs, n_nbr
  *   uint64   nnz (== row_starts[n_relevant])
  *   float64  measure_of_omega
@@ -20,7 +21,8 @@
  *     p_i, p_col, p_j u32[n_pairs], initial_precomputed f64[n_relevant*n_initial_precomputed],
  *     nbr_rank i32[n_nbr], send_off u32[n_nbr+1], send_idx u32[send_off[n_nbr]], recv_off u32[n_nbr+1],
  *     row_send_off u32[n_nbr+1], row_send_row, row_send_col u32[row_send_off[n_nbr]],
- *     positions f64[n_relevant*dim] (flag bit 0), b_positions f64[n_bdry*dim] (flag bit 1)
+ *     positions f64[n_relevant*dim] (flag bit 0), b_positions f64[n_bdry*dim] (flag bit 1),
+ *     incidence f64[nnz], mass_matrix_inverse f64[nnz] (flag bit 2)
  *   uint64   FNV-1a checksum of everything before it
  * One file per rank. The reader validates sizes, index ranges, the diagonal-first convention and the
  * checksum; a file that fails any check is rejected (NULL + message), never partially loaded.

@@ -80,6 +80,9 @@ namespace oracle
     CSR csr;
     std::vector<double> cij, mij, mi, mi_inv;
     double measure_of_omega;
+    /* discontinuous ansatz (hyperbolic_module.template.h:287-293): incidence matrix, full inverse mass matrix */
+    bool discontinuous_ansatz = false;
+    std::vector<double> incidence, mass_matrix_inverse;
 
     std::vector<uint32_t> b_i;
     std::vector<double> b_normal;
@@ -115,6 +118,15 @@ namespace oracle
       mi.assign(o.mi, o.mi + n_relevant);
       mi_inv.assign(o.mi_inv, o.mi_inv + n_relevant);
       measure_of_omega = o.measure_of_omega;
+      discontinuous_ansatz = o.discontinuous_ansatz != 0;
+      if (discontinuous_ansatz) {
+        if (!o.incidence || !o.mass_matrix_inverse)
+          throw std::runtime_error("discontinuous ansatz without incidence / inverse mass matrix");
+        if (o.n_nbr != 0)
+          throw std::runtime_error("discontinuous ansatz: single rank only");
+        incidence = csr.gather(o, o.incidence, 1);
+        mass_matrix_inverse = csr.gather(o, o.mass_matrix_inverse, 1);
+      }
       b_i.assign(o.b_i, o.b_i + o.n_bdry);
       b_normal.assign(o.b_normal, o.b_normal + (size_t)o.n_bdry * dim);
       b_id.assign(o.b_id, o.b_id + o.n_bdry);
@@ -357,7 +369,9 @@ namespace oracle
             const auto U_j = get_state(old_U, j);
             const double alpha_j = alpha[j];
             const double d_ij = dij[e];
-            const double factor = (alpha_i + alpha_j) * .5;
+            double factor = (alpha_i + alpha_j) * .5;
+            if (discontinuous_ansatz) /* :733-737 */
+              factor = std::max(factor, incidence[e]);
             const double d_ijH = d_ij * factor;
 
             const auto c_ij = get_c(e);
@@ -419,6 +433,31 @@ namespace oracle
 
       /* Step 5: second part of p_ij, first l_ij (:892-1041) */
       const int n_iterations = params.limiter_iterations;
+      if (n_iterations != 0 && discontinuous_ansatz) {
+        /* Extend the bounds over the stencil (:938-948, Limiter::combine_bounds limiter.h:366-377).
+         * The reference combines in place while other threads read their neighbours' entries (the
+         * outcome depends on the thread schedule: a neighbour's entry is either its own or its
+         * already extended bound). Here every row combines the ORIGINAL bounds of its stencil, which
+         * is what a row sees in the reference whenever its neighbours have not been visited yet. */
+        const std::vector<double> original(bounds);
+#pragma omp parallel for schedule(static)
+        for (uint32_t i = 0; i < n_owned; ++i) {
+          const uint64_t rs = csr.ptr[i], re = csr.ptr[i + 1];
+          if (re - rs == 1)
+            continue;
+          double rho_min = original[(size_t)i * NB], rho_max = original[(size_t)i * NB + 1],
+                 s_min = original[(size_t)i * NB + 2];
+          for (uint64_t e = rs + 1; e < re; ++e) {
+            const uint32_t j = csr.col[e];
+            rho_min = std::min(rho_min, original[(size_t)j * NB]);
+            rho_max = std::max(rho_max, original[(size_t)j * NB + 1]);
+            s_min = std::min(s_min, original[(size_t)j * NB + 2]);
+          }
+          bounds[(size_t)i * NB] = rho_min;
+          bounds[(size_t)i * NB + 1] = rho_max;
+          bounds[(size_t)i * NB + 2] = s_min;
+        }
+      }
       if (n_iterations != 0) {
 #pragma omp parallel
         {
@@ -446,10 +485,18 @@ namespace oracle
               const auto F_jH = get_state(r, j);
 
               const double kronecker_ij = 0.;
-              const double m_j_inv = mi_inv[j];
-              const double m_ij = mij[e];
-              const double b_ij = kronecker_ij - m_ij * m_j_inv;
-              const double b_ji = kronecker_ij - m_ij * m_i_inv;
+              double b_ij, b_ji;
+              if (discontinuous_ansatz) { /* full consistent mass matrix inverse (:976-986) */
+                const double m_i = mi[i], m_j = mi[j];
+                const double m_ij_inv = mass_matrix_inverse[e];
+                b_ij = m_i * m_ij_inv - kronecker_ij;
+                b_ji = m_j * m_ij_inv - kronecker_ij;
+              } else { /* Neumann series expansion (:988-996) */
+                const double m_j_inv = mi_inv[j];
+                const double m_ij = mij[e];
+                b_ij = kronecker_ij - m_ij * m_j_inv;
+                b_ji = kronecker_ij - m_ij * m_i_inv;
+              }
               for (int q = 0; q < K; ++q) {
                 P_ij[q] += b_ij * F_jH[q] - b_ji * F_iH[q];
                 P_ij[q] *= factor;

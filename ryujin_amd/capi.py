@@ -68,6 +68,7 @@ class Offline(C.Structure):
         ("n_nbr", C.c_int), ("nbr_rank", c_int_p), ("send_off", c_u32_p), ("send_idx", c_u32_p),
         ("recv_off", c_u32_p), ("row_send_off", c_u32_p), ("row_send_row", c_u32_p),
         ("row_send_col", c_u32_p),
+        ("discontinuous_ansatz", C.c_int), ("incidence", c_double_p), ("mass_matrix_inverse", c_double_p),
     ]
 
 

@@ -36,6 +36,8 @@ namespace ryujin_hip
     const double *mij;
     const double *mi, *mi_inv;
     double measure_of_omega_inverse;
+    /* discontinuous ansatz only (NULL otherwise): incidence matrix, full inverse mass matrix, SELL-64 */
+    const double *incidence, *mass_matrix_inverse;
   };
 
   /* device scalars shared between sweeps */
@@ -623,7 +625,7 @@ namespace ryujin_hip
   /* STORE_P = false: the first part of P_ij is not written here but recomputed -- with the identical
    * operation sequence, hence bit-identical -- by k_pij_lij_recompute (saves the 8kS B/row store of
    * this sweep and the 8kS B/row load of step 5 for 8dS+8S B/row of c_ij, d_ij loads there). */
-  template <int DIM, bool HAS_STAGES, bool STORE_P = true>
+  template <int DIM, bool HAS_STAGES, bool STORE_P = true, bool DG = false>
   __global__ void __launch_bounds__(kBlock, RYUJIN_OCC_LOW)
   k_low_order(const EulerParams P, const DeviceMesh M, const DeviceScalars *__restrict__ scalars,
               const double weight, const StageArgs<DIM> S, const double *__restrict__ U,
@@ -694,7 +696,9 @@ namespace ryujin_hip
       if (!active)
         continue;
 
-      const double factor = (alpha_i + alpha_j) * .5;
+      double factor = (alpha_i + alpha_j) * .5;
+      if constexpr (DG) /* hyperbolic_module.template.h:733-737 */
+        factor = fmax(factor, M.incidence[colbase * 64 + r.lane]);
       const double d_ijH = d_ij * factor;
 
       const double regularization = 100. * DBL_MIN;
@@ -802,6 +806,34 @@ namespace ryujin_hip
     bounds[i] = rho_min_r;
     bounds[stride + i] = rho_max_r;
     bounds[2 * stride + i] = s_min_r;
+  }
+
+  /* Discontinuous ansatz: extend the limiter bounds over the stencil (hyperbolic_module.template.h:938-948
+   * with Limiter::combine_bounds, euler/limiter.h:366-377: min, max, min). Reads the ORIGINAL bounds of
+   * the neighbours and writes a second buffer (the reference combines in place with a benign race). */
+  __global__ void __launch_bounds__(kBlock)
+  k_bounds_combine_euler(const DeviceMesh M, const double *__restrict__ in, double *__restrict__ out)
+  {
+    const RowCtx r = row_context(M);
+    if (!r.valid)
+      return;
+    const bool row_active = r.len > 1;
+    const uint32_t i = row_active ? r.row : (r.row < M.n_owned ? r.row : M.n_owned - 1);
+    const size_t stride = (size_t)M.n_slices * 64;
+    double rho_min = in[i], rho_max = in[stride + i], s_min = in[2 * stride + i];
+    for (uint32_t c = 1; c < r.width; ++c) {
+      const uint32_t j = M.cols[((uint64_t)r.base + c) * 64 + r.lane];
+      if (row_active && c < r.len) {
+        rho_min = fmin(rho_min, in[j]);
+        rho_max = fmax(rho_max, in[stride + j]);
+        s_min = fmin(s_min, in[2 * stride + j]);
+      }
+    }
+    if (row_active) {
+      out[i] = rho_min;
+      out[stride + i] = rho_max;
+      out[2 * stride + i] = s_min;
+    }
   }
 
   /* steps 5, 6, 7: kernels_limiter.hpp */

@@ -25,7 +25,9 @@ namespace ryujin_hip
 
   /* ------------------------------------------------------------------ step 5 */
 
-  template <typename E>
+  /* DG: full inverse of the (block-diagonal) consistent mass matrix instead of the Neumann series
+   * (hyperbolic_module.template.h:976-986): b_ij = m_i (M^-1)_ij, b_ji = m_j (M^-1)_ij */
+  template <typename E, bool DG = false>
   __global__ void __launch_bounds__(kBlock, RYUJIN_OCC_PIJ)
   k_pij_lij(const typename E::Params P, const DeviceMesh M, DeviceScalars *__restrict__ scalars,
             const double *__restrict__ new_U, const double *__restrict__ r_in,
@@ -40,8 +42,10 @@ namespace ryujin_hip
     const uint32_t i = row_active ? r.row : (r.row < M.n_owned ? r.row : M.n_owned - 1);
     const double tau = scalars->tau;
     const uint32_t *__restrict__ cols = M.cols;
-    const double *__restrict__ mij = M.mij;
+    /* DG: the matrix stream is (M^-1)_ij and the gathered per-node value is m_j instead of 1/m_j */
+    const double *__restrict__ mij = DG ? M.mass_matrix_inverse : M.mij;
     const double *__restrict__ mi_inv = M.mi_inv;
+    const double *__restrict__ node_j = DG ? M.mi : M.mi_inv;
 
     const size_t stride = (size_t)M.n_slices * 64;
     double bnd[NB];
@@ -49,6 +53,7 @@ namespace ryujin_hip
     for (int b = 0; b < NB; ++b)
       bnd[b] = bounds[(size_t)b * stride + i];
     const double m_i_inv = mi_inv[i];
+    [[maybe_unused]] const double m_i = M.mi[i];
     double U_i_new[K], F_iH[K];
     load_state<K>(new_U, i, U_i_new);
     load_state<K>(r_in, i, F_iH);
@@ -65,7 +70,7 @@ namespace ryujin_hip
     if (r.width > 1) {
       load_entry<K>(pij, (uint64_t)r.base + 1, r.lane, P_n);
       load_state<K>(r_in, j_n, F_n);
-      mjinv_n = mi_inv[j_n];
+      mjinv_n = node_j[j_n];
       mij_n = ld_stream(mij + (((uint64_t)r.base + 1) * 64 + r.lane));
     }
 
@@ -84,7 +89,7 @@ namespace ryujin_hip
         j_n = j_nn;
         load_entry<K>(pij, colbase + 1, r.lane, P_n);
         load_state<K>(r_in, j_n, F_n);
-        mjinv_n = mi_inv[j_n];
+        mjinv_n = node_j[j_n];
         mij_n = ld_stream(mij + ((colbase + 1) * 64 + r.lane));
         j_nn = (c + 2 < r.width) ? ld_stream(cols + ((colbase + 2) * 64 + r.lane)) : i;
       }
@@ -92,8 +97,14 @@ namespace ryujin_hip
         continue;
 
       /* Neumann series: b_ij = delta_ij - m_ij/m_j, b_ji = delta_ij - m_ij/m_i (:987-996) */
-      const double b_ij = 0. - m_ij * m_j_inv;
-      const double b_ji = 0. - m_ij * m_i_inv;
+      double b_ij, b_ji;
+      if constexpr (DG) {
+        b_ij = m_i * m_ij - 0.;     /* m_ij holds (M^-1)_ij, m_j_inv holds m_j */
+        b_ji = m_j_inv * m_ij - 0.;
+      } else {
+        b_ij = 0. - m_ij * m_j_inv;
+        b_ji = 0. - m_ij * m_i_inv;
+      }
 #pragma unroll
       for (int q = 0; q < K; ++q) {
         P_ij[q] += b_ij * F_jH[q] - b_ji * F_iH[q];

@@ -102,7 +102,8 @@ struct ryujin_offline_file {
       row_send_row, row_send_col;
   std::vector<int32_t> nbr_rank;
   std::vector<uint8_t> b_id;
-  std::vector<double> cij, mij, mi, mi_inv, b_normal, initial_precomputed, positions, b_positions;
+  std::vector<double> cij, mij, mi, mi_inv, b_normal, initial_precomputed, positions, b_positions,
+      incidence, mass_matrix_inverse;
 
   void validate() const
   {
@@ -197,6 +198,8 @@ struct ryujin_offline_file {
     o.row_send_off = o.n_nbr ? row_send_off.data() : nullptr;
     o.row_send_row = row_send_row.data();
     o.row_send_col = row_send_col.data();
+    o.incidence = o.discontinuous_ansatz ? incidence.data() : nullptr;
+    o.mass_matrix_inverse = o.discontinuous_ansatz ? mass_matrix_inverse.data() : nullptr;
   }
 };
 
@@ -231,7 +234,10 @@ int ryujin_offline_write(const char *path, const ryujin_hip_offline *o, int dim,
     w.scalar<uint32_t>(kVersion);
     w.scalar<uint32_t>((uint32_t)dim);
     w.scalar<uint32_t>((uint32_t)n_init_prec);
-    w.scalar<uint32_t>((positions ? 1u : 0u) | (b_positions ? 2u : 0u));
+    const bool dg = o->discontinuous_ansatz != 0;
+    if (dg && (!o->incidence || !o->mass_matrix_inverse))
+      throw std::invalid_argument("discontinuous ansatz without incidence / inverse mass matrix");
+    w.scalar<uint32_t>((positions ? 1u : 0u) | (b_positions ? 2u : 0u) | (dg ? 4u : 0u));
     for (uint32_t v : {o->n_export, o->n_internal, o->n_owned, o->n_relevant, sl, o->n_bdry, o->n_pairs, n_nbr})
       w.scalar<uint32_t>(v);
     w.scalar<uint64_t>(nnz);
@@ -261,6 +267,10 @@ int ryujin_offline_write(const char *path, const ryujin_hip_offline *o, int dim,
     w.section(o->row_send_col, n_row_send * 4);
     w.section(positions, positions ? n * dim * 8 : 0);
     w.section(b_positions, b_positions ? (uint64_t)o->n_bdry * dim * 8 : 0);
+    if (dg) { /* flag bit 2: two more sections */
+      w.section(o->incidence, nnz * 8);
+      w.section(o->mass_matrix_inverse, nnz * 8);
+    }
     const uint64_t h = w.sum.h;
     if (std::fwrite(&h, 8, 1, f) != 1)
       throw std::runtime_error("short write");
@@ -297,7 +307,7 @@ ryujin_offline_file *ryujin_offline_read(const char *path)
     const uint32_t dim = r.scalar<uint32_t>();
     const uint32_t nip = r.scalar<uint32_t>();
     const uint32_t flags = r.scalar<uint32_t>();
-    if (dim < 1 || dim > 3 || nip > 16 || flags > 3)
+    if (dim < 1 || dim > 3 || nip > 16 || flags > 7)
       throw std::runtime_error("bad header");
     ryujin_hip_offline &o = file->view;
     o.n_export = r.scalar<uint32_t>();
@@ -348,6 +358,11 @@ ryujin_offline_file *ryujin_offline_read(const char *path)
     file->has_b_positions = flags & 2u;
     r.section(file->positions, file->has_positions ? n * dim : 0, "positions");
     r.section(file->b_positions, file->has_b_positions ? (uint64_t)o.n_bdry * dim : 0, "b_positions");
+    o.discontinuous_ansatz = (flags & 4u) ? 1 : 0;
+    if (o.discontinuous_ansatz) {
+      r.section(file->incidence, nnz, "incidence");
+      r.section(file->mass_matrix_inverse, nnz, "mass_matrix_inverse");
+    }
     const uint64_t expected = r.sum.h;
     uint64_t stored = 0;
     if (std::fread(&stored, 8, 1, f) != 1)

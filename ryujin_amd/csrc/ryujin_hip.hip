@@ -182,6 +182,8 @@ struct ryujin_hip_ctx {
   DeviceBuffer<uint32_t> d_slice_off, d_cols, d_idx_t, d_lower_mask;
   DeviceBuffer<uint8_t> d_row_len;
   DeviceBuffer<double> d_cij, d_mij, d_mi, d_mi_inv;
+  bool dg = false; /* discontinuous ansatz */
+  DeviceBuffer<double> d_incidence, d_minv, d_bounds_combined;
 
   /* boundary data */
   uint32_t n_bdry = 0, n_groups = 0;
@@ -452,6 +454,17 @@ void ryujin_hip_ctx::create(const ryujin_hip_offline &o, const ryujin_hip_params
     d_cij.upload(cij);
     const auto mij = L.scatter(o, o.mij, 1);
     d_mij.upload(mij);
+    dg = o.discontinuous_ansatz != 0;
+    if (dg) {
+      if (p.equation != RYUJIN_EQ_EULER)
+        throw HipError(RYUJIN_ERR_UNSUPPORTED, "discontinuous ansatz: Euler equations only in this version");
+      if (o.n_nbr != 0)
+        throw HipError(RYUJIN_ERR_UNSUPPORTED, "discontinuous ansatz: single rank only in this version");
+      if (!o.incidence || !o.mass_matrix_inverse)
+        throw HipError(RYUJIN_ERR_ARG, "discontinuous ansatz without incidence / inverse mass matrix");
+      d_incidence.upload(L.scatter(o, o.incidence, 1));
+      d_minv.upload(L.scatter(o, o.mass_matrix_inverse, 1));
+    }
 
     /* coupling boundary pairs: position of (i,col_idx) and the value of c_ji */
     n_pairs = o.n_pairs;
@@ -487,6 +500,8 @@ void ryujin_hip_ctx::create(const ryujin_hip_offline &o, const ryujin_hip_params
   mesh.idx_t = d_idx_t.ptr;
   mesh.cij = d_cij.ptr;
   mesh.mij = d_mij.ptr;
+  mesh.incidence = dg ? d_incidence.ptr : nullptr;
+  mesh.mass_matrix_inverse = dg ? d_minv.ptr : nullptr;
   mesh.mi = d_mi.ptr;
   mesh.mi_inv = d_mi_inv.ptr;
   mesh.measure_of_omega_inverse = 1. / o.measure_of_omega;
@@ -524,6 +539,8 @@ void ryujin_hip_ctx::create(const ryujin_hip_offline &o, const ryujin_hip_params
   /* ---- module-owned storage (prepare(): hyperbolic_module.template.h:52-86) ---- */
   d_alpha.alloc(L.n_relevant);
   d_bounds.alloc((size_t)NB * L.rows_padded);
+  if (dg)
+    d_bounds_combined.alloc((size_t)NB * L.rows_padded);
   d_r.alloc((size_t)L.n_relevant * KP);
   d_dij.alloc(L.nnz_total);
   d_lij.alloc(L.nnz_total);
@@ -900,10 +917,18 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
    * A/B on MI355X: -7 % per update in 2-D (k=4, 9 columns); +1 % in 3-D where step 5 turns
    * register/VALU bound (k=5, 27 columns), so only for dim <= 2. */
   const bool recompute_p = is_euler && DIM <= 2 && stages == 0 && params.limiter_iterations != 0 &&
-                           RYUJIN_RECOMPUTE_P;
+                           RYUJIN_RECOMPUTE_P && !dg;
   sweep([&](const DeviceMesh &mm, dim3 grid) {
     if constexpr (is_euler) {
-      if (recompute_p)
+      if (dg && stages == 0)
+        hipLaunchKernelGGL((k_low_order<DIM, false, true, true>), grid, block, 0, stream, eparams, mm,
+                           d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_alpha.ptr, d_dij.ptr,
+                           nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
+      else if (dg)
+        hipLaunchKernelGGL((k_low_order<DIM, true, true, true>), grid, block, 0, stream, eparams, mm,
+                           d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_alpha.ptr, d_dij.ptr,
+                           nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
+      else if (recompute_p)
         hipLaunchKernelGGL((k_low_order<DIM, false, false>), grid, block, 0, stream, eparams, mm,
                            d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_alpha.ptr, d_dij.ptr,
                            nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
@@ -949,6 +974,16 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
 
   /* Step 5: second part of p_ij, first l_ij; ghost rows of l_ij (:892-1041) */
   const int n_iterations = params.limiter_iterations;
+  if constexpr (is_euler) {
+    if (dg && n_iterations != 0) {
+      /* bounds over the stencil (:938-948); steps 5-7 read the extended bounds */
+      sweep([&](const DeviceMesh &mm, dim3 grid) {
+        hipLaunchKernelGGL(k_bounds_combine_euler, grid, block, 0, stream, mm, d_bounds.ptr,
+                           d_bounds_combined.ptr);
+      }, false);
+      std::swap(d_bounds.ptr, d_bounds_combined.ptr);
+    }
+  }
   if (n_iterations != 0) {
     sweep([&](const DeviceMesh &mm, dim3 grid) {
       if constexpr (is_euler) {
@@ -956,6 +991,13 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
           hipLaunchKernelGGL(k_pij_lij_recompute<DIM>, grid, block, 0, stream, eparams, mm,
                              d_scalars.ptr, weight, old.U.ptr, d_alpha.ptr, d_dij.ptr, nw.U.ptr,
                              d_r.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr);
+          return;
+        }
+      }
+      if constexpr (is_euler) {
+        if (dg) {
+          hipLaunchKernelGGL((k_pij_lij<E, true>), grid, block, 0, stream, eparams, mm, d_scalars.ptr,
+                             nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr);
           return;
         }
       }

@@ -916,3 +916,89 @@ def test_wide_ragged_stencil_generic_kernels(oracle):
         mods.append((m, old, new))
     off.row_starts = row_starts
     _compare_step(off, mods)
+
+
+def test_discontinuous_ansatz_branch(oracle, tmp_path):
+    """have_discontinuous_ansatz (hyperbolic_module.template.h:733-737, 938-948, 976-986):
+    incidence matrix in the high-order viscosity, limiter bounds extended over the stencil, full inverse
+    mass matrix instead of the Neumann series. Finite-volume-like (dG Q0) couplings on a Cartesian grid:
+    c_ij = n_ij |F_ij| / 2 across faces, incidence (m_ij-average / |Omega|)^(1/4); the inverse mass matrix
+    gets synthetic symmetric off-diagonal entries so that the b_ij F_j - b_ji F_i term is exercised.
+    Also checks that the dump format carries the two extra matrices."""
+    from helpers_layout import OfflineView
+    nx = ny = 32
+    h = 1.0 / nx
+    idx = lambda ix, iy: iy * nx + ix       # noqa: E731
+    rows, cij, mij, inc, minv = [], [], [], [], []
+    r_ij = (h * h / 1.0) ** (0.5 / 2)
+    for iy in range(ny):
+        for ix in range(nx):
+            i = idx(ix, iy)
+            nb = []
+            for (dx, dy) in ((1, 0), (-1, 0), (0, 1), (0, -1)):
+                jx, jy = ix + dx, iy + dy
+                if 0 <= jx < nx and 0 <= jy < ny:
+                    nb.append((idx(jx, jy), (0.5 * h * dx, 0.5 * h * dy)))
+            nb.sort()
+            cii = (-sum(c[0] for _, c in nb), -sum(c[1] for _, c in nb))
+            rows.append([i] + [j for j, _ in nb])
+            cij.extend([cii] + [c for _, c in nb])
+            mij.extend([h * h] + [0.0] * len(nb))
+            inc.extend([0.0] + [r_ij] * len(nb))
+            minv.extend([1.0 / (h * h)] + [-0.1 / (h * h)] * len(nb))
+    n = nx * ny
+    row_starts = np.cumsum([0] + [len(r) for r in rows]).astype(np.uint64)
+    columns = np.concatenate([np.array(r, dtype=np.uint32) for r in rows])
+    mi = np.full(n, h * h)
+    off = OfflineView(2, 0, 0, n, n, 1, row_starts, columns, np.array(cij), np.array(mij), mi, 1.0 / mi, 1.0,
+                      [], np.zeros((0, 2)), [], [], [], [])
+    off._dg = (np.ascontiguousarray(inc), np.ascontiguousarray(minv))
+    off._o.discontinuous_ansatz = 1
+    off._o.incidence = capi.as_ptr(off._dg[0], capi.c_double_p)
+    off._o.mass_matrix_inverse = capi.as_ptr(off._dg[1], capi.c_double_p)
+    off.row_starts = row_starts
+    pos = np.array([[(ix + 0.5) * h, (iy + 0.5) * h] for iy in range(ny) for ix in range(nx)])
+    U0 = _perturbed(euler_radial_contrast(pos, inner=(1.0, 0.0, 5.0), outer=(0.5, 0.0, 0.5), radius=0.25,
+                                          center=(0.5, 0.5)))
+
+    def run_pair(o):
+        mods = []
+        U_start = U0
+        for backend in ("hip", oracle.backend()):
+            m = HyperbolicModule(o, equation=capi.EQ_EULER, backend=backend)
+            m.cfl = 0.5
+            old, new = m.new_state_vector(U_start), m.new_state_vector()
+            if backend == "hip":
+                for _ in range(6):
+                    m.prepare_state_vector(old, 0.0)
+                    m.step(old, [], [], new)
+                    old, new = new, old
+                U_start = old.download()
+            mods.append((m, old, new))
+        return mods
+    g, c = _compare_step(off, run_pair(off))
+
+    # the branch really is different from the continuous one
+    off._o.discontinuous_ansatz = 0
+    m = HyperbolicModule(off, equation=capi.EQ_EULER, backend="hip")
+    m.cfl = 0.5
+    a, b = m.new_state_vector(g["U_old"]), m.new_state_vector()
+    m.prepare_state_vector(a, 0.0)
+    m.step(a, [], [], b)
+    assert np.abs(b.download() - g["U"]).max() > 1e-6
+    off._o.discontinuous_ansatz = 1
+
+    # dump round trip keeps the two matrices
+    lib = capi.load_synth()
+    path = str(tmp_path / "dg.ryjoffl")
+    assert lib.ryujin_offline_write(path.encode(), off.c, 2, 0, None, None) == 0
+    imp = offline.ImportedOffline(path)
+    assert imp.c.contents.discontinuous_ansatz == 1
+    assert np.array_equal(capi.np_from_ptr(imp.c.contents.incidence, imp.nnz, np.float64), off._dg[0])
+    assert np.array_equal(capi.np_from_ptr(imp.c.contents.mass_matrix_inverse, imp.nnz, np.float64), off._dg[1])
+    m2 = HyperbolicModule(imp, equation=capi.EQ_EULER, backend="hip")
+    m2.cfl = 0.5
+    a2, b2 = m2.new_state_vector(g["U_old"]), m2.new_state_vector()
+    m2.prepare_state_vector(a2, 0.0)
+    m2.step(a2, [], [], b2)
+    assert np.array_equal(b2.download(), g["U"])
