@@ -148,3 +148,41 @@ def test_oracle_is_not_reachable_from_the_product():
                     continue  # build recipe of the checker, not a use of it
                 assert "oracle_py" not in text and "libryujin_oracle" not in text and \
                     "oracle/" not in text.replace("the CPU oracle", ""), f
+
+
+def test_rows_longer_than_a_slice_are_rejected():
+    """A SELL-64 slice holds at most 64 entries per row (row_len is a byte, column bitmasks are 64 bit):
+    a stencil with 65 entries must be refused with a message, not truncated."""
+    from helpers_layout import OfflineView
+    n = 70
+    rows = [[i] for i in range(n)]
+    rows[0] = [0] + list(range(1, 65))          # 65 entries
+    for j in range(1, 65):
+        rows[j] = [j, 0]
+    row_starts = np.cumsum([0] + [len(r) for r in rows]).astype(np.uint64)
+    columns = np.concatenate([np.array(r, dtype=np.uint32) for r in rows])
+    nnz = len(columns)
+    v = OfflineView(1, 0, 0, n, n, 1, row_starts, columns, np.zeros((nnz, 1)), np.ones(nnz), np.ones(n),
+                    np.ones(n), 1.0, [], np.zeros((0, 1)), [], [], [], [])
+    lib = capi.load_hip()
+    ptr = np.zeros(n + 1, dtype=np.uint64)
+    col = np.zeros(nnz, dtype=np.uint32)
+    out = np.zeros(nnz)
+    rc = lib.ryujin_hip_debug_layout(v.c, capi.as_ptr(ptr, capi.c_u64_p), capi.as_ptr(col, capi.c_u32_p), None,
+                                     capi.as_ptr(v._keep["mij"], capi.c_double_p), 1,
+                                     capi.as_ptr(out, capi.c_double_p))
+    assert rc == capi.RYUJIN_ERR_ARG or rc < 0
+    assert b"64" in lib.ryujin_hip_last_error()
+    rows[0] = [0] + list(range(1, 64))          # 64 entries: accepted
+    rows[64] = [64]
+    row_starts = np.cumsum([0] + [len(r) for r in rows]).astype(np.uint64)
+    columns = np.concatenate([np.array(r, dtype=np.uint32) for r in rows])
+    nnz = len(columns)
+    v = OfflineView(1, 0, 0, n, n, 1, row_starts, columns, np.zeros((nnz, 1)), np.ones(nnz), np.ones(n),
+                    np.ones(n), 1.0, [], np.zeros((0, 1)), [], [], [], [])
+    col = np.zeros(nnz, dtype=np.uint32)
+    out = np.zeros(nnz)
+    rc = lib.ryujin_hip_debug_layout(v.c, capi.as_ptr(ptr, capi.c_u64_p), capi.as_ptr(col, capi.c_u32_p), None,
+                                     capi.as_ptr(v._keep["mij"], capi.c_double_p), 1,
+                                     capi.as_ptr(out, capi.c_double_p))
+    assert rc == 0 and np.array_equal(col, columns)
