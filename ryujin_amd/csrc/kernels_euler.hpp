@@ -474,7 +474,7 @@ namespace ryujin_hip
   __global__ void __launch_bounds__(kBlock)
   k_dij_boundary(const typename E::Params P, const uint32_t n_pairs, const uint32_t *__restrict__ p_i,
                  const uint32_t *__restrict__ p_j, const uint32_t *__restrict__ p_pos,
-                 const uint32_t *__restrict__ p_pos_t, const double *__restrict__ cji,
+                 const double *__restrict__ cji,
                  const double *__restrict__ U, double *__restrict__ dij)
   {
     constexpr int K = E::K;
@@ -491,7 +491,6 @@ namespace ryujin_hip
 #pragma unroll
     for (int d = 0; d < DIM; ++d)
       c_ji[d] = cji[(size_t)q * DIM + d];
-    (void)p_pos_t;
     const double d_ji = E::dij_from_states(P, U_j, U_i, c_ji);
     const uint32_t pos = p_pos[q];
     dij[pos] = fmax(dij[pos], d_ji);

@@ -876,8 +876,7 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
                          old.prec.ptr, d_dij.ptr);
     else
       hipLaunchKernelGGL(k_dij_boundary<E>, dim3(grid_for(n_pairs)), block, 0, stream, eparams,
-                         n_pairs, d_p_i.ptr, d_p_j.ptr, d_p_pos.ptr, (const uint32_t *)nullptr,
-                         d_p_cji.ptr, old.U.ptr, d_dij.ptr);
+                         n_pairs, d_p_i.ptr, d_p_j.ptr, d_p_pos.ptr, d_p_cji.ptr, old.U.ptr, d_dij.ptr);
   }
   sweep([&](const DeviceMesh &mm, dim3 grid) {
     if (L.max_row_len <= 3)
