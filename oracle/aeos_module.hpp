@@ -238,8 +238,9 @@ namespace oracle
               norm2 += c_ij[d] * c_ij[d];
             const double norm = std::sqrt(norm2);
             vec_type n_ij;
+            const double inverse_norm = 1. / norm; /* dealii::Tensor / scalar multiplies by the inverse */
             for (int d = 0; d < dim; ++d)
-              n_ij[d] = c_ij[d] / norm;
+              n_ij[d] = c_ij[d] * inverse_norm;
             const double lambda_max = riemann_solver.template compute<dim>(view, U_i, old_prec[(size_t)i * NP], U_j, old_prec[(size_t)j * NP], n_ij);
             dij[e] = norm * lambda_max;
           }
@@ -264,8 +265,9 @@ namespace oracle
           norm2 += c_ji[d] * c_ji[d];
         const double norm_ji = std::sqrt(norm2);
         vec_type n_ji;
+        const double inverse_norm_ji = 1. / norm_ji; /* dealii::Tensor / scalar multiplies by the inverse */
         for (int d = 0; d < dim; ++d)
-          n_ji[d] = c_ji[d] / norm_ji;
+          n_ji[d] = c_ji[d] * inverse_norm_ji;
         const double d_ij = dij[e];
         const double lambda_max = riemann_solver.template compute<dim>(view, U_j, old_prec[(size_t)j * NP], U_i, old_prec[(size_t)i * NP], n_ji);
         const double d_ji = norm_ji * lambda_max;
@@ -349,8 +351,9 @@ namespace oracle
             const double regularization = 100. * std::numeric_limits<double>::min();
             vec_type scaled_c_ij;
             const double denom = std::max(d_ij, regularization);
+            const double inverse_denom = 1. / denom; /* dealii::Tensor / scalar multiplies by the inverse */
             for (int d = 0; d < dim; ++d)
-              scaled_c_ij[d] = c_ij[d] / denom;
+              scaled_c_ij[d] = c_ij[d] * inverse_denom;
 
             const auto flux_j = V::f(U_j, old_prec[(size_t)j * NP]);
             const auto flux_ij = V::flux_divergence(flux_i, flux_j, c_ij);

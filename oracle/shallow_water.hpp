@@ -885,8 +885,9 @@ namespace oracle
           norm2 += c[d] * c[d];
         const double norm = std::sqrt(norm2);
         vec_type n;
+        const double inverse_norm = 1. / norm; /* dealii::Tensor / scalar multiplies by the inverse */
         for (int d = 0; d < dim; ++d)
-          n[d] = c[d] / norm;
+          n[d] = c[d] * inverse_norm;
         return norm * riemann_solver.template compute<dim>(A, B, n);
       };
 
@@ -1014,8 +1015,9 @@ namespace oracle
             const auto c_ij = get_c(e);
             const double denom = std::max(d_ij, 100. * std::numeric_limits<double>::min());
             vec_type scaled_c_ij;
+            const double inverse_denom = 1. / denom; /* dealii::Tensor / scalar multiplies by the inverse */
             for (int d = 0; d < dim; ++d)
-              scaled_c_ij[d] = c_ij[d] / denom;
+              scaled_c_ij[d] = c_ij[d] * inverse_denom;
             const double m_ij = mij[e];
 
             const auto flux_ij = view.flux_divergence(U_i, Z_i, U_j, Z_j, c_ij);

@@ -496,9 +496,10 @@ namespace ryujin_hip
         norm2 += c[d] * c[d];
       const double norm = sqrt(norm2);
       double n[DIM];
+      const double inverse_norm = 1. / norm; /* dealii::Tensor / scalar multiplies by the inverse */
 #pragma unroll
       for (int d = 0; d < DIM; ++d)
-        n[d] = c[d] / norm;
+        n[d] = c[d] * inverse_norm;
       const RiemannData rd_i = riemann_data_from_state(P, U_i, n);
       RYUJIN_FENCE();
       const RiemannData rd_j = riemann_data_from_state(P, U_j, n);

@@ -255,9 +255,10 @@ namespace ryujin_hip
       const double regularization = 100. * DBL_MIN;
       const double denom = fmax(d_ij, regularization);
       double scaled_c_ij[DIM];
+      const double inverse_denom = 1. / denom; /* dealii::Tensor / scalar multiplies by the inverse */
 #pragma unroll
       for (int d = 0; d < DIM; ++d)
-        scaled_c_ij[d] = c_ij[d] / denom;
+        scaled_c_ij[d] = c_ij[d] * inverse_denom;
 
       double f_j[K][DIM];
       E::flux(U_j, p_j, f_j);

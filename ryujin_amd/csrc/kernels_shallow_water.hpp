@@ -135,9 +135,10 @@ namespace ryujin_hip
       const double d_ijH = d_ij * factor;
       const double denom = fmax(d_ij, 100. * DBL_MIN);
       double scaled_c_ij[DIM];
+      const double inverse_denom = 1. / denom; /* dealii::Tensor / scalar multiplies by the inverse */
 #pragma unroll
       for (int d = 0; d < DIM; ++d)
-        scaled_c_ij[d] = c_ij[d] / denom;
+        scaled_c_ij[d] = c_ij[d] * inverse_denom;
 
       double U_star_ij[K], U_star_ji[K];
       E::star_state(P, U_i, Z_i, Z_j, U_star_ij);

@@ -136,9 +136,10 @@ namespace ryujin_hip
         norm2 += c[d] * c[d];
       const double norm = sqrt(norm2);
       double n[DIM];
+      const double inverse_norm = 1. / norm; /* dealii::Tensor / scalar multiplies by the inverse */
 #pragma unroll
       for (int d = 0; d < DIM; ++d)
-        n[d] = c[d] / norm;
+        n[d] = c[d] * inverse_norm;
       return norm * lambda_max(P, u_i, u_j, prec_i, prec_j, n);
     }
 
@@ -333,9 +334,10 @@ namespace ryujin_hip
       const double d_ijH = d_ij * factor;
       const double denom = fmax(d_ij, 100. * DBL_MIN);
       double scaled_c_ij[DIM];
+      const double inverse_denom = 1. / denom; /* dealii::Tensor / scalar multiplies by the inverse */
 #pragma unroll
       for (int d = 0; d < DIM; ++d)
-        scaled_c_ij[d] = c_ij[d] / denom;
+        scaled_c_ij[d] = c_ij[d] * inverse_denom;
 
       /* flux_divergence = -contract(add(flux_i, flux_j), c_ij) */
       double s = (f_i[0] + f_j[0]) * c_ij[0];
