@@ -487,10 +487,13 @@ def test_imported_offline_dump_is_bit_identical_on_the_gpu(tmp_path):
         assert np.array_equal(res[0][1], res[1][1])
 
 
-def test_partitioned_3d_cylinder_erk33_matches_single_rank():
+@pytest.mark.parametrize("scheme", ["erk 33", "ssprk 33"])
+def test_partitioned_3d_cylinder_erk33_matches_single_rank(scheme):
     """BASELINE.json configs[3] in miniature: 3-D Mach-3 cylinder channel (staircase cylinder, Dirichlet
-    inflow, do-nothing outflow, slip walls), ERK33 through the device-resident driver, x-slab partition
-    over 2 and 4 ranks with the in-process transport: identical tau sequence, U to round-off."""
+    inflow, do-nothing outflow, slip walls), ERK33 (the prm's scheme) and SSPRK33 (bench.py's sequence, with
+    sadd over vectors whose ghosts are stale until the next prepare_state_vector) through the
+    device-resident driver, x-slab partition over 2 and 4 ranks with the in-process transport: identical
+    tau sequence, U to round-off."""
     import ctypes as C
     import threading
 
@@ -510,7 +513,7 @@ def test_partitioned_3d_cylinder_erk33_matches_single_rank():
             dirichlet = prim(off.b_positions) if off.n_bdry else None
             state = m.new_state_vector(U0)
             temps = [m.new_state_vector() for _ in range(3)]
-            taus = [m.time_step("erk 33", state, temps, dirichlet) for _ in range(n_steps)]
+            taus = [m.time_step(scheme, state, temps, dirichlet) for _ in range(n_steps)]
             out[key] = (off.global_ids[: off.n_owned].astype(np.int64), state.download()[: off.n_owned], taus)
         except Exception as e:
             out[key] = e
