@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstddef>
 #include <cstring>
 #include <condition_variable>
 #include <limits>
@@ -272,7 +273,7 @@ struct ryujin_hip_ctx {
   void exchange_matrix(double *m, bool after_split_sweep);
   void local_exchange(double *base, const std::vector<size_t> &send_offset,
                       const std::vector<size_t> &recv_offset, const std::vector<size_t> &recv_count);
-  void allreduce_scalar(void *dev_ptr, int op);
+  void allreduce_scalar(void *dev_ptr, int op, int count = 1);
   void wait_comm();
   void finish();
   void begin_exchange(bool after_split_sweep);
@@ -647,7 +648,7 @@ void ryujin_hip_ctx::local_exchange(double *base, const std::vector<size_t> &sen
 }
 
 /* 1-element all-reduce on a device scalar; op: 0 = min (double), 1 = max (int) */
-void ryujin_hip_ctx::allreduce_scalar(void *dev_ptr, int op)
+void ryujin_hip_ctx::allreduce_scalar(void *dev_ptr, int op, int count)
 {
   if (!comm || comm->n_ranks <= 1)
     return;
@@ -655,7 +656,12 @@ void ryujin_hip_ctx::allreduce_scalar(void *dev_ptr, int op)
     if (op == 0)
       NCCL_CHECK(ncclAllReduce(dev_ptr, dev_ptr, 1, ncclDouble, ncclMin, comm->comm, stream));
     else
-      NCCL_CHECK(ncclAllReduce(dev_ptr, dev_ptr, 1, ncclInt, ncclMax, comm->comm, stream));
+      NCCL_CHECK(ncclAllReduce(dev_ptr, dev_ptr, count, ncclInt, ncclMax, comm->comm, stream));
+    return;
+  }
+  if (op == 1 && count == 2) { /* two adjacent flags: reduce one after the other */
+    allreduce_scalar(dev_ptr, 1, 1);
+    allreduce_scalar(static_cast<int *>(dev_ptr) + 1, 1, 1);
     return;
   }
   LocalGroup &g = *comm->local;
@@ -892,7 +898,11 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
       hipLaunchKernelGGL(k_dij_diag, grid, block, 0, stream, mm, params.cfl, d_dij.ptr,
                          d_scalars.ptr);
   }, false);
-  allreduce_scalar(&d_scalars.ptr->tau_max_bits, 0); /* Utilities::MPI::min(tau_max), :571 */
+  /* Utilities::MPI::min(tau_max), :571. Inside a device-resident RK step only the first stage needs the
+   * global minimum (it defines tau); later stages use their local tau_max for the validity check only,
+   * whose flag is reduced once at the end of the RK step together with the restart flag. */
+  if (!(deferred && rk_stage > 0))
+    allreduce_scalar(&d_scalars.ptr->tau_max_bits, 0);
   hipLaunchKernelGGL(k_finalize_tau, dim3(1), dim3(1), 0, stream, tau_in, use_device_tau ? 1 : 0,
                      d_scalars.ptr);
   mark(2);
@@ -1038,7 +1048,8 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
     mark(k);
 
   wait_comm();
-  allreduce_scalar(&d_scalars.ptr->restart_needed, 1); /* MPI::logical_or(restart_needed), :1194 */
+  if (!deferred)
+    allreduce_scalar(&d_scalars.ptr->restart_needed, 1); /* MPI::logical_or(restart_needed), :1194 */
   hipLaunchKernelGGL(k_accumulate_flags, dim3(1), dim3(1), 0, stream, d_scalars.ptr);
 
   HIP_CHECK(hipGetLastError());
@@ -1191,6 +1202,12 @@ int ryujin_hip_ctx::time_step(int scheme, int h_state, int n_tmp, const int *h_t
     }
     /* the only host synchronisation of the RK step */
     wait_comm();
+    /* MPI::logical_or over the ranks of the flags accumulated over all stages (restart_accum and
+     * tau_invalid_accum are adjacent ints): one collective per RK step instead of one per stage */
+    static_assert(offsetof(DeviceScalars, tau_invalid_accum) ==
+                      offsetof(DeviceScalars, restart_accum) + sizeof(int),
+                  "flag accumulators must be adjacent");
+    allreduce_scalar(&d_scalars.ptr->restart_accum, 1, 2);
     HIP_CHECK(hipMemcpyAsync(h_scalars, d_scalars.ptr, sizeof(DeviceScalars), hipMemcpyDeviceToHost,
                              stream));
     HIP_CHECK(hipStreamSynchronize(stream));

@@ -1005,3 +1005,57 @@ def test_discontinuous_ansatz_branch(oracle, tmp_path):
     m2.prepare_state_vector(a2, 0.0)
     m2.step(a2, [], [], b2)
     assert np.array_equal(b2.download(), g["U"])
+
+
+def test_partitioned_bang_bang_recovery_is_collective():
+    """Device-resident RK step on 3 in-process ranks with a violation that happens on ONE rank only
+    (off-centre blast): the flags accumulated over the stages are OR-ed over the ranks once per RK step, so
+    every rank restarts with cfl_min together and the result equals the single-rank run."""
+    import ctypes as C
+    import threading
+    lib = capi.load_hip()
+
+    def initial(off):
+        return euler_radial_contrast(off.positions, inner=(1.0, 0.0, 1000.0), outer=(0.01, 0.0, 0.01),
+                                     radius=0.12, center=(0.15, 0.5))
+
+    def run(off, comm, out, key):
+        try:
+            m = HyperbolicModule(off, equation=capi.EQ_EULER, backend="hip", comm=comm)
+            state = m.new_state_vector(initial(off))
+            temps = [m.new_state_vector() for _ in range(3)]
+            taus = [m.time_step("ssprk 33", state, temps, None, cfl_recovery="bang bang control", cfl_min=0.45,
+                                cfl_max=3.0) for _ in range(2)]
+            out[key] = (off.global_ids[: off.n_owned].astype(np.int64), state.download()[: off.n_owned], taus,
+                        m.n_restarts(), m.cfl)
+        except Exception as e:
+            out[key] = e
+
+    ref = {}
+    run(offline.SyntheticOffline(offline.rectangle_2d(36, (0.0, 0.0), (1.0, 1.0))), None, ref, 0)
+    assert not isinstance(ref[0], Exception), ref[0]
+    gid, U, taus, n_restarts, cfl = ref[0]
+    assert n_restarts >= 1 and abs(cfl - 0.45) < 1e-15
+    n_ranks = 3
+    comms = (C.c_void_p * n_ranks)()
+    assert lib.ryujin_hip_comm_init_local(comms, n_ranks, 0) == 0
+    parts = [offline.SyntheticOffline(offline.rectangle_2d(36, (0.0, 0.0), (1.0, 1.0), n_ranks=n_ranks, rank=r))
+             for r in range(n_ranks)]
+    out = {}
+    threads = [threading.Thread(target=run, args=(parts[r], C.c_void_p(comms[r]), out, r)) for r in range(n_ranks)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+        assert not t.is_alive(), "rank thread hung"
+    for r in range(n_ranks):
+        assert not isinstance(out[r], Exception), out[r]
+        assert np.allclose(out[r][2], taus, rtol=1e-13, atol=0)
+        assert out[r][3] == n_restarts and abs(out[r][4] - 0.45) < 1e-15
+    g = np.concatenate([out[r][0] for r in range(n_ranks)])
+    Up = np.concatenate([out[r][1] for r in range(n_ranks)])
+    o1, o2 = np.argsort(gid), np.argsort(g)
+    scale = np.abs(U).max(axis=0)
+    assert (np.abs(Up[o2] - U[o1]) / scale).max() < 1e-10
+    for r in range(n_ranks):
+        lib.ryujin_hip_comm_destroy(C.c_void_p(comms[r]))
