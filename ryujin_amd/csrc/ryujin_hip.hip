@@ -155,6 +155,9 @@ struct ryujin_hip_ctx {
   hipStream_t stream = nullptr;      /* compute */
   hipStream_t comm_stream = nullptr; /* ghost exchange, overlapped with the interior rows */
   hipEvent_t ev_export = nullptr, ev_comm = nullptr;
+  hipStream_t export_stream = nullptr; /* export slices of a split sweep, concurrent with the interior */
+  hipStream_t launch_stream = nullptr; /* the stream the sweep lambdas launch on (stream or export_stream) */
+  hipEvent_t ev_prev = nullptr;
   bool comm_pending = false;
   uint32_t n_export_slices = 0;
 
@@ -243,6 +246,12 @@ struct ryujin_hip_ctx {
     }
     if (ev_export)
       (void)hipEventDestroy(ev_export);
+    if (export_stream) {
+      (void)hipStreamSynchronize(export_stream);
+      (void)hipStreamDestroy(export_stream);
+    }
+    if (ev_prev)
+      (void)hipEventDestroy(ev_prev);
     if (ev_comm)
       (void)hipEventDestroy(ev_comm);
     for (auto &e : ev)
@@ -346,6 +355,9 @@ void ryujin_hip_ctx::create(const ryujin_hip_offline &o, const ryujin_hip_params
   HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
   HIP_CHECK(hipStreamCreateWithFlags(&comm_stream, hipStreamNonBlocking));
   HIP_CHECK(hipEventCreateWithFlags(&ev_export, hipEventDisableTiming));
+  HIP_CHECK(hipStreamCreateWithFlags(&export_stream, hipStreamNonBlocking));
+  launch_stream = stream;
+  HIP_CHECK(hipEventCreateWithFlags(&ev_prev, hipEventDisableTiming));
   HIP_CHECK(hipEventCreateWithFlags(&ev_comm, hipEventDisableTiming));
   for (auto &e : ev)
     HIP_CHECK(hipEventCreate(&e));
@@ -610,7 +622,7 @@ void ryujin_hip_ctx::end_exchange()
 template <typename F>
 void ryujin_hip_ctx::sweep(F &&launch, bool followed_by_exchange)
 {
-  auto run = [&](uint32_t s0, uint32_t s1) {
+  auto run = [&](uint32_t s0, uint32_t s1, hipStream_t on) {
     if (s1 <= s0)
       return;
     DeviceMesh mm = mesh;
@@ -618,16 +630,25 @@ void ryujin_hip_ctx::sweep(F &&launch, bool followed_by_exchange)
     mm.slice_end = s1;
     /* one wave per slice, 4 slices per block; rounded up to a multiple of 8 for the XCD remap */
     const dim3 grid(((s1 - s0 + kWavesPerBlock - 1) / kWavesPerBlock + 7) / 8 * 8);
+    launch_stream = on;
     launch(mm, grid);
+    launch_stream = stream;
   };
   wait_comm();
   if (n_nbr == 0 || !followed_by_exchange) {
-    run(0, L.n_slices);
+    run(0, L.n_slices, stream);
     return;
   }
-  run(0, n_export_slices);
-  HIP_CHECK(hipEventRecord(ev_export, stream));
-  run(n_export_slices, L.n_slices);
+  /* The few export slices run on their own stream next to the interior slices (a launch of a handful
+   * of blocks would otherwise leave the device idle for the lifetime of one wave): both wait for
+   * everything enqueued so far; the compute stream joins the export part again right away, so that
+   * later kernels see the whole sweep; the exchange only waits for the export part. */
+  HIP_CHECK(hipEventRecord(ev_prev, stream));
+  HIP_CHECK(hipStreamWaitEvent(export_stream, ev_prev, 0));
+  run(0, n_export_slices, export_stream);
+  HIP_CHECK(hipEventRecord(ev_export, export_stream));
+  run(n_export_slices, L.n_slices, stream);
+  HIP_CHECK(hipStreamWaitEvent(stream, ev_export, 0));
 }
 
 /* in-process transport: publish the per-neighbour segments of the send buffer, rendezvous, pull */
@@ -777,24 +798,24 @@ void ryujin_hip_ctx::prepare_state_vector(int h, const double *dirichlet)
   if constexpr (std::is_same<typename E::Params, EulerAeosParams>::value) {
     /* n_precomputation_cycles = 2 (euler_aeos/hyperbolic_system.h:433), ghost update after each */
     sweep([&](const DeviceMesh &mm, dim3 grid) {
-      hipLaunchKernelGGL(k_precompute_aeos0<E::DIMENSION>, grid, block, 0, stream, eparams, mm, s.U.ptr,
+      hipLaunchKernelGGL(k_precompute_aeos0<E::DIMENSION>, grid, block, 0, launch_stream, eparams, mm, s.U.ptr,
                          s.prec.ptr);
     }, true);
     exchange_vector(s.prec.ptr, 4, true);
     sweep([&](const DeviceMesh &mm, dim3 grid) {
-      hipLaunchKernelGGL(k_precompute_aeos1<E::DIMENSION>, grid, block, 0, stream, eparams, mm, s.U.ptr,
+      hipLaunchKernelGGL(k_precompute_aeos1<E::DIMENSION>, grid, block, 0, launch_stream, eparams, mm, s.U.ptr,
                          s.prec.ptr, s.prec.ptr);
     }, true);
     exchange_vector(s.prec.ptr, 4, true);
   } else if constexpr (std::is_same<typename E::Params, ScalarParams>::value) {
     sweep([&](const DeviceMesh &mm, dim3 grid) {
-      hipLaunchKernelGGL(k_precompute_sc<E::DIMENSION>, grid, block, 0, stream, eparams, mm, s.U.ptr,
+      hipLaunchKernelGGL(k_precompute_sc<E::DIMENSION>, grid, block, 0, launch_stream, eparams, mm, s.U.ptr,
                          s.prec.ptr);
     }, true);
     exchange_vector(s.prec.ptr, E::NPREC, true);
   } else {
     sweep([&](const DeviceMesh &mm, dim3 grid) {
-      hipLaunchKernelGGL(k_precompute<E>, grid, block, 0, stream, eparams, mm, s.U.ptr, s.prec.ptr);
+      hipLaunchKernelGGL(k_precompute<E>, grid, block, 0, launch_stream, eparams, mm, s.U.ptr, s.prec.ptr);
     }, true);
     exchange_vector(s.prec.ptr, 2, true); /* :157-160 */
   }
@@ -828,7 +849,7 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
     if (L.max_row_len > 32)
       throw HipError(RYUJIN_ERR_UNSUPPORTED, "euler aeos: stencils of more than 32 entries");
     sweep([&](const DeviceMesh &mm, dim3 grid) {
-      hipLaunchKernelGGL(k_alpha_aeos<DIM>, grid, block, 0, stream, eparams, mm, old.U.ptr, old.prec.ptr,
+      hipLaunchKernelGGL(k_alpha_aeos<DIM>, grid, block, 0, launch_stream, eparams, mm, old.U.ptr, old.prec.ptr,
                          d_alpha.ptr);
     }, true);
     mark(8);
@@ -836,20 +857,20 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
     const bool pending = comm_pending;
     comm_pending = false; /* k_dij does not read alpha: do not join the exchange yet */
     sweep([&](const DeviceMesh &mm, dim3 grid) {
-      hipLaunchKernelGGL(k_dij_aeos<DIM>, grid, block, 0, stream, eparams, mm, d_lower_mask.ptr,
+      hipLaunchKernelGGL(k_dij_aeos<DIM>, grid, block, 0, launch_stream, eparams, mm, d_lower_mask.ptr,
                          old.U.ptr, old.prec.ptr, d_dij.ptr);
     }, false);
     comm_pending = pending;
   } else if constexpr (is_scalar) {
     sweep([&](const DeviceMesh &mm, dim3 grid) {
-      hipLaunchKernelGGL(k_dij_alpha_sc<DIM>, grid, block, 0, stream, eparams, mm, old.U.ptr,
+      hipLaunchKernelGGL(k_dij_alpha_sc<DIM>, grid, block, 0, launch_stream, eparams, mm, old.U.ptr,
                          old.prec.ptr, d_dij.ptr, d_alpha.ptr);
     }, true);
     mark(8);
     exchange_vector(d_alpha.ptr, 1, true);
   } else if (RYUJIN_SPLIT_DIJ && L.max_row_len <= 32) {
     sweep([&](const DeviceMesh &mm, dim3 grid) {
-      hipLaunchKernelGGL(k_alpha<E>, grid, block, 0, stream, eparams, mm, old.U.ptr, old.prec.ptr,
+      hipLaunchKernelGGL(k_alpha<E>, grid, block, 0, launch_stream, eparams, mm, old.U.ptr, old.prec.ptr,
                          d_alpha.ptr);
     }, true);
     mark(8); /* end of the indicator kernel: sweep_ms[0] = k_alpha alone */
@@ -857,13 +878,13 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
     const bool pending = comm_pending;
     comm_pending = false; /* k_dij does not read alpha: do not join the exchange yet */
     sweep([&](const DeviceMesh &mm, dim3 grid) {
-      hipLaunchKernelGGL(k_dij<E>, grid, block, 0, stream, eparams, mm, d_lower_mask.ptr, old.U.ptr,
+      hipLaunchKernelGGL(k_dij<E>, grid, block, 0, launch_stream, eparams, mm, d_lower_mask.ptr, old.U.ptr,
                          d_dij.ptr);
     }, false);
     comm_pending = pending;
   } else {
     sweep([&](const DeviceMesh &mm, dim3 grid) {
-      hipLaunchKernelGGL(k_dij_alpha<E>, grid, block, 0, stream, eparams, mm, old.U.ptr,
+      hipLaunchKernelGGL(k_dij_alpha<E>, grid, block, 0, launch_stream, eparams, mm, old.U.ptr,
                          old.prec.ptr, d_dij.ptr, d_alpha.ptr);
     }, true);
     exchange_vector(d_alpha.ptr, 1, true);
@@ -886,16 +907,16 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
   }
   sweep([&](const DeviceMesh &mm, dim3 grid) {
     if (L.max_row_len <= 3)
-      hipLaunchKernelGGL(k_dij_diag_unrolled<3>, grid, block, 0, stream, mm, d_lower_mask.ptr,
+      hipLaunchKernelGGL(k_dij_diag_unrolled<3>, grid, block, 0, launch_stream, mm, d_lower_mask.ptr,
                          params.cfl, d_dij.ptr, d_scalars.ptr);
     else if (L.max_row_len <= 9)
-      hipLaunchKernelGGL(k_dij_diag_unrolled<9>, grid, block, 0, stream, mm, d_lower_mask.ptr,
+      hipLaunchKernelGGL(k_dij_diag_unrolled<9>, grid, block, 0, launch_stream, mm, d_lower_mask.ptr,
                          params.cfl, d_dij.ptr, d_scalars.ptr);
     else if (L.max_row_len <= 27)
-      hipLaunchKernelGGL(k_dij_diag_unrolled<27>, grid, block, 0, stream, mm, d_lower_mask.ptr,
+      hipLaunchKernelGGL(k_dij_diag_unrolled<27>, grid, block, 0, launch_stream, mm, d_lower_mask.ptr,
                          params.cfl, d_dij.ptr, d_scalars.ptr);
     else
-      hipLaunchKernelGGL(k_dij_diag, grid, block, 0, stream, mm, params.cfl, d_dij.ptr,
+      hipLaunchKernelGGL(k_dij_diag, grid, block, 0, launch_stream, mm, params.cfl, d_dij.ptr,
                          d_scalars.ptr);
   }, false);
   /* Utilities::MPI::min(tau_max), :571. Inside a device-resident RK step only the first stage needs the
@@ -930,50 +951,50 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
   sweep([&](const DeviceMesh &mm, dim3 grid) {
     if constexpr (is_euler) {
       if (dg && stages == 0)
-        hipLaunchKernelGGL((k_low_order<DIM, false, true, true>), grid, block, 0, stream, eparams, mm,
+        hipLaunchKernelGGL((k_low_order<DIM, false, true, true>), grid, block, 0, launch_stream, eparams, mm,
                            d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_alpha.ptr, d_dij.ptr,
                            nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
       else if (dg)
-        hipLaunchKernelGGL((k_low_order<DIM, true, true, true>), grid, block, 0, stream, eparams, mm,
+        hipLaunchKernelGGL((k_low_order<DIM, true, true, true>), grid, block, 0, launch_stream, eparams, mm,
                            d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_alpha.ptr, d_dij.ptr,
                            nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
       else if (recompute_p)
-        hipLaunchKernelGGL((k_low_order<DIM, false, false>), grid, block, 0, stream, eparams, mm,
+        hipLaunchKernelGGL((k_low_order<DIM, false, false>), grid, block, 0, launch_stream, eparams, mm,
                            d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_alpha.ptr, d_dij.ptr,
                            nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
       else if (stages == 0)
-        hipLaunchKernelGGL((k_low_order<DIM, false>), grid, block, 0, stream, eparams, mm,
+        hipLaunchKernelGGL((k_low_order<DIM, false>), grid, block, 0, launch_stream, eparams, mm,
                            d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_alpha.ptr, d_dij.ptr,
                            nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
       else
-        hipLaunchKernelGGL((k_low_order<DIM, true>), grid, block, 0, stream, eparams, mm,
+        hipLaunchKernelGGL((k_low_order<DIM, true>), grid, block, 0, launch_stream, eparams, mm,
                            d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_alpha.ptr, d_dij.ptr,
                            nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
     } else if constexpr (is_scalar) {
       if (stages == 0)
-        hipLaunchKernelGGL((k_low_order_sc<DIM, false>), grid, block, 0, stream, eparams, mm,
+        hipLaunchKernelGGL((k_low_order_sc<DIM, false>), grid, block, 0, launch_stream, eparams, mm,
                            d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_alpha.ptr, d_dij.ptr,
                            nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
       else
-        hipLaunchKernelGGL((k_low_order_sc<DIM, true>), grid, block, 0, stream, eparams, mm,
+        hipLaunchKernelGGL((k_low_order_sc<DIM, true>), grid, block, 0, launch_stream, eparams, mm,
                            d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_alpha.ptr, d_dij.ptr,
                            nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
     } else if constexpr (is_aeos) {
       if (stages == 0)
-        hipLaunchKernelGGL((k_low_order_aeos<DIM, false>), grid, block, 0, stream, eparams, mm,
+        hipLaunchKernelGGL((k_low_order_aeos<DIM, false>), grid, block, 0, launch_stream, eparams, mm,
                            d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_alpha.ptr, d_dij.ptr,
                            nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
       else
-        hipLaunchKernelGGL((k_low_order_aeos<DIM, true>), grid, block, 0, stream, eparams, mm,
+        hipLaunchKernelGGL((k_low_order_aeos<DIM, true>), grid, block, 0, launch_stream, eparams, mm,
                            d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_alpha.ptr, d_dij.ptr,
                            nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
     } else {
       if (stages == 0)
-        hipLaunchKernelGGL((k_low_order_sw<DIM, false>), grid, block, 0, stream, eparams, mm,
+        hipLaunchKernelGGL((k_low_order_sw<DIM, false>), grid, block, 0, launch_stream, eparams, mm,
                            d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_Z.ptr, d_alpha.ptr,
                            d_dij.ptr, nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
       else
-        hipLaunchKernelGGL((k_low_order_sw<DIM, true>), grid, block, 0, stream, eparams, mm,
+        hipLaunchKernelGGL((k_low_order_sw<DIM, true>), grid, block, 0, launch_stream, eparams, mm,
                            d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_Z.ptr, d_alpha.ptr,
                            d_dij.ptr, nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
     }
@@ -987,7 +1008,7 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
     if (dg && n_iterations != 0) {
       /* bounds over the stencil (:938-948); steps 5-7 read the extended bounds */
       sweep([&](const DeviceMesh &mm, dim3 grid) {
-        hipLaunchKernelGGL(k_bounds_combine_euler, grid, block, 0, stream, mm, d_bounds.ptr,
+        hipLaunchKernelGGL(k_bounds_combine_euler, grid, block, 0, launch_stream, mm, d_bounds.ptr,
                            d_bounds_combined.ptr);
       }, false);
       std::swap(d_bounds.ptr, d_bounds_combined.ptr);
@@ -997,7 +1018,7 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
     sweep([&](const DeviceMesh &mm, dim3 grid) {
       if constexpr (is_euler) {
         if (recompute_p) {
-          hipLaunchKernelGGL(k_pij_lij_recompute<DIM>, grid, block, 0, stream, eparams, mm,
+          hipLaunchKernelGGL(k_pij_lij_recompute<DIM>, grid, block, 0, launch_stream, eparams, mm,
                              d_scalars.ptr, weight, old.U.ptr, d_alpha.ptr, d_dij.ptr, nw.U.ptr,
                              d_r.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr);
           return;
@@ -1005,12 +1026,12 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
       }
       if constexpr (is_euler) {
         if (dg) {
-          hipLaunchKernelGGL((k_pij_lij<E, true>), grid, block, 0, stream, eparams, mm, d_scalars.ptr,
+          hipLaunchKernelGGL((k_pij_lij<E, true>), grid, block, 0, launch_stream, eparams, mm, d_scalars.ptr,
                              nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr);
           return;
         }
       }
-      hipLaunchKernelGGL(k_pij_lij<E>, grid, block, 0, stream, eparams, mm, d_scalars.ptr, nw.U.ptr,
+      hipLaunchKernelGGL(k_pij_lij<E>, grid, block, 0, launch_stream, eparams, mm, d_scalars.ptr, nw.U.ptr,
                          d_r.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr);
     }, true);
     exchange_matrix(d_lij.ptr, true);
@@ -1024,7 +1045,7 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
       std::swap(d_lij.ptr, d_lij_next.ptr);
     if (last_round) {
       sweep([&](const DeviceMesh &mm, dim3 grid) {
-        hipLaunchKernelGGL((k_high_order<E, true>), grid, block, 0, stream, eparams, mm, nw.U.ptr,
+        hipLaunchKernelGGL((k_high_order<E, true>), grid, block, 0, launch_stream, eparams, mm, nw.U.ptr,
                            d_bounds.ptr, d_pij.ptr, d_lij.ptr, d_lij_next.ptr);
       }, false);
     } else {
@@ -1034,10 +1055,10 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
       sweep([&](const DeviceMesh &mm, dim3 grid) {
         if ((DIM <= 2 || RYUJIN_HO_CP_3D > 0) && L.max_row_len <= (uint32_t)kCachedWidth)
           hipLaunchKernelGGL((k_high_order_next_cached<E, kCachedWidth, kCachedP>), grid, block, 0,
-                             stream, eparams, mm, nw.U.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr,
+                             launch_stream, eparams, mm, nw.U.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr,
                              d_lij_next.ptr);
         else
-          hipLaunchKernelGGL((k_high_order<E, false>), grid, block, 0, stream, eparams, mm, nw.U.ptr,
+          hipLaunchKernelGGL((k_high_order<E, false>), grid, block, 0, launch_stream, eparams, mm, nw.U.ptr,
                              d_bounds.ptr, d_pij.ptr, d_lij.ptr, d_lij_next.ptr);
       }, true);
       exchange_matrix(d_lij_next.ptr, true);
