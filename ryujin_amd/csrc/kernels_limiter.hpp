@@ -278,12 +278,19 @@ namespace ryujin_hip
 
   /* ------------------------------------------------------------------ steps 6, 7 */
 
+  /* TimeIntegrator::sadd (time_integrator.template.h:18-25) fused into the last sweep of a step:
+   * new_U = s * new_U + b * src for the rows the sweep writes (src == nullptr: plain step). */
+  struct FusedSadd {
+    double s, b;
+    const double *src;
+  };
+
   /* Generic variant: two passes over the row's stencil (the second one re-reads l_ij, l_ji, P_ij). */
   template <typename E, bool LAST_ROUND>
   __global__ void __launch_bounds__(kBlock, RYUJIN_OCC_HO)
   k_high_order(const typename E::Params P, const DeviceMesh M, double *__restrict__ new_U,
                const double *__restrict__ bounds, const double *__restrict__ pij,
-               const double *__restrict__ lij, double *__restrict__ lij_next)
+               const double *__restrict__ lij, double *__restrict__ lij_next, const FusedSadd F)
   {
     constexpr int K = E::K;
     constexpr int NB = E::NB;
@@ -314,6 +321,15 @@ namespace ryujin_hip
         U_i_new[q] += l_ij * lambda * p_ij[q];
     }
 
+    if constexpr (LAST_ROUND) {
+      if (F.src) {
+        double V[K];
+        load_state<K>(F.src, i, V);
+#pragma unroll
+        for (int q = 0; q < K; ++q)
+          U_i_new[q] = F.s * U_i_new[q] + F.b * V[q];
+      }
+    }
     if (row_active)
       store_state<K>(new_U, i, U_i_new);
 

@@ -157,6 +157,7 @@ struct ryujin_hip_ctx {
   hipEvent_t ev_export = nullptr, ev_comm = nullptr;
   hipStream_t export_stream = nullptr; /* export slices of a split sweep, concurrent with the interior */
   hipStream_t launch_stream = nullptr; /* the stream the sweep lambdas launch on (stream or export_stream) */
+  FusedSadd pending_sadd{0., 0., nullptr}; /* set by time_step for the SSPRK stages, consumed by step */
   hipEvent_t ev_prev = nullptr;
   bool comm_pending = false;
   uint32_t n_export_slices = 0;
@@ -1039,6 +1040,11 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
   mark(4);
 
   /* Steps 6, 7: symmetrise l_ij, high-order update, next l_ij (:1053-1182) */
+  /* a pending sadd of the device-resident RK driver is applied by the last sweep */
+  const FusedSadd fused_sadd = pending_sadd;
+  pending_sadd = FusedSadd{0., 0., nullptr};
+  if (fused_sadd.src && n_iterations == 0)
+    throw HipError(RYUJIN_ERR_ARG, "internal: fused sadd without a limiter pass");
   for (int pass = 0; pass < n_iterations; ++pass) {
     const bool last_round = (pass + 1 == n_iterations);
     if (n_iterations == 2 && last_round)
@@ -1046,7 +1052,7 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
     if (last_round) {
       sweep([&](const DeviceMesh &mm, dim3 grid) {
         hipLaunchKernelGGL((k_high_order<E, true>), grid, block, 0, launch_stream, eparams, mm, nw.U.ptr,
-                           d_bounds.ptr, d_pij.ptr, d_lij.ptr, d_lij_next.ptr);
+                           d_bounds.ptr, d_pij.ptr, d_lij.ptr, d_lij_next.ptr, fused_sadd);
       }, false);
     } else {
       constexpr int kCachedWidth = DIM == 1 ? 3 : (DIM == 2 ? 9 : 27);
@@ -1059,7 +1065,7 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
                              d_lij_next.ptr);
         else
           hipLaunchKernelGGL((k_high_order<E, false>), grid, block, 0, launch_stream, eparams, mm, nw.U.ptr,
-                             d_bounds.ptr, d_pij.ptr, d_lij.ptr, d_lij_next.ptr);
+                             d_bounds.ptr, d_pij.ptr, d_lij.ptr, d_lij_next.ptr, FusedSadd{0., 0., nullptr});
       }, true);
       exchange_matrix(d_lij_next.ptr, true);
     }
@@ -1205,19 +1211,27 @@ int ryujin_hip_ctx::time_step(int scheme, int h_state, int n_tmp, const int *h_t
         result = T[st];
       }
     } else {
+      /* sadd(dst, s, b, U) right after step(.., dst): folded into the last sweep of that step when there
+       * is one (limiter iterations >= 1), saving one pass over the state vectors per stage */
+      const bool fuse = params.limiter_iterations >= 1;
+      auto stage_with_sadd = [&](int h_old, int h_new, double sa, double sb) {
+        if (fuse)
+          pending_sadd = FusedSadd{sa, sb, state(U).U.ptr};
+        step<E>(h_old, 0, none, no_w, h_new, 1., no_limit, &dummy);
+        if (!fuse)
+          ryujin_hip_sadd(this, h_new, sa, sb, U);
+      };
       rk_stage = 1;
       prepare_state_vector<E>(T[0], nullptr);
-      step<E>(T[0], 0, none, no_w, T[1], 1., no_limit, &dummy);
       if (scheme == RYUJIN_SCHEME_SSPRK_22)
-        ryujin_hip_sadd(this, T[1], 1. / 2., 1. / 2., U);
+        stage_with_sadd(T[0], T[1], 1. / 2., 1. / 2.);
       else
-        ryujin_hip_sadd(this, T[1], 1. / 4., 3. / 4., U);
+        stage_with_sadd(T[0], T[1], 1. / 4., 3. / 4.);
       result = T[1];
       if (n_stages >= 3) {
         rk_stage = 2;
         prepare_state_vector<E>(T[1], nullptr);
-        step<E>(T[1], 0, none, no_w, T[0], 1., no_limit, &dummy);
-        ryujin_hip_sadd(this, T[0], 2. / 3., 1. / 3., U);
+        stage_with_sadd(T[1], T[0], 2. / 3., 1. / 3.);
         result = T[0];
       }
     }
