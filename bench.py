@@ -213,6 +213,8 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-process code path (torch.distributed + RCCL communicator) even for one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--watchdog", type=int, default=1500,
+                    help="abort the process after this many seconds (a hung collective must not hang the box)")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -220,6 +222,16 @@ def main():
     sys.stdout.flush()
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
+
+    if args.watchdog > 0:
+        import signal
+
+        def _abort(signum, frame):
+            sys.stderr.write(f"bench.py: watchdog expired after {args.watchdog} s, aborting\n")
+            sys.stderr.flush()
+            os._exit(3)
+        signal.signal(signal.SIGALRM, _abort)
+        signal.alarm(args.watchdog)
 
     # the host driver only supports dmabuf IPC: RCCL's cross-process buffers need this
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
