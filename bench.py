@@ -224,14 +224,17 @@ def main():
     os.dup2(2, 1)
 
     if args.watchdog > 0:
-        import signal
+        # a timer thread, not SIGALRM: a Python signal handler does not run while the main thread sits in a
+        # blocking C call (hipStreamSynchronize behind a hung collective); ctypes calls release the GIL
+        import threading
 
-        def _abort(signum, frame):
+        def _abort():
             sys.stderr.write(f"bench.py: watchdog expired after {args.watchdog} s, aborting\n")
             sys.stderr.flush()
             os._exit(3)
-        signal.signal(signal.SIGALRM, _abort)
-        signal.alarm(args.watchdog)
+        _wd = threading.Timer(args.watchdog, _abort)
+        _wd.daemon = True
+        _wd.start()
 
     # the host driver only supports dmabuf IPC: RCCL's cross-process buffers need this
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
