@@ -1597,6 +1597,11 @@ int ryujin_hip_step(ryujin_hip_ctx *ctx, int h_old, int stages, const int *h_sta
   return guarded([&]() {
     if (stages < 0 || stages > 4 || !tau_out)
       throw HipError(RYUJIN_ERR_ARG, "stages must be in [0,4]");
+    /* tau_max = min(tau_max argument, CFL bound) must be positive and finite (:571-576). The device
+     * minimum works on the bit patterns of positive doubles, so a NaN or non-positive argument -- which
+     * makes the reference throw whatever the CFL bound is -- is caught here. */
+    if (std::isnan(tau_max_in) || !(tau_max_in > 0.))
+      return RYUJIN_ERR_TAU;
     HIP_CHECK(hipSetDevice(ctx->device));
     return dispatch_equation(ctx->params.equation, ctx->dim, [&](auto tag) {
       return ctx->template step<typename decltype(tag)::type>(h_old, stages, h_stage, stage_weights,
@@ -1612,6 +1617,8 @@ int ryujin_hip_time_step_n(ryujin_hip_ctx *ctx, int scheme, int h_state, int n_t
   return guarded([&]() {
     if (!h_tmp || !tau_out || n_tmp < 1 || n_tmp > 8)
       throw HipError(RYUJIN_ERR_ARG, "time_step: bad argument");
+    if (std::isnan(tau_max) || !(tau_max > 0.))
+      return RYUJIN_ERR_TAU; /* as in step() */
     HIP_CHECK(hipSetDevice(ctx->device));
     ctx->state(h_state);
     for (int q = 0; q < n_tmp; ++q) {

@@ -1059,3 +1059,53 @@ def test_partitioned_bang_bang_recovery_is_collective():
     assert (np.abs(Up[o2] - U[o1]) / scale).max() < 1e-10
     for r in range(n_ranks):
         lib.ryujin_hip_comm_destroy(C.c_void_p(comms[r]))
+
+
+@pytest.mark.parametrize("iterations", [0, 1])
+def test_limiter_iterations_0_and_1(oracle, iterations):
+    """'limiter iterations' = 0 (low-order update only: steps 5-7 are skipped, :892, :1053) and 1 (a single
+    high-order pass): the module allows [0, 2] (hyperbolic_module.template.h:246-249)."""
+    spec = offline.mach3_step_2d(30)
+    off0 = offline.SyntheticOffline(spec)
+    U0 = _perturbed(euler_uniform(off0.positions))
+    dirichlet = euler_uniform(off0.b_positions)
+
+    def edit(p):
+        p.limiter_iterations = iterations
+    off, mods = _both(spec, U0, oracle, n_warm=8, dirichlet=dirichlet, params_edit=edit)
+    res = []
+    for m, old, new in mods:
+        m.prepare_state_vector(old, 0.0, dirichlet)
+        tau = m.step(old, [], [], new)
+        res.append((tau, new.download()[: off.n_owned], m.debug_fetch("bounds")))
+    assert abs(res[0][0] - res[1][0]) <= 1e-12 * res[1][0]
+    scale = np.abs(res[1][1]).max(axis=0)
+    err = np.abs(res[0][1] - res[1][1]) / scale
+    assert (err > 1e-11).sum() <= max(2, int(1e-4 * err.size)) and err.max() < 1e-9
+    np.testing.assert_allclose(res[0][2], res[1][2], rtol=1e-12)
+
+
+def test_riemann_newton_iterations_and_tau_max(oracle):
+    """'riemann solver / newton max iterations' = 2 (quadratic Newton refinement of the two-rarefaction
+    guess, riemann_solver.template.h:540-575) through a whole step, and the tau_max argument of step()
+    clipping the CFL time step (tau = min(tau_max, CFL tau), :571-578; TimeLoop's final step)."""
+    spec = offline.mach3_step_2d(30)
+    off0 = offline.SyntheticOffline(spec)
+    U0 = _perturbed(euler_uniform(off0.positions))
+    dirichlet = euler_uniform(off0.b_positions)
+
+    def edit(p):
+        p.riemann_newton_max_iterations = 2
+    off, mods = _both(spec, U0, oracle, n_warm=8, dirichlet=dirichlet, params_edit=edit)
+    g, c = _compare_step(off, mods, dirichlet)
+    # the refined wavespeeds are never larger than the unrefined upper bound
+    off_b, mods_b = _both(spec, g["U_old"], oracle, dirichlet=dirichlet)
+    g0, _ = _compare_step(off_b, mods_b, dirichlet)
+    offd = g0["dij"] > 0.0   # off-diagonal entries (d_ii = -sum_j d_ij < 0)
+    assert (g["dij"][offd] <= g0["dij"][offd] * (1 + 1e-12)).all()
+    assert (g["dij"][offd] < g0["dij"][offd] * (1 - 1e-6)).any()
+    for m, old, new in mods:
+        m.prepare_state_vector(old, 0.0, dirichlet)
+        assert m.step(old, [], [], new, 0.0, 1e-7) == 1e-7
+        with pytest.raises(Exception):
+            m.step(old, [], [], new, 0.0, -1.0)       # AssertThrow at :573-576
