@@ -1109,3 +1109,38 @@ def test_riemann_newton_iterations_and_tau_max(oracle):
         assert m.step(old, [], [], new, 0.0, 1e-7) == 1e-7
         with pytest.raises(Exception):
             m.step(old, [], [], new, 0.0, -1.0)       # AssertThrow at :573-576
+
+
+@pytest.mark.parametrize("kinetic,square", [(1, 0), (1, 1), (0, 0)])
+def test_sw_limiter_options(oracle, kinetic, square):
+    """Shallow-water limiter with 'limit on kinetic energy' / 'limit on square velocity' in the three
+    non-default combinations (shallow_water/limiter.h:51-59, limiter.template.h:120-449)."""
+    from ryujin_amd.initial_states import sw_circular_dam_break
+    spec = offline.rectangle_2d(40, (-5.0, -5.0), (5.0, 5.0))
+    off0 = offline.SyntheticOffline(spec)
+    U0 = sw_circular_dam_break(off0.positions, h_outer=0.5)
+
+    def edit(p):
+        p.limiter_limit_on_kinetic_energy = kinetic
+        p.limiter_limit_on_square_velocity = square
+    off, mods = _both(spec, U0, oracle, n_warm=10, equation=capi.EQ_SHALLOW_WATER, params_edit=edit)
+    g, c = _compare_step(off, mods)
+    assert (g["U"][: off.n_owned, 0] > 0.0).all()
+
+
+@pytest.mark.parametrize("mach", [0.5, 3.0])
+def test_euler_dynamic_and_no_slip_boundaries(oracle, mach):
+    """Boundary ids `dynamic` (sub-/supersonic in- and outflow via Riemann
+    characteristics, euler/hyperbolic_system.h:1040-1159) and `no_slip` through whole updates."""
+    spec = offline.rectangle_2d(40, (0.0, 0.0), (2.0, 1.0), ny=20,
+                                bc=(capi.BC_DYNAMIC, capi.BC_DYNAMIC, capi.BC_NO_SLIP, capi.BC_SLIP))
+    off0 = offline.SyntheticOffline(spec)
+    U0 = _perturbed(euler_uniform(off0.positions, rho=1.4, u=mach, p=1.0))      # speed of sound 1
+    dirichlet = euler_uniform(off0.b_positions, rho=1.4, u=mach, p=1.0)
+    ids = set(int(b) for b in off0.b_id)
+    assert capi.BC_DYNAMIC in ids and capi.BC_NO_SLIP in ids
+    off, mods = _both(spec, U0, oracle, n_warm=10, dirichlet=dirichlet)
+    g, c = _compare_step(off, mods, dirichlet)
+    # no-slip rows carry no momentum after the boundary pass
+    ns = off.b_i[off.b_id == capi.BC_NO_SLIP]
+    assert np.abs(g["U_old"][ns, 1:3]).max() == 0.0
