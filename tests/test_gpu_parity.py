@@ -1144,3 +1144,23 @@ def test_euler_dynamic_and_no_slip_boundaries(oracle, mach):
     # no-slip rows carry no momentum after the boundary pass
     ns = off.b_i[off.b_id == capi.BC_NO_SLIP]
     assert np.abs(g["U_old"][ns, 1:3]).max() == 0.0
+
+
+@pytest.mark.parametrize("u", [0.5, 6.0])
+def test_sw_dynamic_dirichlet_momentum_no_slip_boundaries(oracle, u):
+    """Shallow-water boundary ids `dynamic` (sub- and supercritical), `dirichlet momentum` and `no_slip`
+    (shallow_water/hyperbolic_system.h:905-1015) through whole updates."""
+    spec = offline.rectangle_2d(40, (0.0, 0.0), (2.0, 1.0), ny=20,
+                                bc=(capi.BC_DYNAMIC, capi.BC_DIRICHLET_MOMENTUM, capi.BC_NO_SLIP, capi.BC_DYNAMIC))
+    off0 = offline.SyntheticOffline(spec)
+
+    def state(pos):
+        U = np.zeros((len(pos), 3))
+        U[:, 0] = 1.0 + 0.05 * np.sin(3.0 * pos[:, 0])
+        U[:, 1] = u * U[:, 0]
+        return U
+    U0 = _perturbed(state(off0.positions))
+    dirichlet = state(off0.b_positions)
+    off, mods = _both(spec, U0, oracle, n_warm=8, dirichlet=dirichlet, equation=capi.EQ_SHALLOW_WATER)
+    g, c = _compare_step(off, mods, dirichlet)
+    assert (g["U"][: off.n_owned, 0] > 0).all()
