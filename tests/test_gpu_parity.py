@@ -1164,3 +1164,78 @@ def test_sw_dynamic_dirichlet_momentum_no_slip_boundaries(oracle, u):
     off, mods = _both(spec, U0, oracle, n_warm=8, dirichlet=dirichlet, equation=capi.EQ_SHALLOW_WATER)
     g, c = _compare_step(off, mods, dirichlet)
     assert (g["U"][: off.n_owned, 0] > 0).all()
+
+
+@pytest.mark.parametrize("equation", ["aeos", "scalar", "sw"])
+def test_partitioned_other_descriptions_match_single_rank(equation):
+    """The ghost exchange carries n_precomputed_values = 4 (EulerAEOS), 2*dim (scalar conservation) and 2
+    (shallow water) doubles per DoF and k = 4 / 1 / 3 state components: 3 in-process ranks == single rank."""
+    import ctypes as C
+    import threading
+    from ryujin_amd.initial_states import sw_circular_dam_break
+    lib = capi.load_hip()
+    n_steps = 5
+    eq = {"aeos": capi.EQ_EULER_AEOS, "scalar": capi.EQ_SCALAR_CONSERVATION, "sw": capi.EQ_SHALLOW_WATER}[equation]
+
+    def mesh(n_ranks, rank):
+        if equation == "aeos":
+            return offline.mach3_step_2d(20, n_ranks=n_ranks, rank=rank)
+        bc = capi.BC_DIRICHLET if equation == "scalar" else capi.BC_SLIP
+        return offline.rectangle_2d(48, (-5.0, -5.0), (5.0, 5.0), bc=bc, n_ranks=n_ranks, rank=rank)
+
+    def initial(pos):
+        if equation == "aeos":
+            U = euler_uniform(pos)
+            return U * (1.0 + 1e-3 * np.sin(7.0 * pos[:, :1] + 3.0 * pos[:, 1:2]))
+        if equation == "scalar":
+            # smooth, nowhere constant: in constant regions the Roe average |f_i-f_j| / max(|u_i-u_j|, 2e4 eps)
+            # amplifies last-bit differences (different local numbering = different summation order) by 1e11
+            return (1.0 + 0.5 * np.sin(0.7 * pos[:, 0]) * np.cos(0.9 * pos[:, 1] + 0.3)).reshape(-1, 1)
+        return sw_circular_dam_break(pos)
+
+    def run(off, comm, out, key):
+        try:
+            p = capi.Params()
+            lib.ryujin_hip_default_params(p, eq, 2)
+            p.cfl = 0.9
+            if equation == "aeos":
+                p.eos, p.eos_covolume_b, p.eos_pinf, p.eos_q = capi.EOS_NOBLE_ABEL_STIFFENED_GAS, 0.02, 0.1, 0.05
+            m = HyperbolicModule(off, p, backend="hip", comm=comm)
+            U0 = initial(off.positions)
+            d = initial(off.b_positions) if off.n_bdry and equation != "sw" else None
+            state = m.new_state_vector(U0)
+            temps = [m.new_state_vector() for _ in range(3)]
+            taus = [m.time_step("erk 33", state, temps, d if k == 0 else None) for k in range(n_steps)]
+            out[key] = (off.global_ids[: off.n_owned].astype(np.int64), state.download()[: off.n_owned], taus,
+                        m.integrals(state))
+        except Exception as e:
+            out[key] = e
+
+    ref = {}
+    run(offline.SyntheticOffline(mesh(1, 0)), None, ref, 0)
+    assert not isinstance(ref[0], Exception), ref[0]
+    gid, U, taus, integ = ref[0]
+    assert np.all(np.isfinite(U))
+    n_ranks = 3
+    comms = (C.c_void_p * n_ranks)()
+    assert lib.ryujin_hip_comm_init_local(comms, n_ranks, 0) == 0
+    parts = [offline.SyntheticOffline(mesh(n_ranks, r)) for r in range(n_ranks)]
+    out = {}
+    threads = [threading.Thread(target=run, args=(parts[r], C.c_void_p(comms[r]), out, r)) for r in range(n_ranks)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+        assert not t.is_alive(), "rank thread hung"
+    for r in range(n_ranks):
+        assert not isinstance(out[r], Exception), out[r]
+        assert np.allclose(out[r][2], taus, rtol=1e-13, atol=0)
+        np.testing.assert_allclose(out[r][3], integ, rtol=1e-12, atol=1e-12 * np.abs(integ).max())
+    g = np.concatenate([out[r][0] for r in range(n_ranks)])
+    Up = np.concatenate([out[r][1] for r in range(n_ranks)])
+    o1, o2 = np.argsort(gid), np.argsort(g)
+    assert np.array_equal(gid[o1], g[o2])
+    scale = np.maximum(np.abs(U).max(axis=0), 1e-3 * np.abs(U).max())
+    assert (np.abs(Up[o2] - U[o1]) / scale).max() < 1e-11
+    for r in range(n_ranks):
+        lib.ryujin_hip_comm_destroy(C.c_void_p(comms[r]))
