@@ -4,7 +4,7 @@ ghost exchange done over torch.distributed -- vector ghosts, matrix ghost rows, 
 at exactly the reference's synchronisation points -- and rank 0 stores the
 gathered result. The parent test compares it with a single-rank run.
 
-usage: dist_worker.py <out.npz> <cells_per_unit> <n_updates>"""
+usage: dist_worker.py <out.npz> <cells_per_unit> <n_updates> [euler|aeos]"""
 import ctypes as C
 import os
 import sys
@@ -24,6 +24,7 @@ from ryujin_amd.initial_states import euler_uniform  # noqa: E402
 
 def main():
     out_path, cpu, n_updates = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    equation = capi.EQ_EULER_AEOS if (len(sys.argv) > 4 and sys.argv[4] == "aeos") else capi.EQ_EULER
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
 
@@ -73,7 +74,7 @@ def main():
 
     cb = oracle_py.EXCHANGE_FN(exchange)
     lib = oracle_py.load()
-    m = HyperbolicModule(off, equation=capi.EQ_EULER, backend=oracle_py.backend())
+    m = HyperbolicModule(off, equation=equation, backend=oracle_py.backend())
     lib.ryujin_oracle_set_exchange(m._ctx, cb, None)
     m.cfl = 0.9
     U0 = euler_uniform(off.positions)

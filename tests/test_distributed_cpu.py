@@ -24,9 +24,9 @@ def _free_port():
     return p
 
 
-def _single_rank(oracle, cpu, n_updates):
+def _single_rank(oracle, cpu, n_updates, equation=capi.EQ_EULER):
     off = offline.SyntheticOffline(offline.mach3_step_2d(cpu))
-    m = HyperbolicModule(off, equation=capi.EQ_EULER, backend=oracle.backend())
+    m = HyperbolicModule(off, equation=equation, backend=oracle.backend())
     m.cfl = 0.9
     U0 = euler_uniform(off.positions)
     U0 *= 1.0 + 1e-3 * np.sin(7.0 * off.positions[:, :1] + 3.0 * off.positions[:, 1:2])
@@ -40,18 +40,21 @@ def _single_rank(oracle, cpu, n_updates):
     return off.global_ids.astype(np.int64), a.download(), np.array(taus), m.alpha()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_partitioned_oracle_matches_single_rank(oracle, tmp_path, world):
+@pytest.mark.parametrize("world,equation", [(2, "euler"), (3, "euler"), (2, "aeos")])
+def test_partitioned_oracle_matches_single_rank(oracle, tmp_path, world, equation):
+    """world_size 2 and 3 over gloo; the EulerAEOS variant exchanges four precomputed values per DoF after
+    each of its two precomputation cycles."""
     cpu, n_updates = 20, 4
     out = str(tmp_path / "dist.npz")
     env = dict(os.environ, OMP_NUM_THREADS="2")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(ROOT, "tests", "dist_worker.py"), out, str(cpu), str(n_updates)]
+           os.path.join(ROOT, "tests", "dist_worker.py"), out, str(cpu), str(n_updates), equation]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-3000:]
     d = np.load(out)
-    gid, U, taus, alpha = _single_rank(oracle, cpu, n_updates)
+    gid, U, taus, alpha = _single_rank(oracle, cpu, n_updates,
+                                       capi.EQ_EULER_AEOS if equation == "aeos" else capi.EQ_EULER)
     # every rank used the same tau, and it is the single-rank tau
     assert np.all(np.abs(d["taus"] - taus[None, :]) <= 1e-13 * taus[None, :])
     order_ref = np.argsort(gid)
