@@ -186,3 +186,20 @@ def test_rows_longer_than_a_slice_are_rejected():
                                      capi.as_ptr(v._keep["mij"], capi.c_double_p), 1,
                                      capi.as_ptr(out, capi.c_double_p))
     assert rc == 0 and np.array_equal(col, columns)
+
+
+def test_headers_are_plain_c_and_match_the_ctypes_mirror(tmp_path):
+    """The drop-in boundary is a C ABI: the three public headers compile as C99 (no C++ constructs), and
+    the ctypes mirrors of the structs in ryujin_amd/capi.py have the sizes the C compiler gives them."""
+    import ctypes as C
+    import subprocess
+    src = tmp_path / "abi.c"
+    src.write_text('#include <stdio.h>\n#include "ryujin_hip.h"\n#include "ryujin_synth.h"\n'
+                   '#include "ryujin_offline_io.h"\n'
+                   'int main(void) { printf("%zu %zu %zu\\n", sizeof(ryujin_hip_params), '
+                   'sizeof(ryujin_hip_offline), sizeof(ryujin_synth_spec)); return 0; }\n')
+    exe = tmp_path / "abi"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", _build.INCLUDE,
+                    str(src), "-o", str(exe)], check=True, capture_output=True)
+    sizes = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    assert sizes == [C.sizeof(capi.Params), C.sizeof(capi.Offline), C.sizeof(capi.SynthSpec)]
