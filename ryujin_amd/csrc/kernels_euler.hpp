@@ -76,6 +76,9 @@ namespace ryujin_hip
 #ifndef RYUJIN_OCC_LOW
 #define RYUJIN_OCC_LOW 2
 #endif
+#ifndef RYUJIN_OCC_LOW_3D_ALL
+#define RYUJIN_OCC_LOW_3D_ALL 0
+#endif
 #ifndef RYUJIN_OCC_LOW_3D_STAGES
 #define RYUJIN_OCC_LOW_3D_STAGES 1 /* 3-D multi-stage step 4: 1 wave/SIMD without spills instead of 2 with 212 B/lane of scratch */
 #endif
@@ -628,7 +631,7 @@ namespace ryujin_hip
    * operation sequence, hence bit-identical -- by k_pij_lij_recompute (saves the 8kS B/row store of
    * this sweep and the 8kS B/row load of step 5 for 8dS+8S B/row of c_ij, d_ij loads there). */
   template <int DIM, bool HAS_STAGES, bool STORE_P = true, bool DG = false>
-  __global__ void __launch_bounds__(kBlock, (DIM == 3 && HAS_STAGES && RYUJIN_OCC_LOW_3D_STAGES) ? 1 : RYUJIN_OCC_LOW)
+  __global__ void __launch_bounds__(kBlock, (DIM == 3 && (HAS_STAGES || RYUJIN_OCC_LOW_3D_ALL) && RYUJIN_OCC_LOW_3D_STAGES) ? 1 : RYUJIN_OCC_LOW)
   k_low_order(const EulerParams P, const DeviceMesh M, const DeviceScalars *__restrict__ scalars,
               const double weight, const StageArgs<DIM> S, const double *__restrict__ U,
               const double *__restrict__ prec, const double *__restrict__ alpha,

@@ -179,7 +179,7 @@ namespace ryujin_hip
 
   /* step 4 (:597-884) with Limiter::{reset,accumulate,bounds} of euler_aeos/limiter.h:258-410 */
   template <int DIM, bool HAS_STAGES>
-  __global__ void __launch_bounds__(kBlock, RYUJIN_OCC_LOW)
+  __global__ void __launch_bounds__(kBlock, (DIM == 3 && RYUJIN_OCC_LOW_3D_STAGES) ? 1 : RYUJIN_OCC_LOW)
   k_low_order_aeos(const EulerAeosParams P, const DeviceMesh M, const DeviceScalars *__restrict__ scalars,
                    const double weight, const StageArgs<DIM> S, const double *__restrict__ U,
                    const double *__restrict__ prec, const double *__restrict__ alpha,

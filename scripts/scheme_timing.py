@@ -1,11 +1,12 @@
 """Wall time per forward-Euler update of the device-resident RK driver for different schemes (timers off).
-Usage: scheme_timing.py <dim> <size>"""
+Usage: scheme_timing.py <dim> <size> [aeos]"""
 import sys, time
 import numpy as np
 sys.path.insert(0, '.')
 from ryujin_amd import HyperbolicModule, capi, offline
 from ryujin_amd.initial_states import euler_uniform, euler_radial_contrast
 dim, size = int(sys.argv[1]), int(sys.argv[2])
+equation = capi.EQ_EULER_AEOS if (len(sys.argv) > 3 and sys.argv[3] == "aeos") else capi.EQ_EULER
 if dim == 2:
     off = offline.SyntheticOffline(offline.mach3_step_2d(size))
     U0 = euler_uniform(off.positions); d = euler_uniform(off.b_positions)
@@ -14,7 +15,7 @@ else:
     U0 = euler_radial_contrast(off.positions, inner=(1.0, 0.0, 100.0), outer=(1.0, 0.0, 0.1), radius=0.1); d = None
 lib = capi.load_hip()
 for scheme, stages in (("ssprk 33", 3), ("erk 33", 3), ("erk 54", 5)):
-    m = HyperbolicModule(off, equation=capi.EQ_EULER, backend="hip")
+    m = HyperbolicModule(off, equation=equation, backend="hip")
     m.cfl = 0.9
     state = m.new_state_vector(U0); temps = [m.new_state_vector() for _ in range(5)]
     m.time_step(scheme, state, temps, d)
