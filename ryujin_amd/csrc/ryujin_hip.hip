@@ -84,8 +84,14 @@ namespace
       if (count == 0)
         count = 1;
       HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&ptr), count * sizeof(T)));
-      if (zero)
+      if (zero) {
+        /* hipMemset on device memory is asynchronous and ordered on the NULL stream, which does not
+         * synchronise with the non-blocking streams of the context: a kernel launched right after the
+         * allocation could otherwise be overwritten by the late memset (seen as a flaky zero result of
+         * the first ryujin_hip_state_integrals call) */
         HIP_CHECK(hipMemset(ptr, 0, count * sizeof(T)));
+        HIP_CHECK(hipDeviceSynchronize());
+      }
     }
     void upload(const std::vector<T> &host)
     {
