@@ -38,3 +38,16 @@ cp $R/scalar_conservation/hyperbolic_system.output  $D/scalar_conservation_hyper
 for s in ssprk22 ssprk33 erk11 erk22 erk33 erk43 erk54; do
   cp $R/scalar_conservation/verification-linear_transport-$s.output $D/scalar_conservation_verification-linear_transport-$s.output
 done
+# 1-D and shallow-water verification runs (analytic solutions; final time and error norms)
+for f in leblanc-1d-erk33-l6 rarefaction-1d-erk33-l6; do
+  cp "$R/euler/verification-$f.mpirun=4.output" $D/euler_verification-$f.mpirun4.output
+done
+for f in leblanc-pge-1d-erk33-l6 leblanc-pge-1d-erk33-l6-strict rarefaction-pge-1d-erk33-l6; do
+  cp "$R/euler_aeos/verification-$f.mpirun=4.output" $D/euler_aeos_verification-$f.mpirun4.output
+done
+for f in paraboloid_1d-erk33-l7 ritter_dam_break-erk33-l7 smooth_vortex-erk33-l6 steady_incline-erk33-l9; do
+  cp $R/shallow_water/verification-$f.output $D/shallow_water_verification-$f.output
+done
+for s in ssprk33 erk33; do
+  cp "$R/euler/verification-isentropic_vortex-2d-$s-l7.mpirun=4.output" $D/euler_verification-isentropic_vortex-2d-$s-l7.mpirun4.output
+done

@@ -1,0 +1,283 @@
+"""Pins the CPU oracle's whole hot path against the reference's 1-D and shallow-water verification runs
+(tests/{euler,euler_aeos,shallow_water}/verification-*.{prm,output}): configurations with an analytic
+solution, for which the reference prints the final time (which pins tau of every step) and the normalised
+Linf/L1/L2 errors with 16 digits. Together they exercise what the 2-D vortex goldens do not: strong shocks
+and near-vacuum states (Le Blanc), the 1-D stencils, wetting and drying over a bathymetry (paraboloid,
+Ritter), the Manning friction source with "dynamic" boundaries (steady incline), "do nothing" boundaries,
+and both shallow-water limiter options.
+
+Meshes are `rectangular domain` with `subdivisions x = 25` and n global refinements, i.e. uniform: our
+closed-form Q1 stencils equal deal.II's assembly up to the summation order.
+"""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from ryujin_amd import HyperbolicModule, TimeIntegrator, capi, offline
+from ryujin_amd import initial_states as ist
+
+
+def _gauss3():
+    x = np.array([-np.sqrt(3.0 / 5.0), 0.0, np.sqrt(3.0 / 5.0)]) * 0.5 + 0.5
+    return x, np.array([5.0, 8.0, 5.0]) / 18.0
+
+
+def norms_1d(values, h):
+    """L1, L2 of the Q1 interpolant on a uniform 1-D mesh, QGauss<1>(3) per cell (time_loop.template.h:741-795)."""
+    x, w = _gauss3()
+    v0, v1 = values[:-1], values[1:]
+    l1 = l2 = 0.0
+    for a, wa in zip(x, w):
+        val = v0 * (1 - a) + v1 * a
+        l1 += wa * np.abs(val).sum()
+        l2 += wa * (val ** 2).sum()
+    return l1 * h, np.sqrt(l2 * h)
+
+
+def norms_2d(grid, h):
+    x, w = _gauss3()
+    v00, v10, v01, v11 = grid[:-1, :-1], grid[1:, :-1], grid[:-1, 1:], grid[1:, 1:]
+    l1 = l2 = 0.0
+    for a, wa in zip(x, w):
+        for b, wb in zip(x, w):
+            val = v00 * (1 - a) * (1 - b) + v10 * a * (1 - b) + v01 * (1 - a) * b + v11 * a * b
+            l1 += wa * wb * np.abs(val).sum()
+            l2 += wa * wb * (val ** 2).sum()
+    return l1 * h * h, np.sqrt(l2 * h * h)
+
+
+def golden(golden_dir, name):
+    text = open(os.path.join(golden_dir, name)).read()
+    g = lambda k: float(re.search(k + r"\s*=\s*([0-9.e+-]+)", text).group(1))  # noqa: E731
+    return int(g("#dofs")), g("t    "), g("Linf "), g("L1   "), g("L2   ")
+
+
+def run_verification(backend, off, params, exact, components, scheme="erk 33", cfl=0.1, t_final=1.0,
+                     bathymetry=None, with_dirichlet=True):
+    """TimeLoop::run + compute_error (time_loop.template.h:300-420, 694-833) on a uniform mesh:
+    `exact(positions, t)` is the analytic solution (initial values, Dirichlet data and error reference)."""
+    if bathymetry is not None:
+        off.set_initial_precomputed(bathymetry)
+    m = HyperbolicModule(off, params, backend=backend)
+    sv = m.new_state_vector(exact(off.positions, 0.0))
+    bpos = off.b_positions
+    ti = TimeIntegrator(m, scheme, cfl_min=cfl, cfl_max=cfl, cfl_recovery_strategy="none",
+                        dirichlet_fn=(lambda t: exact(bpos, t)) if with_dirichlet else None)
+    t, n_steps = 0.0, 0
+    while t < t_final:
+        sv, tau = ti.step(sv, t)
+        t += tau
+        n_steps += 1
+    m.prepare_state_vector(sv, t, exact(bpos, t) if with_dirichlet else None)
+    U, A = sv.download(), exact(off.positions, t)
+    dim = off.dim
+    n_cells = off.spec.n_cells
+    h = (off.spec.upper[0] - off.spec.lower[0]) / n_cells[0]
+    if dim == 1:
+        order = np.argsort(off.positions[:, 0])
+    else:
+        order = np.lexsort((off.positions[:, 0], off.positions[:, 1]))
+    linf = l1 = l2 = 0.0
+    for c in components:
+        a, e = A[order, c], (U[order, c] - A[order, c])
+        if dim == 1:
+            (l1a, l2a), (l1e, l2e) = norms_1d(a, h), norms_1d(e, h)
+        else:
+            shape = (n_cells[1] + 1, n_cells[0] + 1)
+            (l1a, l2a), (l1e, l2e) = norms_2d(a.reshape(shape).T, h), norms_2d(e.reshape(shape).T, h)
+        linf += np.abs(e).max() / np.abs(a).max()
+        l1 += l1e / l1a
+        l2 += l2e / l2a
+    return dict(t=t, linf=linf, l1=l1, l2=l2, dofs=off.n_owned, n_steps=n_steps,
+                warnings=m.n_warnings(), restarts=m.n_restarts())
+
+
+def interval(n_cells, lower, upper, bc_left, bc_right):
+    return offline.SyntheticOffline(offline.MeshSpec(1, (n_cells,), (lower,), (upper,), (bc_left, bc_right),
+                                                     name="interval"))
+
+
+def check(res, gold, rtol_t=1e-12, rtol_err=1e-7, slack=1.0):
+    rtol_t, rtol_err = rtol_t * slack, rtol_err * slack
+    dofs, t_ref, linf_ref, l1_ref, l2_ref = gold
+    assert res["dofs"] == dofs
+    assert abs(res["t"] - t_ref) <= rtol_t * t_ref, (res["t"], t_ref)
+    assert abs(res["linf"] - linf_ref) <= rtol_err * linf_ref, (res["linf"], linf_ref)
+    assert abs(res["l1"] - l1_ref) <= rtol_err * l1_ref, (res["l1"], l1_ref)
+    assert abs(res["l2"] - l2_ref) <= rtol_err * l2_ref, (res["l2"], l2_ref)
+
+
+# --------------------------------------------------------------------------- Euler, 1-D
+
+# The single-rarefaction runs agree with the goldens to 5.2e-10 in t and 1.8e-5 / 1.2e-6 / 5.9e-6 in the
+# Linf / L1 / L2 errors (2e-8 of the solution) -- identically for the Euler and the EulerAEOS restatement,
+# which share no equation-specific code. The offset does not move with the pow implementation, the limiter's
+# Newton tolerance or iteration count, or the relaxation factor; the isentropic data sit on a cusp, though:
+# scaling the right state's pressure by 1 +- 1.2e-9 moves t by -8e-9 / -1.4e-8 and L1 by -3e-4 / -7e-4, so
+# the initial data themselves agree far better than 1e-9, and an asymmetry of ~6e-11 anywhere in the
+# reference's evaluation (it is within its numdiff acceptance of 1e-6 absolute) explains the offset. Cause not
+# identified; pinned at the observed level.
+RAREFACTION_TOL = dict(rtol_t=2e-9, rtol_err=5e-5)
+
+
+def _euler_1d_params(default_params, equation, gamma, strict=None, evc0=False):
+    p = default_params(equation, 1)
+    p.gamma = gamma
+    p.limiter_iterations = 2
+    p.limiter_newton_max_iterations = 2
+    p.limiter_newton_tolerance = 1e-10
+    p.limiter_relaxation_factor = 8.0
+    if equation == capi.EQ_EULER_AEOS:
+        p.eos = capi.EOS_POLYTROPIC_GAS
+        p.compute_strict_bounds = int(bool(strict))
+    if evc0:
+        p.indicator_evc_factor = 0.0
+    return p
+
+
+def verify_euler_leblanc_1d(backend, default_params, golden_dir, slack=1.0):
+    """tests/euler/verification-leblanc-1d-erk33-l6.prm: [0,1], 25 * 2^6 cells, Dirichlet ends, the
+    discontinuity at 0.326732673267 (a cell centre), gamma = 5/3, cfl 0.1, relaxation factor 8."""
+    p = _euler_1d_params(default_params, capi.EQ_EULER, 1.66666666666667)
+    off = interval(1600, 0.0, 1.0, capi.BC_DIRICHLET, capi.BC_DIRICHLET)
+    exact = lambda pos, t: ist.euler_leblanc(pos, t, position=0.326732673267)  # noqa: E731
+    res = run_verification(backend, off, p, exact, (0, 1, 2), cfl=0.10, t_final=0.66666666666667)
+    # With the entropy-viscosity indicator active this run amplifies round-off: scaling the initial data by
+    # (1 + 1e-15 cos i) moves the final time by 3.6e-10 and the norms by 2e-8 (1e-13: 3e-8 / 5e-7). The
+    # reference evaluates pow with a vectorised implementation and sums stencils in another order; we
+    # observe 1.3e-8 in t and 1.4e-6 in the norms (the reference's own numdiff acceptance is 1e-6 absolute).
+    check(res, golden(golden_dir, "euler_verification-leblanc-1d-erk33-l6.mpirun4.output"), rtol_t=1e-7,
+          rtol_err=1e-5, slack=slack)
+
+
+def verify_euler_rarefaction_1d(backend, default_params, golden_dir, slack=1.0):
+    """tests/euler/verification-rarefaction-1d-erk33-l6.prm (gamma 1.4, position 0.2, t = 0.30558)."""
+    p = _euler_1d_params(default_params, capi.EQ_EULER, 1.4)
+    off = interval(1600, 0.0, 1.0, capi.BC_DIRICHLET, capi.BC_DIRICHLET)
+    exact = lambda pos, t: ist.euler_rarefaction(pos, t, gamma=1.4, position=0.2)  # noqa: E731
+    res = run_verification(backend, off, p, exact, (0, 1, 2), cfl=0.10, t_final=0.30558)
+    check(res, golden(golden_dir, "euler_verification-rarefaction-1d-erk33-l6.mpirun4.output"), slack=slack,
+          **RAREFACTION_TOL)
+
+
+def verify_euler_aeos_leblanc_1d(backend, default_params, golden_dir, strict, slack=1.0):
+    """tests/euler_aeos/verification-leblanc-pge-1d-erk33-l6{,-strict}.prm: polytropic gas through the
+    arbitrary-EOS code path; non-strict: evc factor 0, cfl 0.1; strict bounds: default indicator, cfl 0.75."""
+    p = _euler_1d_params(default_params, capi.EQ_EULER_AEOS, 1.66666666666667, strict=strict,
+                         evc0=not strict)
+    off = interval(1600, 0.0, 1.0, capi.BC_DIRICHLET, capi.BC_DIRICHLET)
+    exact = lambda pos, t: ist.euler_leblanc(pos, t, position=0.326732673267)  # noqa: E731
+    res = run_verification(backend, off, p, exact, (0, 1, 2), cfl=0.75 if strict else 0.10,
+                           t_final=0.66666666666667)
+    name = "euler_aeos_verification-leblanc-pge-1d-erk33-l6" + ("-strict" if strict else "")
+    # observed: 1e-15 / 1.4e-13 (non-strict, 8275 steps), 1.2e-12 / 1.3e-10 (strict, 1081 steps at cfl 0.75)
+    check(res, golden(golden_dir, name + ".mpirun4.output"), rtol_t=1e-10 if strict else 1e-13,
+          rtol_err=1e-8 if strict else 1e-11, slack=slack)
+
+
+def verify_euler_aeos_rarefaction_1d(backend, default_params, golden_dir, slack=1.0):
+    """tests/euler_aeos/verification-rarefaction-pge-1d-erk33-l6.prm."""
+    p = _euler_1d_params(default_params, capi.EQ_EULER_AEOS, 1.4, strict=False, evc0=True)
+    off = interval(1600, 0.0, 1.0, capi.BC_DIRICHLET, capi.BC_DIRICHLET)
+    exact = lambda pos, t: ist.euler_rarefaction(pos, t, gamma=1.4, position=0.2)  # noqa: E731
+    res = run_verification(backend, off, p, exact, (0, 1, 2), cfl=0.10, t_final=0.30558)
+    check(res, golden(golden_dir, "euler_aeos_verification-rarefaction-pge-1d-erk33-l6.mpirun4.output"),
+          slack=slack, **RAREFACTION_TOL)
+
+
+# --------------------------------------------------------------------------- shallow water
+
+def _sw_params(default_params, dim, reference_water_depth, factor, small=1e2, large=1e4, manning=0.0,
+               kinetic=False, square=True):
+    p = default_params(capi.EQ_SHALLOW_WATER, dim)
+    p.gravity = 9.81
+    p.manning_friction_coefficient = manning
+    p.reference_water_depth = reference_water_depth
+    p.dry_state_relaxation_factor = factor
+    p.dry_state_relaxation_small = small
+    p.dry_state_relaxation_large = large
+    p.limiter_limit_on_kinetic_energy = int(kinetic)
+    p.limiter_limit_on_square_velocity = int(square)
+    return p
+
+
+def verify_sw_paraboloid_1d(backend, default_params, golden_dir, slack=1.0):
+    """tests/shallow_water/verification-paraboloid_1d-erk33-l7.prm: the oscillating lake in a parabolic
+    bowl (wetting and drying), [0,10000] with 25 * 2^7 cells, do-nothing ends, one period t = 1345.71."""
+    p = _sw_params(default_params, 1, 10.0, 1.0e-3, kinetic=True, square=False)
+    off = interval(3200, 0.0, 10000.0, capi.BC_DO_NOTHING, capi.BC_DO_NOTHING)
+    exact = lambda pos, t: ist.sw_paraboloid_1d(pos, t)[0]  # noqa: E731
+    Z = ist.sw_paraboloid_1d(off.positions, 0.0)[1]
+    res = run_verification(backend, off, p, exact, (0,), cfl=0.5, t_final=1345.71, bathymetry=Z,
+                           with_dirichlet=False)
+    # Wetting and drying amplifies round-off: the reference itself keeps a second baseline for this test
+    # (verification-paraboloid_1d-erk33-l7.output.gcc-13.3-avx2) that differs from the default one by 5.1e-5
+    # in t and 2.6e-2 / 1.5e-2 / 1.9e-2 in the norms. We land 6.8e-5 / 3.0e-2 / 1.2e-4 / 5.3e-4 from the default.
+    check(res, golden(golden_dir, "shallow_water_verification-paraboloid_1d-erk33-l7.output"), rtol_t=2e-4,
+          rtol_err=5e-2, slack=slack)
+
+
+def verify_sw_ritter_dam_break(backend, default_params, golden_dir, slack=1.0):
+    """tests/shallow_water/verification-ritter_dam_break-erk33-l7.prm: dam break over a dry bed."""
+    p = _sw_params(default_params, 1, 0.005, 1.0e-3, kinetic=True, square=False)
+    off = interval(3200, 0.0, 10.0, capi.BC_DIRICHLET, capi.BC_DIRICHLET)
+    exact = lambda pos, t: ist.sw_ritter_dam_break(pos, t, time_initial=1.0, left_depth=0.005,  # noqa: E731
+                                                   position=5.0)
+    res = run_verification(backend, off, p, exact, (0,), cfl=0.5, t_final=6.0)
+    # t agrees to 3e-14 (1246 steps); the norms of the h error carry the round-off noise of the dry front:
+    # scaling the initial data by (1 + 1e-16 cos i) moves them by 1e-6 .. 1e-5 and t by 1e-14.
+    check(res, golden(golden_dir, "shallow_water_verification-ritter_dam_break-erk33-l7.output"), rtol_t=1e-12,
+          rtol_err=1e-4, slack=slack)
+
+
+def verify_sw_smooth_vortex(backend, default_params, golden_dir, slack=1.0):
+    """tests/shallow_water/verification-smooth_vortex-erk33-l6.prm: 64^2 cells on [-6,6]^2, Dirichlet."""
+    p = _sw_params(default_params, 2, 2.0, 0.0, kinetic=False, square=True)
+    off = offline.SyntheticOffline(offline.rectangle_2d(64, (-6.0, -6.0), (6.0, 6.0), bc=capi.BC_DIRICHLET))
+    exact = lambda pos, t: ist.sw_smooth_vortex(pos, t, reference_depth=2.0, mach=1.0, beta=2.0,  # noqa: E731
+                                                direction=(1.0, 1.0), position=(-1.0, -1.0))
+    res = run_verification(backend, off, p, exact, (0, 1, 2), cfl=0.25, t_final=2.0)
+    # observed: t bit-identical, norms 7e-13
+    check(res, golden(golden_dir, "shallow_water_verification-smooth_vortex-erk33-l6.output"), rtol_t=1e-14,
+          rtol_err=1e-10, slack=slack)
+
+
+def verify_sw_steady_incline(backend, default_params, golden_dir, slack=1.0):
+    """tests/shallow_water/verification-steady_incline-erk33-l9.prm: uniform flow down an incline in
+    balance with Manning friction, "dynamic" boundaries; the reference's error is round-off (1e-14), so the
+    statement pinned here is the final time and that the steady state is preserved to that level."""
+    p = _sw_params(default_params, 1, 1.0, 0.2, small=1e4, large=1e4, manning=1.0e-2, kinetic=False,
+                   square=True)
+    off = interval(512, 0.0, 20.0, capi.BC_DYNAMIC, capi.BC_DYNAMIC)
+    exact = lambda pos, t: ist.sw_sloping_friction(pos, manning=1.0e-2, ramp_slope=1.0e-2,  # noqa: E731
+                                                   initial_discharge=1.0e-1)[0]
+    Z = ist.sw_sloping_friction(off.positions, ramp_slope=1.0e-2)[1]
+    res = run_verification(backend, off, p, exact, (0, 1), cfl=0.5, t_final=1.0, bathymetry=Z)
+    dofs, t_ref, linf_ref, l1_ref, l2_ref = golden(golden_dir,
+                                                   "shallow_water_verification-steady_incline-erk33-l9.output")
+    assert res["dofs"] == dofs == 513
+    assert abs(res["t"] - t_ref) <= 1e-12 * slack * t_ref
+    assert res["linf"] < 20 * linf_ref and res["l1"] < 20 * l1_ref and res["l2"] < 20 * l2_ref
+
+
+# --------------------------------------------------------------------------- the CPU tests proper
+
+CASES = {
+    "euler_leblanc_1d": (verify_euler_leblanc_1d, ()),
+    "euler_rarefaction_1d": (verify_euler_rarefaction_1d, ()),
+    "euler_aeos_leblanc_1d": (verify_euler_aeos_leblanc_1d, (False,)),
+    "euler_aeos_leblanc_1d_strict": (verify_euler_aeos_leblanc_1d, (True,)),
+    "euler_aeos_rarefaction_1d": (verify_euler_aeos_rarefaction_1d, ()),
+    "sw_paraboloid_1d": (verify_sw_paraboloid_1d, ()),
+    "sw_ritter_dam_break": (verify_sw_ritter_dam_break, ()),
+    "sw_smooth_vortex": (verify_sw_smooth_vortex, ()),
+    "sw_steady_incline": (verify_sw_steady_incline, ()),
+}
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_verification_golden(oracle, golden_dir, case):
+    fn, args = CASES[case]
+    fn(oracle.backend(), oracle.default_params, golden_dir, *args)
