@@ -51,3 +51,6 @@ done
 for s in ssprk33 erk33; do
   cp "$R/euler/verification-isentropic_vortex-2d-$s-l7.mpirun=4.output" $D/euler_verification-isentropic_vortex-2d-$s-l7.mpirun4.output
 done
+for s in ssprk33 erk33; do
+  cp "$R/euler_aeos/verification-isentropic_vortex-pge-2d-$s-l7.mpirun=4.output" $D/euler_aeos_verification-isentropic_vortex-pge-2d-$s-l7.mpirun4.output
+done

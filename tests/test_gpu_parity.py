@@ -1260,3 +1260,12 @@ def test_verification_golden_on_gpu(oracle, golden_dir, case):
     from test_oracle_golden_verification import CASES
     fn, args = CASES[case]
     fn("hip", oracle.default_params, golden_dir, *args, slack=VERIFICATION_SLACK.get(case, 1.0))
+
+
+@pytest.mark.parametrize("description,scheme,level", [("euler", "ssprk 33", 6), ("euler", "erk 33", 7),
+                                                      ("euler", "ssprk 33", 7), ("euler_aeos", "erk 33", 6),
+                                                      ("euler_aeos", "ssprk 33", 7), ("euler_aeos", "erk 33", 7)])
+def test_isentropic_vortex_fine_golden_on_gpu(golden_dir, description, scheme, level):
+    """The 64^2 and 128^2 isentropic-vortex baselines (l7: the reference's MPI runs) on the HIP path."""
+    from test_oracle_golden_integration import check_fine_vortex
+    check_fine_vortex("hip", golden_dir, description, scheme, level, rtol=1e-8)

@@ -122,7 +122,8 @@ def run_isentropic_vortex(backend, scheme, refinement=5, t_final=2.0, equation=c
 
 
 def _golden_vortex(golden_dir, scheme, level, prefix="euler_verification-isentropic_vortex-2d"):
-    name = f"{prefix}-{scheme.replace(' ', '')}-l{level}.output"
+    # the l7 baselines of the reference are MPI runs (mpirun=4 and mpirun=8, which differ by 8e-11 in Linf)
+    name = f"{prefix}-{scheme.replace(' ', '')}-l{level}" + (".mpirun4.output" if level == 7 else ".output")
     text = open(os.path.join(golden_dir, name)).read()
     g = lambda k: float(re.search(k + r"\s*=\s*([0-9.e+-]+)", text).group(1))  # noqa: E731
     return int(g("#dofs")), g("t    "), g("Linf "), g("L1   "), g("L2   ")
@@ -155,3 +156,26 @@ def test_aeos_isentropic_vortex_l5_golden(oracle, golden_dir, scheme):
     assert abs(linf - linf_ref) < 1e-9 * linf_ref + 1e-12
     assert abs(l1 - l1_ref) < 1e-9 * l1_ref + 1e-12
     assert abs(l2 - l2_ref) < 1e-9 * l2_ref + 1e-12
+
+
+FINE_VORTEX_CASES = [("euler", "ssprk 33", 6), ("euler", "erk 33", 6), ("euler", "erk 33", 7),
+                     ("euler_aeos", "ssprk 33", 6), ("euler_aeos", "erk 33", 6), ("euler_aeos", "erk 33", 7)]
+
+
+def check_fine_vortex(backend, golden_dir, description, scheme, level, rtol=2e-10):
+    """Levels 6 and 7 (64^2 and 128^2 cells; observed: t to 1e-15, norms to 2.4e-12 and 3e-11; the
+    reference's own mpirun=4 and mpirun=8 baselines at l7 differ by 8e-11)."""
+    eq, prefix = {"euler": (capi.EQ_EULER, "euler_verification-isentropic_vortex-2d"),
+                  "euler_aeos": (capi.EQ_EULER_AEOS, "euler_aeos_verification-isentropic_vortex-pge-2d")}[description]
+    dofs, t_ref, linf_ref, l1_ref, l2_ref = _golden_vortex(golden_dir, scheme, level, prefix)
+    t, linf, l1, l2, n = run_isentropic_vortex(backend, scheme, level, equation=eq)
+    assert n == dofs == (2 ** level + 1) ** 2
+    assert abs(t - t_ref) < 1e-13 * t_ref
+    assert abs(linf - linf_ref) < rtol * linf_ref
+    assert abs(l1 - l1_ref) < rtol * l1_ref
+    assert abs(l2 - l2_ref) < rtol * l2_ref
+
+
+@pytest.mark.parametrize("description,scheme,level", FINE_VORTEX_CASES)
+def test_isentropic_vortex_fine_golden(oracle, golden_dir, description, scheme, level):
+    check_fine_vortex(oracle.backend(), golden_dir, description, scheme, level)
