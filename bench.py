@@ -273,7 +273,10 @@ def main():
     equation = capi.EQ_EULER
     rng = np.random.default_rng(42 + rank)
     if args.workload in ("step2d", "step2d_aeos"):
-        spec = offline.mach3_step_2d(args.cells_per_unit, length_units=3 * n_gpus, n_ranks=n_gpus, rank=rank)
+        # weak scaling: the channel is lengthened so that every GPU keeps the gridpoint count of the
+        # single-GPU mesh (area 0.8 L + 0.12 with the step cut out: 2.52 per GPU)
+        length = 3.0 if n_gpus == 1 else (2.52 * n_gpus - 0.12) / 0.8
+        spec = offline.mach3_step_2d(args.cells_per_unit, length_units=length, n_ranks=n_gpus, rank=rank)
         off = offline.SyntheticOffline(spec)
         U0 = euler_uniform(off.positions)  # prm/benchmarks/euler-mach3-forward-facing-step.prm:55-66
         dirichlet = euler_uniform(off.b_positions) if off.n_bdry else None
@@ -432,7 +435,7 @@ def main():
         "config": {"workload": workload_name,
                    "gridpoints_per_gpu": n_q_local, "gridpoints_total": n_q_total,
                    "dofs_total": k * n_q_total, "nnz_per_row": round(S, 3),
-                   "cells_per_unit": args.cells_per_unit, "partition": f"x-slabs x{n_gpus}",
+                   "cells_per_unit": args.cells_per_unit, "partition": f"x-slabs x{n_gpus}, equal gridpoint counts",
                    "cfl": 0.9, "limiter_iterations": 2, "develop_updates": args.develop,
                    "simulated_time_at_start": drv.t, "perturbation": args.perturbation},
         "mq_per_s": n_q_total * args.steps / wall / 1e6,

@@ -126,10 +126,47 @@ struct ryujin_synth {
     return node_id[box_index(ix, iy, iz)];
   }
 
-  static void slab(int64_t n_planes, int n_ranks, int rank, int64_t &a, int64_t &b)
+  /* x-slab partition of the node planes. Without a cut-out every plane carries the same number of
+   * gridpoints and the planes are dealt out evenly; with one (forward-facing step, cylinder) the planes
+   * are weighted by the active cells next to them, so that all ranks own (nearly) the same number of
+   * gridpoints -- what a graph partitioner would give the reference -- instead of the same length of
+   * channel. Deterministic: every rank computes the same boundaries. */
+  void slab(int n_ranks, int rank, int64_t &a, int64_t &b) const
   {
-    a = n_planes * rank / n_ranks;
-    b = n_planes * (rank + 1) / n_ranks;
+    const int64_t n_planes = nn[0];
+    if (spec.cut_kind == RYUJIN_CUT_NONE || n_ranks == 1) {
+      a = n_planes * rank / n_ranks;
+      b = n_planes * (rank + 1) / n_ranks;
+      return;
+    }
+    std::vector<double> cells((size_t)nc[0], 0.);
+    for (int64_t cx = 0; cx < nc[0]; ++cx) {
+      int64_t n = 0;
+      for (int64_t cz = 0; cz < nc[2]; ++cz)
+        for (int64_t cy = 0; cy < nc[1]; ++cy)
+          n += cell_active(cx, cy, cz) ? 1 : 0;
+      cells[(size_t)cx] = (double)n;
+    }
+    std::vector<double> prefix((size_t)n_planes + 1, 0.); /* weight of the planes [0, ix) */
+    for (int64_t ix = 0; ix < n_planes; ++ix) {
+      const double left = ix > 0 ? cells[(size_t)ix - 1] : 0., right = ix < nc[0] ? cells[(size_t)ix] : 0.;
+      prefix[(size_t)ix + 1] = prefix[(size_t)ix] + 0.5 * (left + right);
+    }
+    const double total = prefix[(size_t)n_planes];
+    auto boundary = [&](int r) -> int64_t {
+      if (r <= 0)
+        return 0;
+      if (r >= n_ranks)
+        return n_planes;
+      const double target = total * (double)r / (double)n_ranks;
+      int64_t ix = std::lower_bound(prefix.begin(), prefix.end(), target) - prefix.begin();
+      /* every rank keeps at least two planes */
+      ix = std::max<int64_t>(ix, 2 * (int64_t)r);
+      ix = std::min<int64_t>(ix, n_planes - 2 * (int64_t)(n_ranks - r));
+      return ix;
+    };
+    a = boundary(rank);
+    b = boundary(rank + 1);
   }
 
   bool build();
@@ -157,7 +194,7 @@ bool ryujin_synth::build()
     g_error = "rank out of range";
     return false;
   }
-  slab(nn[0], R, r, x0, x1);
+  slab(R, r, x0, x1);
   if (R > 1 && x1 - x0 < 2) {
     g_error = "slab partition needs at least two node planes per rank";
     return false;

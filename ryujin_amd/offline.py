@@ -215,10 +215,12 @@ def mach3_step_2d(cells_per_unit: int, length_units: int = 3, n_ranks=1, rank=0)
     (geometry: source/geometry_step.h:41-93 without the rounded corner; data:
     prm/benchmarks/euler-mach3-forward-facing-step.prm). Left dirichlet, right do-nothing,
     everything else slip. cells_per_unit must be a multiple of 5 so that the step is grid aligned.
-    For weak scaling the channel is lengthened (length_units) and slab-partitioned along x."""
+    For weak scaling the channel is lengthened (length_units, not necessarily an integer) and
+    slab-partitioned along x with equal gridpoint counts per rank."""
     assert cells_per_unit % 5 == 0
-    L = float(length_units)
-    return MeshSpec(2, (cells_per_unit * length_units, cells_per_unit), (0.0, 0.0), (L, 1.0),
+    n_x = int(round(cells_per_unit * length_units))  # a fractional length is rounded to whole cells
+    L = n_x / float(cells_per_unit)
+    return MeshSpec(2, (n_x, cells_per_unit), (0.0, 0.0), (L, 1.0),
                     (capi.BC_DIRICHLET, capi.BC_DO_NOTHING, capi.BC_SLIP, capi.BC_SLIP),
                     cut_kind=capi.CUT_BOX, cut_lo=(0.6, -1.0, 0.0), cut_hi=(L + 1.0, 0.2, 0.0),
                     cut_bc=capi.BC_SLIP, n_ranks=n_ranks, rank=rank, name="mach3-step-2d")
