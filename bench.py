@@ -197,7 +197,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=12)
     ap.add_argument("--cells-per-unit", type=int, default=995,
                     help="mesh resolution h=1/N of the step geometry (995 -> ~2.5M gridpoints, ~10M DoFs per GPU)")
-    ap.add_argument("--workload", default="step2d", choices=["step2d", "sedov3d", "sw2d", "step2d_aeos"],
+    ap.add_argument("--workload", default="step2d", choices=["step2d", "sedov3d", "sw2d", "step2d_aeos", "cylinder3d"],
                     help="step2d = BASELINE configs[1] (the bench line); sedov3d = configs[2] (3-D radial "
                          "contrast box, --size cells per direction, default 200 -> 8.1M gridpoints); "
                          "sw2d = configs[4] (shallow-water circular dam break, default 1825^2 gridpoints)")
@@ -286,6 +286,17 @@ def main():
             equation = capi.EQ_EULER_AEOS
             workload_name = ("2D Euler-AEOS (polytropic gas EOS, strict bounds) Mach-3 forward-facing step, "
                              "Q1, SSPRK33 stage sequence")
+    elif args.workload == "cylinder3d":
+        # BASELINE.json configs[3]: h = 1/126 on [0,4]x[-1,1]^2 over 8 GPUs is 4M gridpoints per GPU; fewer
+        # GPUs keep that per-GPU count with a shorter channel (half a unit of length per GPU, at least 1.25)
+        # (the cylinder needs 1.25 units of channel: one or two GPUs run h = 1/96 and 1/120 instead)
+        n = args.size or {1: 96, 2: 120}.get(n_gpus, 126)
+        length = max(1.25, 0.5 * n_gpus)
+        spec = offline.cylinder_channel_3d(n, length_units=length, n_ranks=n_gpus, rank=rank)
+        off = offline.SyntheticOffline(spec)
+        U0 = euler_uniform(off.positions)  # prm/benchmarks/euler-mach3-cylinder-3d.prm:49-91
+        dirichlet = euler_uniform(off.b_positions) if off.n_bdry else None
+        workload_name = "3D Euler Mach-3 cylinder in a channel, Q1 (BASELINE.json configs[3])"
     elif args.workload == "sedov3d":
         from ryujin_amd.initial_states import euler_radial_contrast
         n = args.size or 200
@@ -435,7 +446,7 @@ def main():
         "config": {"workload": workload_name,
                    "gridpoints_per_gpu": n_q_local, "gridpoints_total": n_q_total,
                    "dofs_total": k * n_q_total, "nnz_per_row": round(S, 3),
-                   "cells_per_unit": args.cells_per_unit, "partition": f"x-slabs x{n_gpus}, equal gridpoint counts",
+                   "cells_per_unit": (args.cells_per_unit if args.workload.startswith("step2d") else n), "partition": f"x-slabs x{n_gpus}, equal gridpoint counts",
                    "cfl": 0.9, "limiter_iterations": 2, "develop_updates": args.develop,
                    "simulated_time_at_start": drv.t, "perturbation": args.perturbation},
         "mq_per_s": n_q_total * args.steps / wall / 1e6,

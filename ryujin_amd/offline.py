@@ -235,8 +235,9 @@ def box_3d(n: int, lower=(-1.0, -1.0, -1.0), upper=(1.0, 1.0, 1.0), bc=capi.BC_S
 def cylinder_channel_3d(cells_per_unit: int, length_units: int = 4, n_ranks=1, rank=0) -> MeshSpec:
     """[0,L]x[-1,1]x[-1,1] minus a staircase cylinder r=0.25 at x=0.6 (axis along z);
     prm/benchmarks/euler-mach3-cylinder-3d.prm."""
-    L = float(length_units)
-    return MeshSpec(3, (cells_per_unit * length_units, 2 * cells_per_unit, 2 * cells_per_unit),
+    n_x = int(round(cells_per_unit * length_units))
+    L = n_x / float(cells_per_unit)
+    return MeshSpec(3, (n_x, 2 * cells_per_unit, 2 * cells_per_unit),
                     (0.0, -1.0, -1.0), (L, 1.0, 1.0),
                     (capi.BC_DIRICHLET, capi.BC_DO_NOTHING, capi.BC_SLIP, capi.BC_SLIP, capi.BC_SLIP,
                      capi.BC_SLIP),
