@@ -82,6 +82,11 @@ class OfflineView:
         self.row_starts = k["row_starts"]
         self.mi = k["mi"]
 
+    def set_initial_precomputed(self, values):
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        self._keep["initial_precomputed"] = v
+        self._o.initial_precomputed = capi.as_ptr(v, capi.c_double_p)
+
 
 def to_simd_layout(off, sl):
     """Renumber a single-rank SyntheticOffline so that rows are sorted by (descending) stencil size, and

@@ -1269,3 +1269,81 @@ def test_isentropic_vortex_fine_golden_on_gpu(golden_dir, description, scheme, l
     """The 64^2 and 128^2 isentropic-vortex baselines (l7: the reference's MPI runs) on the HIP path."""
     from test_oracle_golden_integration import check_fine_vortex
     check_fine_vortex("hip", golden_dir, description, scheme, level, rtol=1e-8)
+
+
+def _unstructured_both(oracle, off, U0, equation, n_warm, dirichlet=None, params_edit=None):
+    mods, U_start = [], U0
+    for backend in ("hip", oracle.backend()):
+        p = oracle.default_params(equation, 2)
+        p.cfl = 0.5
+        if params_edit:
+            params_edit(p)
+        m = HyperbolicModule(off, p, backend=backend)
+        old, new = m.new_state_vector(U_start), m.new_state_vector()
+        if backend == "hip":
+            for _ in range(n_warm):
+                m.prepare_state_vector(old, 0.0, dirichlet)
+                m.step(old, [], [], new)
+                old, new = new, old
+            U_start = old.download()
+        mods.append((m, old, new))
+    return mods
+
+
+def test_unstructured_p1_mesh_euler(oracle):
+    """Continuous P1 triangles on a Delaunay triangulation of a disk (tests/helpers_unstructured.py): row
+    lengths 4 .. 10, c_ij antisymmetric only in the interior, boundary normals in every direction, coupling
+    boundary pairs along the whole rim. A blast wave reflecting off slip walls, compared sweep by sweep; then
+    the rim split into slip / dynamic / dirichlet / no-slip quarters."""
+    from helpers_unstructured import disk_points, p1_offline
+    off, info = p1_offline(disk_points(24))
+    assert off.n_owned > 1800 and off.n_pairs > 200
+    U0 = euler_radial_contrast(off.positions, inner=(1.0, 0.0, 10.0), outer=(0.125, 0.0, 0.1), radius=0.35)
+    mods = _unstructured_both(oracle, off, U0, capi.EQ_EULER, n_warm=120)     # the shock has hit the wall
+    g, c = _compare_step(off, mods)
+    mi = off.mi
+    for comp in (0, 3):
+        before, after = (mi * g["U_old"][:, comp]).sum(), (mi * g["U"][:, comp]).sum()
+        assert abs(after - before) < 1e-13 * abs(before)
+
+    bpos = off.positions[off._keep["b_i"]]
+    quarter = (np.arctan2(bpos[:, 1], bpos[:, 0]) // (0.5 * np.pi)).astype(int) % 4
+    ids = np.array([capi.BC_SLIP, capi.BC_DYNAMIC, capi.BC_DIRICHLET, capi.BC_NO_SLIP], dtype=np.uint8)[quarter]
+    off2, _ = p1_offline(disk_points(24))
+    off2._keep["b_id"][:] = ids
+    far = euler_uniform(bpos, rho=0.5, u=0.3, p=0.4)
+    mods = _unstructured_both(oracle, off2, U0, capi.EQ_EULER, n_warm=120, dirichlet=far)
+    _compare_step(off2, mods, dirichlet=far)
+
+
+def test_unstructured_p1_mesh_shallow_water_and_aeos(oracle):
+    """The same mesh for the shallow-water Description (bathymetry, m_ij in the source term, dry rim) and
+    for EulerAEOS with the van der Waals EOS."""
+    from helpers_unstructured import disk_points, p1_offline
+    from ryujin_amd.initial_states import aeos_from_primitive
+    off, _ = p1_offline(disk_points(20))
+    x = off.positions
+    r = np.linalg.norm(x, axis=1)
+    Z = 0.6 * r ** 2 + 0.05 * np.cos(5.0 * x[:, 0]) * np.sin(3.0 * x[:, 1])
+    off.set_initial_precomputed(Z)
+    U0 = np.zeros((off.n_owned, 3))
+    U0[:, 0] = np.maximum(np.where(r < 0.3, 0.9, 0.45) - Z, 0.0)            # dry towards the rim
+    assert (U0[:, 0] == 0).sum() > 50
+
+    def friction(p):
+        p.manning_friction_coefficient = 0.03
+    mods = _unstructured_both(oracle, off, U0, capi.EQ_SHALLOW_WATER, n_warm=60, params_edit=friction)
+    g, c = _compare_step(off, mods)
+    assert (g["U"][:, 0] >= 0.0).all()
+
+    off, _ = p1_offline(disk_points(20))
+
+    def vdw(p):
+        p.eos = capi.EOS_VAN_DER_WAALS
+        p.eos_vdw_a, p.eos_covolume_b = 0.02, 0.05
+    p = oracle.default_params(capi.EQ_EULER_AEOS, 2)
+    vdw(p)
+    inside = r < 0.35
+    U0 = aeos_from_primitive(p, np.where(inside, 1.0, 0.2), np.zeros((off.n_owned, 2)), np.where(inside, 8.0, 0.2))
+    mods = _unstructured_both(oracle, off, U0, capi.EQ_EULER_AEOS, n_warm=100, params_edit=vdw)
+    _compare_step(off, mods)
