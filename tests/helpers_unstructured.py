@@ -93,3 +93,175 @@ def p1_offline(points, boundary_id=capi.BC_SLIP):
     off.positions = x
     off.row_starts, off.columns, off.cij_csr, off.mij_csr, off.mi = row_starts, columns, cij, mij, mi
     return off, dict(triangles=T, area=area_total, rows=rows, is_bdry=is_bdry)
+
+
+def partition(off, info, owner, bathymetry=None):
+    """Split a single-rank OfflineView into per-rank OfflineViews for an ARBITRARY ownership map
+    (owner[g] = rank of global node g), in the reference's local numbering and exchange semantics
+    (include/ryujin_hip.h; source/offline_data.template.h:210-272, sparse_matrix_simd.template.h:61-74,
+    :247-259): owned = [exported | rest], ghosts sorted by (owner, owner's local index); ghost rows keep the
+    diagonal and the columns owned by this rank; a rank sends the owned entries of its exported rows whose
+    column belongs to the receiver. Ranks may have any number of neighbours and a node may be exported
+    to several of them -- topologies the slab partition of the mesh generator never produces."""
+    rows = info["rows"]
+    n = len(rows)
+    n_ranks = int(owner.max()) + 1
+    rs = off.row_starts.astype(np.int64)
+    entry = {(i, int(off.columns[e])): e for i in range(n) for e in range(rs[i], rs[i + 1])}
+    is_bdry = info["is_bdry"]
+    g_normal = np.zeros((n, 2))
+    g_normal[off._keep["b_i"]] = off._keep["b_normal"]
+    g_id = np.zeros(n, dtype=np.uint8)
+    g_id[off._keep["b_i"]] = off._keep["b_id"]
+
+    owned, loc = [], []
+    for r in range(n_ranks):
+        mine = [g for g in range(n) if owner[g] == r]
+        exported = [g for g in mine if any(owner[j] != r for j in rows[g][1:])]
+        rest = [g for g in mine if g not in set(exported)]
+        order = exported + rest
+        owned.append((order, len(exported)))
+        loc.append({g: k for k, g in enumerate(order)})
+
+    views = []
+    for r in range(n_ranks):
+        order, n_export = owned[r]
+        n_owned = len(order)
+        ghosts = sorted({j for g in order for j in rows[g][1:] if owner[j] != r},
+                        key=lambda j: (owner[j], loc[owner[j]][j]))
+        l2g = order + ghosts
+        lidx = dict(loc[r])
+        lidx.update({g: n_owned + k for k, g in enumerate(ghosts)})
+        nbrs = sorted({int(owner[j]) for j in ghosts})
+        recv_off = [n_owned]
+        for p in nbrs:
+            recv_off.append(recv_off[-1] + sum(1 for j in ghosts if owner[j] == p))
+        lrows, lc, lm = [], [], []
+        for g in l2g:
+            keep = rows[g][1:] if owner[g] == r else [j for j in rows[g][1:] if owner[j] == r]
+            cols = sorted(keep, key=lambda j: lidx[j])
+            lrows.append([lidx[g]] + [lidx[j] for j in cols])
+            for j in [g] + cols:
+                lc.append(off.cij_csr[entry[(g, j)]])
+                lm.append(off.mij_csr[entry[(g, j)]])
+        row_starts = np.cumsum([0] + [len(x) for x in lrows]).astype(np.uint64)
+        columns = np.concatenate([np.array(x, dtype=np.uint32) for x in lrows])
+        send_off, send_idx, row_send_off, row_send_row, row_send_col = [0], [], [0], [], []
+        for p in nbrs:
+            exp_p = sorted(lidx[g] for g in order if any(owner[j] == p for j in rows[g][1:]))
+            send_idx.extend(exp_p)
+            send_off.append(len(send_idx))
+            for i in exp_p:
+                row_send_row.append(i)
+                row_send_col.append(0)
+                for c in range(1, len(lrows[i])):
+                    if owner[l2g[lrows[i][c]]] == p:
+                        row_send_row.append(i)
+                        row_send_col.append(c)
+            row_send_off.append(len(row_send_row))
+        b_g = [g for g in order if is_bdry[g]]
+        b_i = np.array([lidx[g] for g in b_g], dtype=np.uint32)
+        p_i, p_col, p_j = [], [], []
+        for g in b_g:
+            i = lidx[g]
+            for c in range(1, len(lrows[i])):
+                if is_bdry[l2g[lrows[i][c]]]:
+                    p_i.append(i), p_col.append(c), p_j.append(lrows[i][c])
+        mi = off.mi[l2g]
+        v = OfflineView(2, n_export, n_owned, n_owned, len(l2g), 1, row_starts, columns, np.array(lc), np.array(lm),
+                        mi, 1.0 / mi, off.measure_of_omega, b_i, g_normal[b_g].reshape(-1, 2), g_id[b_g],
+                        p_i, p_col, p_j)
+        k = v._keep
+        k["nbr_rank"] = np.array(nbrs, dtype=np.int32)
+        for name, val in (("send_off", send_off), ("send_idx", send_idx), ("recv_off", recv_off),
+                          ("row_send_off", row_send_off), ("row_send_row", row_send_row),
+                          ("row_send_col", row_send_col)):
+            k[name] = np.array(val, dtype=np.uint32)
+        o = v._o
+        o.n_nbr = len(nbrs)
+        o.nbr_rank = capi.as_ptr(k["nbr_rank"], capi.c_int_p)
+        for name in ("send_off", "send_idx", "recv_off", "row_send_off", "row_send_row", "row_send_col"):
+            setattr(o, name, capi.as_ptr(k[name], capi.c_u32_p))
+        v.positions = off.positions[l2g]
+        v.global_ids = np.array(l2g, dtype=np.int64)
+        v.b_positions = off.positions[b_g].reshape(-1, 2)
+        if bathymetry is not None:
+            v.set_initial_precomputed(bathymetry[l2g])
+        views.append(v)
+    return views
+
+
+def run_partitioned_oracle(oracle, views, params, U0_global, n_updates, dirichlet_fn=None):
+    """One oracle context per rank, one host thread each; ghost vectors, matrix ghost rows and the min/or
+    reductions are exchanged through shared numpy buffers at the oracle's synchronisation points. Returns
+    (U in global numbering, list of tau per update)."""
+    import ctypes as C
+    import threading
+
+    from ryujin_amd import HyperbolicModule
+    n_ranks = len(views)
+    barrier = threading.Barrier(n_ranks)
+    mail, scratch, out = {}, [0.0] * n_ranks, {}
+    lib = oracle.load()
+
+    def worker(r):
+        try:
+            v = views[r]
+            k = v._keep
+            nbr, ptr = k["nbr_rank"].tolist(), k["row_starts"].astype(np.int64)
+            send_off, recv_off = k["send_off"].tolist(), k["recv_off"].tolist()
+            send_idx = k["send_idx"].astype(np.int64)
+            row_send_off = k["row_send_off"].tolist()
+            row_pos = ptr[k["row_send_row"].astype(np.int64)] + k["row_send_col"].astype(np.int64)
+
+            def exchange(user, what, data, n_comp):
+                if what in (10, 11):
+                    scratch[r] = data[0]
+                    barrier.wait()
+                    val = min(scratch) if what == 10 else max(scratch)
+                    barrier.wait()
+                    data[0] = val
+                    return
+                if what < 4:
+                    a = np.ctypeslib.as_array(data, shape=(v.n_relevant * n_comp,)).reshape(-1, n_comp)
+                    for q, p in enumerate(nbr):
+                        mail[(r, p)] = a[send_idx[send_off[q]:send_off[q + 1]]].copy()
+                    barrier.wait()
+                    for q, p in enumerate(nbr):
+                        a[recv_off[q]:recv_off[q + 1]] = mail[(p, r)]
+                else:
+                    a = np.ctypeslib.as_array(data, shape=(int(ptr[-1]),))
+                    for q, p in enumerate(nbr):
+                        mail[(r, p)] = a[row_pos[row_send_off[q]:row_send_off[q + 1]]].copy()
+                    barrier.wait()
+                    for q, p in enumerate(nbr):
+                        a[int(ptr[recv_off[q]]):int(ptr[recv_off[q + 1]])] = mail[(p, r)]
+                barrier.wait()
+
+            cb = oracle.EXCHANGE_FN(exchange)
+            m = HyperbolicModule(v, params, backend=oracle.backend())
+            lib.ryujin_oracle_set_exchange(m._ctx, cb, None)
+            a, b = m.new_state_vector(U0_global[v.global_ids]), m.new_state_vector()
+            taus = []
+            for _ in range(n_updates):
+                m.prepare_state_vector(a, 0.0, dirichlet_fn(v) if dirichlet_fn else None)
+                taus.append(m.step(a, [], [], b))
+                a, b = b, a
+            out[r] = (a.download()[: v.n_owned], taus)
+        except Exception as e:  # noqa: BLE001 -- surfaced in the main thread
+            out[r] = e
+            barrier.abort()
+
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(n_ranks)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+        assert not t.is_alive(), "rank thread hung"
+    for r in range(n_ranks):
+        if isinstance(out[r], Exception):
+            raise out[r]
+    U = np.empty_like(U0_global)
+    for r in range(n_ranks):
+        U[views[r].global_ids[: views[r].n_owned]] = out[r][0]
+    return U, [out[r][1] for r in range(n_ranks)]

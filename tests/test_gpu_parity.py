@@ -1347,3 +1347,79 @@ def test_unstructured_p1_mesh_shallow_water_and_aeos(oracle):
     U0 = aeos_from_primitive(p, np.where(inside, 1.0, 0.2), np.zeros((off.n_owned, 2)), np.where(inside, 8.0, 0.2))
     mods = _unstructured_both(oracle, off, U0, capi.EQ_EULER_AEOS, n_warm=100, params_edit=vdw)
     _compare_step(off, mods)
+
+
+@pytest.mark.parametrize("equation", ["euler", "shallow_water"])
+def test_unstructured_arbitrary_partition_on_gpu(oracle, equation):
+    """The multi-rank code path on a partition the mesh generator cannot produce: the P1 disk cut into 5
+    angular sectors around an off-centre point -- up to 4 neighbours per rank, nodes exported to several
+    ranks, exchange lists built by tests/helpers_unstructured.py::partition from the contract in
+    include/ryujin_hip.h. Five contexts (one host thread each) on one GPU with the in-process transport must
+    reproduce the single-context run, through prepare_state_vector/step and through the device-resident
+    SSPRK33 driver (deferred collectives)."""
+    import ctypes as C
+    import threading
+
+    from helpers_unstructured import disk_points, p1_offline, partition
+    from test_oracle_unstructured import sector_owner
+    lib = capi.load_hip()
+    n_ranks = 5
+    off, info = p1_offline(disk_points(22))
+    x = off.positions
+    if equation == "euler":
+        eq = capi.EQ_EULER
+        Z = None
+        U0 = euler_radial_contrast(x, inner=(1.0, 0.0, 10.0), outer=(0.125, 0.0, 0.1), radius=0.35,
+                                   center=(0.1, -0.05))
+    else:
+        eq = capi.EQ_SHALLOW_WATER
+        r = np.linalg.norm(x - np.array([0.1, -0.05]), axis=1)
+        Z = 0.5 * np.linalg.norm(x, axis=1) ** 2 + 0.03 * np.cos(6.0 * x[:, 0])
+        off.set_initial_precomputed(Z)
+        U0 = np.zeros((off.n_owned, 3))
+        U0[:, 0] = np.maximum(np.where(r < 0.3, 0.8, 0.4) - Z, 0.0)
+    views = partition(off, info, sector_owner(x, n_ranks), bathymetry=Z)
+    assert max(v._o.n_nbr for v in views) >= 3
+    p = oracle.default_params(eq, 2)
+    p.cfl = 0.5
+    n_updates, n_rk = 12, 4
+
+    def run(view, comm, out, key, U_init):
+        try:
+            m = HyperbolicModule(view, p, backend="hip", comm=comm)
+            a, b = m.new_state_vector(U_init), m.new_state_vector()
+            taus = []
+            for _ in range(n_updates):
+                m.prepare_state_vector(a, 0.0)
+                taus.append(m.step(a, [], [], b))
+                a, b = b, a
+            temps = [b, m.new_state_vector(), m.new_state_vector()]
+            for _ in range(n_rk):
+                taus.append(m.time_step("ssprk 33", a, temps))
+            out[key] = (a.download()[: view.n_owned], taus, m.integrals(a))
+        except Exception as e:  # noqa: BLE001
+            out[key] = e
+
+    ref = {}
+    run(off, None, ref, 0, U0)
+    assert not isinstance(ref[0], Exception), ref[0]
+    U_ref, taus, integ = ref[0]
+    comms = (C.c_void_p * n_ranks)()
+    assert lib.ryujin_hip_comm_init_local(comms, n_ranks, 0) == 0
+    out = {}
+    threads = [threading.Thread(target=run, args=(views[r], C.c_void_p(comms[r]), out, r, U0[views[r].global_ids]))
+               for r in range(n_ranks)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+        assert not t.is_alive(), "rank thread hung"
+    U = np.empty_like(U0)
+    for r in range(n_ranks):
+        assert not isinstance(out[r], Exception), out[r]
+        np.testing.assert_allclose(out[r][1], taus, rtol=1e-13)
+        np.testing.assert_allclose(out[r][2], integ, rtol=1e-11, atol=1e-12 * np.abs(integ).max())
+        U[views[r].global_ids[: views[r].n_owned]] = out[r][0]
+    assert (np.abs(U - U_ref).max(axis=0) / np.abs(U_ref).max(axis=0)).max() < 1e-9
+    for r in range(n_ranks):
+        lib.ryujin_hip_comm_destroy(C.c_void_p(comms[r]))
