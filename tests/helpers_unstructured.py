@@ -1,5 +1,5 @@
 """Test helper: OfflineData of a genuinely unstructured mesh -- continuous P1 elements on a Delaunay
-triangulation of a disk -- assembled with numpy exactly as the reference assembles its matrices
+triangulation of a disk (or P1 tetrahedra in a ball) -- assembled with numpy exactly as the reference assembles its matrices
 (source/offline_data.template.h:566-576 `c_ij = int phi_i grad phi_j`, `m_ij = int phi_i phi_j`;
 :790-802 lumped mass; :1246-1361 boundary normals = normalised sum of the face integrals of phi_i n;
 :1369-1463 coupling boundary pairs). Nothing on the hot path is specific to Q1 quadrilaterals: it sees
@@ -28,48 +28,61 @@ def disk_points(n_rings, seed=7, jitter=0.25):
     return np.concatenate(pts)
 
 
+def ball_points(n_interior, n_surface, seed=11):
+    """Points of a unit ball: a Fibonacci lattice on the sphere (the hull of the triangulation) and
+    uniformly distributed random points inside radius 0.93."""
+    rng = np.random.default_rng(seed)
+    k = np.arange(n_surface) + 0.5
+    phi = np.arccos(1.0 - 2.0 * k / n_surface)
+    theta = np.pi * (1.0 + 5.0 ** 0.5) * k
+    surf = np.column_stack([np.cos(theta) * np.sin(phi), np.sin(theta) * np.sin(phi), np.cos(phi)])
+    inner = []
+    while len(inner) < n_interior:
+        q = rng.uniform(-1.0, 1.0, 3)
+        if np.linalg.norm(q) < 0.93:
+            inner.append(q)
+    return np.concatenate([np.zeros((1, 3)), np.array(inner), surf])
+
+
 def p1_offline(points, boundary_id=capi.BC_SLIP):
-    """Assemble the OfflineData arrays of continuous P1 elements on the Delaunay triangulation of `points`.
-    Returns (OfflineView, dict with triangles, boundary edges and the plain-CSR arrays)."""
+    """Assemble the OfflineData arrays of continuous P1 elements on the Delaunay triangulation (2-D) or
+    tetrahedralisation (3-D) of `points`. Returns (OfflineView, dict with simplices, measure, rows, is_bdry)."""
     tri = Delaunay(points)
     T = tri.simplices
-    n = len(points)
+    n, dim = points.shape
     x = points
+    fact = 2.0 if dim == 2 else 6.0
     c_acc, m_acc = {}, {}
-    area_total = 0.0
+    measure = 0.0
     for t in T:
         p = x[t]
-        d1, d2 = p[1] - p[0], p[2] - p[0]
-        det = d1[0] * d2[1] - d1[1] * d2[0]
-        if det < 0:  # orient counter-clockwise
-            t = t[[0, 2, 1]]
-            p = x[t]
-            det = -det
-        A = 0.5 * det
-        area_total += A
-        # grad phi_a = rot90(edge opposite to a) / (2 A)
-        grads = np.empty((3, 2))
-        for a in range(3):
-            e = p[(a + 2) % 3] - p[(a + 1) % 3]
-            grads[a] = np.array([-e[1], e[0]]) / (2.0 * A)
-        for a in range(3):
-            for b in range(3):
+        M = (p[1:] - p[0]).T                      # columns: edge vectors from vertex 0
+        V = abs(np.linalg.det(M)) / fact
+        if V < 1e-14:                             # degenerate sliver of (nearly) cospherical hull points
+            continue
+        measure += V
+        Minv = np.linalg.inv(M)                   # rows: grad phi_1 .. grad phi_dim
+        grads = np.vstack([-Minv.sum(axis=0), Minv])
+        for a in range(dim + 1):
+            for b in range(dim + 1):
                 key = (int(t[a]), int(t[b]))
-                c_acc[key] = c_acc.get(key, 0.0) + A / 3.0 * grads[b]
-                m_acc[key] = m_acc.get(key, 0.0) + A / 12.0 * (2.0 if a == b else 1.0)
-    # boundary edges: those of the convex hull; outward normal integral of phi_i over the edge = |e| n / 2
-    hull = tri.convex_hull
+                c_acc[key] = c_acc.get(key, 0.0) + V / (dim + 1.0) * grads[b]
+                m_acc[key] = m_acc.get(key, 0.0) + V / ((dim + 1.0) * (dim + 2.0)) * (2.0 if a == b else 1.0)
+    # boundary facets: those of the convex hull; int_F phi_i n dS = |F| n / dim for each of its vertices
     centre = x.mean(axis=0)
-    nrm = np.zeros((n, 2))
+    nrm = np.zeros((n, dim))
     is_bdry = np.zeros(n, dtype=bool)
-    for e in hull:
-        a, b = x[e[0]], x[e[1]]
-        t = b - a
-        nu = np.array([t[1], -t[0]])
-        if np.dot(nu, 0.5 * (a + b) - centre) < 0:
+    for f in tri.convex_hull:
+        q = x[f]
+        if dim == 2:
+            t = q[1] - q[0]
+            nu = np.array([t[1], -t[0]])          # |e| n
+        else:
+            nu = 0.5 * np.cross(q[1] - q[0], q[2] - q[0])   # |F| n
+        if np.dot(nu, q.mean(axis=0) - centre) < 0:
             nu = -nu
-        for v in e:  # |e|/2 * unit normal = nu / 2
-            nrm[v] += 0.5 * nu
+        for v in f:
+            nrm[v] += nu / dim
             is_bdry[v] = True
     rows = [[i] for i in range(n)]
     for (i, j) in c_acc:
@@ -88,11 +101,11 @@ def p1_offline(points, boundary_id=capi.BC_SLIP):
         for col_idx, j in enumerate(rows[i]):
             if col_idx > 0 and is_bdry[j]:
                 p_i.append(i), p_col.append(col_idx), p_j.append(j)
-    off = OfflineView(2, 0, 0, n, n, 1, row_starts, columns, cij, mij, mi, 1.0 / mi, mi.sum(), b_i, b_normal,
+    off = OfflineView(dim, 0, 0, n, n, 1, row_starts, columns, cij, mij, mi, 1.0 / mi, mi.sum(), b_i, b_normal,
                       np.full(len(b_i), boundary_id, dtype=np.uint8), p_i, p_col, p_j)
     off.positions = x
     off.row_starts, off.columns, off.cij_csr, off.mij_csr, off.mi = row_starts, columns, cij, mij, mi
-    return off, dict(triangles=T, area=area_total, rows=rows, is_bdry=is_bdry)
+    return off, dict(triangles=T, area=measure, rows=rows, is_bdry=is_bdry)
 
 
 def partition(off, info, owner, bathymetry=None):
@@ -109,7 +122,7 @@ def partition(off, info, owner, bathymetry=None):
     rs = off.row_starts.astype(np.int64)
     entry = {(i, int(off.columns[e])): e for i in range(n) for e in range(rs[i], rs[i + 1])}
     is_bdry = info["is_bdry"]
-    g_normal = np.zeros((n, 2))
+    g_normal = np.zeros((n, off.dim))
     g_normal[off._keep["b_i"]] = off._keep["b_normal"]
     g_id = np.zeros(n, dtype=np.uint8)
     g_id[off._keep["b_i"]] = off._keep["b_id"]
@@ -168,8 +181,8 @@ def partition(off, info, owner, bathymetry=None):
                 if is_bdry[l2g[lrows[i][c]]]:
                     p_i.append(i), p_col.append(c), p_j.append(lrows[i][c])
         mi = off.mi[l2g]
-        v = OfflineView(2, n_export, n_owned, n_owned, len(l2g), 1, row_starts, columns, np.array(lc), np.array(lm),
-                        mi, 1.0 / mi, off.measure_of_omega, b_i, g_normal[b_g].reshape(-1, 2), g_id[b_g],
+        v = OfflineView(off.dim, n_export, n_owned, n_owned, len(l2g), 1, row_starts, columns, np.array(lc), np.array(lm),
+                        mi, 1.0 / mi, off.measure_of_omega, b_i, g_normal[b_g].reshape(-1, off.dim), g_id[b_g],
                         p_i, p_col, p_j)
         k = v._keep
         k["nbr_rank"] = np.array(nbrs, dtype=np.int32)
@@ -184,7 +197,7 @@ def partition(off, info, owner, bathymetry=None):
             setattr(o, name, capi.as_ptr(k[name], capi.c_u32_p))
         v.positions = off.positions[l2g]
         v.global_ids = np.array(l2g, dtype=np.int64)
-        v.b_positions = off.positions[b_g].reshape(-1, 2)
+        v.b_positions = off.positions[b_g].reshape(-1, off.dim)
         if bathymetry is not None:
             v.set_initial_precomputed(bathymetry[l2g])
         views.append(v)

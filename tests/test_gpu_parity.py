@@ -1423,3 +1423,60 @@ def test_unstructured_arbitrary_partition_on_gpu(oracle, equation):
     assert (np.abs(U - U_ref).max(axis=0) / np.abs(U_ref).max(axis=0)).max() < 1e-9
     for r in range(n_ranks):
         lib.ryujin_hip_comm_destroy(C.c_void_p(comms[r]))
+
+
+@pytest.mark.parametrize("equation", ["euler", "euler_aeos"])
+def test_unstructured_p1_tetrahedra_3d(oracle, equation):
+    """P1 tetrahedra on a Delaunay tetrahedralisation of a ball: rows of 6 .. 30 entries (never the 27 of a
+    Q1 hexahedral mesh), lumped masses over two orders of magnitude, slip walls on a sphere: the generic
+    (non-unrolled) 3-D sweeps against the oracle, single stage and with ERK stage weights."""
+    from helpers_unstructured import ball_points, p1_offline
+    from ryujin_amd.initial_states import aeos_from_primitive
+    off, _ = p1_offline(ball_points(2500, 900))
+    x = off.positions
+    inside = np.linalg.norm(x, axis=1) < 0.5
+    if equation == "euler":
+        eq, edit = capi.EQ_EULER, None
+        U0 = euler_radial_contrast(x, inner=(1.0, 0.0, 10.0), outer=(0.125, 0.0, 0.1), radius=0.5)
+    else:
+        eq = capi.EQ_EULER_AEOS
+
+        def edit(p):
+            p.eos = capi.EOS_NOBLE_ABEL_STIFFENED_GAS
+            p.eos_covolume_b, p.eos_q, p.eos_pinf = 0.1, 0.05, 0.2
+        p = oracle.default_params(eq, 3)
+        edit(p)
+        U0 = aeos_from_primitive(p, np.where(inside, 1.0, 0.2), np.zeros((off.n_owned, 3)),
+                                 np.where(inside, 8.0, 0.2))
+
+    def params(p):
+        p.cfl = 0.5
+        if edit:
+            edit(p)
+    mods, U_start = [], U0
+    for backend in ("hip", oracle.backend()):
+        p = oracle.default_params(eq, 3)
+        params(p)
+        m = HyperbolicModule(off, p, backend=backend)
+        old, new = m.new_state_vector(U_start), m.new_state_vector()
+        if backend == "hip":
+            for _ in range(60):
+                m.prepare_state_vector(old, 0.0)
+                m.step(old, [], [], new)
+                old, new = new, old
+            U_start = old.download()
+        mods.append((m, old, new))
+    _compare_step(off, mods)
+    # four ERK33 steps (step<1>, step<2> with stage weights) from the warmed-up state
+    finals = []
+    for m, old, new in mods:
+        sv = m.new_state_vector(U_start)
+        ti = TimeIntegrator(m, "erk 33", cfl_min=0.5, cfl_max=0.5, cfl_recovery_strategy="none")
+        t = 0.0
+        for _ in range(4):
+            sv, tau = ti.step(sv, t)
+            t += tau
+        finals.append((t, sv.download()))
+    assert abs(finals[0][0] - finals[1][0]) < 1e-12 * finals[1][0]
+    scale = np.abs(finals[1][1]).max(axis=0)
+    assert (np.abs(finals[0][1] - finals[1][1]) / scale).max() < 1e-10
