@@ -1480,3 +1480,22 @@ def test_unstructured_p1_tetrahedra_3d(oracle, equation):
     assert abs(finals[0][0] - finals[1][0]) < 1e-12 * finals[1][0]
     scale = np.abs(finals[1][1]).max(axis=0)
     assert (np.abs(finals[0][1] - finals[1][1]) / scale).max() < 1e-10
+
+
+def test_unstructured_p1_mesh_scalar_conservation(oracle):
+    """Burgers' equation (K = 1, 2 dim precomputed flux-gradient values) on the P1 disk with Dirichlet data
+    on the whole rim: the scalar Description on ragged rows."""
+    from helpers_unstructured import disk_points, p1_offline
+    off, _ = p1_offline(disk_points(20), boundary_id=capi.BC_DIRICHLET)
+    x = off.positions
+    u0 = np.where(np.linalg.norm(x - np.array([0.2, 0.1]), axis=1) < 0.4, 1.0, -0.5) + 0.1 * np.sin(4.0 * x[:, 0])
+    U0 = u0.reshape(-1, 1)
+    dirichlet = U0[off._keep["b_i"]]
+    for greedy, averaged in ((0, 0), (1, 1)):
+        def edit(p):
+            p.cfl = 0.5
+            p.sc_flux = capi.FLUX_BURGERS
+            p.sc_use_greedy_wavespeed = greedy
+            p.sc_use_averaged_entropy = averaged
+        mods = _scalar_both(off, U0, oracle, edit, n_warm=15, dirichlet=dirichlet)
+        _scalar_compare(off, mods, dirichlet)

@@ -156,3 +156,38 @@ def test_oracle_step_on_imported_data_is_bit_identical(oracle, tmp_path):
     assert out[0][1] == out[1][1]
     assert np.array_equal(out[0][0], out[1][0])
     assert os.path.getsize(path) > 0
+
+
+def test_round_trip_unstructured_arbitrary_partition(tmp_path):
+    """Dumps of a mesh the generator cannot produce: P1 triangles on a disk, cut into 4 sectors (ranks with
+    three neighbours, nodes exported to several ranks, ragged rows): every array of every rank survives the
+    round trip through the file format bit for bit."""
+    from helpers_unstructured import disk_points, p1_offline, partition
+    from test_oracle_unstructured import sector_owner
+    off, info = p1_offline(disk_points(10))
+    views = partition(off, info, sector_owner(off.positions, 4))
+    lib = capi.load_synth()
+    for r, v in enumerate(views):
+        path = str(tmp_path / f"disk{r}.ryjoffl")
+        pos = np.ascontiguousarray(v.positions)
+        bpos = np.ascontiguousarray(v.b_positions)
+        rc = lib.ryujin_offline_write(path.encode(), v.c, 2, 0, capi.as_ptr(pos, capi.c_double_p),
+                                      capi.as_ptr(bpos, capi.c_double_p))
+        assert rc == 0, lib.ryujin_offline_io_last_error()
+        imp = offline.ImportedOffline(path)
+        a, b = v._o, imp.c.contents
+        for name in ("n_export", "n_internal", "n_owned", "n_relevant", "simd_length", "n_bdry", "n_pairs",
+                     "n_nbr", "measure_of_omega"):
+            assert getattr(a, name) == getattr(b, name), name
+        nnz = int(v._keep["row_starts"][-1])
+        n_nbr = a.n_nbr
+        assert n_nbr >= 2
+        sizes = dict(row_starts=v.n_relevant + 1, columns=nnz, cij=2 * nnz, mij=nnz, mi=v.n_relevant,
+                     mi_inv=v.n_relevant, b_i=v.n_bdry, b_normal=2 * v.n_bdry, b_id=v.n_bdry, p_i=v.n_pairs,
+                     p_col=v.n_pairs, p_j=v.n_pairs, nbr_rank=n_nbr, send_off=n_nbr + 1,
+                     send_idx=int(a.send_off[n_nbr]), recv_off=n_nbr + 1, row_send_off=n_nbr + 1,
+                     row_send_row=int(a.row_send_off[n_nbr]), row_send_col=int(a.row_send_off[n_nbr]))
+        for name, n in sizes.items():
+            x, y = getattr(a, name), getattr(b, name)
+            assert [x[i] for i in range(n)] == [y[i] for i in range(n)], (r, name)
+        assert np.array_equal(imp.positions, pos) and np.array_equal(imp.b_positions, bpos)
