@@ -172,6 +172,22 @@ namespace ryujin_hip
       v[NC - 1] = b[(NC / 2) * 128 + lane];
   }
 
+  /* the same entry with an ordinary (temporal) load: for streams a kernel reads a second time */
+  template <int NC>
+  RYUJIN_DEV void load_entry_cached(const double *__restrict__ m, const uint64_t colbase,
+                                    const uint32_t lane, double (&v)[NC])
+  {
+    const double *b = m + colbase * 64 * NC;
+#pragma unroll
+    for (int g = 0; g < NC / 2; ++g) {
+      const double2 t = *reinterpret_cast<const double2 *>(b + g * 128 + lane * 2);
+      v[2 * g] = t.x;
+      v[2 * g + 1] = t.y;
+    }
+    if (NC & 1)
+      v[NC - 1] = b[(NC / 2) * 128 + lane];
+  }
+
   template <int NC>
   RYUJIN_DEV void store_entry(double *__restrict__ m, const uint64_t colbase, const uint32_t lane,
                               const double (&v)[NC])

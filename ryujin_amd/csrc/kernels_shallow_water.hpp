@@ -8,6 +8,20 @@
 #include "kernels_euler.hpp"
 #include "shallow_water_device.hpp"
 
+#ifndef RYUJIN_SW_PIPE
+#define RYUJIN_SW_PIPE 1 /* step 4: prefetch the next column (index, c_ij, d_ij, m_ij, gathered U_j, alpha_j, Z_j, h*_j).
+                            A/B on MI355X (3.33 M gridpoints): 0.788 -> 0.695 ms for the kernel, 2.24 -> 2.15 ms per update */
+#endif
+#ifndef RYUJIN_SW_PRE_TEMPORAL
+#define RYUJIN_SW_PRE_TEMPORAL 0 /* affine-shift pre-loop reads c_ij with a temporal load (the main loop reads it again):
+                                    0.788 -> 0.760 ms alone, nothing on top of the pipeline (0.702 vs 0.695) */
+#endif
+#if RYUJIN_SW_PRE_TEMPORAL
+#define SW_LOAD_CIJ_PRE(m, colbase, lane, v) load_entry_cached<DIM>(m, colbase, lane, v)
+#else
+#define SW_LOAD_CIJ_PRE(m, colbase, lane, v) load_entry<DIM>(m, colbase, lane, v)
+#endif
+
 namespace ryujin_hip
 {
   template <int DIM, bool HAS_STAGES>
@@ -69,14 +83,37 @@ namespace ryujin_hip
       affine_shift[q] = 0.;
     {
       const double h_inverse = E::inverse_water_depth_sharp(P, U_i);
+#if RYUJIN_SW_PIPE
+      /* software pipeline: the next column's index, c_ij, d_ij and the gathered Z_j are in flight while
+       * this column is evaluated (as k_low_order) */
+      uint32_t j_n = cols[(uint64_t)r.base * 64 + r.lane];
+      double c_n[DIM];
+      SW_LOAD_CIJ_PRE(cij, r.base, r.lane, c_n);
+      double d_n = dij[(uint64_t)r.base * 64 + r.lane];
+      double Z_n = Z[j_n];
+#endif
       for (uint32_t c = 0; c < r.width; ++c) {
         const uint64_t colbase = (uint64_t)r.base + c;
+#if RYUJIN_SW_PIPE
+        double c_ij[DIM];
+#pragma unroll
+        for (int d = 0; d < DIM; ++d)
+          c_ij[d] = c_n[d];
+        const double d_ij = d_n, Z_j = Z_n;
+        if (c + 1 < r.width) {
+          j_n = cols[(colbase + 1) * 64 + r.lane];
+          SW_LOAD_CIJ_PRE(cij, colbase + 1, r.lane, c_n);
+          d_n = dij[(colbase + 1) * 64 + r.lane];
+          Z_n = Z[j_n];
+        }
+#else
         const uint64_t pos = colbase * 64 + r.lane;
         const uint32_t j = cols[pos];
         double c_ij[DIM];
-        load_entry<DIM>(cij, colbase, r.lane, c_ij);
+        SW_LOAD_CIJ_PRE(cij, colbase, r.lane, c_ij);
         const double d_ij = dij[pos];
         const double Z_j = Z[j];
+#endif
         if (!(row_active && c < r.len))
           continue;
         double U_star_ij[K];
@@ -114,10 +151,44 @@ namespace ryujin_hip
       }
     }
 
+#if RYUJIN_SW_PIPE
+    uint32_t j_n = ld_stream(cols + ((uint64_t)r.base * 64 + r.lane));
+    uint32_t j_nn = r.width > 1 ? ld_stream(cols + (((uint64_t)r.base + 1) * 64 + r.lane)) : i;
+    double c_n[DIM], U_n[K];
+    load_entry<DIM>(cij, r.base, r.lane, c_n);
+    double d_n = dij[(uint64_t)r.base * 64 + r.lane];
+    double m_n = ld_stream(mij + ((uint64_t)r.base * 64 + r.lane));
+    load_state<K>(U, j_n, U_n);
+    double alpha_n = alpha[j_n];
+    double Z_n = Z[j_n];
+    double h_star_n = prec[(size_t)j_n * 2 + 1];
+#endif
     for (uint32_t c = 0; c < r.width; ++c) {
       const uint64_t colbase = (uint64_t)r.base + c;
-      const uint64_t pos = colbase * 64 + r.lane;
       const bool active = row_active && c < r.len;
+#if RYUJIN_SW_PIPE
+      const uint32_t j = j_n;
+      double c_ij[DIM], U_j[K];
+#pragma unroll
+      for (int d = 0; d < DIM; ++d)
+        c_ij[d] = c_n[d];
+#pragma unroll
+      for (int q = 0; q < K; ++q)
+        U_j[q] = U_n[q];
+      const double d_ij = d_n, m_ij = m_n, alpha_j = alpha_n, Z_j = Z_n, h_star_j = h_star_n;
+      if (c + 1 < r.width) {
+        j_n = j_nn;
+        load_entry<DIM>(cij, colbase + 1, r.lane, c_n);
+        d_n = dij[(colbase + 1) * 64 + r.lane];
+        m_n = ld_stream(mij + ((colbase + 1) * 64 + r.lane));
+        load_state<K>(U, j_n, U_n);
+        alpha_n = alpha[j_n];
+        Z_n = Z[j_n];
+        h_star_n = prec[(size_t)j_n * 2 + 1];
+        j_nn = (c + 2 < r.width) ? ld_stream(cols + ((colbase + 2) * 64 + r.lane)) : i;
+      }
+#else
+      const uint64_t pos = colbase * 64 + r.lane;
       const uint32_t j = cols[pos];
       double c_ij[DIM];
       load_entry<DIM>(cij, colbase, r.lane, c_ij);
@@ -128,6 +199,7 @@ namespace ryujin_hip
       const double alpha_j = alpha[j];
       const double Z_j = Z[j];
       const double h_star_j = prec[(size_t)j * 2 + 1];
+#endif
       if (!active)
         continue;
 
