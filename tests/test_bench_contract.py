@@ -1,0 +1,42 @@
+"""bench.py's accounting, checked without a GPU: the algorithmic bytes per gridpoint-update are the ones
+SURVEY.md section 8d derives (3164 / 10020 / 2844 B), and the committed bench lines in profiles/ carry every
+field of the driver's contract."""
+import glob
+import json
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_algorithmic_bytes_match_the_survey():
+    import bench
+    assert sum(bench.algorithmic_bytes(2, 4, 9).values()) == 48 + 316 + 224 + 700 + 860 + 556 + 460 == 3164
+    assert sum(bench.algorithmic_bytes(3, 5, 27).values()) == 56 + 1044 + 656 + 2236 + 2820 + 1724 + 1484 == 10020
+    sw = bench.algorithmic_bytes(2, 3, 9, n_prec=2, n_bounds=5)
+    sw["4 low_order"] += 8 + 8 * 9        # bathymetry and m_ij in step 4
+    assert sum(sw.values()) == 40 + 308 + 224 + 700 + 716 + 484 + 372 == 2844
+    assert list(bench.algorithmic_bytes(2, 4, 9).values()) == [48, 316, 224, 700, 860, 556, 460]
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(ROOT, "profiles", "r01k_bench*.json"))))
+def test_committed_bench_lines_follow_the_contract(path):
+    lines = [ln for ln in open(path).read().splitlines() if ln.strip()]
+    assert len(lines) == 1                                     # ONE JSON line
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in d, key
+    assert d["metric"] == json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    assert d["dtype"] == "f64" and d["vs_baseline"] is None and d["scaling"] == "weak" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    # value is consistent with the time per step and the size of the job
+    dofs = d["config"]["dofs_total"]
+    assert abs(d["value"] - dofs / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * d["value"]
+    if "cpu_baseline" in d:
+        c = d["cpu_baseline"]
+        assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["unit"] == d["unit"] and c["sample"]
