@@ -53,7 +53,7 @@ def build_synth(force: bool = False) -> str:
     src = [os.path.join(CSRC, "offline_synthetic.cc"), os.path.join(CSRC, "offline_io.cc")]
     if force or not _newer(SYNTH_SO, src + _headers()):
         os.makedirs(LIBDIR, exist_ok=True)
-        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I" + INCLUDE, "-I" + CSRC,
+        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-Wall", "-I" + INCLUDE, "-I" + CSRC,
               *src, "-o", SYNTH_SO])
     return SYNTH_SO
 

@@ -14,6 +14,9 @@
 #include <map>
 #include <string>
 #include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 namespace
 {
@@ -289,12 +292,26 @@ bool ryujin_synth::build()
   cij.clear();
   mi.assign(n_relevant, 0.);
   mi_inv.assign(n_relevant, 0.);
-  columns.reserve((size_t)n_owned * (dim == 3 ? 27 : dim == 2 ? 9 : 3));
 
   const int ny_off = dim >= 2 ? 1 : 0, nz_off = dim >= 3 ? 1 : 0;
 
+  /* rows are assembled in contiguous chunks, one per thread, and concatenated in order afterwards */
+  int n_chunks = 1;
+#ifdef _OPENMP
+  n_chunks = std::max(1, omp_get_max_threads());
+#endif
+  struct Chunk {
+    std::vector<uint32_t> cols, lengths;
+    std::vector<double> m, c;
+  };
+  std::vector<Chunk> chunks((size_t)n_chunks);
+#pragma omp parallel for schedule(static, 1)
+  for (int ch = 0; ch < n_chunks; ++ch) {
+  Chunk &out = chunks[(size_t)ch];
+  const uint32_t row_begin = (uint32_t)((uint64_t)n_relevant * ch / n_chunks);
+  const uint32_t row_end = (uint32_t)((uint64_t)n_relevant * (ch + 1) / n_chunks);
   std::vector<Entry> row;
-  for (uint32_t i = 0; i < n_relevant; ++i) {
+  for (uint32_t i = row_begin; i < row_end; ++i) {
     const auto gi = grid_index[i];
     const bool ghost_row = i >= n_owned;
     row.clear();
@@ -359,16 +376,36 @@ bool ryujin_synth::build()
     });
     double mass = 0.;
     for (const auto &e : row) {
-      columns.push_back(e.j);
-      mij.push_back(e.m);
+      out.cols.push_back(e.j);
+      out.m.push_back(e.m);
       for (int d = 0; d < dim; ++d)
-        cij.push_back(e.c[d]);
+        out.c.push_back(e.c[d]);
       mass += e.m;
     }
-    row_starts[i + 1] = columns.size();
+    out.lengths.push_back((uint32_t)row.size());
     if (!ghost_row) {
       mi[i] = mass;
       mi_inv[i] = 1. / mass;
+    }
+  }
+  }
+  {
+    size_t nnz = 0;
+    for (const auto &ch : chunks)
+      nnz += ch.cols.size();
+    columns.reserve(nnz);
+    mij.reserve(nnz);
+    cij.reserve(nnz * dim);
+    uint32_t i = 0;
+    for (auto &ch : chunks) {
+      columns.insert(columns.end(), ch.cols.begin(), ch.cols.end());
+      mij.insert(mij.end(), ch.m.begin(), ch.m.end());
+      cij.insert(cij.end(), ch.c.begin(), ch.c.end());
+      for (const uint32_t len : ch.lengths) {
+        row_starts[i + 1] = row_starts[i] + len;
+        ++i;
+      }
+      ch = Chunk{}; /* release the chunk: peak memory stays at the final arrays plus one chunk */
     }
   }
 
