@@ -161,12 +161,8 @@ def cpu_baseline(spec, U0, dirichlet, budget_s: float = 15.0, equation: int = 0)
         path = native
     except Exception:
         path = None  # fall back to the portable build shipped with the snapshot
-    cores = usable_cores()
-    # libgomp reads these when it is loaded: one thread per usable core, pinned
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
-    os.environ.setdefault("OMP_PROC_BIND", "close")
-    os.environ.setdefault("OMP_PLACES", "cores")
-    cores = int(os.environ["OMP_NUM_THREADS"])
+    # OMP_NUM_THREADS / OMP_PROC_BIND / OMP_PLACES were exported at the top of main(), before libgomp was loaded
+    cores = int(os.environ.get("OMP_NUM_THREADS", usable_cores()))
     lib = oracle_py.load(path)
     lib.ryujin_oracle_set_flush_denormals(1)  # source/main.cc:26-36
     off = offline.SyntheticOffline(spec)
@@ -238,6 +234,12 @@ def main():
 
     # the host driver only supports dmabuf IPC: RCCL's cross-process buffers need this
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # libgomp reads these when it is first loaded (the mesh generator and the CPU baseline use OpenMP): one
+    # thread per usable core (cgroup quota / affinity, not the host's CPU count), pinned. torch.distributed.run
+    # already exports OMP_NUM_THREADS=1 for multi-rank launches.
+    os.environ.setdefault("OMP_NUM_THREADS", str(usable_cores()))
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_PLACES", "cores")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -298,14 +298,14 @@ bool ryujin_synth::build()
   /* rows are assembled in contiguous chunks, one per thread, and concatenated in order afterwards */
   int n_chunks = 1;
 #ifdef _OPENMP
-  n_chunks = std::max(1, omp_get_max_threads());
+  n_chunks = std::min(16, std::max(1, omp_get_max_threads()));
 #endif
   struct Chunk {
     std::vector<uint32_t> cols, lengths;
     std::vector<double> m, c;
   };
   std::vector<Chunk> chunks((size_t)n_chunks);
-#pragma omp parallel for schedule(static, 1)
+#pragma omp parallel for schedule(static, 1) num_threads(n_chunks)
   for (int ch = 0; ch < n_chunks; ++ch) {
   Chunk &out = chunks[(size_t)ch];
   const uint32_t row_begin = (uint32_t)((uint64_t)n_relevant * ch / n_chunks);
