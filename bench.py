@@ -52,7 +52,6 @@ def pmc_traffic_bytes(sweep: str, workload: str):
     command (profiles/r*_pmc.md: (2*FETCH_SIZE + WRITE_SIZE)*1024, the gfx950 correction of
     MI355X_MICROARCH.md). PMC cannot be collected inside this process; None if no profile matches."""
     import glob
-    import re
     if workload != "step2d":
         return None
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.md")))

@@ -1,7 +1,7 @@
 """Wall time per forward-Euler update of the device-resident RK driver for different schemes (timers off).
 Usage: scheme_timing.py <dim> <size> [aeos]"""
 import sys, time
-import numpy as np
+
 sys.path.insert(0, '.')
 from ryujin_amd import HyperbolicModule, capi, offline
 from ryujin_amd.initial_states import euler_uniform, euler_radial_contrast

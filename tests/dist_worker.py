@@ -5,7 +5,6 @@ at exactly the reference's synchronisation points -- and
 gathered result. The parent test compares it with a single-rank run.
 
 usage: dist_worker.py <out.npz> <cells_per_unit> <n_updates> [euler|aeos]"""
-import ctypes as C
 import os
 import sys
 

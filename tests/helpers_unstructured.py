@@ -208,7 +208,6 @@ def run_partitioned_oracle(oracle, views, params, U0_global, n_updates, dirichle
     """One oracle context per rank, one host thread each; ghost vectors, matrix ghost rows and the min/or
     reductions are exchanged through shared numpy buffers at the oracle's synchronisation points. Returns
     (U in global numbering, list of tau per update)."""
-    import ctypes as C
     import threading
 
     from ryujin_amd import HyperbolicModule
