@@ -314,7 +314,6 @@ namespace ryujin_hip
                double *__restrict__ prec)
   {
     constexpr int K = E::K;
-    constexpr int DIM = E::DIMENSION;
     const uint32_t i = M.slice_begin * 64 + blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M.n_owned || i >= M.slice_end * 64)
       return;

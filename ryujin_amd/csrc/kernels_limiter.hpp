@@ -337,8 +337,8 @@ namespace ryujin_hip
       const size_t stride = (size_t)M.n_slices * 64;
       double bnd[NB];
 #pragma unroll
-    for (int b = 0; b < NB; ++b)
-      bnd[b] = bounds[(size_t)b * stride + i];
+      for (int b = 0; b < NB; ++b)
+        bnd[b] = bounds[(size_t)b * stride + i];
       unsigned long long undecided_mask = 0;
       for (uint32_t c = 1; c < r.width; ++c) {
         const uint64_t colbase = (uint64_t)r.base + c;
