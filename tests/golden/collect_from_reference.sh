@@ -54,3 +54,5 @@ done
 for s in ssprk33 erk33; do
   cp "$R/euler_aeos/verification-isentropic_vortex-pge-2d-$s-l7.mpirun=4.output" $D/euler_aeos_verification-isentropic_vortex-pge-2d-$s-l7.mpirun4.output
 done
+# the reference's second baseline of the wetting/drying run: its own platform spread
+cp $R/shallow_water/verification-paraboloid_1d-erk33-l7.output.gcc-13.3-avx2 $D/shallow_water_verification-paraboloid_1d-erk33-l7.output.gcc-13.3-avx2

@@ -217,6 +217,14 @@ def verify_sw_paraboloid_1d(backend, default_params, golden_dir, slack=1.0):
     # in t and 2.6e-2 / 1.5e-2 / 1.9e-2 in the norms. We land 6.8e-5 / 3.0e-2 / 1.2e-4 / 5.3e-4 from the default.
     check(res, golden(golden_dir, "shallow_water_verification-paraboloid_1d-erk33-l7.output"), rtol_t=2e-4,
           rtol_err=5e-2, slack=slack)
+    # ... stated through the reference's own numbers: no further from its default baseline than twice the
+    # distance between its two baselines
+    _, t_a, linf_a, l1_a, l2_a = golden(golden_dir, "shallow_water_verification-paraboloid_1d-erk33-l7.output")
+    _, t_b, linf_b, l1_b, l2_b = golden(golden_dir,
+                                        "shallow_water_verification-paraboloid_1d-erk33-l7.output.gcc-13.3-avx2")
+    for ours, a, b in ((res["t"], t_a, t_b), (res["linf"], linf_a, linf_b), (res["l1"], l1_a, l1_b),
+                       (res["l2"], l2_a, l2_b)):
+        assert abs(ours - a) <= 2.0 * slack * abs(b - a), (ours, a, b)
 
 
 def verify_sw_ritter_dam_break(backend, default_params, golden_dir, slack=1.0):
