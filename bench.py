@@ -48,15 +48,16 @@ KERNEL_OF_SWEEP = {  # sweep name -> kernel-name prefixes in the rocprof summari
 
 
 def pmc_traffic_bytes(sweep: str, workload: str):
-    """HBM bytes per launch of the sweep's kernel from the committed rocprofv3 --pmc passes of this same
-    command (profiles/r*_pmc.md: (2*FETCH_SIZE + WRITE_SIZE)*1024, the gfx950 correction of
-    MI355X_MICROARCH.md). PMC cannot be collected inside this process; None if no profile matches."""
+    """(HBM bytes per launch of the sweep's kernel, profile file) from the newest committed rocprofv3 --pmc
+    passes of this same command (profiles/r*_pmc.md for the bench line, profiles/r*_pmc_<workload>.md for the
+    other workloads: (2*FETCH_SIZE + WRITE_SIZE)*1024, the gfx950 correction of MI355X_MICROARCH.md). PMC
+    cannot be collected inside this process; (None, None) if no profile matches. The file name travels
+    with the number so that a stale profile is visible in the bench line."""
     import glob
-    if workload != "step2d":
-        return None
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.md")))
+    suffix = "" if workload == "step2d" else "_" + workload
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc{suffix}.md")))
     if not files:
-        return None
+        return None, None
     rows = {}
     for line in open(files[-1]):
         if line.startswith("| k_"):
@@ -71,8 +72,8 @@ def pmc_traffic_bytes(sweep: str, workload: str):
             if name.startswith(prefix):
                 if prefix == "k_high_order<" and (("true" in name) != last):
                     continue
-                return val
-    return None
+                return val, os.path.relpath(files[-1], ROOT)
+    return None, None
 
 
 class Ssprk33Stages:
@@ -185,6 +186,18 @@ def cpu_baseline(spec, U0, dirichlet, budget_s: float = 15.0, equation: int = 0)
             "mq_per_s": off.n_owned * n / dt / 1e6}
 
 
+def self_launch_command(n_gpus: int, argv: list) -> list:
+    """The command line that runs this script on n_gpus ranks of one node (one process per GPU, RCCL over
+    xGMI inside the library; rendezvous on 127.0.0.1 -- the container hostname may not resolve)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -207,6 +220,9 @@ def main():
                          "(one host synchronisation per update) instead of ryujin_hip_time_step")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-process code path (torch.distributed + RCCL communicator) even for one rank")
+    ap.add_argument("--probe-launch", action="store_true",
+                    help="(test hook) initialise torch.distributed, print the rank layout as the JSON line and exit "
+                         "before anything touches a GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--watchdog", type=int, default=1500,
                     help="abort the process after this many seconds (a hung collective must not hang the box)")
@@ -242,8 +258,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # called like the single-GPU line (`python bench.py --gpus N ...`): launch the N ranks ourselves, one
+        # per GPU, exactly as the driver's torch.distributed.run command would; rank 0 of the child job prints
+        # the ONE JSON line on the stdout we inherited
+        os.dup2(saved_stdout, 1)
+        cmd = self_launch_command(args.gpus, sys.argv[1:])
+        sys.stderr.write("bench.py: launching " + " ".join(cmd) + "\n")
+        sys.stderr.flush()
+        os.execv(cmd[0], cmd)
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch {args.gpus} ranks "
+                         f"(torch.distributed.run --nproc-per-node {args.gpus}) or none at all")
     n_gpus = max(1, world)
 
     dist = None
@@ -255,6 +281,16 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    if args.probe_launch:
+        import torch
+        tt = torch.tensor([rank], dtype=torch.int64)
+        if dist is not None:
+            dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        if rank == 0:
+            os.dup2(saved_stdout, 1)
+            print(json.dumps({"probe": True, "world": world, "n_gpus": n_gpus, "rank_sum": int(tt[0])}), flush=True)
+        return
 
     import ctypes as C
 
@@ -327,6 +363,8 @@ def main():
         n_visible = torch.cuda.device_count()  # a launcher may expose one GPU per rank
         if n_visible > 0:
             device = local_rank % n_visible
+        if n_gpus > 1 and 1 < n_visible < n_gpus:
+            raise SystemExit(f"--gpus {n_gpus} but only {n_visible} devices are visible: RCCL needs one GPU per rank")
         uid = C.create_string_buffer(capi.UNIQUE_ID_BYTES)
         if rank == 0:
             assert lib.ryujin_hip_comm_unique_id(uid) == 0, lib.ryujin_hip_last_error()
@@ -436,6 +474,7 @@ def main():
     dom_gbs = alg[dom] * n_q_local / (per_sweep[dom] * 1e-3) / 1e9
     upd_gbs = b_alg * n_q_local / (ev_ms.value / args.steps * 1e-3) / 1e9
 
+    traffic, traffic_file = pmc_traffic_bytes(dom, args.workload)
     out = {
         "metric": "MDoF-updates/s per Euler forward step; achieved HBM GB/s vs roofline",
         "value": k * n_q_total * args.steps / wall / 1e6,
@@ -453,8 +492,9 @@ def main():
         "mq_per_s": n_q_total * args.steps / wall / 1e6,
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": dom_gbs, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": dom_gbs / HBM_PEAK_GBS,
-                     "traffic": pmc_traffic_bytes(dom, args.workload),
-                     "traffic_source": "profiles/r*_pmc.md (separate rocprofv3 --pmc passes, bytes per launch)",
+                     "traffic": traffic,
+                     "traffic_source": (f"{traffic_file} (separate rocprofv3 --pmc passes of this command, "
+                                        "bytes per launch)") if traffic_file else None,
                      "algorithmic_bytes_per_gridpoint": alg[dom],
                      "mean_launch_ms": per_sweep[dom]},
         "roofline_update": {"bound": "hbm", "achieved": upd_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -71,15 +71,20 @@ namespace oracle
       for (uint32_t i = 0; i < n_rows; ++i)
         ptr[i + 1] = ptr[i] + ref.row_length(i);
       col.resize(ptr[n_rows]);
+      bool diagonal_first = true;
+#pragma omp parallel for schedule(static) reduction(&& : diagonal_first)
       for (uint32_t i = 0; i < n_rows; ++i) {
         const uint32_t len = ref.row_length(i);
         for (uint32_t c = 0; c < len; ++c)
           col[ptr[i] + c] = o.columns[ref.col_pos(i, c)];
         if (len > 0 && col[ptr[i]] != i)
-          throw std::runtime_error("row does not start with its diagonal");
+          diagonal_first = false;
       }
+      if (!diagonal_first)
+        throw std::runtime_error("row does not start with its diagonal");
       /* transposed positions: rows are (diag, ascending...) */
       transpose.assign(col.size(), ~uint64_t(0));
+#pragma omp parallel for schedule(static)
       for (uint32_t i = 0; i < n_rows; ++i)
         for (uint64_t e = ptr[i]; e < ptr[i + 1]; ++e) {
           const uint32_t j = col[e];
@@ -101,6 +106,7 @@ namespace oracle
     {
       const RefLayout ref(o);
       std::vector<double> out((size_t)nnz() * n_comp);
+#pragma omp parallel for schedule(static)
       for (uint32_t i = 0; i < n_rows; ++i)
         for (uint64_t e = ptr[i]; e < ptr[i + 1]; ++e)
           for (uint32_t d = 0; d < n_comp; ++d)

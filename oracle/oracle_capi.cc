@@ -380,6 +380,39 @@ int ryujin_oracle_euler_limit(const ryujin_hip_params *p, const double *bounds, 
   return RYUJIN_OK;
 }
 
+/* generic-dim limiter with its trace (parity tests: classify HIP-vs-oracle differences of l_ij).
+ * out[0] = l, out[1] = success, out[2] = t_r after the density clip, out[3] = psi_r of the first Newton
+ * iteration (the sign of which decides "accept t_r" against "iterate from t_l = 0",
+ * limiter.template.h:188-216), out[4] = number of recorded iterations */
+int ryujin_oracle_euler_limit_trace(const ryujin_hip_params *p, const double *bounds, const double *U,
+                                    const double *P, double out[5])
+{
+  auto run = [&](auto dim_tag) {
+    constexpr int dim = decltype(dim_tag)::value;
+    euler::View<dim> view(*p);
+    euler::Limiter<dim> lim(view, *p);
+    typename euler::View<dim>::state_type u, pp;
+    for (int q = 0; q < dim + 2; ++q) {
+      u[q] = U[q];
+      pp[q] = P[q];
+    }
+    euler::LimiterTrace tr;
+    const auto [t, s] = lim.limit({{bounds[0], bounds[1], bounds[2]}}, u, pp, 0., 1., &tr);
+    out[0] = t;
+    out[1] = s ? 1. : 0.;
+    out[2] = tr.t_r_start;
+    out[3] = tr.iterations.empty() ? 0. : tr.iterations[0].psi_r;
+    out[4] = (double)tr.iterations.size();
+  };
+  if (p->dim == 1)
+    run(std::integral_constant<int, 1>{});
+  else if (p->dim == 2)
+    run(std::integral_constant<int, 2>{});
+  else
+    run(std::integral_constant<int, 3>{});
+  return RYUJIN_OK;
+}
+
 /* Euler HyperbolicSystemView scalar functions for state U in dimension p->dim:
  * out layout: internal_energy, internal_energy_derivative[k], pressure, specific_entropy,
  * harten_entropy, harten_entropy_derivative[k], mathematical_entropy,

@@ -39,6 +39,7 @@ def load(path: str | None = None):
     lib.ryujin_oracle_euler_lambda_max.restype = C.c_double
     lib.ryujin_oracle_euler_limit_1d.argtypes = [C.POINTER(capi.Params), C.c_int, dp, dp, dp, dp, dp, C.c_int]
     lib.ryujin_oracle_euler_limit.argtypes = [C.POINTER(capi.Params), dp, dp, dp, dp, capi.c_int_p]
+    lib.ryujin_oracle_euler_limit_trace.argtypes = [C.POINTER(capi.Params), dp, dp, dp, dp]
     lib.ryujin_oracle_euler_view.argtypes = [C.POINTER(capi.Params), dp, dp]
     lib.ryujin_oracle_euler_apply_bc.argtypes = [C.POINTER(capi.Params), C.c_int, dp, dp, dp, dp]
     lib.ryujin_oracle_sw_riemann.argtypes = [C.POINTER(capi.Params), dp, dp, dp]

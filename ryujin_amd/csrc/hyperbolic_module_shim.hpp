@@ -97,7 +97,10 @@ namespace ryujin_hip_shim
         ctx_ = nullptr;
       }
       check(ryujin_hip_create(&ctx_, &offline_, &params_, comm_, device_));
-      k_ = params_.equation == RYUJIN_EQ_SHALLOW_WATER ? params_.dim + 1 : params_.dim + 2;
+      /* problem_dimension of the Description: shallow water dim+1, scalar conservation 1, Euler(AEOS) dim+2 */
+      k_ = params_.equation == RYUJIN_EQ_SHALLOW_WATER
+               ? params_.dim + 1
+               : (params_.equation == RYUJIN_EQ_SCALAR_CONSERVATION ? 1 : params_.dim + 2);
     }
 
     StateVector create_state_vector() const

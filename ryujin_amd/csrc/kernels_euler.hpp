@@ -49,9 +49,14 @@ namespace ryujin_hip
     /* device-resident Runge-Kutta driver (ryujin_hip_time_step): the tau of the first stage and the
      * flags of all stages stay on the device until the end of the RK step */
     double tau_rk;
+    /* 0 = never raised, otherwise kStageCode - (index of the FIRST stage that raised it): a max-reduction
+     * over stages and ranks then yields the earliest stage, which the host needs to give a Restart raised
+     * at the end of stage s precedence over an invalid tau_max of a later stage (the reference never runs
+     * that later stage: hyperbolic_module.template.h:1194-1207 throws first) */
     int restart_accum;
     int tau_invalid_accum;
   };
+  constexpr int kStageCode = 100;
 
   /* minimum waves per SIMD requested from the register allocator for the heavy sweeps (second
    * __launch_bounds__ argument): 512 registers / waves. Tuned on MI355X, see DESIGN.md. */
@@ -610,13 +615,14 @@ namespace ryujin_hip
 
   /* tau = (tau_in == 0 ? tau_max : tau_in), validity check (:571-578); use_device_tau: later stages of
    * a device-resident RK step reuse the tau of the first stage without a host round trip */
-  __global__ void k_finalize_tau(const double tau_in, const int use_device_tau,
+  __global__ void k_finalize_tau(const double tau_in, const int use_device_tau, const int stage,
                                  DeviceScalars *__restrict__ scalars)
   {
     const double tau_max = __longlong_as_double((long long)scalars->tau_max_bits);
     const int invalid = (isnan(tau_max) || isinf(tau_max) || !(tau_max > 0.)) ? 1 : 0;
     scalars->tau_invalid = invalid;
-    scalars->tau_invalid_accum |= invalid;
+    if (invalid && scalars->tau_invalid_accum < kStageCode - stage)
+      scalars->tau_invalid_accum = kStageCode - stage;
     if (use_device_tau) {
       scalars->tau = scalars->tau_rk;
     } else {
@@ -627,9 +633,10 @@ namespace ryujin_hip
   }
 
   /* end of a step: fold the (all-reduced) restart flag into the accumulator */
-  __global__ void k_accumulate_flags(DeviceScalars *__restrict__ scalars)
+  __global__ void k_accumulate_flags(const int stage, DeviceScalars *__restrict__ scalars)
   {
-    scalars->restart_accum |= scalars->restart_needed;
+    if (scalars->restart_needed && scalars->restart_accum < kStageCode - stage)
+      scalars->restart_accum = kStageCode - stage;
   }
 
   /* ------------------------------------------------------------------ step 4 */
@@ -933,6 +940,38 @@ namespace ryujin_hip
     const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q < n)
       out[q] = dev_pow(x[q], y[q]);
+  }
+
+  /* in-process transport (test facility), all-reduce on device scalars: every rank copies its value(s)
+   * into its slot, then -- behind the events of all ranks -- reduces all slots. op 0: min over positive
+   * doubles (compared through their bit patterns, as tau_max_bits), op 1: max over `count` <= 2 ints. */
+  __global__ void k_slot_write(const void *__restrict__ value, const int op, const int count,
+                               unsigned long long *__restrict__ slot)
+  {
+    if (op == 0) {
+      slot[0] = *static_cast<const unsigned long long *>(value);
+    } else {
+      for (int q = 0; q < count; ++q)
+        slot[q] = (unsigned long long)(long long)static_cast<const int *>(value)[q];
+    }
+  }
+
+  __global__ void k_slot_reduce(const unsigned long long *__restrict__ slots, const int n_ranks, const int op,
+                                const int count, void *__restrict__ value)
+  {
+    if (op == 0) {
+      unsigned long long m = slots[0];
+      for (int r = 1; r < n_ranks; ++r)
+        m = slots[2 * r] < m ? slots[2 * r] : m;
+      *static_cast<unsigned long long *>(value) = m;
+    } else {
+      for (int q = 0; q < count; ++q) {
+        long long m = (long long)slots[q];
+        for (int r = 1; r < n_ranks; ++r)
+          m = (long long)slots[2 * r + q] > m ? (long long)slots[2 * r + q] : m;
+        static_cast<int *>(value)[q] = (int)m;
+      }
+    }
   }
 
   /* pack owned entries of an n_comp-strided AoS vector into a contiguous send buffer */

@@ -330,7 +330,9 @@ namespace ryujin_hip
           U_i_new[q] = F.s * U_i_new[q] + F.b * V[q];
       }
     }
-    if (row_active)
+    /* the fused sadd covers every owned entry, constrained rows (row length 1) included, as k_sadd and the
+     * reference's sadd do (time_integrator.template.h:18-25) */
+    if (row_active || (LAST_ROUND && F.src != nullptr && r.row < M.n_owned))
       store_state<K>(new_U, i, U_i_new);
 
     if constexpr (!LAST_ROUND) {

@@ -110,30 +110,82 @@ namespace
   int grid_for(size_t n, int block = kBlock) { return (int)std::max<size_t>(1, (n + block - 1) / block); }
 } // namespace
 
-/* In-process transport (test facility): several contexts of ONE process, each driven by its own
- * host thread, exchange ghost data with device-to-device copies and rendezvous on a barrier. It
- * exercises exactly the pack kernels, send/receive offsets and ghost-row layout of the RCCL path
- * on a single GPU (RCCL itself refuses two ranks on one device). */
+/* In-process transport (test facility): several contexts of ONE process, each driven by its own host
+ * thread, exchange ghost data on a single GPU (RCCL refuses two ranks on one device). It shares the pack
+ * kernels, send/receive offsets, ghost-row layout, streams and events with the RCCL path and -- like RCCL --
+ * is purely STREAM ORDERED: no hipStreamSynchronize, no device-side idle point. An ncclSend/ncclRecv pair
+ * becomes "neighbour records an event behind its pack kernel; my comm_stream waits for that event and pulls
+ * the segment with a device-to-device copy"; because the pull runs on the RECEIVER's stream, a second event
+ * in the opposite direction keeps the sender from re-packing its send buffer before every neighbour has
+ * pulled (with RCCL the send kernel itself sits on the sender's stream). The host threads only rendezvous
+ * on generation counters so that an event is always recorded before a wait on it is enqueued (the one
+ * ordering HIP requires; it also makes the cross-stream dependency graph acyclic). A missing
+ * hipStreamWaitEvent in the shared choreography is therefore a real data race here, as it would be with
+ * RCCL. All-reduces: every rank writes its value into a device slot (double buffered by parity), records
+ * an event, waits for the events of all other ranks and reduces the slots with a one-thread kernel. */
 struct LocalGroup {
+  static constexpr int kRing = 2;
   int n_ranks;
   std::mutex mtx;
   std::condition_variable cv;
   int arrived = 0;
   unsigned long generation = 0;
-  std::vector<std::vector<const double *>> mail; /* [src][dst] -> segment in src's send buffer */
-  std::vector<double> scratch;                    /* all-reduce */
-  std::vector<double> scratch_vec;                /* [n_ranks][8] vector sums */
+  /* exchange number g: packed[r] / pulled[r] = number of exchanges whose event rank r has recorded */
+  std::vector<unsigned long> packed, pulled, reduced;
+  std::vector<hipEvent_t> ev_packed, ev_pulled, ev_reduced; /* [rank * kRing + g % kRing] */
+  std::vector<std::vector<const double *>> mail;           /* [src][dst] -> segment in src's send buffer */
+  unsigned long long *slots = nullptr;                      /* device: [2][n_ranks][2] 8-byte slots */
+  std::vector<double> scratch_vec;                          /* [n_ranks][8] vector sums (host) */
   int refs = 0;
+  int device = 0;
 
-  explicit LocalGroup(int n)
+  LocalGroup(int n, int dev)
       : n_ranks(n)
+      , packed(n, 0)
+      , pulled(n, 0)
+      , reduced(n, 0)
+      , ev_packed((size_t)n * kRing, nullptr)
+      , ev_pulled((size_t)n * kRing, nullptr)
+      , ev_reduced((size_t)n * kRing, nullptr)
       , mail(n, std::vector<const double *>(n, nullptr))
-      , scratch(n, 0.)
       , scratch_vec((size_t)n * 8, 0.)
+      , device(dev)
   {
+    HIP_CHECK(hipSetDevice(dev));
+    for (auto *set : {&ev_packed, &ev_pulled, &ev_reduced})
+      for (auto &e : *set)
+        HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&slots), sizeof(unsigned long long) * 4 * n));
+    HIP_CHECK(hipMemset(slots, 0, sizeof(unsigned long long) * 4 * n));
+    HIP_CHECK(hipDeviceSynchronize());
   }
 
-  void barrier()
+  ~LocalGroup()
+  {
+    for (auto *set : {&ev_packed, &ev_pulled, &ev_reduced})
+      for (auto &e : *set)
+        if (e)
+          (void)hipEventDestroy(e);
+    if (slots)
+      (void)hipFree(slots);
+  }
+
+  /* host-side: publish / await a generation counter (never touches the device) */
+  void publish(std::vector<unsigned long> &counter, int rank, unsigned long value)
+  {
+    {
+      std::lock_guard<std::mutex> lock(mtx);
+      counter[rank] = value;
+    }
+    cv.notify_all();
+  }
+  void await(const std::vector<unsigned long> &counter, int rank, unsigned long value)
+  {
+    std::unique_lock<std::mutex> lock(mtx);
+    cv.wait(lock, [&] { return counter[rank] >= value; });
+  }
+
+  void barrier() /* host rendezvous for the host-valued reductions (state_integrals) */
   {
     std::unique_lock<std::mutex> lock(mtx);
     const unsigned long gen = generation;
@@ -202,7 +254,7 @@ struct ryujin_hip_ctx {
   DeviceBuffer<uint32_t> d_grp_start, d_b_i;
   DeviceBuffer<double> d_b_normal, d_dirichlet;
   DeviceBuffer<uint8_t> d_b_id;
-  bool have_dirichlet = false;
+  bool have_dirichlet = false, needs_dirichlet = false;
 
   /* coupling boundary pairs */
   uint32_t n_pairs = 0;
@@ -287,6 +339,8 @@ struct ryujin_hip_ctx {
   void create(const ryujin_hip_offline &o, const ryujin_hip_params &p, ryujin_hip_comm *c, int dev);
   void exchange_vector(double *v, int stride, bool after_split_sweep);
   void exchange_matrix(double *m, bool after_split_sweep);
+  unsigned long local_exchanges = 0, local_reduces = 0; /* in-process transport: generation counters */
+  void local_before_pack();
   void local_exchange(double *base, const std::vector<size_t> &send_offset,
                       const std::vector<size_t> &recv_offset, const std::vector<size_t> &recv_count);
   void allreduce_scalar(void *dev_ptr, int op, int count = 1);
@@ -542,6 +596,10 @@ void ryujin_hip_ctx::create(const ryujin_hip_offline &o, const ryujin_hip_params
       if (b_i[e] >= o.n_owned)
         throw HipError(RYUJIN_ERR_ARG, "boundary_map entry refers to a non-owned DoF");
       b_id[e] = o.b_id[src];
+      /* ids whose boundary condition reads the Dirichlet state (hyperbolic_system.h:1099-1159) */
+      if (b_id[e] == RYUJIN_BC_DIRICHLET || b_id[e] == RYUJIN_BC_DYNAMIC ||
+          b_id[e] == RYUJIN_BC_DIRICHLET_MOMENTUM)
+        needs_dirichlet = true;
       for (int d = 0; d < dim; ++d)
         b_normal[(size_t)e * dim + d] = o.b_normal[(size_t)src * dim + d];
       if (e == 0 || b_i[e] != b_i[e - 1])
@@ -658,21 +716,46 @@ void ryujin_hip_ctx::sweep(F &&launch, bool followed_by_exchange)
   HIP_CHECK(hipStreamWaitEvent(stream, ev_export, 0));
 }
 
-/* in-process transport: publish the per-neighbour segments of the send buffer, rendezvous, pull */
+/* in-process transport, part 1 (before the pack kernel): the send buffer may only be overwritten once
+ * every neighbour has pulled the segments of the previous exchange */
+void ryujin_hip_ctx::local_before_pack()
+{
+  LocalGroup &g = *comm->local;
+  const unsigned long x = local_exchanges;
+  if (x == 0)
+    return;
+  for (int q = 0; q < n_nbr; ++q) {
+    g.await(g.pulled, nbr_rank[q], x);
+    HIP_CHECK(hipStreamWaitEvent(
+        comm_stream, g.ev_pulled[(size_t)nbr_rank[q] * LocalGroup::kRing + (x - 1) % LocalGroup::kRing], 0));
+  }
+}
+
+/* part 2 (behind the pack kernel): publish the per-neighbour segments of the send buffer behind an event,
+ * pull the neighbours' segments behind theirs. Stream ordered throughout, see LocalGroup. */
 void ryujin_hip_ctx::local_exchange(double *base, const std::vector<size_t> &send_offset,
                                     const std::vector<size_t> &recv_offset,
                                     const std::vector<size_t> &recv_count)
 {
   LocalGroup &g = *comm->local;
-  HIP_CHECK(hipStreamSynchronize(comm_stream)); /* packed data is complete */
+  const unsigned long x = local_exchanges;
+  const size_t slot = x % LocalGroup::kRing;
+  const int me = comm->rank;
   for (int q = 0; q < n_nbr; ++q)
-    g.mail[comm->rank][nbr_rank[q]] = d_send_buf.ptr + send_offset[q];
-  g.barrier();
-  for (int q = 0; q < n_nbr; ++q)
-    HIP_CHECK(hipMemcpyAsync(base + recv_offset[q], g.mail[nbr_rank[q]][comm->rank],
-                             recv_count[q] * sizeof(double), hipMemcpyDeviceToDevice, comm_stream));
-  HIP_CHECK(hipStreamSynchronize(comm_stream));
-  g.barrier(); /* send buffers may be reused */
+    g.mail[me][nbr_rank[q]] = d_send_buf.ptr + send_offset[q];
+  HIP_CHECK(hipEventRecord(g.ev_packed[(size_t)me * LocalGroup::kRing + slot], comm_stream));
+  g.publish(g.packed, me, x + 1);
+  for (int q = 0; q < n_nbr; ++q) {
+    g.await(g.packed, nbr_rank[q], x + 1);
+    HIP_CHECK(hipStreamWaitEvent(comm_stream,
+                                 g.ev_packed[(size_t)nbr_rank[q] * LocalGroup::kRing + slot], 0));
+    if (recv_count[q])
+      HIP_CHECK(hipMemcpyAsync(base + recv_offset[q], g.mail[nbr_rank[q]][me],
+                               recv_count[q] * sizeof(double), hipMemcpyDeviceToDevice, comm_stream));
+  }
+  HIP_CHECK(hipEventRecord(g.ev_pulled[(size_t)me * LocalGroup::kRing + slot], comm_stream));
+  g.publish(g.pulled, me, x + 1);
+  ++local_exchanges;
 }
 
 /* 1-element all-reduce on a device scalar; op: 0 = min (double), 1 = max (int) */
@@ -687,35 +770,24 @@ void ryujin_hip_ctx::allreduce_scalar(void *dev_ptr, int op, int count)
       NCCL_CHECK(ncclAllReduce(dev_ptr, dev_ptr, count, ncclInt, ncclMax, comm->comm, stream));
     return;
   }
-  if (op == 1 && count == 2) { /* two adjacent flags: reduce one after the other */
-    allreduce_scalar(dev_ptr, 1, 1);
-    allreduce_scalar(static_cast<int *>(dev_ptr) + 1, 1, 1);
-    return;
-  }
+  /* in-process transport: slot write -> event -> wait for everybody's event -> slot reduce, all on the
+   * compute stream (see LocalGroup) */
   LocalGroup &g = *comm->local;
-  double mine = 0.;
-  if (op == 0) {
-    HIP_CHECK(hipMemcpyAsync(&mine, dev_ptr, sizeof(double), hipMemcpyDeviceToHost, stream));
-    HIP_CHECK(hipStreamSynchronize(stream));
-  } else {
-    int v = 0;
-    HIP_CHECK(hipMemcpyAsync(&v, dev_ptr, sizeof(int), hipMemcpyDeviceToHost, stream));
-    HIP_CHECK(hipStreamSynchronize(stream));
-    mine = v;
+  const unsigned long a = local_reduces;
+  const size_t par = a & 1;
+  const int me = comm->rank;
+  unsigned long long *slots = g.slots + par * (size_t)g.n_ranks * 2;
+  hipLaunchKernelGGL(k_slot_write, dim3(1), dim3(1), 0, stream, dev_ptr, op, count, slots + (size_t)me * 2);
+  HIP_CHECK(hipEventRecord(g.ev_reduced[(size_t)me * LocalGroup::kRing + par], stream));
+  g.publish(g.reduced, me, a + 1);
+  for (int q = 0; q < g.n_ranks; ++q) {
+    if (q == me)
+      continue;
+    g.await(g.reduced, q, a + 1);
+    HIP_CHECK(hipStreamWaitEvent(stream, g.ev_reduced[(size_t)q * LocalGroup::kRing + par], 0));
   }
-  g.scratch[comm->rank] = mine;
-  g.barrier();
-  double r = g.scratch[0];
-  for (int q = 1; q < g.n_ranks; ++q)
-    r = op == 0 ? std::min(r, g.scratch[q]) : std::max(r, g.scratch[q]);
-  g.barrier();
-  if (op == 0) {
-    HIP_CHECK(hipMemcpyAsync(dev_ptr, &r, sizeof(double), hipMemcpyHostToDevice, stream));
-  } else {
-    const int v = (int)r;
-    HIP_CHECK(hipMemcpyAsync(dev_ptr, &v, sizeof(int), hipMemcpyHostToDevice, stream));
-  }
-  HIP_CHECK(hipStreamSynchronize(stream));
+  hipLaunchKernelGGL(k_slot_reduce, dim3(1), dim3(1), 0, stream, slots, g.n_ranks, op, count, dev_ptr);
+  ++local_reduces;
 }
 
 void ryujin_hip_ctx::exchange_vector(double *v, int stride, bool after_split_sweep)
@@ -723,11 +795,13 @@ void ryujin_hip_ctx::exchange_vector(double *v, int stride, bool after_split_swe
   if (n_nbr == 0)
     return;
   begin_exchange(after_split_sweep);
+  if (comm->local)
+    local_before_pack();
   const uint32_t n_send = send_off[n_nbr];
   hipLaunchKernelGGL(k_pack_vector, dim3(grid_for((size_t)n_send * stride)), dim3(kBlock), 0, comm_stream,
                      n_send, d_send_idx.ptr, stride, v, d_send_buf.ptr);
   if (comm->local) {
-    std::vector<size_t> off(n_nbr), cnt(n_nbr), dst(n_nbr), rcnt(n_nbr);
+    std::vector<size_t> off(n_nbr), dst(n_nbr), rcnt(n_nbr);
     for (int q = 0; q < n_nbr; ++q) {
       off[q] = (size_t)send_off[q] * stride;
       dst[q] = (size_t)recv_off[q] * stride;
@@ -755,6 +829,8 @@ void ryujin_hip_ctx::exchange_matrix(double *m, bool after_split_sweep)
   if (n_nbr == 0)
     return;
   begin_exchange(after_split_sweep);
+  if (comm->local)
+    local_before_pack();
   const uint32_t n_send = row_send_off[n_nbr];
   hipLaunchKernelGGL(k_pack_matrix, dim3(grid_for(n_send)), dim3(kBlock), 0, comm_stream, n_send,
                      d_row_send_pos.ptr, m, d_send_buf.ptr);
@@ -796,6 +872,9 @@ void ryujin_hip_ctx::prepare_state_vector(int h, const double *dirichlet)
     HIP_CHECK(hipStreamSynchronize(stream)); /* tmp goes out of scope */
     have_dirichlet = true;
   }
+  if (needs_dirichlet && !have_dirichlet)
+    throw HipError(RYUJIN_ERR_ARG, "prepare_state_vector: the boundary map holds dirichlet / dynamic / "
+                                   "dirichlet_momentum ids but no Dirichlet data was ever passed");
   wait_comm();
   if (n_groups)
     hipLaunchKernelGGL(k_apply_bc<E>, dim3(grid_for(n_groups)), block, 0, stream, eparams, n_groups,
@@ -932,7 +1011,7 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
   if (!(deferred && rk_stage > 0))
     allreduce_scalar(&d_scalars.ptr->tau_max_bits, 0);
   hipLaunchKernelGGL(k_finalize_tau, dim3(1), dim3(1), 0, stream, tau_in, use_device_tau ? 1 : 0,
-                     d_scalars.ptr);
+                     deferred ? rk_stage : 0, d_scalars.ptr);
   mark(2);
 
   /* Step 4: low-order update, bounds, r_i, p_ij; ghost r (:597-884) */
@@ -1083,7 +1162,8 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
   wait_comm();
   if (!deferred)
     allreduce_scalar(&d_scalars.ptr->restart_needed, 1); /* MPI::logical_or(restart_needed), :1194 */
-  hipLaunchKernelGGL(k_accumulate_flags, dim3(1), dim3(1), 0, stream, d_scalars.ptr);
+  hipLaunchKernelGGL(k_accumulate_flags, dim3(1), dim3(1), 0, stream, deferred ? rk_stage : 0,
+                     d_scalars.ptr);
 
   HIP_CHECK(hipGetLastError());
   if (deferred) {
@@ -1221,6 +1301,10 @@ int ryujin_hip_ctx::time_step(int scheme, int h_state, int n_tmp, const int *h_t
        * is one (limiter iterations >= 1), saving one pass over the state vectors per stage */
       const bool fuse = params.limiter_iterations >= 1;
       auto stage_with_sadd = [&](int h_old, int h_new, double sa, double sb) {
+        struct Disarm { /* a step that throws before its last sweep must not leave the sadd armed */
+          FusedSadd &p;
+          ~Disarm() { p = FusedSadd{0., 0., nullptr}; }
+        } disarm{pending_sadd};
         if (fuse)
           pending_sadd = FusedSadd{sa, sb, state(U).U.ptr};
         step<E>(h_old, 0, none, no_w, h_new, 1., no_limit, &dummy);
@@ -1275,8 +1359,17 @@ int ryujin_hip_ctx::time_step(int scheme, int h_state, int n_tmp, const int *h_t
     params.cfl = cfl_max;
   }
   int result = single_step();
-  if (h_scalars->tau_invalid_accum)
-    return RYUJIN_ERR_TAU;
+  /* Both accumulators hold kStageCode - (first stage that raised the flag), max-reduced over the ranks.
+   * Under raise_exception the reference throws Restart at the end of the offending stage and never
+   * evaluates tau_max of a later one (hyperbolic_module.template.h:1194-1207), whereas here all stages are
+   * already enqueued and run on the inadmissible state: an invalid tau_max only counts ("We crashed",
+   * :573-576) if it was found in a stage not later than the first Restart. */
+  {
+    const int t = h_scalars->tau_invalid_accum, r = h_scalars->restart_accum;
+    const bool restart_wins = params.id_violation_strategy == RYUJIN_IDV_RAISE_EXCEPTION && r > t;
+    if (t > 0 && !restart_wins)
+      return RYUJIN_ERR_TAU;
+  }
   int status = RYUJIN_OK;
   if (h_scalars->restart_accum) {
     if (params.id_violation_strategy == RYUJIN_IDV_RAISE_EXCEPTION) {
@@ -1322,6 +1415,19 @@ namespace
       g_error = e.what();
       return RYUJIN_ERR_HIP;
     }
+  }
+
+  /* entry points that touch the device: make the context's device current first (a host thread may drive
+   * contexts on several devices) */
+  template <typename F>
+  int guarded_ctx(ryujin_hip_ctx *ctx, F &&f)
+  {
+    return guarded([&]() {
+      if (!ctx)
+        throw HipError(RYUJIN_ERR_ARG, "null context");
+      HIP_CHECK(hipSetDevice(ctx->device));
+      return f();
+    });
   }
 
   template <typename E>
@@ -1454,7 +1560,7 @@ int ryujin_hip_comm_init_local(ryujin_hip_comm **comms, int n_ranks, int device)
   return guarded([&]() {
     if (n_ranks < 1)
       throw HipError(RYUJIN_ERR_ARG, "n_ranks must be positive");
-    auto *group = new LocalGroup(n_ranks);
+    auto *group = new LocalGroup(n_ranks, device);
     group->refs = n_ranks;
     for (int r = 0; r < n_ranks; ++r) {
       auto *c = new ryujin_hip_comm;
@@ -1506,8 +1612,7 @@ void ryujin_hip_destroy(ryujin_hip_ctx *ctx)
 
 int ryujin_hip_state_alloc(ryujin_hip_ctx *ctx, int *handle)
 {
-  return guarded([&]() {
-    HIP_CHECK(hipSetDevice(ctx->device));
+  return guarded_ctx(ctx, [&]() {
     int h = -1;
     for (size_t q = 0; q < ctx->states.size(); ++q)
       if (!ctx->states[q]->used) {
@@ -1528,7 +1633,7 @@ int ryujin_hip_state_alloc(ryujin_hip_ctx *ctx, int *handle)
 
 int ryujin_hip_state_free(ryujin_hip_ctx *ctx, int handle)
 {
-  return guarded([&]() {
+  return guarded_ctx(ctx, [&]() {
     ctx->state(handle).used = false;
     return RYUJIN_OK;
   });
@@ -1536,7 +1641,7 @@ int ryujin_hip_state_free(ryujin_hip_ctx *ctx, int handle)
 
 int ryujin_hip_state_upload(ryujin_hip_ctx *ctx, int handle, const double *U_aos)
 {
-  return guarded([&]() {
+  return guarded_ctx(ctx, [&]() {
     auto &s = ctx->state(handle);
     const size_t n = ctx->L.n_relevant;
     const int K = ctx->K, KP = ctx->KP;
@@ -1555,7 +1660,7 @@ int ryujin_hip_state_upload(ryujin_hip_ctx *ctx, int handle, const double *U_aos
 
 int ryujin_hip_state_download(ryujin_hip_ctx *ctx, int handle, double *U_aos)
 {
-  return guarded([&]() {
+  return guarded_ctx(ctx, [&]() {
     auto &s = ctx->state(handle);
     const size_t n = ctx->L.n_relevant;
     const int K = ctx->K, KP = ctx->KP;
@@ -1574,7 +1679,7 @@ int ryujin_hip_state_download(ryujin_hip_ctx *ctx, int handle, double *U_aos)
 
 int ryujin_hip_state_download_precomputed(ryujin_hip_ctx *ctx, int handle, double *prec_aos)
 {
-  return guarded([&]() {
+  return guarded_ctx(ctx, [&]() {
     auto &s = ctx->state(handle);
     ctx->finish();
     HIP_CHECK(hipMemcpy(prec_aos, s.prec.ptr, (size_t)ctx->L.n_relevant * ctx->NPREC * sizeof(double),
@@ -1586,8 +1691,7 @@ int ryujin_hip_state_download_precomputed(ryujin_hip_ctx *ctx, int handle, doubl
 int ryujin_hip_prepare_state_vector(ryujin_hip_ctx *ctx, int handle, double /*t*/,
                                     const double *dirichlet_aos)
 {
-  return guarded([&]() {
-    HIP_CHECK(hipSetDevice(ctx->device));
+  return guarded_ctx(ctx, [&]() {
     dispatch_equation(ctx->params.equation, ctx->dim, [&](auto tag) {
       ctx->template prepare_state_vector<typename decltype(tag)::type>(handle, dirichlet_aos);
       return 0;
@@ -1600,7 +1704,7 @@ int ryujin_hip_step(ryujin_hip_ctx *ctx, int h_old, int stages, const int *h_sta
                     const double *stage_weights, int h_new, double tau_in, double tau_max_in,
                     double *tau_out)
 {
-  return guarded([&]() {
+  return guarded_ctx(ctx, [&]() {
     if (stages < 0 || stages > 4 || !tau_out)
       throw HipError(RYUJIN_ERR_ARG, "stages must be in [0,4]");
     /* tau_max = min(tau_max argument, CFL bound) must be positive and finite (:571-576). The device
@@ -1608,7 +1712,6 @@ int ryujin_hip_step(ryujin_hip_ctx *ctx, int h_old, int stages, const int *h_sta
      * makes the reference throw whatever the CFL bound is -- is caught here. */
     if (std::isnan(tau_max_in) || !(tau_max_in > 0.))
       return RYUJIN_ERR_TAU;
-    HIP_CHECK(hipSetDevice(ctx->device));
     return dispatch_equation(ctx->params.equation, ctx->dim, [&](auto tag) {
       return ctx->template step<typename decltype(tag)::type>(h_old, stages, h_stage, stage_weights,
                                                               h_new, tau_in, tau_max_in, tau_out);
@@ -1620,12 +1723,11 @@ int ryujin_hip_time_step_n(ryujin_hip_ctx *ctx, int scheme, int h_state, int n_t
                            const double *dirichlet_aos, double tau_max, int cfl_recovery,
                            double cfl_min, double cfl_max, double *tau_out)
 {
-  return guarded([&]() {
+  return guarded_ctx(ctx, [&]() {
     if (!h_tmp || !tau_out || n_tmp < 1 || n_tmp > 8)
       throw HipError(RYUJIN_ERR_ARG, "time_step: bad argument");
     if (std::isnan(tau_max) || !(tau_max > 0.))
       return RYUJIN_ERR_TAU; /* as in step() */
-    HIP_CHECK(hipSetDevice(ctx->device));
     ctx->state(h_state);
     for (int q = 0; q < n_tmp; ++q) {
       ctx->state(h_tmp[q]);
@@ -1653,20 +1755,24 @@ int ryujin_hip_time_step(ryujin_hip_ctx *ctx, int scheme, int h_state, const int
 
 int ryujin_hip_get_timers_accum(ryujin_hip_ctx *ctx, double ms[8], unsigned *n_updates, int reset)
 {
-  for (int k = 0; k < 8; ++k)
-    ms[k] = ctx->sweep_ms_accum[k];
-  *n_updates = ctx->sweep_updates_accum;
-  if (reset) {
-    for (auto &v : ctx->sweep_ms_accum)
-      v = 0.;
-    ctx->sweep_updates_accum = 0;
-  }
-  return RYUJIN_OK;
+  return guarded([&]() {
+    if (!ctx || !ms || !n_updates)
+      throw HipError(RYUJIN_ERR_ARG, "null argument");
+    for (int k = 0; k < 8; ++k)
+      ms[k] = ctx->sweep_ms_accum[k];
+    *n_updates = ctx->sweep_updates_accum;
+    if (reset) {
+      for (auto &v : ctx->sweep_ms_accum)
+        v = 0.;
+      ctx->sweep_updates_accum = 0;
+    }
+    return RYUJIN_OK;
+  });
 }
 
 int ryujin_hip_sadd(ryujin_hip_ctx *ctx, int h_dst, double s, double b, int h_src)
 {
-  return guarded([&]() {
+  return guarded_ctx(ctx, [&]() {
     auto &dst = ctx->state(h_dst);
     auto &src = ctx->state(h_src);
     const size_t n = (size_t)ctx->L.n_relevant * ctx->KP;
@@ -1699,7 +1805,7 @@ int ryujin_hip_set_id_violation_strategy(ryujin_hip_ctx *ctx, int strategy)
 
 int ryujin_hip_get_alpha(ryujin_hip_ctx *ctx, double *alpha)
 {
-  return guarded([&]() {
+  return guarded_ctx(ctx, [&]() {
     ctx->finish();
     HIP_CHECK(hipMemcpy(alpha, ctx->d_alpha.ptr, (size_t)ctx->L.n_relevant * sizeof(double),
                         hipMemcpyDeviceToHost));
@@ -1709,10 +1815,9 @@ int ryujin_hip_get_alpha(ryujin_hip_ctx *ctx, double *alpha)
 
 int ryujin_hip_state_integrals(ryujin_hip_ctx *ctx, int handle, double *out)
 {
-  return guarded([&]() {
+  return guarded_ctx(ctx, [&]() {
     if (!out)
       throw HipError(RYUJIN_ERR_ARG, "null argument");
-    HIP_CHECK(hipSetDevice(ctx->device));
     auto &st = ctx->state(handle);
     ctx->wait_comm();
     constexpr uint32_t n_blocks = 512;
@@ -1769,7 +1874,7 @@ int ryujin_hip_get_counters(ryujin_hip_ctx *ctx, unsigned *n_restarts, unsigned 
 
 int ryujin_hip_debug_fetch(ryujin_hip_ctx *ctx, int what, double *out, size_t n_doubles)
 {
-  return guarded([&]() {
+  return guarded_ctx(ctx, [&]() {
     const auto &L = ctx->L;
     ctx->finish();
     auto fetch_matrix = [&](const double *dev, uint32_t n_comp) {
@@ -1878,7 +1983,7 @@ int ryujin_hip_get_timers(ryujin_hip_ctx *ctx, double ms[8])
 
 int ryujin_hip_synchronize(ryujin_hip_ctx *ctx)
 {
-  return guarded([&]() {
+  return guarded_ctx(ctx, [&]() {
     ctx->finish();
     return RYUJIN_OK;
   });
@@ -1886,7 +1991,7 @@ int ryujin_hip_synchronize(ryujin_hip_ctx *ctx)
 
 int ryujin_hip_event_record(ryujin_hip_ctx *ctx, int which)
 {
-  return guarded([&]() {
+  return guarded_ctx(ctx, [&]() {
     if (which < 0 || which > 1)
       throw HipError(RYUJIN_ERR_ARG, "which must be 0 or 1");
     HIP_CHECK(hipEventRecord(ctx->ev_user[which], ctx->stream));
@@ -1896,7 +2001,7 @@ int ryujin_hip_event_record(ryujin_hip_ctx *ctx, int which)
 
 int ryujin_hip_event_elapsed_ms(ryujin_hip_ctx *ctx, double *ms)
 {
-  return guarded([&]() {
+  return guarded_ctx(ctx, [&]() {
     HIP_CHECK(hipEventSynchronize(ctx->ev_user[1]));
     float f = 0.f;
     HIP_CHECK(hipEventElapsedTime(&f, ctx->ev_user[0], ctx->ev_user[1]));

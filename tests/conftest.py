@@ -13,6 +13,8 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "multigpu: needs >= 2 GPUs (RCCL with more than one rank); also carries "
+                                       "`gpu`, skips itself on a single-GPU box")
 
 
 @pytest.fixture(scope="session")

@@ -1,0 +1,85 @@
+"""The RCCL transport with MORE THAN ONE RANK: real processes, one per GPU, ncclSend/ncclRecv ghost exchange
+over xGMI, ncclAllReduce of tau_max and of the restart flags (SURVEY.md section 8 row a-13 / e). RCCL refuses
+two ranks on one device, so these tests need >= 2 GPUs and skip on the single-GPU box; there the same stream /
+event choreography runs through the in-process transport (test_gpu_parity.py::test_partitioned_*).
+The reference pins its exchange the same way, with real `mpirun -np 4` runs
+(tests/euler/check-mass-conservation_02.mpirun=4.output)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = [pytest.mark.gpu, pytest.mark.multigpu]
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _n_gpus():
+    try:
+        import torch
+        return torch.cuda.device_count()
+    except Exception:
+        return 0
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _launch(world, script_args, timeout=900):
+    env = dict(os.environ, OMP_NUM_THREADS="4", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), *script_args]
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+@pytest.mark.parametrize("world,case", [(2, "step2d:40"), (4, "step2d:40"), (8, "step2d:60"), (2, "cylinder3d:16"),
+                                        (8, "cylinder3d:24")])
+def test_rccl_partitioned_run_matches_single_gpu(tmp_path, world, case):
+    if _n_gpus() < world:
+        pytest.skip(f"needs {world} GPUs (RCCL refuses several ranks on one device)")
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import rccl_worker
+    from ryujin_amd import offline
+
+    n_updates = 5
+    out = str(tmp_path / "rccl.npz")
+    res = _launch(world, [os.path.join(ROOT, "tests", "rccl_worker.py"), out, case, str(n_updates)])
+    assert res.returncode == 0, res.stderr[-4000:]
+    d = np.load(out)
+    gid, U, taus, alpha, integrals = rccl_worker.run(offline.SyntheticOffline(rccl_worker.make_spec(case)), None, 0,
+                                                     n_updates)
+    # every rank used the same tau (the all-reduced minimum), and it is the single-GPU tau
+    assert np.all(np.abs(d["taus"] - taus[None, :]) <= 1e-12 * taus[None, :])
+    o1, o2 = np.argsort(gid), np.argsort(d["gid"])
+    assert np.array_equal(gid[o1], d["gid"][o2])          # ownership is a partition of the mesh
+    scale = np.abs(U).max(axis=0)
+    # different local numbering = different summation order: round-off, amplified over 5 + 6 updates
+    assert (np.abs(d["U"][o2] - U[o1]) / scale).max() < 1e-11
+    assert np.abs(d["alpha"][o2] - alpha[o1]).max() < 1e-10
+    # ncclAllReduce(sum) of the conservation monitor: every rank holds the global integrals
+    assert np.allclose(d["integrals"], integrals[None, :], rtol=1e-12)
+
+
+@pytest.mark.parametrize("n", [2, 8])
+def test_bench_self_launches_its_ranks(n):
+    """`python bench.py --gpus N` invoked like the single-GPU line: launches N ranks itself and prints ONE
+    JSON line with n_gpus == N."""
+    if _n_gpus() < n:
+        pytest.skip(f"needs {n} GPUs")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "6",
+                          "--warmup", "3", "--develop", "30", "--cells-per-unit", "200"],
+                         capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-4000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, res.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == n and d["scaling"] == "weak" and d["value"] > 0 and d["n_warnings"] == 0
