@@ -359,6 +359,27 @@ int ryujin_hip_debug_layout(const ryujin_hip_offline *offline, uint64_t *ptr, ui
 /* Evaluate the device implementation of ryujin::pow (source/simd.template.h:196-272) on n pairs:
  * out[i] = pow(x[i], y[i]). Needs a GPU; used by the parity tests only. */
 int ryujin_hip_debug_pow(int device, const double *x, const double *y, double *out, size_t n);
+/* Evaluate a device function of the Euler / shallow-water Description on n independent items (needs a GPU;
+ * parity tests only): the device code is pinned directly against the baselines of the reference's unit tests.
+ *   RYUJIN_DEBUG_EULER_RIEMANN   in: rd_i[4], rd_j[4] = (rho, u, p, a)      out: lambda_max
+ *                                (RiemannSolver::compute(rd_i, rd_j), riemann_solver.template.h:406-582;
+ *                                 tests/euler/riemann_solver.cc:79-98)
+ *   RYUJIN_DEBUG_EULER_LIMIT_1D  in: bounds[3], U[3], P[3] (dim = 1)        out: l, success, took the Newton tail
+ *                                (Limiter::limit, limiter.template.h:15-327; tests/euler/limiter.cc:61-139)
+ *   RYUJIN_DEBUG_SW_RIEMANN      in: rd_i[3], rd_j[3] = (h, u, a)           out: h_star, lambda_max
+ *                                (shallow_water/riemann_solver.template.h:110-251;
+ *                                 tests/shallow_water/riemann_solver.cc:75-77)
+ *   RYUJIN_DEBUG_EULER_DIJ_2D/3D in: U_i[k], U_j[k], c_ij[dim]              out: d_ij = |c_ij| lambda_max
+ *                                (hyperbolic_module.template.h:402-406) */
+enum {
+  RYUJIN_DEBUG_EULER_RIEMANN = 0,
+  RYUJIN_DEBUG_EULER_LIMIT_1D = 1,
+  RYUJIN_DEBUG_SW_RIEMANN = 2,
+  RYUJIN_DEBUG_EULER_DIJ_2D = 3,
+  RYUJIN_DEBUG_EULER_DIJ_3D = 4
+};
+int ryujin_hip_debug_function(int device, const ryujin_hip_params *params, int which, const double *in,
+                              double *out, size_t n);
 const char *ryujin_hip_last_error(void);
 const char *ryujin_hip_version(void);
 

@@ -323,6 +323,26 @@ double ryujin_oracle_euler_lambda_max(const ryujin_hip_params *p, const double *
                        {{U_j[0], U_j[1], U_j[2], U_j[3], U_j[4]}}, {{n_ij[0], n_ij[1], n_ij[2]}});
 }
 
+/* d_ij = |c_ij| lambda_max(U_i, U_j, c_ij / |c_ij|) for n independent pairs (hyperbolic_module.template.h:402-406;
+ * dealii::Tensor / scalar multiplies by the inverse) */
+int ryujin_oracle_euler_dij_batch(const ryujin_hip_params *p, size_t n, const double *U_i, const double *U_j,
+                                  const double *c, double *out)
+{
+  const int dim = p->dim, k = dim + 2;
+#pragma omp parallel for schedule(static)
+  for (size_t q = 0; q < n; ++q) {
+    double norm2 = 0.;
+    for (int d = 0; d < dim; ++d)
+      norm2 += c[q * dim + d] * c[q * dim + d];
+    const double norm = std::sqrt(norm2), inverse = 1. / norm;
+    double nrm[3] = {0., 0., 0.};
+    for (int d = 0; d < dim; ++d)
+      nrm[d] = c[q * dim + d] * inverse;
+    out[q] = norm * ryujin_oracle_euler_lambda_max(p, U_i + q * k, U_j + q * k, nrm);
+  }
+  return RYUJIN_OK;
+}
+
 /* Euler Limiter::limit in 1-D (the reference's unit test is dim = 1).
  * out[0]=l, out[1]=success, out[2]=t_l start, out[3]=t_r start, out[4..7]= violation flags
  * (density low, density high, entropy low, entropy high), out[8] = n recorded iterations

@@ -37,6 +37,7 @@ def load(path: str | None = None):
     lib.ryujin_oracle_euler_riemann.argtypes = [C.POINTER(capi.Params), dp, dp, dp, dp, C.c_int]
     lib.ryujin_oracle_euler_lambda_max.argtypes = [C.POINTER(capi.Params), dp, dp, dp]
     lib.ryujin_oracle_euler_lambda_max.restype = C.c_double
+    lib.ryujin_oracle_euler_dij_batch.argtypes = [C.POINTER(capi.Params), C.c_size_t, dp, dp, dp, dp]
     lib.ryujin_oracle_euler_limit_1d.argtypes = [C.POINTER(capi.Params), C.c_int, dp, dp, dp, dp, dp, C.c_int]
     lib.ryujin_oracle_euler_limit.argtypes = [C.POINTER(capi.Params), dp, dp, dp, dp, capi.c_int_p]
     lib.ryujin_oracle_euler_limit_trace.argtypes = [C.POINTER(capi.Params), dp, dp, dp, dp]

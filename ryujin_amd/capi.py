@@ -28,6 +28,7 @@ CUT_NONE, CUT_BOX, CUT_CYLINDER = 0, 1, 2
 SCHEME_SSPRK_22, SCHEME_SSPRK_33, SCHEME_ERK_11, SCHEME_ERK_22, SCHEME_ERK_33, SCHEME_ERK_43, SCHEME_ERK_54 = range(7)
 CFL_RECOVERY_NONE, CFL_RECOVERY_BANG_BANG = 0, 1
 UNIQUE_ID_BYTES = 128
+DEBUG_EULER_RIEMANN, DEBUG_EULER_LIMIT_1D, DEBUG_SW_RIEMANN, DEBUG_EULER_DIJ_2D, DEBUG_EULER_DIJ_3D = range(5)
 
 
 class Params(C.Structure):
@@ -156,7 +157,7 @@ HIP_SYMBOLS = [
     "ryujin_hip_get_alpha", "ryujin_hip_get_counters", "ryujin_hip_debug_fetch",
     "ryujin_hip_set_timers", "ryujin_hip_get_timers", "ryujin_hip_synchronize",
     "ryujin_hip_event_record", "ryujin_hip_event_elapsed_ms", "ryujin_hip_last_error",
-    "ryujin_hip_version", "ryujin_hip_debug_layout", "ryujin_hip_debug_pow",
+    "ryujin_hip_version", "ryujin_hip_debug_layout", "ryujin_hip_debug_pow", "ryujin_hip_debug_function",
 ]
 
 
@@ -224,5 +225,7 @@ def load_hip():
         lib.ryujin_hip_debug_layout.argtypes = [C.POINTER(Offline), c_u64_p, c_u32_p, c_u64_p,
                                                 c_double_p, C.c_uint32, c_double_p]
         lib.ryujin_hip_debug_pow.argtypes = [C.c_int, c_double_p, c_double_p, c_double_p, C.c_size_t]
+        lib.ryujin_hip_debug_function.argtypes = [C.c_int, C.POINTER(Params), C.c_int, c_double_p, c_double_p,
+                                                  C.c_size_t]
         _hip = lib
     return _hip

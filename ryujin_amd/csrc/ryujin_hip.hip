@@ -107,6 +107,43 @@ namespace
     }
   };
 
+  EulerParams make_euler_params(const ryujin_hip_params &p)
+  {
+    EulerParams q{};
+    q.gamma = p.gamma;
+    q.gamma_inverse = 1. / p.gamma;
+    q.gamma_plus_one_inverse = 1. / (p.gamma + 1.);
+    q.gamma_minus_one_inverse = 1. / (p.gamma - 1.);
+    q.reference_density = p.reference_density;
+    q.vacuum_small = p.vacuum_state_relaxation_small;
+    q.vacuum_large = p.vacuum_state_relaxation_large;
+    q.evc_factor = p.indicator_evc_factor;
+    q.lim_newton_tolerance = p.limiter_newton_tolerance;
+    q.lim_relaxation_factor = p.limiter_relaxation_factor;
+    q.lim_newton_max_iterations = p.limiter_newton_max_iterations;
+    q.riemann_newton_max_iterations = p.riemann_newton_max_iterations;
+    q.riemann_newton_tolerance = p.riemann_newton_tolerance;
+  
+    return q;
+  }
+
+  ShallowWaterParams make_sw_params(const ryujin_hip_params &p)
+  {
+    ShallowWaterParams q{};
+    q.gravity = p.gravity;
+    q.manning = p.manning_friction_coefficient;
+    q.reference_water_depth = p.reference_water_depth;
+    q.dry_state_relaxation_factor = p.dry_state_relaxation_factor;
+    q.dry_small = p.dry_state_relaxation_small;
+    q.dry_large = p.dry_state_relaxation_large;
+    q.evc_factor = p.indicator_evc_factor;
+    q.lim_newton_tolerance = p.limiter_newton_tolerance;
+    q.lim_relaxation_factor = p.limiter_relaxation_factor;
+    q.limit_on_kinetic_energy = p.limiter_limit_on_kinetic_energy;
+    q.limit_on_square_velocity = p.limiter_limit_on_square_velocity;
+    return q;
+  }
+
   int grid_for(size_t n, int block = kBlock) { return (int)std::max<size_t>(1, (n + block - 1) / block); }
 } // namespace
 
@@ -429,20 +466,7 @@ void ryujin_hip_ctx::create(const ryujin_hip_offline &o, const ryujin_hip_params
     HIP_CHECK(hipEventCreate(&e));
   HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&h_scalars), sizeof(DeviceScalars)));
 
-  eparams.gamma = p.gamma;
-  eparams.gamma_inverse = 1. / p.gamma;
-  eparams.gamma_plus_one_inverse = 1. / (p.gamma + 1.);
-  eparams.gamma_minus_one_inverse = 1. / (p.gamma - 1.);
-  eparams.reference_density = p.reference_density;
-  eparams.vacuum_small = p.vacuum_state_relaxation_small;
-  eparams.vacuum_large = p.vacuum_state_relaxation_large;
-  eparams.evc_factor = p.indicator_evc_factor;
-  eparams.lim_newton_tolerance = p.limiter_newton_tolerance;
-  eparams.lim_relaxation_factor = p.limiter_relaxation_factor;
-  eparams.lim_newton_max_iterations = p.limiter_newton_max_iterations;
-  eparams.riemann_newton_max_iterations = p.riemann_newton_max_iterations;
-  eparams.riemann_newton_tolerance = p.riemann_newton_tolerance;
-
+  eparams = make_euler_params(p);
   aeosparams.eos = p.eos;
   aeosparams.strict = p.compute_strict_bounds != 0;
   aeosparams.gamma = p.gamma;
@@ -489,17 +513,7 @@ void ryujin_hip_ctx::create(const ryujin_hip_offline &o, const ryujin_hip_params
   scparams.evc_factor = p.indicator_evc_factor;
   scparams.lim_relaxation_factor = p.limiter_relaxation_factor;
 
-  swparams.gravity = p.gravity;
-  swparams.manning = p.manning_friction_coefficient;
-  swparams.reference_water_depth = p.reference_water_depth;
-  swparams.dry_state_relaxation_factor = p.dry_state_relaxation_factor;
-  swparams.dry_small = p.dry_state_relaxation_small;
-  swparams.dry_large = p.dry_state_relaxation_large;
-  swparams.evc_factor = p.indicator_evc_factor;
-  swparams.lim_newton_tolerance = p.limiter_newton_tolerance;
-  swparams.lim_relaxation_factor = p.limiter_relaxation_factor;
-  swparams.limit_on_kinetic_energy = p.limiter_limit_on_kinetic_energy;
-  swparams.limit_on_square_velocity = p.limiter_limit_on_square_velocity;
+  swparams = make_sw_params(p);
   if (p.equation == RYUJIN_EQ_SHALLOW_WATER) {
     if (o.initial_precomputed)
       d_Z.upload(o.initial_precomputed, o.n_relevant);
@@ -1964,6 +1978,77 @@ int ryujin_hip_debug_pow(int device, const double *x, const double *y, double *o
                        dout.ptr);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemcpy(out, dout.ptr, n * sizeof(double), hipMemcpyDeviceToHost));
+    return RYUJIN_OK;
+  });
+}
+
+/* device functions evaluated on n independent items (parity tests against the reference's unit-test
+ * baselines: tests/euler/riemann_solver.cc, tests/euler/limiter.cc, tests/shallow_water/riemann_solver.cc) */
+namespace
+{
+  __global__ void __launch_bounds__(kBlock)
+  k_debug_function(const EulerParams PE, const ShallowWaterParams PS, const int which, const size_t n,
+                   const double *__restrict__ in, double *__restrict__ out)
+  {
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n)
+      return;
+    if (which == RYUJIN_DEBUG_EULER_RIEMANN) {
+      const double *v = in + q * 8;
+      const Euler<1>::RiemannData rd_i{v[0], v[1], v[2], v[3]}, rd_j{v[4], v[5], v[6], v[7]};
+      out[q] = Euler<1>::riemann_compute(PE, rd_i, rd_j);
+    } else if (which == RYUJIN_DEBUG_EULER_LIMIT_1D) {
+      /* the composition the sweeps use: limit_fast(), and limit() for the undecided pairs */
+      const double *v = in + q * 9;
+      const double bnd[3] = {v[0], v[1], v[2]}, U[3] = {v[3], v[4], v[5]}, Pij[3] = {v[6], v[7], v[8]};
+      bool success, undecided;
+      double l = Euler<1>::limit_fast(PE, bnd, U, Pij, success, undecided);
+      if (undecided)
+        l = Euler<1>::limit(PE, bnd, U, Pij, success);
+      out[q * 3 + 0] = l;
+      out[q * 3 + 1] = success ? 1. : 0.;
+      out[q * 3 + 2] = undecided ? 1. : 0.;
+    } else if (which == RYUJIN_DEBUG_SW_RIEMANN) {
+      const double *v = in + q * 6;
+      const ShallowWater<1>::RiemannData rd_i{v[0], v[1], v[2]}, rd_j{v[3], v[4], v[5]};
+      out[q * 2 + 0] = ShallowWater<1>::compute_h_star(PS, rd_i, rd_j);
+      out[q * 2 + 1] = ShallowWater<1>::lambda_max(PS, rd_i, rd_j);
+    } else if (which == RYUJIN_DEBUG_EULER_DIJ_2D) {
+      const double *v = in + q * 10;
+      const double U_i[4] = {v[0], v[1], v[2], v[3]}, U_j[4] = {v[4], v[5], v[6], v[7]}, c[2] = {v[8], v[9]};
+      out[q] = Euler<2>::dij_from_states(PE, U_i, U_j, c);
+    } else if (which == RYUJIN_DEBUG_EULER_DIJ_3D) {
+      const double *v = in + q * 13;
+      const double U_i[5] = {v[0], v[1], v[2], v[3], v[4]}, U_j[5] = {v[5], v[6], v[7], v[8], v[9]},
+                   c[3] = {v[10], v[11], v[12]};
+      out[q] = Euler<3>::dij_from_states(PE, U_i, U_j, c);
+    }
+  }
+} // namespace
+
+int ryujin_hip_debug_function(int device, const ryujin_hip_params *params, int which, const double *in,
+                              double *out, size_t n)
+{
+  return guarded([&]() {
+    if (!params || !in || !out)
+      throw HipError(RYUJIN_ERR_ARG, "null argument");
+    size_t n_in, n_out;
+    switch (which) {
+    case RYUJIN_DEBUG_EULER_RIEMANN: n_in = 8; n_out = 1; break;
+    case RYUJIN_DEBUG_EULER_LIMIT_1D: n_in = 9; n_out = 3; break;
+    case RYUJIN_DEBUG_SW_RIEMANN: n_in = 6; n_out = 2; break;
+    case RYUJIN_DEBUG_EULER_DIJ_2D: n_in = 10; n_out = 1; break;
+    case RYUJIN_DEBUG_EULER_DIJ_3D: n_in = 13; n_out = 1; break;
+    default: throw HipError(RYUJIN_ERR_ARG, "unknown debug function");
+    }
+    HIP_CHECK(hipSetDevice(device));
+    DeviceBuffer<double> din, dout;
+    din.upload(in, n * n_in);
+    dout.alloc(n * n_out);
+    hipLaunchKernelGGL(k_debug_function, dim3(grid_for(n)), dim3(kBlock), 0, nullptr,
+                       make_euler_params(*params), make_sw_params(*params), which, n, din.ptr, dout.ptr);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpy(out, dout.ptr, n * n_out * sizeof(double), hipMemcpyDeviceToHost));
     return RYUJIN_OK;
   });
 }

@@ -128,7 +128,8 @@ class EulerFlipClassifier:
         return abs(psi) / terms, i, j
 
 
-def compare_step(off, mods, dirichlet=None, tau=0.0, *, oracle=None, params=None, label="", fetch_pij=True):
+def compare_step(off, mods, dirichlet=None, tau=0.0, *, oracle=None, params=None, label="", fetch_pij=True,
+                 keep_matrices=True):
     """mods = [(hip module, old, new), (oracle module, old, new)] holding the SAME old state. Runs one update on
     both and compares every intermediate array, fetching them one after the other (full-size meshes: the P_ij
     of a 3-D mesh alone is 8.7 GB per backend). Returns (g, c): dicts of the small arrays of both backends."""
@@ -155,7 +156,8 @@ def compare_step(off, mods, dirichlet=None, tau=0.0, *, oracle=None, params=None
     _check(d_alpha <= 1e-12, label, 'alpha', d_alpha)
     a, b = both(lambda m, o, nw: m.debug_fetch("dij"))
     np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-300)
-    g["dij"], c["dij"] = a, b
+    if keep_matrices:
+        g["dij"], c["dij"] = a, b
     assert abs(tau_g - tau_c) <= 1e-12 * tau_c
     a, b = both(lambda m, o, nw: m.debug_fetch("bounds"))
     np.testing.assert_allclose(a, b, rtol=1e-12)
@@ -173,9 +175,17 @@ def compare_step(off, mods, dirichlet=None, tau=0.0, *, oracle=None, params=None
     scale = np.maximum(np.abs(U_c).max(axis=0), 1e-3 * np.abs(U_c).max())
 
     lg, lc = both(lambda m, o, nw: m.debug_fetch("lij"))
-    g["lij"], c["lij"] = lg, lc
+    c["lij"] = lc
+    dl_first = np.abs(lg - lc)
+    if keep_matrices:
+        g["lij"] = lg
+    del lg
     ln_g, ln_c = both(lambda m, o, nw: m.debug_fetch("lij_next"))
-    g["lij_next"], c["lij_next"] = ln_g, ln_c
+    c["lij_next"] = ln_c
+    dl_next = np.abs(ln_g - ln_c)
+    if keep_matrices:
+        g["lij_next"] = ln_g
+    del ln_g
 
     if fetch_pij:
         pg, pc = both(lambda m, o, nw: m.debug_fetch("pij"))
@@ -183,15 +193,17 @@ def compare_step(off, mods, dirichlet=None, tau=0.0, *, oracle=None, params=None
         p_err = (np.abs(pg - pc).reshape(-1, k) / np.maximum(p_scale, 1e-300)).max()
         _stat(label, what="pij", rel_to_max=p_err)
         _check(p_err <= 1e-12, label, 'pij', p_err)
-        g["pij"], c["pij"] = pg, pc
+        c["pij"] = pc
+        if keep_matrices:
+            g["pij"] = pg
+        del pg
     # (l_ij below: where |P_ij| < 1e-3 max|U| the quotient (rho_max - rho_U) / |rho_P| is round-off dominated in
     # the reference itself; there the EFFECT |dl| |P_ij| on the update is what the U_new check bounds)
 
     # ---- l_ij: 1e-10 absolute; anything beyond must sit on the psi_r = 0 discontinuity
     flipped_rows = set()
     n_flips = {}
-    for name, a, b in (("lij", lg, lc), ("lij_next", ln_g, ln_c)):
-        dl = np.abs(a - b)
+    for name, dl in (("lij", dl_first), ("lij_next", dl_next)):
         assert np.median(dl) == 0.0 or np.median(dl) < 1e-14, name
         idx = np.nonzero(dl > L_TOL)[0]
         if idx.size and "pij" not in c:   # full-size run: P_ij of the oracle only, and only now

@@ -164,13 +164,11 @@ def partition(off, info, owner, bathymetry=None):
             exp_p = sorted(lidx[g] for g in order if any(owner[j] == p for j in rows[g][1:]))
             send_idx.extend(exp_p)
             send_off.append(len(send_idx))
-            for i in exp_p:
+            ghosts_of_p = [lidx[j] for j in ghosts if owner[j] == p]
+            ghost_range = (min(ghosts_of_p), max(ghosts_of_p) + 1) if ghosts_of_p else None
+            for i, c in ghost_row_send_entries(lrows, exp_p, ghost_range):
                 row_send_row.append(i)
-                row_send_col.append(0)
-                for c in range(1, len(lrows[i])):
-                    if owner[l2g[lrows[i][c]]] == p:
-                        row_send_row.append(i)
-                        row_send_col.append(c)
+                row_send_col.append(c)
             row_send_off.append(len(row_send_row))
         b_g = [g for g in order if is_bdry[g]]
         b_i = np.array([lidx[g] for g in b_g], dtype=np.uint32)
@@ -202,6 +200,27 @@ def partition(off, info, owner, bathymetry=None):
             v.set_initial_precomputed(bathymetry[l2g])
         views.append(v)
     return views
+
+
+def ghost_row_send_entries(local_rows, exported_rows, ghost_range):
+    """The (row, col_idx) entries of a matrix that ONE neighbour rank receives into its ghost rows
+    (ryujin_hip_offline::row_send_row / row_send_col, include/ryujin_hip.h; the reference's
+    SparsityPatternSIMD::entries_to_be_sent, source/sparse_matrix_simd.template.h:196-264): for every row
+    exported to that rank, in export order, the diagonal and then the entries whose column lies in the ghost
+    range RECEIVED from the same rank -- a ghost row only holds the transposes of owned entries (:61-74).
+    ghost_range = (begin, end) in local indices, or None if that rank sends us nothing: then nothing is sent
+    to it either (:229-247, the unmatched import target). Pinned against the reference's
+    tests/common/sparsity_pattern_simd_01.mpirun=4.output in tests/test_send_lists_golden.py."""
+    out = []
+    if ghost_range is None:
+        return out
+    lo, hi = ghost_range
+    for i in exported_rows:
+        out.append((i, 0))
+        for c in range(1, len(local_rows[i])):
+            if lo <= local_rows[i][c] < hi:
+                out.append((i, c))
+    return out
 
 
 def run_partitioned_oracle(oracle, views, params, U0_global, n_updates, dirichlet_fn=None):

@@ -1,0 +1,141 @@
+"""The DEVICE implementations of the Riemann solvers and the convex limiter, run on the reference's own unit-test
+inputs and compared with the reference-held baselines directly:
+
+  tests/euler/riemann_solver.cc:79-98 + riemann_solver{,-iterated-2,-iterated-10}.output  (10 states x 3 Newton settings)
+  tests/euler/limiter.cc:61-139 + limiter.output                                          (12 cases)
+  tests/shallow_water/riemann_solver.cc:75-77 + riemann_solver.output                     (3 states, incl. dry)
+
+through ryujin_hip_debug_function (one thread per item, the same inlined device functions the sweeps call).
+Tolerance: 1e-13 relative at function level (the reference's own std::pow / vcl::pow
+builds differ in the last digits); the iterated Riemann baselines are printed with 16 decimals.
+"""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from ryujin_amd import capi
+from test_oracle_golden_euler import LIMITER_CASES, RIEMANN_CASES, _blocks, _grab, _limiter_blocks, _riemann_data
+
+pytestmark = pytest.mark.gpu
+
+
+def _device(params, which, items, n_out):
+    lib = capi.load_hip()
+    a = np.ascontiguousarray(np.array(items, dtype=np.float64))
+    out = np.zeros((a.shape[0], n_out))
+    rc = lib.ryujin_hip_debug_function(0, C.byref(params), which, capi.as_ptr(a, capi.c_double_p),
+                                       capi.as_ptr(out, capi.c_double_p), a.shape[0])
+    assert rc == 0, lib.ryujin_hip_last_error()
+    return out
+
+
+@pytest.mark.parametrize("n_newton,golden", [(0, "euler_riemann_solver.output"),
+                                             (2, "euler_riemann_solver-iterated-2.output"),
+                                             (10, "euler_riemann_solver-iterated-10.output")])
+def test_device_riemann_solver_against_the_reference_baselines(oracle, golden_dir, n_newton, golden):
+    params = oracle.default_params(capi.EQ_EULER, 1)
+    params.riemann_newton_max_iterations = n_newton
+    blocks = _blocks(os.path.join(golden_dir, golden))
+    assert len(blocks) == len(RIEMANN_CASES) == 10
+    items = [np.concatenate([_riemann_data(left, params.gamma), _riemann_data(right, params.gamma)])
+             for left, right in RIEMANN_CASES]
+    lam = _device(params, capi.DEBUG_EULER_RIEMANN, items, 1)[:, 0]
+    for got, block in zip(lam, blocks):
+        ref = _grab(block, "-> lambda_max =")[0]
+        if n_newton == 0:
+            assert abs(got - ref) <= 1e-13 * abs(ref), (got, ref)
+        else:   # printed with 16 decimals (not 17 significant digits)
+            assert abs(got - ref) <= 1e-12 * abs(ref) + 1e-15, (got, ref)
+    if n_newton == 0:   # the values SURVEY.md 8c quotes
+        expected = [1.5084890784907763, 1.7620896140769147, 2.6335650740600323, 34.018686867258801,
+                    12.617757915202823, 11.832159566199232, 10.832159566199232, 9.7758781271580943,
+                    6.6963146691962327, 9.7758781271580943]
+        np.testing.assert_allclose(lam, expected, rtol=1e-13, atol=0)
+
+
+def test_device_limiter_against_the_reference_baseline(oracle, golden_dir):
+    """limiter.output is the EXPENSIVE_BOUNDS_CHECK build (limiter.cc:10); the device runs the production
+    control flow (limiter.template.h:183-217). For the six in-bounds cases both return the same l up to the
+    Newton tolerance -- the well-conditioned ones to round-off; for the six
+    cases whose LOW-ORDER state violates the bounds both report failure."""
+    params = oracle.default_params(capi.EQ_EULER, 1)
+    blocks = _limiter_blocks(os.path.join(golden_dir, "euler_limiter.output"))
+    assert len(blocks) == len(LIMITER_CASES) == 12
+    items = [np.concatenate([bounds, U, P]) for _, U, P, bounds in LIMITER_CASES]
+    out = _device(params, capi.DEBUG_EULER_LIMIT_1D, items, 3)
+    lib = oracle.load()
+    for (label, U, P, bounds), block, (l, success, _) in zip(LIMITER_CASES, blocks, out):
+        l_ref = _grab(block, "\nl:")[0]
+        low_order_violation = "low-order" in block
+        assert bool(success) == (not low_order_violation), label
+        if not low_order_violation:
+            assert "Success!" in block
+            assert abs(l - l_ref) <= 1e-10, (label, l, l_ref)
+        # and the oracle's production flow (same control flow as the device): round-off
+        lo, so = C.c_double(), C.c_int()
+        arr = lambda t: capi.as_ptr(np.array(t, dtype=np.float64), capi.c_double_p)  # noqa: E731
+        lib.ryujin_oracle_euler_limit(C.byref(params), arr(bounds), arr(U), arr(P), C.byref(lo), C.byref(so))
+        assert abs(l - lo.value) <= 1e-13, (label, l, lo.value)
+        assert bool(success) == bool(so.value), label
+    # the l values SURVEY.md 8c quotes for the bound cases
+    expected = {6: 0.4999999999999993, 7: 0.1999999188484877, 8: 0.4999999999999998, 9: 0.1999999188484877,
+                10: 0.0336589067585305, 11: 0.0000000003370627}
+    for n, l_ref in expected.items():
+        assert abs(out[n, 0] - l_ref) <= 1e-10, (n, out[n, 0], l_ref)
+
+
+def test_device_sw_riemann_solver_against_the_reference_baseline(oracle, golden_dir):
+    text = open(os.path.join(golden_dir, "shallow_water_riemann_solver.output")).read()
+    lam = [float(x) for x in re.findall(r"lambda_max: ([0-9.e+-]+)", text)]
+    hst = [float(x) for x in re.findall(r"h_star: ([0-9.e+-]+)", text)]
+    assert len(lam) == len(hst) == 3
+    params = oracle.default_params(capi.EQ_SHALLOW_WATER, 1)
+    eps = np.finfo(np.float64).eps
+
+    def riemann_data(state):   # tests/shallow_water/riemann_solver.cc:33-44
+        h = max(state[0], params.reference_water_depth * params.dry_state_relaxation_small * eps)
+        return [h, state[1] / h, np.sqrt(params.gravity * h)]
+
+    cases = [((0.0, 0.0), (0.0, 0.0)), ((1.0, 1.0), (0.0, 0.0)), ((1.8, 0.0), (1.0, 0.0))]
+    out = _device(params, capi.DEBUG_SW_RIEMANN, [riemann_data(a) + riemann_data(b) for a, b in cases], 2)
+    for (h_star, l), h_ref, l_ref in zip(out, hst, lam):
+        assert abs(h_star - h_ref) <= 1e-13 * abs(h_ref), (h_star, h_ref)
+        assert abs(l - l_ref) <= 1e-13 * abs(l_ref), (l, l_ref)
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_device_dij_against_the_oracle_on_random_states(oracle, dim):
+    """d_ij = |c_ij| lambda_max(U_i, U_j, c_ij/|c_ij|) for 200 k random admissible state pairs and directions,
+    Mach numbers up to 5, pressure ratios up to 1e6: 1e-12 relative (the stated d_ij contract)."""
+    rng = np.random.default_rng(7)
+    n = 200_000
+    params = oracle.default_params(capi.EQ_EULER, dim)
+    k = dim + 2
+
+    def states():
+        rho = 10.0 ** rng.uniform(-3, 1, n)
+        p = 10.0 ** rng.uniform(-4, 2, n)
+        a = np.sqrt(params.gamma * p / rho)
+        v = rng.normal(size=(n, dim))
+        v *= (rng.uniform(0, 5, n) * a / np.linalg.norm(v, axis=1))[:, None]
+        U = np.empty((n, k))
+        U[:, 0] = rho
+        U[:, 1:1 + dim] = rho[:, None] * v
+        U[:, -1] = p / (params.gamma - 1.0) + 0.5 * rho * (v ** 2).sum(1)
+        return U
+
+    U_i, U_j = states(), states()
+    c = rng.normal(size=(n, dim)) * 10.0 ** rng.uniform(-4, 0, n)[:, None]
+    got = _device(params, capi.DEBUG_EULER_DIJ_2D if dim == 2 else capi.DEBUG_EULER_DIJ_3D,
+                  np.hstack([U_i, U_j, c]), 1)[:, 0]
+    lib = oracle.load()
+    ref = np.empty(n)
+    dp = capi.c_double_p
+    U_i, U_j, c = (np.ascontiguousarray(x) for x in (U_i, U_j, c))
+    lib.ryujin_oracle_euler_dij_batch(C.byref(params), n, capi.as_ptr(U_i, dp), capi.as_ptr(U_j, dp),
+                                      capi.as_ptr(c, dp), capi.as_ptr(ref, dp))
+    rel = np.abs(got - ref) / np.abs(ref)
+    assert rel.max() <= 1e-12, (rel.max(), int(rel.argmax()))

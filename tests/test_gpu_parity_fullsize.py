@@ -1,0 +1,138 @@
+"""HIP vs oracle AT THE SIZES BASELINE.json NAMES: one test per config. The flow is developed on the GPU (device
+resident SSPRK33 steps), the developed state is handed to the CPU oracle, and ONE update (prepare_state_vector +
+step<0>) is compared array by array with the tolerances and the psi_r branch-flip classification of
+tests/helpers_parity.py. This is where 32-bit position arithmetic, the large-grid launch paths and the
+slice/ghost layout of multi-million-row meshes are exercised against the oracle (the small-mesh tests cannot).
+
+  C2  2-D Euler Mach-3 forward-facing step, h = 1/995          2.50 M gridpoints (bench.py's workload)
+  C3  3-D Euler radial contrast ("Sedov-like"), 200^3 cells     8.12 M gridpoints, 216 M stencil entries
+  C4  3-D Euler Mach-3 cylinder in a channel, per-GPU share     4.18 M gridpoints (h = 1/96, 1.25 units long)
+  C5  2-D shallow-water circular dam break, 1824^2 cells        3.33 M gridpoints
+
+Host memory: the oracle holds the whole problem (C3: 33 GB) next to the generator's arrays and the fetched
+device arrays; a box with less memory runs the largest mesh that fits (and says so)."""
+import gc
+import os
+
+import numpy as np
+import pytest
+
+from helpers_parity import compare_step
+from ryujin_amd import HyperbolicModule, capi, offline
+from ryujin_amd.initial_states import euler_radial_contrast, euler_uniform, sw_circular_dam_break
+
+pytestmark = pytest.mark.gpu
+
+
+def _available_gb():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                return int(line.split()[1]) / 1e6
+    except OSError:
+        pass
+    return 64.0
+
+
+def _fullsize(oracle, spec, initial, equation, n_develop_rk, with_dirichlet, label, fetch_pij):
+    off = offline.SyntheticOffline(spec)
+    U0 = initial(off.positions)
+    dirichlet = euler_uniform(off.b_positions) if with_dirichlet else None
+    p = oracle.default_params(equation, off.dim)
+    p.cfl = 0.9
+    mg = HyperbolicModule(off, p, backend="hip")
+    state = mg.new_state_vector(U0)
+    temps = [mg.new_state_vector() for _ in range(3)]
+    for _ in range(n_develop_rk):
+        mg.time_step("ssprk 33", state, temps, dirichlet)
+    assert mg.n_warnings() == 0
+    U_start = state.download()
+    assert np.isfinite(U_start).all()
+    mc = HyperbolicModule(off, p, backend=oracle.backend())
+    mods = [(mg, state, temps[0]), (mc, mc.new_state_vector(U_start), mc.new_state_vector())]
+    del U0
+    gc.collect()
+    g, c = compare_step(off, mods, dirichlet, oracle=oracle, params=p, label=label, fetch_pij=fetch_pij,
+                        keep_matrices=False)
+    n = off.n_owned
+    # the developed flow exercises the limiter: a non-trivial share of the pairs is limited (l < 1)
+    limited = float((c["lij_next"] < 1.0).mean())
+    # invariant domain preserved in sign on every DoF, on both backends alike
+    rho_g, rho_c = g["U"][:n, 0], c["U"][:n, 0]
+    assert (rho_g > 0).all() and (np.sign(rho_g) == np.sign(rho_c)).all()
+    if equation == capi.EQ_EULER:
+        e_g = g["U"][:n, -1] - 0.5 * (g["U"][:n, 1:-1] ** 2).sum(1) / rho_g
+        assert (e_g > 0).all()
+    mc.close()
+    mg.close()
+    return off, g, c, limited
+
+
+def test_fullsize_c2_step_2d(oracle):
+    """BASELINE configs[1], the bench line's mesh: 2 498 844 gridpoints = 9 995 376 DoFs."""
+    def initial(pos):
+        rng = np.random.default_rng(42)
+        return euler_uniform(pos) * (1.0 + 1e-3 * rng.uniform(-1.0, 1.0, size=(len(pos), 4)))
+    off, g, c, limited = _fullsize(oracle, offline.mach3_step_2d(995), initial, capi.EQ_EULER, 100, True,
+                                   "fullsize_c2", True)
+    assert off.n_owned == 2498844
+    assert limited > 1e-3, limited
+
+
+def test_fullsize_c3_radial_contrast_3d(oracle):
+    """BASELINE configs[2]: 200^3 cells = 8 120 601 gridpoints = 40.6 M DoFs (needs ~60 GB of host memory for
+    oracle + fetched arrays; smaller boxes run 160^3 or 128^3)."""
+    avail = _available_gb()
+    n = 200 if avail > 75 else (160 if avail > 40 else 128)
+    if n != 200:
+        print(f"only {avail:.0f} GB of host memory available: running {n}^3 cells instead of 200^3")
+
+    def initial(pos):
+        return euler_radial_contrast(pos, inner=(1.0, 0.0, 100.0), outer=(1.0, 0.0, 0.1), radius=0.1)
+    off, g, c, limited = _fullsize(oracle, offline.box_3d(n), initial, capi.EQ_EULER, 20, False, "fullsize_c3",
+                                   False)
+    assert off.n_owned == (n + 1) ** 3
+    assert limited > 1e-5, limited
+
+
+def test_fullsize_c4_cylinder_share_3d(oracle):
+    """BASELINE configs[3], one GPU's share: h = 1/96, 1.25 units of channel, 4.18 M gridpoints; staircase
+    cylinder with slip boundary, Dirichlet inflow, do-nothing outflow, slip walls, 3-D coupling boundary pairs."""
+    def initial(pos):
+        return euler_uniform(pos)
+    off, g, c, limited = _fullsize(oracle, offline.cylinder_channel_3d(96, length_units=1.25), initial,
+                                   capi.EQ_EULER, 30, True, "fullsize_c4", False)
+    assert off.n_owned > 4_000_000
+    assert limited > 1e-5, limited
+
+
+def test_fullsize_c5_shallow_water_2d(oracle):
+    """BASELINE configs[4]: 1824^2 cells = 3 330 625 gridpoints = 10.0 M DoFs, circular dam break."""
+    off, g, c, limited = _fullsize(oracle, offline.rectangle_2d(1824, (-5.0, -5.0), (5.0, 5.0)),
+                                   sw_circular_dam_break, capi.EQ_SHALLOW_WATER, 60, False, "fullsize_c5", True)
+    assert off.n_owned == 1825 ** 2
+    assert limited > 1e-4, limited
+
+
+def test_miniature_cylinder_against_the_oracle(oracle):
+    """configs[3]'s geometry (3-D Dirichlet + do-nothing + slip + staircase cylinder with 3-D coupling boundary
+    pairs) on 10 k gridpoints, every sweep against the ORACLE (the partitioned cylinder tests compare HIP with
+    HIP)."""
+    spec = offline.cylinder_channel_3d(8, length_units=2)
+    off = offline.SyntheticOffline(spec)
+    rng = np.random.default_rng(3)
+    U0 = euler_uniform(off.positions) * (1.0 + 1e-3 * rng.uniform(-1.0, 1.0, size=(off.n_relevant, 5)))
+    dirichlet = euler_uniform(off.b_positions)
+    p = oracle.default_params(capi.EQ_EULER, 3)
+    p.cfl = 0.9
+    mg = HyperbolicModule(off, p, backend="hip")
+    a, b = mg.new_state_vector(U0), mg.new_state_vector()
+    for _ in range(25):
+        mg.prepare_state_vector(a, 0.0, dirichlet)
+        mg.step(a, [], [], b)
+        a, b = b, a
+    mc = HyperbolicModule(off, p, backend=oracle.backend())
+    mods = [(mg, a, b), (mc, mc.new_state_vector(a.download()), mc.new_state_vector())]
+    assert off.n_pairs > 0 and set(np.unique(off.b_id)) >= {capi.BC_DIRICHLET, capi.BC_SLIP}
+    g, c = compare_step(off, mods, dirichlet, oracle=oracle, params=p, label="mini_cylinder")
+    assert (g["U"][: off.n_owned, 0] > 0).all()

@@ -1,0 +1,63 @@
+"""The ghost-row exchange lists against the reference's own multi-process
+baseline tests/common/sparsity_pattern_simd_01.{cc, mpirun=4.output}: an artificial 16-DoF pattern on 4 ranks
+(rank 0 import-only, rank 3 export-only), for which SparsityPatternSIMD prints, per rank, the pairs
+(target rank, cumulative number of entries to be sent). The index sets and pattern entries below restate the
+inputs of that test (sparsity_pattern_simd_01.cc:66-161); the expected numbers are read from the committed
+baseline. The function under test, helpers_unstructured.ghost_row_send_entries, is the one that builds
+row_send_row / row_send_col for every partitioned run of the test-suite (CPU oracle and HIP)."""
+import os
+import re
+
+from helpers_unstructured import ghost_row_send_entries
+
+OWNED = {0: range(0, 4), 1: range(4, 8), 2: range(8, 12), 3: range(12, 16)}
+# locally relevant = owned + ghosts, ghosts listed by owner rank (sparsity_pattern_simd_01.cc:69-98)
+GHOSTS = {0: {1: [4, 5], 2: [8, 9], 3: [12, 13]},
+          1: {2: [8, 9], 3: [12, 13]},
+          2: {1: [4, 5], 3: [14, 15]},
+          3: {}}
+# dsp.add(row, column) per rank (:107-159)
+ENTRIES = {0: [(0, 0), (1, 1), (2, 2), (3, 3), (8, 3), (9, 3), (3, 8), (3, 9), (3, 12)],
+           1: [(4, 4), (5, 5), (6, 6), (7, 7), (5, 8), (5, 9), (5, 12), (5, 13), (8, 5), (9, 5), (12, 5), (13, 5)],
+           2: [(8, 8), (9, 9), (10, 10), (11, 11), (10, 4), (10, 5), (4, 10), (5, 10), (11, 14), (11, 15), (14, 11),
+               (15, 11)],
+           3: [(12, 12), (13, 13), (14, 14), (15, 15)]}
+
+
+def _golden(golden_dir):
+    text = open(os.path.join(golden_dir, "common_sparsity_pattern_simd_01.mpirun4.output")).read()
+    per_rank = []
+    for block in text.strip().split("\n\n"):
+        targets = block.split("Entries to be sent:")[0]
+        per_rank.append([(int(a), int(b)) for a, b in re.findall(r"^(\d+) : (\d+)$", targets, flags=re.M)])
+    return per_rank
+
+
+def test_send_targets_match_the_reference_baseline(golden_dir):
+    golden = _golden(golden_dir)
+    assert len(golden) == 4
+    for rank in range(4):
+        # local numbering: owned first, then ghosts sorted by owner (dealii Partitioner; offline_data.template.h)
+        l2g = list(OWNED[rank]) + [g for p in sorted(GHOSTS[rank]) for g in GHOSTS[rank][p]]
+        lidx = {g: i for i, g in enumerate(l2g)}
+        rows = {i: [i] for i in range(len(l2g))}                      # diagonal first
+        for r, c in ENTRIES[rank]:
+            if r != c:
+                rows[lidx[r]].append(lidx[c])
+        local_rows = [[rows[i][0]] + sorted(rows[i][1:]) for i in range(len(l2g))]
+        ghost_range, begin = {}, len(OWNED[rank])
+        for p in sorted(GHOSTS[rank]):
+            ghost_range[p] = (begin, begin + len(GHOSTS[rank][p]))
+            begin += len(GHOSTS[rank][p])
+        # import targets: the ranks that hold some of our owned rows as ghosts, with those rows in index order
+        # (dealii Partitioner::import_targets / import_indices)
+        import_targets = {q: sorted(lidx[g] for g in GHOSTS[q].get(rank, [])) for q in range(4)
+                          if q != rank and GHOSTS[q].get(rank)}
+        cumulative, got = 0, []
+        # a rank without ghost rows sets up no exchange pattern at all (sparse_matrix_simd.template.h:150)
+        for q in (sorted(import_targets) if GHOSTS[rank] else []):
+            cumulative += len(ghost_row_send_entries(local_rows, import_targets[q], ghost_range.get(q)))
+            got.append((q, cumulative))
+        assert got == golden[rank], (rank, got, golden[rank])
+    # what the baseline says in words: rank 0 only imports, rank 3 only exports, 1 <-> 2 swap 4 and 2 entries
+    assert golden == [[], [(0, 0), (2, 4)], [(0, 0), (1, 2)], []]
