@@ -376,7 +376,9 @@ enum {
   RYUJIN_DEBUG_EULER_LIMIT_1D = 1,
   RYUJIN_DEBUG_SW_RIEMANN = 2,
   RYUJIN_DEBUG_EULER_DIJ_2D = 3,
-  RYUJIN_DEBUG_EULER_DIJ_3D = 4
+  RYUJIN_DEBUG_EULER_DIJ_3D = 4,
+  RYUJIN_DEBUG_EULER_DIJ_RECORDS_2D = 5, /* the same through the per-node Riemann records the sweep uses */
+  RYUJIN_DEBUG_EULER_DIJ_RECORDS_3D = 6
 };
 int ryujin_hip_debug_function(int device, const ryujin_hip_params *params, int which, const double *in,
                               double *out, size_t n);

@@ -29,6 +29,7 @@ SCHEME_SSPRK_22, SCHEME_SSPRK_33, SCHEME_ERK_11, SCHEME_ERK_22, SCHEME_ERK_33, S
 CFL_RECOVERY_NONE, CFL_RECOVERY_BANG_BANG = 0, 1
 UNIQUE_ID_BYTES = 128
 DEBUG_EULER_RIEMANN, DEBUG_EULER_LIMIT_1D, DEBUG_SW_RIEMANN, DEBUG_EULER_DIJ_2D, DEBUG_EULER_DIJ_3D = range(5)
+DEBUG_EULER_DIJ_RECORDS_2D, DEBUG_EULER_DIJ_RECORDS_3D = 5, 6
 
 
 class Params(C.Structure):

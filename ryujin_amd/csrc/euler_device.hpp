@@ -29,6 +29,9 @@ namespace ryujin_hip
     int lim_newton_max_iterations;
     int riemann_newton_max_iterations;
     double riemann_newton_tolerance;
+    /* 2 gamma / (gamma - 1), the exponent of p_star_two_rarefaction, when it is a small integer
+     * (gamma = 7/5: 7, 5/3: 5, 2: 4, 3: 3): evaluated by multiplications; 0: general pow */
+    int rarefaction_power;
   };
 
 #define RYUJIN_DEV __device__ __forceinline__
@@ -57,6 +60,94 @@ namespace ryujin_hip
    * (the reference's own pow variants already differ in the last digits).
    * Everything else (x <= 0, subnormal, inf, nan) is forwarded to ocml's pow().
    */
+#ifndef RYUJIN_POW_SELFCONTAINED
+#define RYUJIN_POW_SELFCONTAINED 1
+#endif
+#if RYUJIN_POW_SELFCONTAINED
+  /* Self-contained: the special cases (zero, negative base, inf, nan, subnormal, overflow) are resolved with a
+   * handful of selects instead of forwarding to ocml's pow(). Inlined ocml pow() costs every kernel that calls
+   * pow its register high-water mark (~100 VGPRs on top of the state live at the call site), although the
+   * hot path never takes it. */
+  RYUJIN_DEV double dev_pow(const double x, const double y)
+  {
+    double ax = fabs(x);
+    long long bits = __double_as_longlong(ax);
+    int biased = (int)((bits >> 52) & 0x7ff);
+    int e = -1023;
+    if (__builtin_expect(biased == 0, 0)) { /* subnormal (or zero, resolved below): renormalise */
+      ax *= 18014398509481984.; /* 2^54 */
+      bits = __double_as_longlong(ax);
+      biased = (int)((bits >> 52) & 0x7ff);
+      e = -1023 - 54;
+    }
+    e += biased;
+    /* ax = m * 2^e, m in [sqrt(1/2), sqrt(2)) */
+    double m = __longlong_as_double((bits & 0x000fffffffffffffLL) | 0x3ff0000000000000LL);
+    if (m > 1.4142135623730951) {
+      m *= 0.5;
+      e += 1;
+    }
+    const double s = (m - 1.) / (m + 1.);
+    const double s2 = s * s;
+    double p = 2. / 21.;
+    p = __builtin_fma(p, s2, 2. / 19.);
+    p = __builtin_fma(p, s2, 2. / 17.);
+    p = __builtin_fma(p, s2, 2. / 15.);
+    p = __builtin_fma(p, s2, 2. / 13.);
+    p = __builtin_fma(p, s2, 2. / 11.);
+    p = __builtin_fma(p, s2, 2. / 9.);
+    p = __builtin_fma(p, s2, 2. / 7.);
+    p = __builtin_fma(p, s2, 2. / 5.);
+    p = __builtin_fma(p, s2, 2. / 3.);
+    /* log m = 2s + s^3 p */
+    const double log_m = __builtin_fma(s * s2, p, 2. * s);
+    constexpr double ln2_hi = 6.93147180369123816490e-01; /* 0x3fe62e42fee00000 */
+    constexpr double ln2_lo = 1.90821492927058770002e-10; /* 0x3dea39ef35793c76 */
+    const double ed = (double)e;
+    const double log_x = __builtin_fma(ed, ln2_hi, __builtin_fma(ed, ln2_lo, log_m));
+
+    /* beyond +-800 the result is inf / 0 anyway; the clamp keeps n inside the range of ldexp */
+    const double z = fmin(fmax(y * log_x, -800.), 800.);
+    const double n = __builtin_rint(z * 1.44269504088896338700e+00);
+    double r = __builtin_fma(-n, ln2_hi, z);
+    r = __builtin_fma(-n, ln2_lo, r);
+    double q = 1. / 6227020800.;               /* 1/13! */
+    q = __builtin_fma(q, r, 1. / 479001600.);  /* 1/12! */
+    q = __builtin_fma(q, r, 1. / 39916800.);
+    q = __builtin_fma(q, r, 1. / 3628800.);
+    q = __builtin_fma(q, r, 1. / 362880.);
+    q = __builtin_fma(q, r, 1. / 40320.);
+    q = __builtin_fma(q, r, 1. / 5040.);
+    q = __builtin_fma(q, r, 1. / 720.);
+    q = __builtin_fma(q, r, 1. / 120.);
+    q = __builtin_fma(q, r, 1. / 24.);
+    q = __builtin_fma(q, r, 1. / 6.);
+    q = __builtin_fma(q, r, 0.5);
+    q = __builtin_fma(q, r, 1.);
+    q = __builtin_fma(q, r, 1.);
+    double result = ldexp(q, (int)n);
+
+    /* special cases as std::pow */
+    if (__builtin_expect(!(ax > 0.) || biased == 0x7ff || x < 0., 0)) {
+      if (ax == 0.)
+        result = y > 0. ? 0. : __builtin_inf();
+      else if (ax == __builtin_inf())
+        result = y > 0. ? __builtin_inf() : 0.;
+      if (x < 0.) {
+        const double half = 0.5 * y;
+        if (y != __builtin_rint(y))
+          result = __builtin_nan("");
+        else if (half != __builtin_rint(half))
+          result = -result; /* odd integer exponent */
+      }
+      if (x != x || y != y)
+        result = __builtin_nan("");
+    }
+    if (__builtin_expect(y == 0. || x == 1., 0))
+      result = 1.;
+    return result;
+  }
+#else
   RYUJIN_DEV double dev_pow(double x, double y)
   {
     const long long bits = __double_as_longlong(x);
@@ -112,6 +203,7 @@ namespace ryujin_hip
     q = __builtin_fma(q, r, 1.);
     return ldexp(q, (int)n);
   }
+#endif
   RYUJIN_DEV double positive_part(double x) { return fmax(0., x); }
   RYUJIN_DEV double negative_part(double x) { return -fmin(0., x); }
 
@@ -505,6 +597,123 @@ namespace ryujin_hip
       const RiemannData rd_j = riemann_data_from_state(P, U_j, n);
       RYUJIN_FENCE();
       return norm * riemann_compute(P, rd_i, rd_j);
+    }
+
+    /* ------------------------------------------------------------------ Riemann solver, node records
+     *
+     * The Riemann sweep is bound by the latency of its FP64 division / sqrt / pow chains, not by bandwidth
+     * (DESIGN.md section 3). Everything riemann_data_from_state (:377-403) derives from ONE state except the
+     * normal velocity does not depend on the direction n_ij: |m|^2 = (m.n)^2 + |m - (m.n) n|^2 for |n| = 1,
+     * hence p = (gamma - 1)(E - |m|^2 / (2 rho)) and a = sqrt(gamma p / rho). A row recomputes these for
+     * itself and every neighbour, ~4 (2-D) to ~13 (3-D) times per node. They are therefore computed ONCE per
+     * node next to the precomputed values (k_precompute) together with p^((gamma-1)/(2 gamma)), which turns
+     *   (p_i / p_j)^(-(gamma-1)/(2 gamma))  into  pw_j / pw_i        (p_star_two_rarefaction, :296-313),
+     * and the second pow of that formula has the exponent 2 gamma / (gamma - 1) = 7 for gamma = 7/5.
+     * phi(p_max) (:134-148) shares its square roots with p_star_failsafe (:348-368):
+     *   1 / sqrt(rho/2 ((gamma+1) p_max + (gamma-1) p_Z)) = x_Z / sqrt(p_max).
+     * Per (i,j) pair this leaves 5 divisions and 7 square roots (before: 2 pow, 11 divisions, 10 square
+     * roots). The results differ from the reference's operation order by a few ulp (1e-15 relative): inside
+     * the 1e-12 contract on d_ij, checked against the oracle on 2 x 200 k random state pairs
+     * (tests/test_gpu_device_functions.py) and in every sweep comparison. With Newton iterations of the
+     * Riemann solver switched on (non-default) the reference path (riemann_compute) is used on the same data.
+     *
+     * record = (rho, p, a, pw, a / pw, 1 / p, v[DIM]), padded to an even number of doubles */
+    static constexpr int RS = (6 + DIM + 1) / 2 * 2;
+
+    static RYUJIN_DEV void riemann_record(const EulerParams &P, const double (&U)[K], double (&rec)[RS])
+    {
+      const double rho = U[0];
+      const double rho_inverse = 1. / rho;
+      const double p = (P.gamma - 1.) * internal_energy(U);
+      const double a = sqrt(P.gamma * p * rho_inverse);
+      const double pw = dev_pow(p, (P.gamma - 1.) * 0.5 * P.gamma_inverse);
+      rec[0] = rho;
+      rec[1] = p;
+      rec[2] = a;
+      rec[3] = pw;
+      rec[4] = a / pw;
+      rec[5] = 1. / p;
+#pragma unroll
+      for (int d = 0; d < DIM; ++d)
+        rec[6 + d] = U[1 + d] * rho_inverse;
+#pragma unroll
+      for (int d = 6 + DIM; d < RS; ++d)
+        rec[d] = 0.;
+    }
+
+    /* GENERAL = false: Newton iterations off and integral rarefaction exponent (the defaults with
+     * gamma = 7/5), known on the host -- the kernel then contains neither pow nor the Newton loop */
+    template <bool GENERAL = true>
+    static RYUJIN_DEV double dij_from_records(const EulerParams &P, const double (&ri)[RS],
+                                              const double (&rj)[RS], const double (&c)[DIM])
+    {
+      double norm2 = c[0] * c[0];
+      double vc_i = ri[6] * c[0], vc_j = rj[6] * c[0];
+#pragma unroll
+      for (int d = 1; d < DIM; ++d) {
+        norm2 += c[d] * c[d];
+        vc_i += ri[6 + d] * c[d];
+        vc_j += rj[6 + d] * c[d];
+      }
+      const double norm = sqrt(norm2);
+      const double inverse_norm = 1. / norm;
+      const double u_i = vc_i * inverse_norm, u_j = vc_j * inverse_norm;
+
+      if constexpr (GENERAL) {
+        if (P.riemann_newton_max_iterations != 0) {
+          const RiemannData rd_i{ri[0], u_i, ri[1], ri[2]}, rd_j{rj[0], u_j, rj[1], rj[2]};
+          return norm * riemann_compute(P, rd_i, rd_j);
+        }
+      }
+
+      const double rho_i = ri[0], p_i = ri[1], a_i = ri[2];
+      const double rho_j = rj[0], p_j = rj[1], a_j = rj[2];
+      const double p_max = fmax(p_i, p_j);
+      const double du = u_j - u_i;
+
+      /* p_star_two_rarefaction :274-319 */
+      double rarefaction;
+      {
+        const double factor = (P.gamma - 1.) * 0.5;
+        const double numerator = positive_part(a_i + a_j - factor * du);
+        const double denominator = ri[4] * rj[3] + a_j; /* a_i (p_i/p_j)^(-(gamma-1)/(2 gamma)) + a_j */
+        const double x = numerator / denominator;
+        double power;
+        if (!GENERAL || P.rarefaction_power > 0) {
+          power = 1.;
+          double b = x;
+          for (int n = P.rarefaction_power; n; n >>= 1) { /* wave-uniform: at most 4 squarings */
+            if (n & 1)
+              power *= b;
+            b *= b;
+          }
+        } else {
+          power = dev_pow(x, 2.0 * P.gamma * P.gamma_minus_one_inverse);
+        }
+        rarefaction = p_j * power;
+      }
+
+      /* p_star_failsafe :330-374 and phi_of_p_max :122-149 on shared square roots */
+      const double gp1 = P.gamma + 1., gm1 = P.gamma - 1.;
+      const double x_i = sqrt(2. * p_max / (rho_i * (gp1 * p_max + gm1 * p_i)));
+      const double x_j = sqrt(2. * p_max / (rho_j * (gp1 * p_max + gm1 * p_j)));
+      double failsafe;
+      {
+        const double a = x_i + x_j;
+        const double b = du;
+        const double cc = -p_i * x_i - p_j * x_j;
+        const double base = (-b + sqrt(b * b - 4. * a * cc)) / (2. * a);
+        failsafe = base * base;
+      }
+      const double p_star_tilde = fmin(rarefaction, failsafe);
+      const double phi_p_max = ((p_max - p_i) * x_i + (p_max - p_j) * x_j) * (1. / sqrt(p_max)) + du;
+      const double p_2 = phi_p_max < 0. ? p_star_tilde : fmin(p_max, p_star_tilde);
+
+      /* compute_lambda :252-263 with lambda1_minus / lambda3_plus :164-205 */
+      const double f = (P.gamma + 1.0) * 0.5 * P.gamma_inverse;
+      const double nu_11 = u_i - a_i * sqrt(1.0 + f * positive_part((p_2 - p_i) * ri[5]));
+      const double nu_32 = u_j + a_j * sqrt(1.0 + f * positive_part((p_2 - p_j) * rj[5]));
+      return norm * fmax(positive_part(nu_32), negative_part(nu_11));
     }
 
     /* ------------------------------------------------------------------ Limiter::limit */

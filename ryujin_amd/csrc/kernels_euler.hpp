@@ -69,6 +69,12 @@ namespace ryujin_hip
 #ifndef RYUJIN_SPLIT_DIJ
 #define RYUJIN_SPLIT_DIJ 1
 #endif
+#ifndef RYUJIN_DIJ_RECORDS
+#define RYUJIN_DIJ_RECORDS 1 /* Riemann sweep on per-node records (euler_device.hpp, "node records") */
+#endif
+#ifndef RYUJIN_PREFETCH
+#define RYUJIN_PREFETCH 1 /* software pipelining of the stencil loops of steps 4 and 5 (column c+1 in flight while c is processed); 0: plain loads, fewer live registers */
+#endif
 #ifndef RYUJIN_PIPE_DIJ
 #define RYUJIN_PIPE_DIJ 0 /* A/B: the pipelined variant spills (60 B scratch per lane) and is 6 % slower */
 #endif
@@ -329,6 +335,54 @@ namespace ryujin_hip
     reinterpret_cast<double2 *>(prec)[i] = E::precompute(P, U_i);
   }
 
+  /* Euler: precomputed values AND the per-node Riemann record (Euler<DIM>::riemann_record) in one pass
+   * over the owned rows */
+  template <int DIM>
+  __global__ void __launch_bounds__(kBlock)
+  k_precompute_euler(const EulerParams P, const DeviceMesh M, const double *__restrict__ U,
+                     double *__restrict__ prec, double *__restrict__ rec)
+  {
+    using E = Euler<DIM>;
+    constexpr int K = E::K, RS = E::RS;
+    const uint32_t i = M.slice_begin * 64 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M.n_owned || i >= M.slice_end * 64)
+      return;
+    if (M.row_len[i] == 1)
+      return;
+    double U_i[K], r[RS];
+    load_state<K>(U, i, U_i);
+    reinterpret_cast<double2 *>(prec)[i] = E::precompute(P, U_i);
+    E::riemann_record(P, U_i, r);
+    double2 *out = reinterpret_cast<double2 *>(rec + (size_t)i * RS);
+#pragma unroll
+    for (int g = 0; g < RS / 2; ++g) {
+      double2 t;
+      t.x = r[2 * g];
+      t.y = r[2 * g + 1];
+      out[g] = t;
+    }
+  }
+
+  /* the same record for the ghost rows [first, last): computed locally from the exchanged ghost states
+   * (nothing to exchange: the record is a function of U_j alone) */
+  template <int DIM>
+  __global__ void __launch_bounds__(kBlock)
+  k_riemann_record_rows(const EulerParams P, const uint32_t first, const uint32_t last,
+                        const double *__restrict__ U, double *__restrict__ rec)
+  {
+    using E = Euler<DIM>;
+    constexpr int K = E::K, RS = E::RS;
+    const uint32_t i = first + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= last)
+      return;
+    double U_i[K], r[RS];
+    load_state<K>(U, i, U_i);
+    E::riemann_record(P, U_i, r);
+#pragma unroll
+    for (int g = 0; g < RS; ++g)
+      rec[(size_t)i * RS + g] = r[g];
+  }
+
   /* ------------------------------------------------------------------ step 2 */
 
   template <typename E>
@@ -490,6 +544,55 @@ namespace ryujin_hip
       load_state<K>(U, j, U_j);
       if (mine)
         dij[pos] = E::dij_from_states(P, U_i, U_j, c_ij);
+    }
+  }
+
+  /* The Riemann sweep on per-node records: no state loads, no per-pair pow (see euler_device.hpp) */
+  template <int DIM, bool GENERAL>
+  __global__ void __launch_bounds__(kBlock, RYUJIN_OCC_DIJ)
+  k_dij_records(const EulerParams P, const DeviceMesh M, const uint32_t *__restrict__ lower_mask,
+                const double *__restrict__ rec, double *__restrict__ dij)
+  {
+    using E = Euler<DIM>;
+    constexpr int RS = E::RS;
+    const RowCtx r = row_context(M);
+    if (!r.valid)
+      return;
+    const bool row_active = r.len > 1;
+    const uint32_t i = row_active ? r.row : (r.row < M.n_owned ? r.row : M.n_owned - 1);
+    const uint32_t *__restrict__ cols = M.cols;
+    const double *__restrict__ cij = M.cij;
+    const uint32_t upper =
+        row_active ? (~lower_mask[r.row] & (r.len >= 32 ? 0xFFFFFFFFu : ((1u << r.len) - 1u)) & ~1u) : 0u;
+
+    double rec_i[RS];
+    {
+      const double2 *b = reinterpret_cast<const double2 *>(rec + (size_t)i * RS);
+#pragma unroll
+      for (int g = 0; g < RS / 2; ++g) {
+        const double2 t = b[g];
+        rec_i[2 * g] = t.x;
+        rec_i[2 * g + 1] = t.y;
+      }
+    }
+    for (uint32_t c = 1; c < r.width; ++c) {
+      const bool mine = (upper >> c) & 1u;
+      if (!__any(mine))
+        continue; /* wave-uniform: no loads at all for lower-triangle columns */
+      const uint64_t colbase = (uint64_t)r.base + c;
+      const uint64_t pos = colbase * 64 + r.lane;
+      const uint32_t j = ld_stream(cols + (pos));
+      double c_ij[DIM], rec_j[RS];
+      load_entry<DIM>(cij, colbase, r.lane, c_ij);
+      const double2 *b = reinterpret_cast<const double2 *>(rec + (size_t)j * RS);
+#pragma unroll
+      for (int g = 0; g < RS / 2; ++g) {
+        const double2 t = b[g];
+        rec_j[2 * g] = t.x;
+        rec_j[2 * g + 1] = t.y;
+      }
+      if (mine)
+        dij[pos] = E::template dij_from_records<GENERAL>(P, rec_i, rec_j, c_ij);
     }
   }
 
@@ -689,6 +792,7 @@ namespace ryujin_hip
     /* software pipeline (see k_dij_alpha) */
     const uint32_t *__restrict__ cols = M.cols;
     const double *__restrict__ cij = M.cij;
+#if RYUJIN_PREFETCH
     uint32_t j_n = ld_stream(cols + ((uint64_t)r.base * 64 + r.lane));
     uint32_t j_nn = r.width > 1 ? ld_stream(cols + (((uint64_t)r.base + 1) * 64 + r.lane)) : i;
     double c_n[DIM], U_n[K];
@@ -697,12 +801,14 @@ namespace ryujin_hip
     load_state<K>(U, j_n, U_n);
     double alpha_n = alpha[j_n];
     double s_n = prec[(size_t)j_n * 2 + 0];
+#endif
 
     for (uint32_t c = 0; c < r.width; ++c) {
       const uint64_t colbase = (uint64_t)r.base + c;
       const bool active = row_active && c < r.len;
-      const uint32_t j = j_n;
       double c_ij[DIM], U_j[K];
+#if RYUJIN_PREFETCH
+      const uint32_t j = j_n;
 #pragma unroll
       for (int d = 0; d < DIM; ++d)
         c_ij[d] = c_n[d];
@@ -719,6 +825,14 @@ namespace ryujin_hip
         s_n = prec[(size_t)j_n * 2 + 0];
         j_nn = (c + 2 < r.width) ? ld_stream(cols + ((colbase + 2) * 64 + r.lane)) : i;
       }
+#else
+      const uint32_t j = ld_stream(cols + (colbase * 64 + r.lane));
+      load_entry<DIM>(cij, colbase, r.lane, c_ij);
+      const double d_ij = dij[colbase * 64 + r.lane];
+      load_state<K>(U, j, U_j);
+      const double alpha_j = alpha[j];
+      const double s_j = prec[(size_t)j * 2 + 0];
+#endif
 
       if (!active)
         continue;

@@ -13,8 +13,22 @@
 
 #include "kernels_euler.hpp"
 
+#ifndef RYUJIN_SKIP_UNLIMITED
+#define RYUJIN_SKIP_UNLIMITED 1
+#endif
+
 namespace ryujin_hip
 {
+  /* Data-dependent shortcuts of steps 6 and 7 (exact: the skipped work contributes +0):
+   *  - second limiter pass: a pair with l_ij = min(l_ij, l_ji) == 1 was not limited; the limiter would see
+   *    (1 - l) P_ij = 0 and the stored value (1 - l) l'_ij is 0 whatever l'_ij is -- store 0, skip the
+   *    limiter (a pow per pair) and, where P_ij is not register cached, its second read;
+   *  - last high-order update: a pair with l == 0 adds l lambda P_ij = 0 to U_i -- skip the read of P_ij,
+   *    8k of the 8k + 12 bytes a pair moves in this sweep.
+   * Both tests are wave-uniform (__any over the 64 rows of the slice, per column), so nothing diverges.
+   * Away from shocks the first pass returns l == 1 exactly (t_r stays t_max and psi_r > 0,
+   * limiter.template.h:88-108,188-216) and the second pass therefore stores exact zeros: in a developed
+   * Mach-3 flow the large majority of (slice, column) tiles take the shortcut. */
   RYUJIN_DEV void flag_restart(DeviceScalars *scalars, const bool all_ok, const uint32_t lane)
   {
     if (__any(!all_ok)) {
@@ -182,6 +196,7 @@ namespace ryujin_hip
     bool all_ok = true;
     unsigned long long undecided_mask = 0;
 
+#if RYUJIN_PREFETCH
     /* software pipeline: loads of column c+1 are in flight while column c is processed */
     uint32_t j_n = r.width > 1 ? ld_stream(cols + (((uint64_t)r.base + 1) * 64 + r.lane)) : i;
     uint32_t j_nn = r.width > 2 ? ld_stream(cols + (((uint64_t)r.base + 2) * 64 + r.lane)) : i;
@@ -196,12 +211,14 @@ namespace ryujin_hip
       mjinv_n = mi_inv[j_n];
       alpha_n = alpha[j_n];
     }
+#endif
 
     for (uint32_t c = 1; c < r.width; ++c) {
       const uint64_t colbase = (uint64_t)r.base + c;
       const uint64_t pos = colbase * 64 + r.lane;
       const bool active = row_active && c < r.len;
       double c_ij[DIM], U_j[K], F_jH[K];
+#if RYUJIN_PREFETCH
 #pragma unroll
       for (int d = 0; d < DIM; ++d)
         c_ij[d] = c_n[d];
@@ -222,6 +239,16 @@ namespace ryujin_hip
         alpha_n = alpha[j_n];
         j_nn = (c + 2 < r.width) ? ld_stream(cols + ((colbase + 2) * 64 + r.lane)) : i;
       }
+#else
+      const uint32_t j = ld_stream(cols + pos);
+      load_entry<DIM>(cij, colbase, r.lane, c_ij);
+      const double d_ij = dij[pos];
+      const double m_ij = ld_stream(mij + pos);
+      load_state<K>(old_U, j, U_j);
+      load_state<K>(r_in, j, F_jH);
+      const double m_j_inv = mi_inv[j];
+      const double alpha_j = alpha[j];
+#endif
       if (!active)
         continue;
 
@@ -311,11 +338,15 @@ namespace ryujin_hip
       const bool active = row_active && c < r.len;
       const double l_a = lij[pos];
       const double l_b = lij[idx_t[pos]];
+      const double l_ij = fmin(l_a, l_b);
+#if RYUJIN_SKIP_UNLIMITED
+      if (LAST_ROUND && !__any(active && l_ij != 0.))
+        continue;
+#endif
       double p_ij[K];
       load_entry<K>(pij, colbase, r.lane, p_ij);
       if (!active)
         continue;
-      const double l_ij = fmin(l_a, l_b);
 #pragma unroll
       for (int q = 0; q < K; ++q)
         U_i_new[q] += l_ij * lambda * p_ij[q];
@@ -348,11 +379,18 @@ namespace ryujin_hip
         const bool active = row_active && c < r.len;
         const double l_a = lij[pos];
         const double l_b = lij[idx_t[pos]];
+        const double old_l_ij = fmin(l_a, l_b);
+#if RYUJIN_SKIP_UNLIMITED
+        if (!__any(active && old_l_ij != 1.)) {
+          if (active)
+            st_stream(lij_next + (pos), 0.);
+          continue;
+        }
+#endif
         double p_ij[K];
         load_entry<K>(pij, colbase, r.lane, p_ij);
         if (!active)
           continue;
-        const double old_l_ij = fmin(l_a, l_b);
         double new_p_ij[K];
 #pragma unroll
         for (int q = 0; q < K; ++q)
@@ -381,6 +419,77 @@ namespace ryujin_hip
         st_stream(lij_next + (pos), (1. - old_l_ij) * new_l_ij);
       }
     }
+  }
+
+  /* Last round for stencils of at most MAXW columns: all l_ij = min(l_ij, l_ji) of the row are fetched up
+   * front (independent loads), then P_ij is read -- in chunks of CHUNK columns whose loads are issued back to
+   * back -- only for the columns in which some row of the slice has l != 0 (see the note at the top). */
+  template <typename E, int MAXW, int CHUNK>
+  __global__ void __launch_bounds__(kBlock)
+  k_high_order_last_cached(const typename E::Params, const DeviceMesh M, double *__restrict__ new_U,
+                           const double *__restrict__ pij, const double *__restrict__ lij, const FusedSadd F)
+  {
+    constexpr int K = E::K;
+    const RowCtx r = row_context(M);
+    if (!r.valid)
+      return;
+    const bool row_active = r.len > 1;
+    const uint32_t i = row_active ? r.row : (r.row < M.n_owned ? r.row : M.n_owned - 1);
+    const uint32_t *__restrict__ idx_t = M.idx_t;
+
+    double U_i_new[K];
+    load_state<K>(new_U, i, U_i_new);
+    double V[K];
+    if (F.src)
+      load_state<K>(F.src, i, V);
+    const double lambda = 1. / (double)(r.len - 1);
+
+    double l[MAXW];
+    uint32_t needed = 0; /* wave-uniform: bit c <=> some row of the slice has l(c) != 0 */
+#pragma unroll
+    for (int c = 1; c < MAXW; ++c) {
+      l[c] = 0.;
+      if ((uint32_t)c < r.width) {
+        const uint32_t pos = (uint32_t)(((uint64_t)r.base + c) * 64 + r.lane);
+        const double l_a = lij[pos];
+        const double l_b = lij[idx_t[pos]];
+        l[c] = (row_active && (uint32_t)c < r.len) ? fmin(l_a, l_b) : 0.;
+      }
+    }
+#pragma unroll
+    for (int c = 1; c < MAXW; ++c)
+      if (__any(l[c] != 0.))
+        needed |= 1u << c;
+
+#pragma unroll
+    for (int c0 = 1; c0 < MAXW; c0 += CHUNK) {
+      double p[CHUNK][K];
+#pragma unroll
+      for (int cc = 0; cc < CHUNK; ++cc) {
+        const int c = c0 + cc;
+        if (c < MAXW && ((needed >> c) & 1u))
+          load_entry<K>(pij, (uint64_t)r.base + c, r.lane, p[cc]);
+      }
+#pragma unroll
+      for (int cc = 0; cc < CHUNK; ++cc) {
+        const int c = c0 + cc;
+        if (c < MAXW && ((needed >> c) & 1u)) {
+          if (row_active && (uint32_t)c < r.len) { /* padding entries of P_ij are never read into U */
+#pragma unroll
+            for (int q = 0; q < K; ++q)
+              U_i_new[q] += l[c] * lambda * p[cc][q];
+          }
+        }
+      }
+    }
+
+    if (F.src) {
+#pragma unroll
+      for (int q = 0; q < K; ++q)
+        U_i_new[q] = F.s * U_i_new[q] + F.b * V[q];
+    }
+    if (row_active || (F.src != nullptr && r.row < M.n_owned))
+      store_state<K>(new_U, i, U_i_new);
   }
 
   /* Register-cached variant for stencils of at most MAXW columns (2-D Q1: 9, 1-D: 3): the row's
@@ -459,6 +568,16 @@ namespace ryujin_hip
     for (int c = 1; c < MAXW; ++c) {
       if ((uint32_t)c >= r.width)
         continue;
+#if RYUJIN_SKIP_UNLIMITED
+      {
+        const bool lane_on = row_active && (uint32_t)c < r.len;
+        if (!__any(lane_on && l[c] != 1.)) {
+          if (lane_on)
+            st_stream(lij_next + ((r.base + c) * 64 + r.lane), 0.);
+          continue;
+        }
+      }
+#endif
       double pc[K];
       if (c < CP) {
 #pragma unroll

@@ -123,6 +123,15 @@ namespace
     q.lim_newton_max_iterations = p.limiter_newton_max_iterations;
     q.riemann_newton_max_iterations = p.riemann_newton_max_iterations;
     q.riemann_newton_tolerance = p.riemann_newton_tolerance;
+    {
+      /* gamma = 7/5 in binary gives 2 gamma / (gamma - 1) = 7 (1 + 3e-16): integral to round-off counts
+       * (x^7 against x^(7 + 2e-15) differs by 2e-15 |ln x|, far inside the 1e-12 contract on d_ij) */
+      const double e = 2. * p.gamma / (p.gamma - 1.);
+      q.rarefaction_power =
+          (std::fabs(e - std::rint(e)) <= 8. * std::numeric_limits<double>::epsilon() * e && e >= 1. && e <= 16.)
+              ? (int)std::rint(e)
+              : 0;
+    }
   
     return q;
   }
@@ -306,6 +315,7 @@ struct ryujin_hip_ctx {
 
   struct State {
     DeviceBuffer<double> U, prec;
+    DeviceBuffer<double> rrec; /* Euler: per-node Riemann records (Euler<DIM>::riemann_record) */
     bool used = false;
   };
   std::vector<std::unique_ptr<State>> states;
@@ -913,6 +923,16 @@ void ryujin_hip_ctx::prepare_state_vector(int h, const double *dirichlet)
                          s.prec.ptr);
     }, true);
     exchange_vector(s.prec.ptr, E::NPREC, true);
+  } else if constexpr (std::is_same<typename E::Params, EulerParams>::value && RYUJIN_DIJ_RECORDS) {
+    /* sweep() has joined the U exchange: the ghost states are valid, their records are computed locally */
+    sweep([&](const DeviceMesh &mm, dim3 grid) {
+      hipLaunchKernelGGL(k_precompute_euler<E::DIMENSION>, grid, block, 0, launch_stream, eparams, mm,
+                         s.U.ptr, s.prec.ptr, s.rrec.ptr);
+    }, true);
+    exchange_vector(s.prec.ptr, 2, true); /* :157-160 */
+    if (L.n_relevant > L.n_owned)
+      hipLaunchKernelGGL(k_riemann_record_rows<E::DIMENSION>, dim3(grid_for(L.n_relevant - L.n_owned)), block,
+                         0, stream, eparams, L.n_owned, L.n_relevant, s.U.ptr, s.rrec.ptr);
   } else {
     sweep([&](const DeviceMesh &mm, dim3 grid) {
       hipLaunchKernelGGL(k_precompute<E>, grid, block, 0, launch_stream, eparams, mm, s.U.ptr, s.prec.ptr);
@@ -978,8 +998,16 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
     const bool pending = comm_pending;
     comm_pending = false; /* k_dij does not read alpha: do not join the exchange yet */
     sweep([&](const DeviceMesh &mm, dim3 grid) {
-      hipLaunchKernelGGL(k_dij<E>, grid, block, 0, launch_stream, eparams, mm, d_lower_mask.ptr, old.U.ptr,
-                         d_dij.ptr);
+      if constexpr (is_euler && RYUJIN_DIJ_RECORDS) {
+        if (eparams.riemann_newton_max_iterations == 0 && eparams.rarefaction_power > 0)
+          hipLaunchKernelGGL((k_dij_records<DIM, false>), grid, block, 0, launch_stream, eparams, mm,
+                             d_lower_mask.ptr, old.rrec.ptr, d_dij.ptr);
+        else
+          hipLaunchKernelGGL((k_dij_records<DIM, true>), grid, block, 0, launch_stream, eparams, mm,
+                             d_lower_mask.ptr, old.rrec.ptr, d_dij.ptr);
+      } else
+        hipLaunchKernelGGL(k_dij<E>, grid, block, 0, launch_stream, eparams, mm, d_lower_mask.ptr, old.U.ptr,
+                           d_dij.ptr);
     }, false);
     comm_pending = pending;
   } else {
@@ -1148,13 +1176,17 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
     const bool last_round = (pass + 1 == n_iterations);
     if (n_iterations == 2 && last_round)
       std::swap(d_lij.ptr, d_lij_next.ptr);
+    constexpr int kCachedWidth = DIM == 1 ? 3 : (DIM == 2 ? 9 : 27);
     if (last_round) {
       sweep([&](const DeviceMesh &mm, dim3 grid) {
-        hipLaunchKernelGGL((k_high_order<E, true>), grid, block, 0, launch_stream, eparams, mm, nw.U.ptr,
-                           d_bounds.ptr, d_pij.ptr, d_lij.ptr, d_lij_next.ptr, fused_sadd);
+        if (RYUJIN_SKIP_UNLIMITED && L.max_row_len <= (uint32_t)kCachedWidth)
+          hipLaunchKernelGGL((k_high_order_last_cached<E, kCachedWidth, (DIM == 3 ? 9 : kCachedWidth)>), grid,
+                             block, 0, launch_stream, eparams, mm, nw.U.ptr, d_pij.ptr, d_lij.ptr, fused_sadd);
+        else
+          hipLaunchKernelGGL((k_high_order<E, true>), grid, block, 0, launch_stream, eparams, mm, nw.U.ptr,
+                             d_bounds.ptr, d_pij.ptr, d_lij.ptr, d_lij_next.ptr, fused_sadd);
       }, false);
     } else {
-      constexpr int kCachedWidth = DIM == 1 ? 3 : (DIM == 2 ? 9 : 27);
       /* 3-D: cache all l_ij and the P_ij of the first RYUJIN_HO_CP_3D columns (0: two-pass kernel) */
       constexpr int kCachedP = DIM == 3 ? (RYUJIN_HO_CP_3D > 0 ? RYUJIN_HO_CP_3D : 27) : kCachedWidth;
       sweep([&](const DeviceMesh &mm, dim3 grid) {
@@ -1638,6 +1670,8 @@ int ryujin_hip_state_alloc(ryujin_hip_ctx *ctx, int *handle)
       h = (int)ctx->states.size() - 1;
       ctx->states[h]->U.alloc((size_t)ctx->L.n_relevant * ctx->KP);
       ctx->states[h]->prec.alloc((size_t)ctx->L.n_relevant * ctx->NPREC);
+      if (ctx->params.equation == RYUJIN_EQ_EULER && RYUJIN_DIJ_RECORDS)
+        ctx->states[h]->rrec.alloc((size_t)ctx->L.n_relevant * ((6 + ctx->dim + 1) / 2 * 2));
     }
     ctx->states[h]->used = true;
     *handle = h;
@@ -2022,6 +2056,25 @@ namespace
       const double U_i[5] = {v[0], v[1], v[2], v[3], v[4]}, U_j[5] = {v[5], v[6], v[7], v[8], v[9]},
                    c[3] = {v[10], v[11], v[12]};
       out[q] = Euler<3>::dij_from_states(PE, U_i, U_j, c);
+    } else if (which == RYUJIN_DEBUG_EULER_DIJ_RECORDS_2D) {
+      const double *v = in + q * 10;
+      const double U_i[4] = {v[0], v[1], v[2], v[3]}, U_j[4] = {v[4], v[5], v[6], v[7]}, c[2] = {v[8], v[9]};
+      double r_i[Euler<2>::RS], r_j[Euler<2>::RS];
+      Euler<2>::riemann_record(PE, U_i, r_i);
+      Euler<2>::riemann_record(PE, U_j, r_j);
+      out[q] = PE.riemann_newton_max_iterations == 0 && PE.rarefaction_power > 0
+                   ? Euler<2>::dij_from_records<false>(PE, r_i, r_j, c)
+                   : Euler<2>::dij_from_records<true>(PE, r_i, r_j, c);
+    } else if (which == RYUJIN_DEBUG_EULER_DIJ_RECORDS_3D) {
+      const double *v = in + q * 13;
+      const double U_i[5] = {v[0], v[1], v[2], v[3], v[4]}, U_j[5] = {v[5], v[6], v[7], v[8], v[9]},
+                   c[3] = {v[10], v[11], v[12]};
+      double r_i[Euler<3>::RS], r_j[Euler<3>::RS];
+      Euler<3>::riemann_record(PE, U_i, r_i);
+      Euler<3>::riemann_record(PE, U_j, r_j);
+      out[q] = PE.riemann_newton_max_iterations == 0 && PE.rarefaction_power > 0
+                   ? Euler<3>::dij_from_records<false>(PE, r_i, r_j, c)
+                   : Euler<3>::dij_from_records<true>(PE, r_i, r_j, c);
     }
   }
 } // namespace
@@ -2037,8 +2090,10 @@ int ryujin_hip_debug_function(int device, const ryujin_hip_params *params, int w
     case RYUJIN_DEBUG_EULER_RIEMANN: n_in = 8; n_out = 1; break;
     case RYUJIN_DEBUG_EULER_LIMIT_1D: n_in = 9; n_out = 3; break;
     case RYUJIN_DEBUG_SW_RIEMANN: n_in = 6; n_out = 2; break;
-    case RYUJIN_DEBUG_EULER_DIJ_2D: n_in = 10; n_out = 1; break;
-    case RYUJIN_DEBUG_EULER_DIJ_3D: n_in = 13; n_out = 1; break;
+    case RYUJIN_DEBUG_EULER_DIJ_2D:
+    case RYUJIN_DEBUG_EULER_DIJ_RECORDS_2D: n_in = 10; n_out = 1; break;
+    case RYUJIN_DEBUG_EULER_DIJ_3D:
+    case RYUJIN_DEBUG_EULER_DIJ_RECORDS_3D: n_in = 13; n_out = 1; break;
     default: throw HipError(RYUJIN_ERR_ARG, "unknown debug function");
     }
     HIP_CHECK(hipSetDevice(device));

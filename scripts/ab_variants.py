@@ -21,13 +21,14 @@ ap.add_argument("--develop", type=int, default=300)
 ap.add_argument("--steps", type=int, default=15)
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--dim", type=int, default=2)
+ap.add_argument("--length", type=float, default=1.25, help="3-D: channel length in units")
 ap.add_argument("variants", nargs="+")
 args = ap.parse_args()
 
 if args.dim == 2:
     spec = offline.mach3_step_2d(args.cells_per_unit)
 else:
-    spec = offline.cylinder_channel_3d(args.cells_per_unit, length_units=2)
+    spec = offline.cylinder_channel_3d(args.cells_per_unit, length_units=args.length)
 off = offline.SyntheticOffline(spec)
 U0 = euler_uniform(off.positions)
 dirichlet = euler_uniform(off.b_positions)
@@ -42,6 +43,8 @@ for v in args.variants:
     lib.ryujin_hip_set_timers.argtypes = [C.c_void_p, C.c_int]
     lib.ryujin_hip_get_timers.argtypes = [C.c_void_p, capi.c_double_p]
     lib.ryujin_hip_synchronize.argtypes = [C.c_void_p]
+    lib.ryujin_hip_event_record.argtypes = [C.c_void_p, C.c_int]
+    lib.ryujin_hip_event_elapsed_ms.argtypes = [C.c_void_p, capi.c_double_p]
     m = HyperbolicModule(off, equation=capi.EQ_EULER, backend=(lib, "ryujin_hip_"))
     m.cfl = 0.9
     if U_dev is None:
@@ -53,18 +56,23 @@ for v in args.variants:
     for _ in range(3):
         drv.update()
     lib.ryujin_hip_set_timers(m._ctx, 1)
-    mods[name] = (lib, m, drv, np.zeros(8), [0])
+    mods[name] = (lib, m, drv, np.zeros(8), [0, 0.0])
 
 tmp = (C.c_double * 8)()
 for r in range(args.rounds):
     for name, (lib, m, drv, acc, cnt) in mods.items():
+        lib.ryujin_hip_event_record(m._ctx, 0)
         for _ in range(args.steps):
             drv.update()
             lib.ryujin_hip_get_timers(m._ctx, tmp)
             acc += np.array(tmp[:])
             cnt[0] += 1
+        lib.ryujin_hip_event_record(m._ctx, 1)
+        ms = C.c_double()
+        lib.ryujin_hip_event_elapsed_ms(m._ctx, C.byref(ms))
+        cnt[1] += ms.value
 names = ["dij_alpha", "diag", "low_order", "pij_lij", "ho_next", "ho_last"]
-print("%-8s " % "variant" + " ".join("%9s" % n for n in names) + "     total(2-7)")
+print("%-8s " % "variant" + " ".join("%9s" % n for n in names) + "     total(2-7)  update(events, incl. step 1 and host syncs)")
 for name, (lib, m, drv, acc, cnt) in mods.items():
     ms = acc[1:7] / cnt[0]
-    print("%-8s " % name + " ".join("%9.4f" % x for x in ms) + "  %9.4f" % ms.sum(), flush=True)
+    print("%-8s " % name + " ".join("%9.4f" % x for x in ms) + "  %9.4f  %9.4f" % (ms.sum(), cnt[1] / cnt[0]), flush=True)

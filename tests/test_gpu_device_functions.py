@@ -106,10 +106,13 @@ def test_device_sw_riemann_solver_against_the_reference_baseline(oracle, golden_
         assert abs(l - l_ref) <= 1e-13 * abs(l_ref), (l, l_ref)
 
 
+@pytest.mark.parametrize("records", [False, True])
 @pytest.mark.parametrize("dim", [2, 3])
-def test_device_dij_against_the_oracle_on_random_states(oracle, dim):
+def test_device_dij_against_the_oracle_on_random_states(oracle, dim, records):
     """d_ij = |c_ij| lambda_max(U_i, U_j, c_ij/|c_ij|) for 200 k random admissible state pairs and directions,
-    Mach numbers up to 5, pressure ratios up to 1e6: 1e-12 relative (the stated d_ij contract)."""
+    Mach numbers up to 5, pressure ratios up to 1e6: 1e-12 relative (the stated d_ij contract) -- through
+    dij_from_states (the reference's operation order) and through the per-node Riemann records of the sweep
+    (k_dij_records: a different but equivalent evaluation, see euler_device.hpp)."""
     rng = np.random.default_rng(7)
     n = 200_000
     params = oracle.default_params(capi.EQ_EULER, dim)
@@ -129,8 +132,9 @@ def test_device_dij_against_the_oracle_on_random_states(oracle, dim):
 
     U_i, U_j = states(), states()
     c = rng.normal(size=(n, dim)) * 10.0 ** rng.uniform(-4, 0, n)[:, None]
-    got = _device(params, capi.DEBUG_EULER_DIJ_2D if dim == 2 else capi.DEBUG_EULER_DIJ_3D,
-                  np.hstack([U_i, U_j, c]), 1)[:, 0]
+    which = {(2, False): capi.DEBUG_EULER_DIJ_2D, (3, False): capi.DEBUG_EULER_DIJ_3D,
+             (2, True): capi.DEBUG_EULER_DIJ_RECORDS_2D, (3, True): capi.DEBUG_EULER_DIJ_RECORDS_3D}[(dim, records)]
+    got = _device(params, which, np.hstack([U_i, U_j, c]), 1)[:, 0]
     lib = oracle.load()
     ref = np.empty(n)
     dp = capi.c_double_p
