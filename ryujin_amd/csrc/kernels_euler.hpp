@@ -75,6 +75,12 @@ namespace ryujin_hip
 #ifndef RYUJIN_PREFETCH
 #define RYUJIN_PREFETCH 1 /* software pipelining of the stencil loops of steps 4 and 5 (column c+1 in flight while c is processed); 0: plain loads, fewer live registers */
 #endif
+#ifndef RYUJIN_FUSE_DIJ_ALPHA
+#define RYUJIN_FUSE_DIJ_ALPHA 1 /* step 2 as one kernel on top of the node records (k_dij_alpha_records) */
+#endif
+#ifndef RYUJIN_RECOMPUTE_P_3D
+#define RYUJIN_RECOMPUTE_P_3D 0 /* P_ij recompute in step 5 (instead of store in 4 / load in 5) also in 3-D */
+#endif
 #ifndef RYUJIN_PIPE_DIJ
 #define RYUJIN_PIPE_DIJ 0 /* A/B: the pipelined variant spills (60 B scratch per lane) and is 6 % slower */
 #endif
@@ -594,6 +600,87 @@ namespace ryujin_hip
       if (mine)
         dij[pos] = E::template dij_from_records<GENERAL>(P, rec_i, rec_j, c_ij);
     }
+  }
+
+  /* Step 2 in ONE kernel on top of the node records: the indicator sweep streams the stencil at HBM speed and
+   * leaves the VALU mostly idle, the Riemann sweep on records is short and needs few registers -- fused, its
+   * arithmetic hides behind the indicator's loads and the column indices / c_ij are read once instead of twice
+   * (the round-1 fusion lost because the old Riemann solver held 200+ registers). */
+  template <int DIM, bool GENERAL>
+  __global__ void __launch_bounds__(kBlock, RYUJIN_OCC_DIJ)
+  k_dij_alpha_records(const EulerParams P, const DeviceMesh M, const double *__restrict__ U,
+                      const double *__restrict__ prec, const double *__restrict__ rec,
+                      double *__restrict__ dij, double *__restrict__ alpha)
+  {
+    using E = Euler<DIM>;
+    constexpr int K = E::K, RS = E::RS;
+    const RowCtx r = row_context(M);
+    if (!r.valid)
+      return;
+    const bool row_active = r.len > 1;
+    const uint32_t i = row_active ? r.row : (r.row < M.n_owned ? r.row : M.n_owned - 1);
+    const double2 *__restrict__ prec2 = reinterpret_cast<const double2 *>(prec);
+    const uint32_t *__restrict__ cols = M.cols;
+    const double *__restrict__ cij = M.cij;
+
+    double U_i[K], rec_i[RS];
+    load_state<K>(U, i, U_i);
+    {
+      const double2 *b = reinterpret_cast<const double2 *>(rec + (size_t)i * RS);
+#pragma unroll
+      for (int g = 0; g < RS / 2; ++g) {
+        const double2 t = b[g];
+        rec_i[2 * g] = t.x;
+        rec_i[2 * g + 1] = t.y;
+      }
+    }
+    typename E::Indicator indicator;
+    indicator.reset(P, U_i, prec2[i]);
+
+    uint32_t j_n = ld_stream(cols + ((uint64_t)r.base * 64 + r.lane));
+    uint32_t j_nn = r.width > 1 ? ld_stream(cols + (((uint64_t)r.base + 1) * 64 + r.lane)) : i;
+    double c_n[DIM], U_n[K];
+    load_entry<DIM>(cij, r.base, r.lane, c_n);
+    load_state<K>(U, j_n, U_n);
+    double2 prec_n = prec2[j_n];
+    for (uint32_t c = 0; c < r.width; ++c) {
+      const uint64_t colbase = (uint64_t)r.base + c;
+      const uint32_t j = j_n;
+      double c_ij[DIM], U_j[K];
+#pragma unroll
+      for (int d = 0; d < DIM; ++d)
+        c_ij[d] = c_n[d];
+#pragma unroll
+      for (int q = 0; q < K; ++q)
+        U_j[q] = U_n[q];
+      const double2 prec_j = prec_n;
+      if (c + 1 < r.width) {
+        j_n = j_nn;
+        load_entry<DIM>(cij, colbase + 1, r.lane, c_n);
+        load_state<K>(U, j_n, U_n);
+        prec_n = prec2[j_n];
+        j_nn = (c + 2 < r.width) ? ld_stream(cols + ((colbase + 2) * 64 + r.lane)) : i;
+      }
+      const bool active = row_active && c < r.len;
+      if (active)
+        indicator.accumulate(P, U_j, prec_j, c_ij);
+      /* upper triangle only (:394-408) */
+      const bool mine = active && c > 0 && j > i;
+      if (__any(mine)) {
+        double rec_j[RS];
+        const double2 *b = reinterpret_cast<const double2 *>(rec + (size_t)j * RS);
+#pragma unroll
+        for (int g = 0; g < RS / 2; ++g) {
+          const double2 t = b[g];
+          rec_j[2 * g] = t.x;
+          rec_j[2 * g + 1] = t.y;
+        }
+        if (mine)
+          dij[colbase * 64 + r.lane] = E::template dij_from_records<GENERAL>(P, rec_i, rec_j, c_ij);
+      }
+    }
+    if (row_active)
+      alpha[i] = indicator.alpha(P, M.mi[i] * M.measure_of_omega_inverse);
   }
 
   /* ------------------------------------------------------------------ step 3 */

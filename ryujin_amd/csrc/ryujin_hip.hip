@@ -332,6 +332,7 @@ struct ryujin_hip_ctx {
 
   /* profiling */
   bool timers_enabled = false;
+  bool step2_split = false; /* step 2 ran as indicator kernel + Riemann kernel (event 8 recorded in between) */
   /* device-resident RK driver: per-step host synchronisation is deferred to the end of the RK step */
   bool deferred = false;
   int rk_stage = 0; /* selects the event set while deferred */
@@ -963,7 +964,11 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
   hipLaunchKernelGGL(k_reset_scalars, dim3(1), dim3(1), 0, stream, tau_max_in,
                      (!deferred || rk_stage == 0) ? 1 : 0, d_scalars.ptr);
 
+  bool euler_fast_riemann = false;
+  if constexpr (is_euler)
+    euler_fast_riemann = eparams.riemann_newton_max_iterations == 0 && eparams.rarefaction_power > 0;
   mark(0);
+  step2_split = false;
   /* Step 2: d_ij (upper triangle), alpha_i; ghost alpha (:341-424) */
   if constexpr (is_aeos) {
     if (L.max_row_len > 32)
@@ -973,6 +978,7 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
                          d_alpha.ptr);
     }, true);
     mark(8);
+    step2_split = true;
     exchange_vector(d_alpha.ptr, 1, true);
     const bool pending = comm_pending;
     comm_pending = false; /* k_dij does not read alpha: do not join the exchange yet */
@@ -987,13 +993,25 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
                          old.prec.ptr, d_dij.ptr, d_alpha.ptr);
     }, true);
     mark(8);
+    step2_split = true;
     exchange_vector(d_alpha.ptr, 1, true);
+  } else if (is_euler && RYUJIN_DIJ_RECORDS && RYUJIN_FUSE_DIJ_ALPHA && euler_fast_riemann) {
+    /* (the general Riemann path -- Newton iterations or a non-integral exponent -- holds twice the
+     * registers and keeps the two-kernel form below) */
+    if constexpr (is_euler) {
+      sweep([&](const DeviceMesh &mm, dim3 grid) {
+        hipLaunchKernelGGL((k_dij_alpha_records<DIM, false>), grid, block, 0, launch_stream, eparams, mm,
+                           old.U.ptr, old.prec.ptr, old.rrec.ptr, d_dij.ptr, d_alpha.ptr);
+      }, true);
+      exchange_vector(d_alpha.ptr, 1, true);
+    }
   } else if (RYUJIN_SPLIT_DIJ && L.max_row_len <= 32) {
     sweep([&](const DeviceMesh &mm, dim3 grid) {
       hipLaunchKernelGGL(k_alpha<E>, grid, block, 0, launch_stream, eparams, mm, old.U.ptr, old.prec.ptr,
                          d_alpha.ptr);
     }, true);
     mark(8); /* end of the indicator kernel: sweep_ms[0] = k_alpha alone */
+    step2_split = true;
     exchange_vector(d_alpha.ptr, 1, true); /* overlaps with the Riemann sweep as well */
     const bool pending = comm_pending;
     comm_pending = false; /* k_dij does not read alpha: do not join the exchange yet */
@@ -1074,7 +1092,7 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
   /* Euler, stages == 0, limiter on: P_ij (part 1) is recomputed in step 5 instead of stored here.
    * A/B on MI355X: -7 % per update in 2-D (k=4, 9 columns); +1 % in 3-D where step 5 turns
    * register/VALU bound (k=5, 27 columns), so only for dim <= 2. */
-  const bool recompute_p = is_euler && DIM <= 2 && stages == 0 && params.limiter_iterations != 0 &&
+  const bool recompute_p = is_euler && (DIM <= 2 || RYUJIN_RECOMPUTE_P_3D) && stages == 0 && params.limiter_iterations != 0 &&
                            RYUJIN_RECOMPUTE_P && !dg;
   sweep([&](const DeviceMesh &mm, dim3 grid) {
     if constexpr (is_euler) {
@@ -1227,7 +1245,7 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
       sweep_ms[k + 1] = ms;
     }
     sweep_ms[0] = 0.;
-    if (RYUJIN_SPLIT_DIJ && L.max_row_len <= 32) {
+    if (step2_split) {
       float ms = 0.f;
       HIP_CHECK(hipEventElapsedTime(&ms, ev[0], ev[8]));
       sweep_ms[0] = ms;
@@ -1389,7 +1407,7 @@ int ryujin_hip_ctx::time_step(int scheme, int h_state, int n_tmp, const int *h_t
           HIP_CHECK(hipEventElapsedTime(&ms, ev_rk[st][k], ev_rk[st][k + 1]));
           sweep_ms_accum[k + 1] += ms;
         }
-        if (RYUJIN_SPLIT_DIJ && L.max_row_len <= 32) {
+        if (step2_split) {
           float ms = 0.f;
           HIP_CHECK(hipEventElapsedTime(&ms, ev_rk[st][0], ev_rk[st][8]));
           sweep_ms_accum[0] += ms;
