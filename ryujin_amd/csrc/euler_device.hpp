@@ -15,9 +15,6 @@
 
 #include <cfloat>
 
-#ifndef RYUJIN_SCHED_FENCE
-#define RYUJIN_SCHED_FENCE 0
-#endif
 
 namespace ryujin_hip
 {
@@ -36,14 +33,6 @@ namespace ryujin_hip
 
 #define RYUJIN_DEV __device__ __forceinline__
 
-/* Scheduling fence between independent blocks of the Riemann solver: keeps the compiler from
- * interleaving the expansions of several pow/sqrt/div at once (which needs >250 registers) so that the
- * sweep fits a higher occupancy without spilling. Purely a scheduling hint: no effect on results. */
-#if RYUJIN_SCHED_FENCE
-#define RYUJIN_FENCE() __builtin_amdgcn_sched_barrier(0)
-#else
-#define RYUJIN_FENCE() ((void)0)
-#endif
 
   /*
    * ryujin::pow (source/simd.template.h:196-272) on the device.
@@ -60,10 +49,6 @@ namespace ryujin_hip
    * (the reference's own pow variants already differ in the last digits).
    * Everything else (x <= 0, subnormal, inf, nan) is forwarded to ocml's pow().
    */
-#ifndef RYUJIN_POW_SELFCONTAINED
-#define RYUJIN_POW_SELFCONTAINED 1
-#endif
-#if RYUJIN_POW_SELFCONTAINED
   /* Self-contained: the special cases (zero, negative base, inf, nan, subnormal, overflow) are resolved with a
    * handful of selects instead of forwarding to ocml's pow(). Inlined ocml pow() costs every kernel that calls
    * pow its register high-water mark (~100 VGPRs on top of the state live at the call site), although the
@@ -147,63 +132,6 @@ namespace ryujin_hip
       result = 1.;
     return result;
   }
-#else
-  RYUJIN_DEV double dev_pow(double x, double y)
-  {
-    const long long bits = __double_as_longlong(x);
-    const int biased = (int)((bits >> 52) & 0x7ff);
-    if (__builtin_expect(bits <= 0 || biased == 0 || biased == 0x7ff, 0))
-      return pow(x, y);
-
-    /* x = m * 2^e, m in [sqrt(1/2), sqrt(2)) */
-    int e = biased - 1023;
-    double m = __longlong_as_double((bits & 0x000fffffffffffffLL) | 0x3ff0000000000000LL);
-    if (m > 1.4142135623730951) {
-      m *= 0.5;
-      e += 1;
-    }
-    const double s = (m - 1.) / (m + 1.);
-    const double s2 = s * s;
-    double p = 2. / 21.;
-    p = __builtin_fma(p, s2, 2. / 19.);
-    p = __builtin_fma(p, s2, 2. / 17.);
-    p = __builtin_fma(p, s2, 2. / 15.);
-    p = __builtin_fma(p, s2, 2. / 13.);
-    p = __builtin_fma(p, s2, 2. / 11.);
-    p = __builtin_fma(p, s2, 2. / 9.);
-    p = __builtin_fma(p, s2, 2. / 7.);
-    p = __builtin_fma(p, s2, 2. / 5.);
-    p = __builtin_fma(p, s2, 2. / 3.);
-    /* log m = 2s + s^3 p */
-    const double log_m = __builtin_fma(s * s2, p, 2. * s);
-    constexpr double ln2_hi = 6.93147180369123816490e-01; /* 0x3fe62e42fee00000 */
-    constexpr double ln2_lo = 1.90821492927058770002e-10; /* 0x3dea39ef35793c76 */
-    const double ed = (double)e;
-    const double log_x = __builtin_fma(ed, ln2_hi, __builtin_fma(ed, ln2_lo, log_m));
-
-    const double z = y * log_x;
-    if (__builtin_expect(!(fabs(z) < 700.), 0))
-      return pow(x, y);
-    const double n = __builtin_rint(z * 1.44269504088896338700e+00);
-    double r = __builtin_fma(-n, ln2_hi, z);
-    r = __builtin_fma(-n, ln2_lo, r);
-    double q = 1. / 6227020800.;               /* 1/13! */
-    q = __builtin_fma(q, r, 1. / 479001600.);  /* 1/12! */
-    q = __builtin_fma(q, r, 1. / 39916800.);
-    q = __builtin_fma(q, r, 1. / 3628800.);
-    q = __builtin_fma(q, r, 1. / 362880.);
-    q = __builtin_fma(q, r, 1. / 40320.);
-    q = __builtin_fma(q, r, 1. / 5040.);
-    q = __builtin_fma(q, r, 1. / 720.);
-    q = __builtin_fma(q, r, 1. / 120.);
-    q = __builtin_fma(q, r, 1. / 24.);
-    q = __builtin_fma(q, r, 1. / 6.);
-    q = __builtin_fma(q, r, 0.5);
-    q = __builtin_fma(q, r, 1.);
-    q = __builtin_fma(q, r, 1.);
-    return ldexp(q, (int)n);
-  }
-#endif
   RYUJIN_DEV double positive_part(double x) { return fmax(0., x); }
   RYUJIN_DEV double negative_part(double x) { return -fmin(0., x); }
 
@@ -512,11 +440,9 @@ namespace ryujin_hip
         const double numerator = positive_part(rd_i.a + rd_j.a - factor * (rd_j.u - rd_i.u));
         const double denominator =
             rd_i.a * dev_pow(rd_i.p * inv_p_j, -factor * P.gamma_inverse) + rd_j.a;
-        RYUJIN_FENCE();
         const double exponent = 2.0 * P.gamma * P.gamma_minus_one_inverse;
         rarefaction = rd_j.p * dev_pow(numerator / denominator, exponent);
       }
-      RYUJIN_FENCE();
 
       /* p_star_failsafe :330-374 */
       double failsafe;
@@ -533,7 +459,6 @@ namespace ryujin_hip
         const double base = (-b + sqrt(b * b - 4. * a * c)) / (2. * a);
         failsafe = base * base;
       }
-      RYUJIN_FENCE();
       const double p_star_tilde = fmin(rarefaction, failsafe);
 
       /* phi_of_p_max :122-149 */
@@ -547,7 +472,6 @@ namespace ryujin_hip
         const double value_j = (p_max - rd_j.p) / sqrt(radicand_inverse_j);
         phi_p_max = value_i + value_j + rd_j.u - rd_i.u;
       }
-      RYUJIN_FENCE();
 
       double p_2 = phi_p_max < 0. ? p_star_tilde : fmin(p_max, p_star_tilde);
 
@@ -593,9 +517,7 @@ namespace ryujin_hip
       for (int d = 0; d < DIM; ++d)
         n[d] = c[d] * inverse_norm;
       const RiemannData rd_i = riemann_data_from_state(P, U_i, n);
-      RYUJIN_FENCE();
       const RiemannData rd_j = riemann_data_from_state(P, U_j, n);
-      RYUJIN_FENCE();
       return norm * riemann_compute(P, rd_i, rd_j);
     }
 

@@ -55,37 +55,17 @@ namespace ryujin_hip
      * that later stage: hyperbolic_module.template.h:1194-1207 throws first) */
     int restart_accum;
     int tau_invalid_accum;
+    /* arguments of the running step, stored by k_step_begin for finalize_tau() */
+    double tau_in;
+    int use_device_tau;
+    int stage;
   };
   constexpr int kStageCode = 100;
 
   /* minimum waves per SIMD requested from the register allocator for the heavy sweeps (second
    * __launch_bounds__ argument): 512 registers / waves. Tuned on MI355X, see DESIGN.md. */
-#ifndef RYUJIN_XCD_REMAP
-#define RYUJIN_XCD_REMAP 0 /* A/B on MI355X: no gain in 2-D (1.80 vs 1.77 ms), +0.4 % in 3-D: the 256 MiB Infinity Cache already serves the cross-XCD reuse */
-#endif
 #ifndef RYUJIN_HO_CP_3D
 #define RYUJIN_HO_CP_3D 14 /* step 6 in 3-D: 0 = two-pass kernel, n = l_ij and the first n P_ij columns in registers. A/B on MI355X (3.98 M gridpoints): 3.07 ms (0), 2.64 (1), 2.43 (8), 2.24 (14), 2.36 (18) */
-#endif
-#ifndef RYUJIN_SPLIT_DIJ
-#define RYUJIN_SPLIT_DIJ 1
-#endif
-#ifndef RYUJIN_DIJ_RECORDS
-#define RYUJIN_DIJ_RECORDS 1 /* Riemann sweep on per-node records (euler_device.hpp, "node records") */
-#endif
-#ifndef RYUJIN_PREFETCH
-#define RYUJIN_PREFETCH 1 /* software pipelining of the stencil loops of steps 4 and 5 (column c+1 in flight while c is processed); 0: plain loads, fewer live registers */
-#endif
-#ifndef RYUJIN_FUSE_DIJ_ALPHA
-#define RYUJIN_FUSE_DIJ_ALPHA 1 /* step 2 as one kernel on top of the node records (k_dij_alpha_records) */
-#endif
-#ifndef RYUJIN_RECOMPUTE_P_3D
-#define RYUJIN_RECOMPUTE_P_3D 0 /* P_ij recompute in step 5 (instead of store in 4 / load in 5) also in 3-D */
-#endif
-#ifndef RYUJIN_PIPE_DIJ
-#define RYUJIN_PIPE_DIJ 0 /* A/B: the pipelined variant spills (60 B scratch per lane) and is 6 % slower */
-#endif
-#ifndef RYUJIN_RECOMPUTE_P
-#define RYUJIN_RECOMPUTE_P 1
 #endif
 #ifndef RYUJIN_OCC_DIJ
 #define RYUJIN_OCC_DIJ 2
@@ -260,15 +240,7 @@ namespace ryujin_hip
   {
     RowCtx r;
     r.lane = threadIdx.x & 63;
-#if RYUJIN_XCD_REMAP
-    /* Workgroups are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8, observed, not a
-     * contract; speed only). Give every XCD a contiguous range of slices so that the U_j / r_j /
-     * alpha_j gathers of neighbouring grid lines hit the same 4 MiB L2. gridDim.x is a multiple of 8. */
-    const uint32_t blocks_per_xcd = gridDim.x >> 3;
-    const uint32_t block = (blockIdx.x & 7u) * blocks_per_xcd + (blockIdx.x >> 3);
-#else
     const uint32_t block = blockIdx.x;
-#endif
     r.slice = M.slice_begin + block * kWavesPerBlock + (threadIdx.x >> 6);
     r.valid = r.slice < M.slice_end;
     if (!r.valid) {
@@ -412,44 +384,16 @@ namespace ryujin_hip
 
     const uint32_t *__restrict__ cols = M.cols;
     const double *__restrict__ cij = M.cij;
-#if RYUJIN_PIPE_DIJ
-    /* software pipeline: the loads of column c+1 (and the column index of c+2) are in flight while
-     * column c is processed, so the gather latency hides behind the Riemann solve */
-    uint32_t j_n = ld_stream(cols + ((uint64_t)r.base * 64 + r.lane));
-    uint32_t j_nn = r.width > 1 ? ld_stream(cols + (((uint64_t)r.base + 1) * 64 + r.lane)) : i;
-    double c_n[DIM], U_n[K];
-    load_entry<DIM>(cij, r.base, r.lane, c_n);
-    load_state<K>(U, j_n, U_n);
-    double2 prec_n = prec2[j_n];
-#endif
 
     for (uint32_t c = 0; c < r.width; ++c) {
       const uint64_t colbase = (uint64_t)r.base + c;
       const uint64_t pos = colbase * 64 + r.lane;
       const bool active = row_active && c < r.len;
       double c_ij[DIM], U_j[K];
-#if RYUJIN_PIPE_DIJ
-      const uint32_t j = j_n;
-#pragma unroll
-      for (int d = 0; d < DIM; ++d)
-        c_ij[d] = c_n[d];
-#pragma unroll
-      for (int q = 0; q < K; ++q)
-        U_j[q] = U_n[q];
-      const double2 prec_j = prec_n;
-      if (c + 1 < r.width) {
-        j_n = j_nn;
-        load_entry<DIM>(cij, colbase + 1, r.lane, c_n);
-        load_state<K>(U, j_n, U_n);
-        prec_n = prec2[j_n];
-        j_nn = (c + 2 < r.width) ? ld_stream(cols + ((colbase + 2) * 64 + r.lane)) : i;
-      }
-#else
       const uint32_t j = ld_stream(cols + (pos));
       load_entry<DIM>(cij, colbase, r.lane, c_ij);
       load_state<K>(U, j, U_j);
       const double2 prec_j = prec2[j];
-#endif
 
       if (active) {
         indicator.accumulate(P, U_j, prec_j, c_ij);
@@ -463,7 +407,7 @@ namespace ryujin_hip
       alpha[i] = indicator.alpha(P, M.mi[i] * M.measure_of_omega_inverse);
   }
 
-  /* Step 2 as two kernels (RYUJIN_SPLIT_DIJ): the streaming indicator sweep and the compute-bound
+  /* Step 2 as two kernels (shallow water; Euler with the general Riemann path): the streaming indicator sweep and the compute-bound
    * Riemann sweep have very different register needs; split, the Riemann kernel only touches the
    * upper-triangle columns (known from the per-row bitmask, no loads for the others) and runs at a
    * higher occupancy. */
@@ -790,39 +734,54 @@ namespace ryujin_hip
     publish_tau_min(scalars, wave_min(tau), r.lane);
   }
 
-  /* start of a step: tau_max := tau_max_in, per-step flags := 0 (accumulators untouched) */
-  __global__ void k_reset_scalars(const double tau_max_in, const int reset_accumulators,
-                                  DeviceScalars *__restrict__ scalars)
+  /* Start of a step (one thread): fold the restart flag of the PREVIOUS stage of a device-resident RK step
+   * into its accumulator, then tau_max := tau_max_in, per-step flags := 0, and remember the arguments that
+   * finalize_tau() needs. (Three single-thread kernels per step -- reset, finalize tau, accumulate flags -- were
+   * three dependent launches of ~5-8 us each; on small meshes that was a fifth of the update.) */
+  __global__ void k_step_begin(const double tau_max_in, const int reset_accumulators,
+                               const int accumulate_stage /* < 0: nothing to fold */, const double tau_in,
+                               const int use_device_tau, const int stage, DeviceScalars *__restrict__ scalars)
   {
-    scalars->tau_max_bits = (unsigned long long)__double_as_longlong(tau_max_in);
-    scalars->restart_needed = 0;
-    scalars->tau_invalid = 0;
     if (reset_accumulators) {
       scalars->restart_accum = 0;
       scalars->tau_invalid_accum = 0;
+    } else if (accumulate_stage >= 0) {
+      if (scalars->restart_needed && scalars->restart_accum < kStageCode - accumulate_stage)
+        scalars->restart_accum = kStageCode - accumulate_stage;
     }
+    scalars->tau_max_bits = (unsigned long long)__double_as_longlong(tau_max_in);
+    scalars->restart_needed = 0;
+    scalars->tau_invalid = 0;
+    scalars->tau_in = tau_in;
+    scalars->use_device_tau = use_device_tau;
+    scalars->stage = stage;
   }
 
-  /* tau = (tau_in == 0 ? tau_max : tau_in), validity check (:571-578); use_device_tau: later stages of
-   * a device-resident RK step reuse the tau of the first stage without a host round trip */
-  __global__ void k_finalize_tau(const double tau_in, const int use_device_tau, const int stage,
-                                 DeviceScalars *__restrict__ scalars)
+  /* tau = (tau_in == 0 ? tau_max : tau_in) with the validity check of :571-578, evaluated by EVERY thread of
+   * the step-4 kernel from the finished (and, on several ranks, all-reduced) tau_max -- the kernel boundary
+   * behind step 3 orders it. The first thread of the launch also publishes tau / the validity flags for the
+   * later sweeps and the host (idempotent when a sweep runs as an export and an interior launch).
+   * use_device_tau: later stages of a device-resident RK step reuse the tau of the first stage. */
+  RYUJIN_DEV double finalize_tau(DeviceScalars *scalars)
   {
     const double tau_max = __longlong_as_double((long long)scalars->tau_max_bits);
-    const int invalid = (isnan(tau_max) || isinf(tau_max) || !(tau_max > 0.)) ? 1 : 0;
-    scalars->tau_invalid = invalid;
-    if (invalid && scalars->tau_invalid_accum < kStageCode - stage)
-      scalars->tau_invalid_accum = kStageCode - stage;
-    if (use_device_tau) {
-      scalars->tau = scalars->tau_rk;
-    } else {
-      const double tau = (tau_in == 0. ? tau_max : tau_in);
+    const int use_device_tau = scalars->use_device_tau;
+    const double tau_in = scalars->tau_in;
+    const double tau = use_device_tau ? scalars->tau_rk : (tau_in == 0. ? tau_max : tau_in);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      const int invalid = (isnan(tau_max) || isinf(tau_max) || !(tau_max > 0.)) ? 1 : 0;
+      const int stage = scalars->stage;
+      scalars->tau_invalid = invalid;
+      if (invalid && scalars->tau_invalid_accum < kStageCode - stage)
+        scalars->tau_invalid_accum = kStageCode - stage;
       scalars->tau = tau;
-      scalars->tau_rk = tau;
+      if (!use_device_tau)
+        scalars->tau_rk = tau;
     }
+    return tau;
   }
 
-  /* end of a step: fold the (all-reduced) restart flag into the accumulator */
+  /* end of a device-resident RK step: fold the restart flag of the last stage into the accumulator */
   __global__ void k_accumulate_flags(const int stage, DeviceScalars *__restrict__ scalars)
   {
     if (scalars->restart_needed && scalars->restart_accum < kStageCode - stage)
@@ -844,7 +803,7 @@ namespace ryujin_hip
    * this sweep and the 8kS B/row load of step 5 for 8dS+8S B/row of c_ij, d_ij loads there). */
   template <int DIM, bool HAS_STAGES, bool STORE_P = true, bool DG = false>
   __global__ void __launch_bounds__(kBlock, (DIM == 3 && (HAS_STAGES || RYUJIN_OCC_LOW_3D_ALL) && RYUJIN_OCC_LOW_3D_STAGES) ? 1 : RYUJIN_OCC_LOW)
-  k_low_order(const EulerParams P, const DeviceMesh M, const DeviceScalars *__restrict__ scalars,
+  k_low_order(const EulerParams P, const DeviceMesh M, DeviceScalars *scalars,
               const double weight, const StageArgs<DIM> S, const double *__restrict__ U,
               const double *__restrict__ prec, const double *__restrict__ alpha,
               const double *__restrict__ dij, double *__restrict__ new_U, double *__restrict__ r_out,
@@ -857,7 +816,7 @@ namespace ryujin_hip
       return;
     const bool row_active = r.len > 1;
     const uint32_t i = row_active ? r.row : (r.row < M.n_owned ? r.row : M.n_owned - 1);
-    const double tau = scalars->tau;
+    const double tau = finalize_tau(scalars);
 
     double U_i[K], U_i_new[K], F_iH[K];
     load_state<K>(U, i, U_i);
@@ -879,7 +838,6 @@ namespace ryujin_hip
     /* software pipeline (see k_dij_alpha) */
     const uint32_t *__restrict__ cols = M.cols;
     const double *__restrict__ cij = M.cij;
-#if RYUJIN_PREFETCH
     uint32_t j_n = ld_stream(cols + ((uint64_t)r.base * 64 + r.lane));
     uint32_t j_nn = r.width > 1 ? ld_stream(cols + (((uint64_t)r.base + 1) * 64 + r.lane)) : i;
     double c_n[DIM], U_n[K];
@@ -888,13 +846,11 @@ namespace ryujin_hip
     load_state<K>(U, j_n, U_n);
     double alpha_n = alpha[j_n];
     double s_n = prec[(size_t)j_n * 2 + 0];
-#endif
 
     for (uint32_t c = 0; c < r.width; ++c) {
       const uint64_t colbase = (uint64_t)r.base + c;
       const bool active = row_active && c < r.len;
       double c_ij[DIM], U_j[K];
-#if RYUJIN_PREFETCH
       const uint32_t j = j_n;
 #pragma unroll
       for (int d = 0; d < DIM; ++d)
@@ -912,14 +868,6 @@ namespace ryujin_hip
         s_n = prec[(size_t)j_n * 2 + 0];
         j_nn = (c + 2 < r.width) ? ld_stream(cols + ((colbase + 2) * 64 + r.lane)) : i;
       }
-#else
-      const uint32_t j = ld_stream(cols + (colbase * 64 + r.lane));
-      load_entry<DIM>(cij, colbase, r.lane, c_ij);
-      const double d_ij = dij[colbase * 64 + r.lane];
-      load_state<K>(U, j, U_j);
-      const double alpha_j = alpha[j];
-      const double s_j = prec[(size_t)j * 2 + 0];
-#endif
 
       if (!active)
         continue;

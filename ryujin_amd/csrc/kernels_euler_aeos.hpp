@@ -180,7 +180,7 @@ namespace ryujin_hip
   /* step 4 (:597-884) with Limiter::{reset,accumulate,bounds} of euler_aeos/limiter.h:258-410 */
   template <int DIM, bool HAS_STAGES>
   __global__ void __launch_bounds__(kBlock, (DIM == 3 && RYUJIN_OCC_LOW_3D_STAGES) ? 1 : RYUJIN_OCC_LOW)
-  k_low_order_aeos(const EulerAeosParams P, const DeviceMesh M, const DeviceScalars *__restrict__ scalars,
+  k_low_order_aeos(const EulerAeosParams P, const DeviceMesh M, DeviceScalars *scalars,
                    const double weight, const StageArgs<DIM> S, const double *__restrict__ U,
                    const double *__restrict__ prec, const double *__restrict__ alpha,
                    const double *__restrict__ dij, double *__restrict__ new_U, double *__restrict__ r_out,
@@ -193,7 +193,7 @@ namespace ryujin_hip
       return;
     const bool row_active = r.len > 1;
     const uint32_t i = row_active ? r.row : (r.row < M.n_owned ? r.row : M.n_owned - 1);
-    const double tau = scalars->tau;
+    const double tau = finalize_tau(scalars);
 
     double U_i[K], U_i_new[K], F_iH[K];
     load_state<K>(U, i, U_i);

@@ -13,9 +13,6 @@
 
 #include "kernels_euler.hpp"
 
-#ifndef RYUJIN_SKIP_UNLIMITED
-#define RYUJIN_SKIP_UNLIMITED 1
-#endif
 
 namespace ryujin_hip
 {
@@ -196,7 +193,6 @@ namespace ryujin_hip
     bool all_ok = true;
     unsigned long long undecided_mask = 0;
 
-#if RYUJIN_PREFETCH
     /* software pipeline: loads of column c+1 are in flight while column c is processed */
     uint32_t j_n = r.width > 1 ? ld_stream(cols + (((uint64_t)r.base + 1) * 64 + r.lane)) : i;
     uint32_t j_nn = r.width > 2 ? ld_stream(cols + (((uint64_t)r.base + 2) * 64 + r.lane)) : i;
@@ -211,14 +207,12 @@ namespace ryujin_hip
       mjinv_n = mi_inv[j_n];
       alpha_n = alpha[j_n];
     }
-#endif
 
     for (uint32_t c = 1; c < r.width; ++c) {
       const uint64_t colbase = (uint64_t)r.base + c;
       const uint64_t pos = colbase * 64 + r.lane;
       const bool active = row_active && c < r.len;
       double c_ij[DIM], U_j[K], F_jH[K];
-#if RYUJIN_PREFETCH
 #pragma unroll
       for (int d = 0; d < DIM; ++d)
         c_ij[d] = c_n[d];
@@ -239,16 +233,6 @@ namespace ryujin_hip
         alpha_n = alpha[j_n];
         j_nn = (c + 2 < r.width) ? ld_stream(cols + ((colbase + 2) * 64 + r.lane)) : i;
       }
-#else
-      const uint32_t j = ld_stream(cols + pos);
-      load_entry<DIM>(cij, colbase, r.lane, c_ij);
-      const double d_ij = dij[pos];
-      const double m_ij = ld_stream(mij + pos);
-      load_state<K>(old_U, j, U_j);
-      load_state<K>(r_in, j, F_jH);
-      const double m_j_inv = mi_inv[j];
-      const double alpha_j = alpha[j];
-#endif
       if (!active)
         continue;
 
@@ -339,10 +323,8 @@ namespace ryujin_hip
       const double l_a = lij[pos];
       const double l_b = lij[idx_t[pos]];
       const double l_ij = fmin(l_a, l_b);
-#if RYUJIN_SKIP_UNLIMITED
       if (LAST_ROUND && !__any(active && l_ij != 0.))
         continue;
-#endif
       double p_ij[K];
       load_entry<K>(pij, colbase, r.lane, p_ij);
       if (!active)
@@ -380,13 +362,11 @@ namespace ryujin_hip
         const double l_a = lij[pos];
         const double l_b = lij[idx_t[pos]];
         const double old_l_ij = fmin(l_a, l_b);
-#if RYUJIN_SKIP_UNLIMITED
         if (!__any(active && old_l_ij != 1.)) {
           if (active)
             st_stream(lij_next + (pos), 0.);
           continue;
         }
-#endif
         double p_ij[K];
         load_entry<K>(pij, colbase, r.lane, p_ij);
         if (!active)
@@ -568,7 +548,6 @@ namespace ryujin_hip
     for (int c = 1; c < MAXW; ++c) {
       if ((uint32_t)c >= r.width)
         continue;
-#if RYUJIN_SKIP_UNLIMITED
       {
         const bool lane_on = row_active && (uint32_t)c < r.len;
         if (!__any(lane_on && l[c] != 1.)) {
@@ -577,7 +556,6 @@ namespace ryujin_hip
           continue;
         }
       }
-#endif
       double pc[K];
       if (c < CP) {
 #pragma unroll

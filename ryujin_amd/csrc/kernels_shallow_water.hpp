@@ -8,26 +8,13 @@
 #include "kernels_euler.hpp"
 #include "shallow_water_device.hpp"
 
-#ifndef RYUJIN_SW_PIPE
-#define RYUJIN_SW_PIPE 1 /* step 4: prefetch the next column (index, c_ij, d_ij, m_ij, gathered U_j, alpha_j, Z_j, h*_j).
-                            A/B on MI355X (3.33 M gridpoints): 0.788 -> 0.695 ms for the kernel, 2.24 -> 2.15 ms per update */
-#endif
-#ifndef RYUJIN_SW_PRE_TEMPORAL
-#define RYUJIN_SW_PRE_TEMPORAL 0 /* affine-shift pre-loop reads c_ij with a temporal load (the main loop reads it again):
-                                    0.788 -> 0.760 ms alone, nothing on top of the pipeline (0.702 vs 0.695) */
-#endif
-#if RYUJIN_SW_PRE_TEMPORAL
-#define SW_LOAD_CIJ_PRE(m, colbase, lane, v) load_entry_cached<DIM>(m, colbase, lane, v)
-#else
-#define SW_LOAD_CIJ_PRE(m, colbase, lane, v) load_entry<DIM>(m, colbase, lane, v)
-#endif
 
 namespace ryujin_hip
 {
   template <int DIM, bool HAS_STAGES>
   __global__ void __launch_bounds__(kBlock, RYUJIN_OCC_LOW)
   k_low_order_sw(const ShallowWaterParams P, const DeviceMesh M,
-                 const DeviceScalars *__restrict__ scalars, const double weight,
+                 DeviceScalars *scalars, const double weight,
                  const StageArgs<DIM> S, const double *__restrict__ U,
                  const double *__restrict__ prec, const double *__restrict__ Z,
                  const double *__restrict__ alpha, const double *__restrict__ dij,
@@ -41,7 +28,7 @@ namespace ryujin_hip
       return;
     const bool row_active = r.len > 1;
     const uint32_t i = row_active ? r.row : (r.row < M.n_owned ? r.row : M.n_owned - 1);
-    const double tau = scalars->tau;
+    const double tau = finalize_tau(scalars);
     const uint32_t *__restrict__ cols = M.cols;
     const double *__restrict__ cij = M.cij;
     const double *__restrict__ mij = M.mij;
@@ -83,18 +70,15 @@ namespace ryujin_hip
       affine_shift[q] = 0.;
     {
       const double h_inverse = E::inverse_water_depth_sharp(P, U_i);
-#if RYUJIN_SW_PIPE
       /* software pipeline: the next column's index, c_ij, d_ij and the gathered Z_j are in flight while
        * this column is evaluated (as k_low_order) */
       uint32_t j_n = cols[(uint64_t)r.base * 64 + r.lane];
       double c_n[DIM];
-      SW_LOAD_CIJ_PRE(cij, r.base, r.lane, c_n);
+      load_entry<DIM>(cij, r.base, r.lane, c_n);
       double d_n = dij[(uint64_t)r.base * 64 + r.lane];
       double Z_n = Z[j_n];
-#endif
       for (uint32_t c = 0; c < r.width; ++c) {
         const uint64_t colbase = (uint64_t)r.base + c;
-#if RYUJIN_SW_PIPE
         double c_ij[DIM];
 #pragma unroll
         for (int d = 0; d < DIM; ++d)
@@ -102,18 +86,10 @@ namespace ryujin_hip
         const double d_ij = d_n, Z_j = Z_n;
         if (c + 1 < r.width) {
           j_n = cols[(colbase + 1) * 64 + r.lane];
-          SW_LOAD_CIJ_PRE(cij, colbase + 1, r.lane, c_n);
+          load_entry<DIM>(cij, colbase + 1, r.lane, c_n);
           d_n = dij[(colbase + 1) * 64 + r.lane];
           Z_n = Z[j_n];
         }
-#else
-        const uint64_t pos = colbase * 64 + r.lane;
-        const uint32_t j = cols[pos];
-        double c_ij[DIM];
-        SW_LOAD_CIJ_PRE(cij, colbase, r.lane, c_ij);
-        const double d_ij = dij[pos];
-        const double Z_j = Z[j];
-#endif
         if (!(row_active && c < r.len))
           continue;
         double U_star_ij[K];
@@ -151,7 +127,6 @@ namespace ryujin_hip
       }
     }
 
-#if RYUJIN_SW_PIPE
     uint32_t j_n = ld_stream(cols + ((uint64_t)r.base * 64 + r.lane));
     uint32_t j_nn = r.width > 1 ? ld_stream(cols + (((uint64_t)r.base + 1) * 64 + r.lane)) : i;
     double c_n[DIM], U_n[K];
@@ -162,11 +137,9 @@ namespace ryujin_hip
     double alpha_n = alpha[j_n];
     double Z_n = Z[j_n];
     double h_star_n = prec[(size_t)j_n * 2 + 1];
-#endif
     for (uint32_t c = 0; c < r.width; ++c) {
       const uint64_t colbase = (uint64_t)r.base + c;
       const bool active = row_active && c < r.len;
-#if RYUJIN_SW_PIPE
       const uint32_t j = j_n;
       double c_ij[DIM], U_j[K];
 #pragma unroll
@@ -187,19 +160,6 @@ namespace ryujin_hip
         h_star_n = prec[(size_t)j_n * 2 + 1];
         j_nn = (c + 2 < r.width) ? ld_stream(cols + ((colbase + 2) * 64 + r.lane)) : i;
       }
-#else
-      const uint64_t pos = colbase * 64 + r.lane;
-      const uint32_t j = cols[pos];
-      double c_ij[DIM];
-      load_entry<DIM>(cij, colbase, r.lane, c_ij);
-      const double d_ij = dij[pos];
-      const double m_ij = mij[pos];
-      double U_j[K];
-      load_state<K>(U, j, U_j);
-      const double alpha_j = alpha[j];
-      const double Z_j = Z[j];
-      const double h_star_j = prec[(size_t)j * 2 + 1];
-#endif
       if (!active)
         continue;
 

@@ -924,7 +924,7 @@ void ryujin_hip_ctx::prepare_state_vector(int h, const double *dirichlet)
                          s.prec.ptr);
     }, true);
     exchange_vector(s.prec.ptr, E::NPREC, true);
-  } else if constexpr (std::is_same<typename E::Params, EulerParams>::value && RYUJIN_DIJ_RECORDS) {
+  } else if constexpr (std::is_same<typename E::Params, EulerParams>::value) {
     /* sweep() has joined the U exchange: the ghost states are valid, their records are computed locally */
     sweep([&](const DeviceMesh &mm, dim3 grid) {
       hipLaunchKernelGGL(k_precompute_euler<E::DIMENSION>, grid, block, 0, launch_stream, eparams, mm,
@@ -961,8 +961,9 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
 
   /* scalars: tau_max := tau_max_in, flags := 0 */
   const bool use_device_tau = deferred && rk_stage > 0;
-  hipLaunchKernelGGL(k_reset_scalars, dim3(1), dim3(1), 0, stream, tau_max_in,
-                     (!deferred || rk_stage == 0) ? 1 : 0, d_scalars.ptr);
+  hipLaunchKernelGGL(k_step_begin, dim3(1), dim3(1), 0, stream, tau_max_in,
+                     (!deferred || rk_stage == 0) ? 1 : 0, (deferred && rk_stage > 0) ? rk_stage - 1 : -1,
+                     tau_in, use_device_tau ? 1 : 0, deferred ? rk_stage : 0, d_scalars.ptr);
 
   bool euler_fast_riemann = false;
   if constexpr (is_euler)
@@ -995,7 +996,7 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
     mark(8);
     step2_split = true;
     exchange_vector(d_alpha.ptr, 1, true);
-  } else if (is_euler && RYUJIN_DIJ_RECORDS && RYUJIN_FUSE_DIJ_ALPHA && euler_fast_riemann) {
+  } else if (is_euler && euler_fast_riemann && L.max_row_len <= 32) {
     /* (the general Riemann path -- Newton iterations or a non-integral exponent -- holds twice the
      * registers and keeps the two-kernel form below) */
     if constexpr (is_euler) {
@@ -1005,7 +1006,7 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
       }, true);
       exchange_vector(d_alpha.ptr, 1, true);
     }
-  } else if (RYUJIN_SPLIT_DIJ && L.max_row_len <= 32) {
+  } else if (L.max_row_len <= 32) {
     sweep([&](const DeviceMesh &mm, dim3 grid) {
       hipLaunchKernelGGL(k_alpha<E>, grid, block, 0, launch_stream, eparams, mm, old.U.ptr, old.prec.ptr,
                          d_alpha.ptr);
@@ -1016,7 +1017,7 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
     const bool pending = comm_pending;
     comm_pending = false; /* k_dij does not read alpha: do not join the exchange yet */
     sweep([&](const DeviceMesh &mm, dim3 grid) {
-      if constexpr (is_euler && RYUJIN_DIJ_RECORDS) {
+      if constexpr (is_euler) {
         if (eparams.riemann_newton_max_iterations == 0 && eparams.rarefaction_power > 0)
           hipLaunchKernelGGL((k_dij_records<DIM, false>), grid, block, 0, launch_stream, eparams, mm,
                              d_lower_mask.ptr, old.rrec.ptr, d_dij.ptr);
@@ -1070,8 +1071,7 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
    * whose flag is reduced once at the end of the RK step together with the restart flag. */
   if (!(deferred && rk_stage > 0))
     allreduce_scalar(&d_scalars.ptr->tau_max_bits, 0);
-  hipLaunchKernelGGL(k_finalize_tau, dim3(1), dim3(1), 0, stream, tau_in, use_device_tau ? 1 : 0,
-                     deferred ? rk_stage : 0, d_scalars.ptr);
+  /* tau itself is resolved inside the step-4 kernel (finalize_tau) */
   mark(2);
 
   /* Step 4: low-order update, bounds, r_i, p_ij; ghost r (:597-884) */
@@ -1090,10 +1090,10 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
     S.w[s] = w[s];
   }
   /* Euler, stages == 0, limiter on: P_ij (part 1) is recomputed in step 5 instead of stored here.
-   * A/B on MI355X: -7 % per update in 2-D (k=4, 9 columns); +1 % in 3-D where step 5 turns
-   * register/VALU bound (k=5, 27 columns), so only for dim <= 2. */
-  const bool recompute_p = is_euler && (DIM <= 2 || RYUJIN_RECOMPUTE_P_3D) && stages == 0 && params.limiter_iterations != 0 &&
-                           RYUJIN_RECOMPUTE_P && !dg;
+   * A/B on MI355X: -7 % per update in 2-D (k=4, 9 columns). In 3-D (k=5, 27 columns) step 4 drops from 2.01
+   * to 1.34 ms on 4.2 M gridpoints but step 5 grows from 2.16 to 2.77-2.94 ms (27 flux evaluations per row at
+   * 240 registers): -0.7 % ... +1.5 % per update, inside the run-to-run spread -- so only for dim <= 2. */
+  const bool recompute_p = is_euler && DIM <= 2 && stages == 0 && params.limiter_iterations != 0 && !dg;
   sweep([&](const DeviceMesh &mm, dim3 grid) {
     if constexpr (is_euler) {
       if (dg && stages == 0)
@@ -1197,7 +1197,7 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
     constexpr int kCachedWidth = DIM == 1 ? 3 : (DIM == 2 ? 9 : 27);
     if (last_round) {
       sweep([&](const DeviceMesh &mm, dim3 grid) {
-        if (RYUJIN_SKIP_UNLIMITED && L.max_row_len <= (uint32_t)kCachedWidth)
+        if (L.max_row_len <= (uint32_t)kCachedWidth)
           hipLaunchKernelGGL((k_high_order_last_cached<E, kCachedWidth, (DIM == 3 ? 9 : kCachedWidth)>), grid,
                              block, 0, launch_stream, eparams, mm, nw.U.ptr, d_pij.ptr, d_lij.ptr, fused_sadd);
         else
@@ -1226,8 +1226,8 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
   wait_comm();
   if (!deferred)
     allreduce_scalar(&d_scalars.ptr->restart_needed, 1); /* MPI::logical_or(restart_needed), :1194 */
-  hipLaunchKernelGGL(k_accumulate_flags, dim3(1), dim3(1), 0, stream, deferred ? rk_stage : 0,
-                     d_scalars.ptr);
+  /* (deferred: the restart flag is folded into its accumulator by the next stage's k_step_begin, or by
+   * time_step() behind the last stage) */
 
   HIP_CHECK(hipGetLastError());
   if (deferred) {
@@ -1391,6 +1391,7 @@ int ryujin_hip_ctx::time_step(int scheme, int h_state, int n_tmp, const int *h_t
     }
     /* the only host synchronisation of the RK step */
     wait_comm();
+    hipLaunchKernelGGL(k_accumulate_flags, dim3(1), dim3(1), 0, stream, rk_stage, d_scalars.ptr);
     /* MPI::logical_or over the ranks of the flags accumulated over all stages (restart_accum and
      * tau_invalid_accum are adjacent ints): one collective per RK step instead of one per stage */
     static_assert(offsetof(DeviceScalars, tau_invalid_accum) ==
@@ -1688,7 +1689,7 @@ int ryujin_hip_state_alloc(ryujin_hip_ctx *ctx, int *handle)
       h = (int)ctx->states.size() - 1;
       ctx->states[h]->U.alloc((size_t)ctx->L.n_relevant * ctx->KP);
       ctx->states[h]->prec.alloc((size_t)ctx->L.n_relevant * ctx->NPREC);
-      if (ctx->params.equation == RYUJIN_EQ_EULER && RYUJIN_DIJ_RECORDS)
+      if (ctx->params.equation == RYUJIN_EQ_EULER)
         ctx->states[h]->rrec.alloc((size_t)ctx->L.n_relevant * ((6 + ctx->dim + 1) / 2 * 2));
     }
     ctx->states[h]->used = true;

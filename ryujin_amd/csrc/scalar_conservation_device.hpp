@@ -287,7 +287,7 @@ namespace ryujin_hip
   /* ------------------------------------------------------------------ step 4 */
   template <int DIM, bool HAS_STAGES>
   __global__ void __launch_bounds__(kBlock)
-  k_low_order_sc(const ScalarParams P, const DeviceMesh M, const DeviceScalars *__restrict__ scalars,
+  k_low_order_sc(const ScalarParams P, const DeviceMesh M, DeviceScalars *scalars,
                  const double weight, const StageArgs<DIM> S, const double *__restrict__ U,
                  const double *__restrict__ prec, const double *__restrict__ alpha,
                  const double *__restrict__ dij, double *__restrict__ new_U, double *__restrict__ r_out,
@@ -300,7 +300,7 @@ namespace ryujin_hip
       return;
     const bool row_active = r.len > 1;
     const uint32_t i = row_active ? r.row : (r.row < M.n_owned ? r.row : M.n_owned - 1);
-    const double tau = scalars->tau;
+    const double tau = finalize_tau(scalars);
     const double u_i = U[(size_t)i * 2];
     double u_i_new = u_i, F_iH = 0.;
     const double alpha_i = alpha[i];

@@ -19,9 +19,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _n_gpus():
+    """hipGetDeviceCount through the runtime libryujin_hip.so is linked against. (NOT torch.cuda: importing
+    torch into a process that already loaded libryujin_hip.so brings a second copy of the ROCm runtime with it,
+    which corrupts the heap at exit; bench.py imports torch first for the same reason.)"""
+    import ctypes as C
     try:
-        import torch
-        return torch.cuda.device_count()
+        from ryujin_amd import capi
+        capi.load_hip()
+        n = C.c_int(0)
+        if C.CDLL("libamdhip64.so").hipGetDeviceCount(C.byref(n)) != 0:
+            return 0
+        return n.value
     except Exception:
         return 0
 
