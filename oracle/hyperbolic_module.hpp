@@ -36,6 +36,7 @@ namespace oracle
     EX_R = 3,
     EX_LIJ = 4,
     EX_LIJ_NEXT = 5,
+    EX_BOUNDS = 6, /* vector exchange (n_bounds components): discontinuous ansatz only */
     EX_MIN = 10,
     EX_OR = 11
   };
@@ -122,8 +123,6 @@ namespace oracle
       if (discontinuous_ansatz) {
         if (!o.incidence || !o.mass_matrix_inverse)
           throw std::runtime_error("discontinuous ansatz without incidence / inverse mass matrix");
-        if (o.n_nbr != 0)
-          throw std::runtime_error("discontinuous ansatz: single rank only");
         incidence = csr.gather(o, o.incidence, 1);
         mass_matrix_inverse = csr.gather(o, o.mass_matrix_inverse, 1);
       }
@@ -433,6 +432,8 @@ namespace oracle
         }
       }
       do_exchange(EX_R, r.data(), K); /* :601-613 */
+      if (discontinuous_ansatz) /* the bounds are extended over the stencil below: ghost range (:603-612) */
+        do_exchange(EX_BOUNDS, bounds.data(), NB);
 
       /* Step 5: second part of p_ij, first l_ij (:892-1041) */
       const int n_iterations = params.limiter_iterations;

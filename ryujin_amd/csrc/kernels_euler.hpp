@@ -27,6 +27,7 @@ namespace ryujin_hip
 {
   struct DeviceMesh {
     uint32_t n_owned, n_relevant, n_slices;
+    uint32_t bounds_stride; /* limiter bounds are SoA [n_bounds][bounds_stride], bounds_stride >= n_relevant */
     uint32_t slice_begin, slice_end; /* slice range of this launch (export rows first, then interior) */
     const uint32_t *slice_off; /* [n_slices+1] */
     const uint8_t *row_len;    /* [n_slices*64] */
@@ -979,7 +980,7 @@ namespace ryujin_hip
     const double s_min_r = fmax((1. - r_i) * s_min, s_min - entropy_relaxation);
 
     /* bounds stored SoA: [NB][rows_padded] */
-    const size_t stride = (size_t)M.n_slices * 64;
+    const size_t stride = M.bounds_stride;
     bounds[i] = rho_min_r;
     bounds[stride + i] = rho_max_r;
     bounds[2 * stride + i] = s_min_r;
@@ -996,7 +997,7 @@ namespace ryujin_hip
       return;
     const bool row_active = r.len > 1;
     const uint32_t i = row_active ? r.row : (r.row < M.n_owned ? r.row : M.n_owned - 1);
-    const size_t stride = (size_t)M.n_slices * 64;
+    const size_t stride = M.bounds_stride;
     double rho_min = in[i], rho_max = in[stride + i], s_min = in[2 * stride + i];
     for (uint32_t c = 1; c < r.width; ++c) {
       const uint32_t j = M.cols[((uint64_t)r.base + c) * 64 + r.lane];

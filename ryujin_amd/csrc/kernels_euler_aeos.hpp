@@ -367,7 +367,7 @@ namespace ryujin_hip
     const double upper_bound = numerator / denominator;
     rho_max_r = fmin(upper_bound, rho_max_r);
 
-    const size_t stride = (size_t)M.n_slices * 64;
+    const size_t stride = M.bounds_stride;
     bounds[i] = rho_min_r;
     bounds[stride + i] = rho_max_r;
     bounds[2 * stride + i] = s_min_r;

@@ -58,7 +58,7 @@ namespace ryujin_hip
     const double *__restrict__ mi_inv = M.mi_inv;
     const double *__restrict__ node_j = DG ? M.mi : M.mi_inv;
 
-    const size_t stride = (size_t)M.n_slices * 64;
+    const size_t stride = M.bounds_stride;
     double bnd[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b)
@@ -175,7 +175,7 @@ namespace ryujin_hip
     const double *__restrict__ mij = M.mij;
     const double *__restrict__ mi_inv = M.mi_inv;
 
-    const size_t stride = (size_t)M.n_slices * 64;
+    const size_t stride = M.bounds_stride;
     double bnd[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b)
@@ -349,7 +349,7 @@ namespace ryujin_hip
       store_state<K>(new_U, i, U_i_new);
 
     if constexpr (!LAST_ROUND) {
-      const size_t stride = (size_t)M.n_slices * 64;
+      const size_t stride = M.bounds_stride;
       double bnd[NB];
 #pragma unroll
       for (int b = 0; b < NB; ++b)
@@ -496,7 +496,7 @@ namespace ryujin_hip
     double U_i_new[K];
     load_state<K>(new_U, i, U_i_new);
     const double lambda = 1. / (double)(r.len - 1);
-    const size_t stride = (size_t)M.n_slices * 64;
+    const size_t stride = M.bounds_stride;
     double bnd[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b)

@@ -315,7 +315,7 @@ namespace ryujin_hip
     r2 *= P.dry_state_relaxation_factor;
     const double h_small = P.reference_water_depth * r2;
 
-    const size_t stride = (size_t)M.n_slices * 64;
+    const size_t stride = M.bounds_stride;
     bounds[i] = h_min_r;
     bounds[stride + i] = h_max_r;
     bounds[2 * stride + i] = h_small;

@@ -265,6 +265,7 @@ struct ryujin_hip_ctx {
   hipEvent_t ev_prev = nullptr;
   bool comm_pending = false;
   uint32_t n_export_slices = 0;
+  uint32_t bounds_stride = 0; /* SoA stride of the limiter bounds: covers the ghost range (dG reads bounds_j) */
 
   SellLayout L;
   DeviceMesh mesh{};
@@ -557,8 +558,6 @@ void ryujin_hip_ctx::create(const ryujin_hip_offline &o, const ryujin_hip_params
     if (dg) {
       if (p.equation != RYUJIN_EQ_EULER)
         throw HipError(RYUJIN_ERR_UNSUPPORTED, "discontinuous ansatz: Euler equations only in this version");
-      if (o.n_nbr != 0)
-        throw HipError(RYUJIN_ERR_UNSUPPORTED, "discontinuous ansatz: single rank only in this version");
       if (!o.incidence || !o.mass_matrix_inverse)
         throw HipError(RYUJIN_ERR_ARG, "discontinuous ansatz without incidence / inverse mass matrix");
       d_incidence.upload(L.scatter(o, o.incidence, 1));
@@ -589,6 +588,8 @@ void ryujin_hip_ctx::create(const ryujin_hip_offline &o, const ryujin_hip_params
   mesh.n_owned = L.n_owned;
   mesh.n_relevant = L.n_relevant;
   mesh.n_slices = L.n_slices;
+  bounds_stride = (std::max<uint32_t>(L.rows_padded, L.n_relevant) + 63u) / 64u * 64u;
+  mesh.bounds_stride = bounds_stride;
   mesh.slice_begin = 0;
   mesh.slice_end = L.n_slices;
   /* rows [0, n_export) are the ones other ranks hold as ghosts (offline_data.template.h:213-249) */
@@ -641,9 +642,9 @@ void ryujin_hip_ctx::create(const ryujin_hip_offline &o, const ryujin_hip_params
 
   /* ---- module-owned storage (prepare(): hyperbolic_module.template.h:52-86) ---- */
   d_alpha.alloc(L.n_relevant);
-  d_bounds.alloc((size_t)NB * L.rows_padded);
+  d_bounds.alloc((size_t)NB * bounds_stride);
   if (dg)
-    d_bounds_combined.alloc((size_t)NB * L.rows_padded);
+    d_bounds_combined.alloc((size_t)NB * bounds_stride);
   d_r.alloc((size_t)L.n_relevant * KP);
   d_dij.alloc(L.nnz_total);
   d_lij.alloc(L.nnz_total);
@@ -1146,6 +1147,12 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
     }
   }, true);
   exchange_vector(d_r.ptr, KP, true);
+  if (dg && params.limiter_iterations != 0) {
+    /* the bounds are extended over the stencil in step 5: their ghost range has to be current
+     * (hyperbolic_module.template.h:601-613); SoA, one scalar vector per bound */
+    for (int b = 0; b < NB; ++b)
+      exchange_vector(d_bounds.ptr + (size_t)b * bounds_stride, 1, true);
+  }
   mark(3);
 
   /* Step 5: second part of p_ij, first l_ij; ghost rows of l_ij (:892-1041) */
@@ -1959,12 +1966,12 @@ int ryujin_hip_debug_fetch(ryujin_hip_ctx *ctx, int what, double *out, size_t n_
     case 3: {
       if (n_doubles < (size_t)L.n_owned * ctx->NB)
         throw HipError(RYUJIN_ERR_ARG, "output buffer too small");
-      std::vector<double> tmp((size_t)ctx->NB * L.rows_padded);
+      std::vector<double> tmp((size_t)ctx->NB * ctx->bounds_stride);
       HIP_CHECK(hipMemcpy(tmp.data(), ctx->d_bounds.ptr, tmp.size() * sizeof(double),
                           hipMemcpyDeviceToHost));
       for (uint32_t i = 0; i < L.n_owned; ++i)
         for (int b = 0; b < ctx->NB; ++b)
-          out[(size_t)i * ctx->NB + b] = tmp[(size_t)b * L.rows_padded + i];
+          out[(size_t)i * ctx->NB + b] = tmp[(size_t)b * ctx->bounds_stride + i];
       break;
     }
     case 4: {

@@ -410,7 +410,7 @@ namespace ryujin_hip
         fmax(fmin((1. - r_i) * u_min, (1. + r_i) * u_min), u_min - 2. * u_relaxation);
     const double u_max_r =
         fmin(fmax((1. + r_i) * u_max, (1. - r_i) * u_max), u_max + 2. * u_relaxation);
-    const size_t stride = (size_t)M.n_slices * 64;
+    const size_t stride = M.bounds_stride;
     bounds[i] = u_min_r;
     bounds[stride + i] = u_max_r;
   }

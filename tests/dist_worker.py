@@ -47,7 +47,7 @@ def main():
             data[0] = float(t[0])
             return
         reqs, recvs = [], []
-        if what < 4:   # vector ghosts: dealii Partitioner::update_ghost_values
+        if what < 4 or what == 6:   # vector ghosts: dealii Partitioner::update_ghost_values
             v = np.ctypeslib.as_array(data, shape=(off.n_relevant * n_comp,)).reshape(-1, n_comp)
             for q in range(n_nbr):
                 buf = torch.from_numpy(np.ascontiguousarray(v[send_idx[send_off[q]:send_off[q + 1]]]))

@@ -149,7 +149,8 @@ def partition(off, info, owner, bathymetry=None):
         recv_off = [n_owned]
         for p in nbrs:
             recv_off.append(recv_off[-1] + sum(1 for j in ghosts if owner[j] == p))
-        lrows, lc, lm = [], [], []
+        lrows, lc, lm, l_inc, l_minv = [], [], [], [], []
+        dg = getattr(off, "_dg", None)       # discontinuous ansatz: (incidence, mass_matrix_inverse)
         for g in l2g:
             keep = rows[g][1:] if owner[g] == r else [j for j in rows[g][1:] if owner[j] == r]
             cols = sorted(keep, key=lambda j: lidx[j])
@@ -157,6 +158,9 @@ def partition(off, info, owner, bathymetry=None):
             for j in [g] + cols:
                 lc.append(off.cij_csr[entry[(g, j)]])
                 lm.append(off.mij_csr[entry[(g, j)]])
+                if dg is not None:
+                    l_inc.append(dg[0][entry[(g, j)]])
+                    l_minv.append(dg[1][entry[(g, j)]])
         row_starts = np.cumsum([0] + [len(x) for x in lrows]).astype(np.uint64)
         columns = np.concatenate([np.array(x, dtype=np.uint32) for x in lrows])
         send_off, send_idx, row_send_off, row_send_row, row_send_col = [0], [], [0], [], []
@@ -193,6 +197,9 @@ def partition(off, info, owner, bathymetry=None):
         o.nbr_rank = capi.as_ptr(k["nbr_rank"], capi.c_int_p)
         for name in ("send_off", "send_idx", "recv_off", "row_send_off", "row_send_row", "row_send_col"):
             setattr(o, name, capi.as_ptr(k[name], capi.c_u32_p))
+        if dg is not None:
+            from helpers_dg import attach_dg
+            attach_dg(v, np.array(l_inc), np.array(l_minv))
         v.positions = off.positions[l2g]
         v.global_ids = np.array(l2g, dtype=np.int64)
         v.b_positions = off.positions[b_g].reshape(-1, off.dim)
@@ -253,7 +260,7 @@ def run_partitioned_oracle(oracle, views, params, U0_global, n_updates, dirichle
                     barrier.wait()
                     data[0] = val
                     return
-                if what < 4:
+                if what < 4 or what == 6:
                     a = np.ctypeslib.as_array(data, shape=(v.n_relevant * n_comp,)).reshape(-1, n_comp)
                     for q, p in enumerate(nbr):
                         mail[(r, p)] = a[send_idx[send_off[q]:send_off[q + 1]]].copy()

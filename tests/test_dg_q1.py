@@ -1,0 +1,164 @@
+"""The discontinuous-ansatz branch of HyperbolicModule::step (SURVEY.md section 8 row f-4;
+hyperbolic_module.template.h:601-613 ghost bounds, :733-737 incidence matrix in the high-order viscosity,
+:938-948 bounds extended over the stencil, :976-986 full inverse mass matrix) on a real dG-Q1 stencil:
+Cartesian mesh, 2^dim DoFs per cell, face terms in c_ij, block-diagonal inverse mass matrix, incidence matrix
+between co-located face DoFs -- assembled in tests/helpers_dg.py the way the reference assembles them
+(offline_data.template.h:560-674, 809-906). Rows of 6 (1-D) and 12/16/20 (2-D) entries, many structural zeros.
+
+CPU part: the oracle on this stencil conserves mass, momentum and energy to round-off while the waves stay away
+from the (do-nothing) boundary, and a partitioned run (bounds ghost exchange) reproduces the single-rank run.
+GPU part: HIP against the oracle sweep by sweep, and five HIP ranks on one GPU against the single-rank run."""
+import numpy as np
+import pytest
+
+from helpers_dg import dg_q1_offline
+from ryujin_amd import HyperbolicModule, capi
+
+
+def _blast(positions, centre, radius=0.18):
+    """smooth compact pressure / density bump: (rho, m, E) for gamma = 7/5"""
+    dim = positions.shape[1]
+    r2 = ((positions - np.asarray(centre)) ** 2).sum(1) / radius ** 2
+    bump = np.where(r2 < 1.0, np.exp(1.0 - 1.0 / np.maximum(1.0 - r2, 1e-300)), 0.0)
+    rho = 1.0 + 0.6 * bump
+    p = 1.0 + 4.0 * bump
+    U = np.zeros((len(positions), dim + 2))
+    U[:, 0] = rho
+    U[:, -1] = p / 0.4
+    return U
+
+
+def _params(oracle, dim):
+    p = oracle.default_params(capi.EQ_EULER, dim)
+    p.cfl = 0.5
+    return p
+
+
+@pytest.mark.parametrize("n_cells,h", [((64,), 1.0 / 64), ((32, 32), 1.0 / 32)])
+def test_oracle_conserves_on_a_dg_q1_stencil(oracle, n_cells, h):
+    off, info = dg_q1_offline(n_cells, h)
+    dim = len(n_cells)
+    p = _params(oracle, dim)
+    m = HyperbolicModule(off, p, backend=oracle.backend())
+    U0 = _blast(off.positions, [0.5] * dim, radius=0.15)
+    a, b = m.new_state_vector(U0), m.new_state_vector()
+    before = (off.mi[:, None] * U0).sum(0)
+    for _ in range(12 if dim == 1 else 7):
+        m.prepare_state_vector(a, 0.0)
+        m.step(a, [], [], b)
+        a, b = b, a
+    U = a.download()
+    assert np.isfinite(U).all() and U[:, 0].min() > 0.5
+    assert np.abs(U - U0).max() > 1e-3                       # something happened ...
+    assert np.abs(U - U0)[info["is_bdry"]].max() < 1e-12      # ... and has not reached the boundary yet
+    after = (off.mi[:, None] * U).sum(0)
+    scale = (off.mi[:, None] * np.abs(U)).sum(0).max()
+    assert np.abs(after - before).max() <= 1e-13 * scale, (after - before) / scale
+    assert m.n_warnings() == 0
+
+
+def _owner_by_cells(n_cells, n_per_cell, n_ranks):
+    """ownership by cells: x-slabs of cells (all DoFs of a cell on one rank, as a dG DoFHandler distributes)"""
+    nx = n_cells[0]
+    n = int(np.prod(n_cells)) * n_per_cell
+    cell = np.arange(n) // n_per_cell
+    cx = cell % nx
+    return np.minimum(cx * n_ranks // nx, n_ranks - 1).astype(np.int64)
+
+
+def test_partitioned_oracle_dg_matches_single_rank(oracle):
+    """three ranks: the ghost range of the limiter bounds is exchanged before it is combined over the stencil"""
+    from helpers_unstructured import partition, run_partitioned_oracle
+    n_cells, h = (18, 10), 1.0 / 18
+    off, info = dg_q1_offline(n_cells, h)
+    p = _params(oracle, 2)
+    U0 = _blast(off.positions, [0.5, 0.28], radius=0.2)
+    m = HyperbolicModule(off, p, backend=oracle.backend())
+    a, b = m.new_state_vector(U0), m.new_state_vector()
+    taus = []
+    for _ in range(8):
+        m.prepare_state_vector(a, 0.0)
+        taus.append(m.step(a, [], [], b))
+        a, b = b, a
+    U_ref = a.download()
+    views = partition(off, info, _owner_by_cells(n_cells, info["n_per_cell"], 3))
+    assert all(v.c.contents.discontinuous_ansatz == 1 and v.c.contents.n_nbr >= 1 for v in views)
+    U, taus_p = run_partitioned_oracle(oracle, views, p, U0, 8)
+    for t in taus_p:
+        assert np.allclose(t, taus, rtol=1e-13, atol=0)
+    scale = np.abs(U_ref).max(axis=0)
+    assert (np.abs(U - U_ref) / scale).max() < 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_cells,h", [((96,), 1.0 / 96), ((24, 24), 1.0 / 24)])
+def test_dg_q1_hip_against_the_oracle(oracle, n_cells, h):
+    from helpers_parity import compare_step
+    off, info = dg_q1_offline(n_cells, h)
+    dim = len(n_cells)
+    p = _params(oracle, dim)
+    mg = HyperbolicModule(off, p, backend="hip")
+    a, b = mg.new_state_vector(_blast(off.positions, [0.45] * dim)), mg.new_state_vector()
+    for _ in range(15):                      # steepen the fronts so that the limiter is active
+        mg.prepare_state_vector(a, 0.0)
+        mg.step(a, [], [], b)
+        a, b = b, a
+    mc = HyperbolicModule(off, p, backend=oracle.backend())
+    mods = [(mg, a, b), (mc, mc.new_state_vector(a.download()), mc.new_state_vector())]
+    g, c = compare_step(off, mods, oracle=oracle, params=p, label="dg_q1_%dd" % dim)
+    assert (c["lij_next"] < 1.0).mean() > 1e-3           # the limiter did limit
+    assert (g["U"][:, 0] > 0).all()
+
+
+@pytest.mark.gpu
+def test_dg_q1_partitioned_hip_matches_single_rank():
+    """four HIP contexts on one GPU (in-process transport, one host thread each): ghost exchange of U, the
+    precomputed values, alpha, r, the THREE bound vectors and the l_ij ghost rows on a dG stencil"""
+    import ctypes as C
+    import threading
+
+    from helpers_unstructured import partition
+    lib = capi.load_hip()
+    n_cells, h, n_ranks, n_updates = (24, 12), 1.0 / 24, 4, 8
+    off, info = dg_q1_offline(n_cells, h)
+    U0 = _blast(off.positions, [0.5, 0.25], radius=0.2)
+
+    def run(o, comm, U_local, out, key):
+        try:
+            p = capi.Params()
+            lib.ryujin_hip_default_params(C.byref(p), capi.EQ_EULER, 2)
+            p.cfl = 0.5
+            m = HyperbolicModule(o, p, backend="hip", comm=comm)
+            a, b = m.new_state_vector(U_local), m.new_state_vector()
+            taus = []
+            for _ in range(n_updates):
+                m.prepare_state_vector(a, 0.0)
+                taus.append(m.step(a, [], [], b))
+                a, b = b, a
+            out[key] = (a.download()[: o.n_owned], taus)
+        except Exception as e:  # noqa: BLE001 -- surfaced in the main thread
+            out[key] = e
+
+    ref = {}
+    run(off, None, U0, ref, 0)
+    assert not isinstance(ref[0], Exception), ref[0]
+    U_ref, taus = ref[0]
+    views = partition(off, info, _owner_by_cells(n_cells, info["n_per_cell"], n_ranks))
+    comms = (C.c_void_p * n_ranks)()
+    assert lib.ryujin_hip_comm_init_local(comms, n_ranks, 0) == 0
+    out = {}
+    threads = [threading.Thread(target=run, args=(views[r], C.c_void_p(comms[r]), U0[views[r].global_ids], out, r))
+               for r in range(n_ranks)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+        assert not t.is_alive(), "rank thread hung"
+    U = np.empty_like(U0)
+    for r in range(n_ranks):
+        assert not isinstance(out[r], Exception), out[r]
+        assert np.allclose(out[r][1], taus, rtol=1e-13, atol=0)
+        U[views[r].global_ids[: views[r].n_owned]] = out[r][0]
+    assert (np.abs(U - U_ref) / np.abs(U_ref).max(axis=0)).max() < 1e-12
+    for r in range(n_ranks):
+        lib.ryujin_hip_comm_destroy(C.c_void_p(comms[r]))
