@@ -68,6 +68,15 @@ namespace ryujin_hip
 #ifndef RYUJIN_HO_CP_3D
 #define RYUJIN_HO_CP_3D 14 /* step 6 in 3-D: 0 = two-pass kernel, n = l_ij and the first n P_ij columns in registers. A/B on MI355X (3.98 M gridpoints): 3.07 ms (0), 2.64 (1), 2.43 (8), 2.24 (14), 2.36 (18) */
 #endif
+#ifndef RYUJIN_OCC_HO_3D
+#define RYUJIN_OCC_HO_3D 2 /* step 6 in 3-D: waves per SIMD asked of the register allocator */
+#endif
+#ifndef RYUJIN_OCC_LAST_3D
+#define RYUJIN_OCC_LAST_3D 1 /* step 7 in 3-D */
+#endif
+#ifndef RYUJIN_LAST_CHUNK_3D
+#define RYUJIN_LAST_CHUNK_3D 9 /* step 7 in 3-D: P_ij columns whose loads are issued back to back */
+#endif
 #ifndef RYUJIN_OCC_DIJ
 #define RYUJIN_OCC_DIJ 2
 #endif

@@ -405,7 +405,7 @@ namespace ryujin_hip
    * front (independent loads), then P_ij is read -- in chunks of CHUNK columns whose loads are issued back to
    * back -- only for the columns in which some row of the slice has l != 0 (see the note at the top). */
   template <typename E, int MAXW, int CHUNK>
-  __global__ void __launch_bounds__(kBlock)
+  __global__ void __launch_bounds__(kBlock, (MAXW > 9 ? RYUJIN_OCC_LAST_3D : 1))
   k_high_order_last_cached(const typename E::Params, const DeviceMesh M, double *__restrict__ new_U,
                            const double *__restrict__ pij, const double *__restrict__ lij, const FusedSadd F)
   {
@@ -479,7 +479,7 @@ namespace ryujin_hip
    * CP < MAXW (3-D Q1: 27 columns of 5 components do not fit the register file at a useful occupancy):
    * all l_ij but only the P_ij of columns < CP are cached, the others are fetched a second time. */
   template <typename E, int MAXW, int CP = MAXW>
-  __global__ void __launch_bounds__(kBlock, (MAXW > 9 ? (CP < MAXW ? 2 : 1) : RYUJIN_OCC_HO))
+  __global__ void __launch_bounds__(kBlock, (MAXW > 9 ? (CP < MAXW ? RYUJIN_OCC_HO_3D : 1) : RYUJIN_OCC_HO))
   k_high_order_next_cached(const typename E::Params P, const DeviceMesh M, double *__restrict__ new_U,
                            const double *__restrict__ bounds, const double *__restrict__ pij,
                            const double *__restrict__ lij, double *__restrict__ lij_next)

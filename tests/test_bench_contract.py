@@ -20,7 +20,7 @@ def test_algorithmic_bytes_match_the_survey():
     assert list(bench.algorithmic_bytes(2, 4, 9).values()) == [48, 316, 224, 700, 860, 556, 460]
 
 
-@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(ROOT, "profiles", "r01k_bench*.json"))))
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(ROOT, "profiles", "r02[e-z]_bench*.json"))))
 def test_committed_bench_lines_follow_the_contract(path):
     lines = [ln for ln in open(path).read().splitlines() if ln.strip()]
     assert len(lines) == 1                                     # ONE JSON line
