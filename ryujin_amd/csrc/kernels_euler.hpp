@@ -66,16 +66,19 @@ namespace ryujin_hip
   /* minimum waves per SIMD requested from the register allocator for the heavy sweeps (second
    * __launch_bounds__ argument): 512 registers / waves. Tuned on MI355X, see DESIGN.md. */
 #ifndef RYUJIN_HO_CP_3D
-#define RYUJIN_HO_CP_3D 14 /* step 6 in 3-D: 0 = two-pass kernel, n = l_ij and the first n P_ij columns in registers. A/B on MI355X (3.98 M gridpoints): 3.07 ms (0), 2.64 (1), 2.43 (8), 2.24 (14), 2.36 (18) */
+#define RYUJIN_HO_CP_3D 6 /* step 6 in 3-D: 0 = two-pass kernel, n = l_ij and the first n P_ij columns in registers (the others are read a second time, unless the whole tile is unlimited). Round 1, all at 2 waves/SIMD: 3.07 ms (0), 2.43 (8), 2.24 (14), 2.36 (18); round 2 see RYUJIN_OCC_HO_3D */
 #endif
 #ifndef RYUJIN_OCC_HO_3D
-#define RYUJIN_OCC_HO_3D 2 /* step 6 in 3-D: waves per SIMD asked of the register allocator */
+#define RYUJIN_OCC_HO_3D 3 /* step 6 in 3-D: waves per SIMD asked of the register allocator. A/B on MI355X (4.2 M gridpoints): CP 14 at 2 waves 1.96 ms, CP 6 at 3 waves 1.72 ms */
 #endif
 #ifndef RYUJIN_OCC_LAST_3D
-#define RYUJIN_OCC_LAST_3D 1 /* step 7 in 3-D */
+#define RYUJIN_OCC_LAST_3D 4 /* step 7 in 3-D. A/B (4.2 M gridpoints): chunk 9 at 2 waves 0.99 ms, 5 at 3 waves 0.76 ms, 3 at 4 waves 0.68 ms */
 #endif
 #ifndef RYUJIN_LAST_CHUNK_3D
-#define RYUJIN_LAST_CHUNK_3D 9 /* step 7 in 3-D: P_ij columns whose loads are issued back to back */
+#define RYUJIN_LAST_CHUNK_3D 3 /* step 7 in 3-D: P_ij columns whose loads are issued back to back */
+#endif
+#ifndef RYUJIN_LAST_CHUNK_2D
+#define RYUJIN_LAST_CHUNK_2D 9
 #endif
 #ifndef RYUJIN_OCC_DIJ
 #define RYUJIN_OCC_DIJ 2

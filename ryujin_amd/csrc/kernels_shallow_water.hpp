@@ -9,10 +9,6 @@
 #include "shallow_water_device.hpp"
 
 
-#ifndef RYUJIN_SW_LDS
-#define RYUJIN_SW_LDS 1
-#endif
-
 namespace ryujin_hip
 {
   template <int DIM, bool HAS_STAGES>
@@ -36,19 +32,6 @@ namespace ryujin_hip
     const uint32_t *__restrict__ cols = M.cols;
     const double *__restrict__ cij = M.cij;
     const double *__restrict__ mij = M.mij;
-
-    /* The sweep walks the row's stencil twice (affine-shift pre-loop, then the update loop; the reference does
-     * the same, hyperbolic_module.template.h:700-720 and :739-846). The second walk used to fetch the column
-     * indices, c_ij and d_ij a second time from HBM (252 B per row in 2-D, 22 % of the kernel's traffic: they
-     * are single-use streams for every other kernel and bypass the caches). The pre-loop now parks them in LDS
-     * -- [column][lane], one wave per slice, conflict free -- and the update loop reads them from there.
-     * 16 KiB per wave; slices wider than kLdsCols columns (unstructured meshes) keep the second global read. */
-    constexpr int kLdsCols = DIM == 1 ? 3 : 9;
-    __shared__ uint32_t lds_j[kWavesPerBlock][kLdsCols][64];
-    __shared__ double lds_c[kWavesPerBlock][kLdsCols][DIM][64];
-    __shared__ double lds_d[kWavesPerBlock][kLdsCols][64];
-    const uint32_t wv = threadIdx.x >> 6;
-    const bool use_lds = RYUJIN_SW_LDS && r.width <= (uint32_t)kLdsCols; /* wave-uniform */
 
     double U_i[K], U_i_new[K], F_iH[K], S_iH[K], S_i[K];
     load_state<K>(U, i, U_i);
@@ -101,13 +84,6 @@ namespace ryujin_hip
         for (int d = 0; d < DIM; ++d)
           c_ij[d] = c_n[d];
         const double d_ij = d_n, Z_j = Z_n;
-        if (use_lds) {
-          lds_j[wv][c][r.lane] = j_n;
-#pragma unroll
-          for (int d = 0; d < DIM; ++d)
-            lds_c[wv][c][d][r.lane] = c_ij[d];
-          lds_d[wv][c][r.lane] = d_ij;
-        }
         if (c + 1 < r.width) {
           j_n = cols[(colbase + 1) * 64 + r.lane];
           load_entry<DIM>(cij, colbase + 1, r.lane, c_n);
@@ -151,27 +127,11 @@ namespace ryujin_hip
       }
     }
 
-    /* (a wave reads back its own lanes' entries: no barrier beyond the LDS counter the compiler waits on) */
-    auto stencil_j = [&](const uint32_t c) -> uint32_t {
-      return use_lds ? lds_j[wv][c][r.lane] : ld_stream(cols + (((uint64_t)r.base + c) * 64 + r.lane));
-    };
-    auto stencil_c = [&](const uint32_t c, double (&out)[DIM]) {
-      if (use_lds) {
-#pragma unroll
-        for (int d = 0; d < DIM; ++d)
-          out[d] = lds_c[wv][c][d][r.lane];
-      } else {
-        load_entry<DIM>(cij, (uint64_t)r.base + c, r.lane, out);
-      }
-    };
-    auto stencil_d = [&](const uint32_t c) -> double {
-      return use_lds ? lds_d[wv][c][r.lane] : dij[((uint64_t)r.base + c) * 64 + r.lane];
-    };
-    uint32_t j_n = stencil_j(0);
-    uint32_t j_nn = r.width > 1 ? stencil_j(1) : i;
+    uint32_t j_n = ld_stream(cols + ((uint64_t)r.base * 64 + r.lane));
+    uint32_t j_nn = r.width > 1 ? ld_stream(cols + (((uint64_t)r.base + 1) * 64 + r.lane)) : i;
     double c_n[DIM], U_n[K];
-    stencil_c(0, c_n);
-    double d_n = stencil_d(0);
+    load_entry<DIM>(cij, r.base, r.lane, c_n);
+    double d_n = dij[(uint64_t)r.base * 64 + r.lane];
     double m_n = ld_stream(mij + ((uint64_t)r.base * 64 + r.lane));
     load_state<K>(U, j_n, U_n);
     double alpha_n = alpha[j_n];
@@ -191,14 +151,14 @@ namespace ryujin_hip
       const double d_ij = d_n, m_ij = m_n, alpha_j = alpha_n, Z_j = Z_n, h_star_j = h_star_n;
       if (c + 1 < r.width) {
         j_n = j_nn;
-        stencil_c(c + 1, c_n);
-        d_n = stencil_d(c + 1);
+        load_entry<DIM>(cij, colbase + 1, r.lane, c_n);
+        d_n = dij[(colbase + 1) * 64 + r.lane];
         m_n = ld_stream(mij + ((colbase + 1) * 64 + r.lane));
         load_state<K>(U, j_n, U_n);
         alpha_n = alpha[j_n];
         Z_n = Z[j_n];
         h_star_n = prec[(size_t)j_n * 2 + 1];
-        j_nn = (c + 2 < r.width) ? stencil_j(c + 2) : i;
+        j_nn = (c + 2 < r.width) ? ld_stream(cols + ((colbase + 2) * 64 + r.lane)) : i;
       }
       if (!active)
         continue;

@@ -1205,7 +1205,7 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
     if (last_round) {
       sweep([&](const DeviceMesh &mm, dim3 grid) {
         if (L.max_row_len <= (uint32_t)kCachedWidth)
-          hipLaunchKernelGGL((k_high_order_last_cached<E, kCachedWidth, (DIM == 3 ? RYUJIN_LAST_CHUNK_3D : kCachedWidth)>), grid,
+          hipLaunchKernelGGL((k_high_order_last_cached<E, kCachedWidth, (DIM == 3 ? RYUJIN_LAST_CHUNK_3D : (DIM == 2 ? RYUJIN_LAST_CHUNK_2D : kCachedWidth))>), grid,
                              block, 0, launch_stream, eparams, mm, nw.U.ptr, d_pij.ptr, d_lij.ptr, fused_sadd);
         else
           hipLaunchKernelGGL((k_high_order<E, true>), grid, block, 0, launch_stream, eparams, mm, nw.U.ptr,

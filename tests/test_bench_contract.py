@@ -40,3 +40,25 @@ def test_committed_bench_lines_follow_the_contract(path):
     if "cpu_baseline" in d:
         c = d["cpu_baseline"]
         assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["unit"] == d["unit"] and c["sample"]
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` invoked exactly like the single-GPU line (no launcher around it) starts N ranks
+    itself -- torch.distributed.run, one process per GPU, rendezvous on 127.0.0.1 -- and rank 0 prints the ONE
+    JSON line. Checked on CPU with the launch probe (gloo, 2 ranks; nothing touches a GPU)."""
+    import subprocess
+    import sys
+
+    import bench
+    cmd = bench.self_launch_command(4, ["--gpus", "4", "--steps", "3"])
+    assert cmd[0] == sys.executable and cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-5:] == [os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "3"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--probe-launch"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, res.stdout
+    assert json.loads(lines[0]) == {"probe": True, "world": 2, "n_gpus": 2, "rank_sum": 1}
