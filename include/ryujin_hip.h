@@ -378,7 +378,9 @@ enum {
   RYUJIN_DEBUG_EULER_DIJ_2D = 3,
   RYUJIN_DEBUG_EULER_DIJ_3D = 4,
   RYUJIN_DEBUG_EULER_DIJ_RECORDS_2D = 5, /* the same through the per-node Riemann records the sweep uses */
-  RYUJIN_DEBUG_EULER_DIJ_RECORDS_3D = 6
+  RYUJIN_DEBUG_EULER_DIJ_RECORDS_3D = 6,
+  RYUJIN_DEBUG_SW_DIJ_2D = 7,          /* in: U_i[3], U_j[3], c_ij[2]   out: d_ij (shallow water, dim = 2) */
+  RYUJIN_DEBUG_SW_DIJ_RECORDS_2D = 8   /* the same through the per-node Riemann records the sweep uses */
 };
 int ryujin_hip_debug_function(int device, const ryujin_hip_params *params, int which, const double *in,
                               double *out, size_t n);

@@ -513,6 +513,30 @@ int ryujin_oracle_sw_riemann(const ryujin_hip_params *p, const double rd_i[3], c
   return RYUJIN_OK;
 }
 
+/* shallow water d_ij = |c_ij| lambda_max(U_i, U_j, c_ij / |c_ij|) for n independent pairs, dim = p->dim */
+int ryujin_oracle_sw_dij_batch(const ryujin_hip_params *p, size_t n, const double *U_i, const double *U_j,
+                               const double *c, double *out)
+{
+  const shallow_water::RiemannSolver rs(*p);
+  const int dim = p->dim, k = dim + 1;
+#pragma omp parallel for schedule(static)
+  for (size_t q = 0; q < n; ++q) {
+    double norm2 = 0.;
+    for (int d = 0; d < dim; ++d)
+      norm2 += c[q * dim + d] * c[q * dim + d];
+    const double norm = std::sqrt(norm2), inverse = 1. / norm;
+    if (dim == 1) {
+      out[q] = norm * rs.compute<1>({{U_i[q * k], U_i[q * k + 1]}}, {{U_j[q * k], U_j[q * k + 1]}},
+                                    {{c[q] * inverse}});
+    } else {
+      out[q] = norm * rs.compute<2>({{U_i[q * k], U_i[q * k + 1], U_i[q * k + 2]}},
+                                    {{U_j[q * k], U_j[q * k + 1], U_j[q * k + 2]}},
+                                    {{c[q * 2] * inverse, c[q * 2 + 1] * inverse}});
+    }
+  }
+  return RYUJIN_OK;
+}
+
 /* import check: logical CSR view (ptr, col, transposed position) of a reference layout */
 int ryujin_oracle_import_csr(const ryujin_hip_offline *o, uint64_t *ptr, uint32_t *col,
                              uint64_t *transpose, const double *data, uint32_t n_comp, double *out)

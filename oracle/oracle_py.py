@@ -43,6 +43,7 @@ def load(path: str | None = None):
     lib.ryujin_oracle_euler_limit_trace.argtypes = [C.POINTER(capi.Params), dp, dp, dp, dp]
     lib.ryujin_oracle_euler_view.argtypes = [C.POINTER(capi.Params), dp, dp]
     lib.ryujin_oracle_euler_apply_bc.argtypes = [C.POINTER(capi.Params), C.c_int, dp, dp, dp, dp]
+    lib.ryujin_oracle_sw_dij_batch.argtypes = [C.POINTER(capi.Params), C.c_size_t, dp, dp, dp, dp]
     lib.ryujin_oracle_sw_riemann.argtypes = [C.POINTER(capi.Params), dp, dp, dp]
     lib.ryujin_oracle_import_csr.argtypes = [C.POINTER(capi.Offline), capi.c_u64_p, capi.c_u32_p,
                                              capi.c_u64_p, dp, C.c_uint32, dp]

@@ -326,14 +326,13 @@ namespace ryujin_hip
     reinterpret_cast<double2 *>(prec)[i] = E::precompute(P, U_i);
   }
 
-  /* Euler: precomputed values AND the per-node Riemann record (Euler<DIM>::riemann_record) in one pass
-   * over the owned rows */
-  template <int DIM>
+  /* Euler, shallow water: precomputed values AND the per-node Riemann record (E::riemann_record) in one
+   * pass over the owned rows */
+  template <typename E>
   __global__ void __launch_bounds__(kBlock)
-  k_precompute_euler(const EulerParams P, const DeviceMesh M, const double *__restrict__ U,
-                     double *__restrict__ prec, double *__restrict__ rec)
+  k_precompute_records(const typename E::Params P, const DeviceMesh M, const double *__restrict__ U,
+                       double *__restrict__ prec, double *__restrict__ rec)
   {
-    using E = Euler<DIM>;
     constexpr int K = E::K, RS = E::RS;
     const uint32_t i = M.slice_begin * 64 + blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M.n_owned || i >= M.slice_end * 64)
@@ -356,12 +355,11 @@ namespace ryujin_hip
 
   /* the same record for the ghost rows [first, last): computed locally from the exchanged ghost states
    * (nothing to exchange: the record is a function of U_j alone) */
-  template <int DIM>
+  template <typename E>
   __global__ void __launch_bounds__(kBlock)
-  k_riemann_record_rows(const EulerParams P, const uint32_t first, const uint32_t last,
+  k_riemann_record_rows(const typename E::Params P, const uint32_t first, const uint32_t last,
                         const double *__restrict__ U, double *__restrict__ rec)
   {
-    using E = Euler<DIM>;
     constexpr int K = E::K, RS = E::RS;
     const uint32_t i = first + blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= last)
@@ -475,48 +473,13 @@ namespace ryujin_hip
       alpha[i] = indicator.alpha(P, M.mi[i] * M.measure_of_omega_inverse);
   }
 
-  template <typename E>
-  __global__ void __launch_bounds__(kBlock, RYUJIN_OCC_DIJ)
-  k_dij(const typename E::Params P, const DeviceMesh M, const uint32_t *__restrict__ lower_mask,
-        const double *__restrict__ U, double *__restrict__ dij)
-  {
-    constexpr int K = E::K;
-    constexpr int DIM = E::DIMENSION;
-    const RowCtx r = row_context(M);
-    if (!r.valid)
-      return;
-    const bool row_active = r.len > 1;
-    const uint32_t i = row_active ? r.row : (r.row < M.n_owned ? r.row : M.n_owned - 1);
-    const uint32_t *__restrict__ cols = M.cols;
-    const double *__restrict__ cij = M.cij;
-    /* columns 1..len-1 that lie above the diagonal */
-    const uint32_t upper =
-        row_active ? (~lower_mask[r.row] & (r.len >= 32 ? 0xFFFFFFFFu : ((1u << r.len) - 1u)) & ~1u) : 0u;
-
-    double U_i[K];
-    load_state<K>(U, i, U_i);
-    for (uint32_t c = 1; c < r.width; ++c) {
-      const bool mine = (upper >> c) & 1u;
-      if (!__any(mine))
-        continue; /* wave-uniform: no loads at all for lower-triangle columns */
-      const uint64_t colbase = (uint64_t)r.base + c;
-      const uint64_t pos = colbase * 64 + r.lane;
-      const uint32_t j = ld_stream(cols + (pos));
-      double c_ij[DIM], U_j[K];
-      load_entry<DIM>(cij, colbase, r.lane, c_ij);
-      load_state<K>(U, j, U_j);
-      if (mine)
-        dij[pos] = E::dij_from_states(P, U_i, U_j, c_ij);
-    }
-  }
-
   /* The Riemann sweep on per-node records: no state loads, no per-pair pow (see euler_device.hpp) */
-  template <int DIM, bool GENERAL>
+  template <typename E, bool GENERAL>
   __global__ void __launch_bounds__(kBlock, RYUJIN_OCC_DIJ)
-  k_dij_records(const EulerParams P, const DeviceMesh M, const uint32_t *__restrict__ lower_mask,
+  k_dij_records(const typename E::Params P, const DeviceMesh M, const uint32_t *__restrict__ lower_mask,
                 const double *__restrict__ rec, double *__restrict__ dij)
   {
-    using E = Euler<DIM>;
+    constexpr int DIM = E::DIMENSION;
     constexpr int RS = E::RS;
     const RowCtx r = row_context(M);
     if (!r.valid)
@@ -563,14 +526,13 @@ namespace ryujin_hip
    * leaves the VALU mostly idle, the Riemann sweep on records is short and needs few registers -- fused, its
    * arithmetic hides behind the indicator's loads and the column indices / c_ij are read once instead of twice
    * (the round-1 fusion lost because the old Riemann solver held 200+ registers). */
-  template <int DIM, bool GENERAL>
+  template <typename E, bool GENERAL>
   __global__ void __launch_bounds__(kBlock, RYUJIN_OCC_DIJ)
-  k_dij_alpha_records(const EulerParams P, const DeviceMesh M, const double *__restrict__ U,
+  k_dij_alpha_records(const typename E::Params P, const DeviceMesh M, const double *__restrict__ U,
                       const double *__restrict__ prec, const double *__restrict__ rec,
                       double *__restrict__ dij, double *__restrict__ alpha)
   {
-    using E = Euler<DIM>;
-    constexpr int K = E::K, RS = E::RS;
+    constexpr int K = E::K, RS = E::RS, DIM = E::DIMENSION;
     const RowCtx r = row_context(M);
     if (!r.valid)
       return;

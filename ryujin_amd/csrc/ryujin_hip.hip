@@ -316,7 +316,7 @@ struct ryujin_hip_ctx {
 
   struct State {
     DeviceBuffer<double> U, prec;
-    DeviceBuffer<double> rrec; /* Euler: per-node Riemann records (Euler<DIM>::riemann_record) */
+    DeviceBuffer<double> rrec; /* Euler, shallow water: per-node Riemann records (E::riemann_record) */
     bool used = false;
   };
   std::vector<std::unique_ptr<State>> states;
@@ -925,16 +925,17 @@ void ryujin_hip_ctx::prepare_state_vector(int h, const double *dirichlet)
                          s.prec.ptr);
     }, true);
     exchange_vector(s.prec.ptr, E::NPREC, true);
-  } else if constexpr (std::is_same<typename E::Params, EulerParams>::value) {
+  } else if constexpr (std::is_same<typename E::Params, EulerParams>::value ||
+                       std::is_same<typename E::Params, ShallowWaterParams>::value) {
     /* sweep() has joined the U exchange: the ghost states are valid, their records are computed locally */
     sweep([&](const DeviceMesh &mm, dim3 grid) {
-      hipLaunchKernelGGL(k_precompute_euler<E::DIMENSION>, grid, block, 0, launch_stream, eparams, mm,
-                         s.U.ptr, s.prec.ptr, s.rrec.ptr);
+      hipLaunchKernelGGL(k_precompute_records<E>, grid, block, 0, launch_stream, eparams, mm, s.U.ptr,
+                         s.prec.ptr, s.rrec.ptr);
     }, true);
     exchange_vector(s.prec.ptr, 2, true); /* :157-160 */
     if (L.n_relevant > L.n_owned)
-      hipLaunchKernelGGL(k_riemann_record_rows<E::DIMENSION>, dim3(grid_for(L.n_relevant - L.n_owned)), block,
-                         0, stream, eparams, L.n_owned, L.n_relevant, s.U.ptr, s.rrec.ptr);
+      hipLaunchKernelGGL(k_riemann_record_rows<E>, dim3(grid_for(L.n_relevant - L.n_owned)), block, 0, stream,
+                         eparams, L.n_owned, L.n_relevant, s.U.ptr, s.rrec.ptr);
   } else {
     sweep([&](const DeviceMesh &mm, dim3 grid) {
       hipLaunchKernelGGL(k_precompute<E>, grid, block, 0, launch_stream, eparams, mm, s.U.ptr, s.prec.ptr);
@@ -952,6 +953,7 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
   constexpr bool is_euler = std::is_same<typename E::Params, EulerParams>::value;
   constexpr bool is_aeos = std::is_same<typename E::Params, EulerAeosParams>::value;
   constexpr bool is_scalar = std::is_same<typename E::Params, ScalarParams>::value;
+  constexpr bool is_sw = std::is_same<typename E::Params, ShallowWaterParams>::value;
   const auto &eparams = eq_params<E>(); /* shadows the member: the equation's parameter block */
   State &old = state(h_old);
   State &nw = state(h_new);
@@ -997,17 +999,18 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
     mark(8);
     step2_split = true;
     exchange_vector(d_alpha.ptr, 1, true);
-  } else if (is_euler && euler_fast_riemann && L.max_row_len <= 32) {
-    /* (the general Riemann path -- Newton iterations or a non-integral exponent -- holds twice the
+  } else if (((is_euler && euler_fast_riemann) || is_sw) && L.max_row_len <= 32) {
+    /* (Euler's general Riemann path -- Newton iterations or a non-integral exponent -- holds twice the
      * registers and keeps the two-kernel form below) */
-    if constexpr (is_euler) {
+    if constexpr (is_euler || is_sw) {
       sweep([&](const DeviceMesh &mm, dim3 grid) {
-        hipLaunchKernelGGL((k_dij_alpha_records<DIM, false>), grid, block, 0, launch_stream, eparams, mm,
+        hipLaunchKernelGGL((k_dij_alpha_records<E, false>), grid, block, 0, launch_stream, eparams, mm,
                            old.U.ptr, old.prec.ptr, old.rrec.ptr, d_dij.ptr, d_alpha.ptr);
       }, true);
       exchange_vector(d_alpha.ptr, 1, true);
     }
-  } else if (L.max_row_len <= 32) {
+  } else if (is_euler && L.max_row_len <= 32) {
+    /* Euler with the general Riemann path: the indicator sweep and the Riemann sweep as two kernels */
     sweep([&](const DeviceMesh &mm, dim3 grid) {
       hipLaunchKernelGGL(k_alpha<E>, grid, block, 0, launch_stream, eparams, mm, old.U.ptr, old.prec.ptr,
                          d_alpha.ptr);
@@ -1020,14 +1023,12 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
     sweep([&](const DeviceMesh &mm, dim3 grid) {
       if constexpr (is_euler) {
         if (eparams.riemann_newton_max_iterations == 0 && eparams.rarefaction_power > 0)
-          hipLaunchKernelGGL((k_dij_records<DIM, false>), grid, block, 0, launch_stream, eparams, mm,
+          hipLaunchKernelGGL((k_dij_records<E, false>), grid, block, 0, launch_stream, eparams, mm,
                              d_lower_mask.ptr, old.rrec.ptr, d_dij.ptr);
         else
-          hipLaunchKernelGGL((k_dij_records<DIM, true>), grid, block, 0, launch_stream, eparams, mm,
+          hipLaunchKernelGGL((k_dij_records<E, true>), grid, block, 0, launch_stream, eparams, mm,
                              d_lower_mask.ptr, old.rrec.ptr, d_dij.ptr);
-      } else
-        hipLaunchKernelGGL(k_dij<E>, grid, block, 0, launch_stream, eparams, mm, d_lower_mask.ptr, old.U.ptr,
-                           d_dij.ptr);
+      }
     }, false);
     comm_pending = pending;
   } else {
@@ -1698,6 +1699,8 @@ int ryujin_hip_state_alloc(ryujin_hip_ctx *ctx, int *handle)
       ctx->states[h]->prec.alloc((size_t)ctx->L.n_relevant * ctx->NPREC);
       if (ctx->params.equation == RYUJIN_EQ_EULER)
         ctx->states[h]->rrec.alloc((size_t)ctx->L.n_relevant * ((6 + ctx->dim + 1) / 2 * 2));
+      else if (ctx->params.equation == RYUJIN_EQ_SHALLOW_WATER)
+        ctx->states[h]->rrec.alloc((size_t)ctx->L.n_relevant * ((3 + ctx->dim + 1) / 2 * 2));
     }
     ctx->states[h]->used = true;
     *handle = h;
@@ -2101,6 +2104,17 @@ namespace
       out[q] = PE.riemann_newton_max_iterations == 0 && PE.rarefaction_power > 0
                    ? Euler<3>::dij_from_records<false>(PE, r_i, r_j, c)
                    : Euler<3>::dij_from_records<true>(PE, r_i, r_j, c);
+    } else if (which == RYUJIN_DEBUG_SW_DIJ_2D || which == RYUJIN_DEBUG_SW_DIJ_RECORDS_2D) {
+      const double *v = in + q * 8;
+      const double U_i[3] = {v[0], v[1], v[2]}, U_j[3] = {v[3], v[4], v[5]}, c[2] = {v[6], v[7]};
+      if (which == RYUJIN_DEBUG_SW_DIJ_2D) {
+        out[q] = ShallowWater<2>::dij_from_states(PS, U_i, U_j, c);
+      } else {
+        double r_i[ShallowWater<2>::RS], r_j[ShallowWater<2>::RS];
+        ShallowWater<2>::riemann_record(PS, U_i, r_i);
+        ShallowWater<2>::riemann_record(PS, U_j, r_j);
+        out[q] = ShallowWater<2>::dij_from_records<false>(PS, r_i, r_j, c);
+      }
     }
   }
 } // namespace
@@ -2120,6 +2134,8 @@ int ryujin_hip_debug_function(int device, const ryujin_hip_params *params, int w
     case RYUJIN_DEBUG_EULER_DIJ_RECORDS_2D: n_in = 10; n_out = 1; break;
     case RYUJIN_DEBUG_EULER_DIJ_3D:
     case RYUJIN_DEBUG_EULER_DIJ_RECORDS_3D: n_in = 13; n_out = 1; break;
+    case RYUJIN_DEBUG_SW_DIJ_2D:
+    case RYUJIN_DEBUG_SW_DIJ_RECORDS_2D: n_in = 8; n_out = 1; break;
     default: throw HipError(RYUJIN_ERR_ARG, "unknown debug function");
     }
     HIP_CHECK(hipSetDevice(device));

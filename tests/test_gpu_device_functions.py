@@ -143,3 +143,37 @@ def test_device_dij_against_the_oracle_on_random_states(oracle, dim, records):
                                       capi.as_ptr(c, dp), capi.as_ptr(ref, dp))
     rel = np.abs(got - ref) / np.abs(ref)
     assert rel.max() <= 1e-12, (rel.max(), int(rel.argmax()))
+
+
+@pytest.mark.parametrize("records", [False, True])
+def test_device_sw_dij_against_the_oracle_on_random_states(oracle, records):
+    """shallow water d_ij for 200 k random state pairs incl. dry and nearly dry states, Froude numbers up to 4 --
+    through dij_from_states (the reference's operation order) and through the per-node records of the sweep."""
+    rng = np.random.default_rng(11)
+    n = 200_000
+    params = oracle.default_params(capi.EQ_SHALLOW_WATER, 2)
+
+    def states():
+        h = 10.0 ** rng.uniform(-6, 1, n)
+        h[rng.uniform(size=n) < 0.05] = 0.0                      # dry
+        a = np.sqrt(params.gravity * np.maximum(h, 1e-300))
+        v = rng.normal(size=(n, 2))
+        v *= (rng.uniform(0, 4, n) * a / np.linalg.norm(v, axis=1))[:, None]
+        return np.column_stack([h, h * v[:, 0], h * v[:, 1]])
+
+    U_i, U_j = states(), states()
+    c = rng.normal(size=(n, 2)) * 10.0 ** rng.uniform(-4, 0, n)[:, None]
+    got = _device(params, capi.DEBUG_SW_DIJ_RECORDS_2D if records else capi.DEBUG_SW_DIJ_2D,
+                  np.hstack([U_i, U_j, c]), 1)[:, 0]
+    ref = np.empty(n)
+    dp = capi.c_double_p
+    U_i, U_j, c = (np.ascontiguousarray(x) for x in (U_i, U_j, c))
+    oracle.load().ryujin_oracle_sw_dij_batch(C.byref(params), n, capi.as_ptr(U_i, dp), capi.as_ptr(U_j, dp),
+                                             capi.as_ptr(c, dp), capi.as_ptr(ref, dp))
+    # the wave speed is a difference u -+ a sqrt(..): scale by |c| (|u| + a) of the faster state
+    h = np.maximum(np.maximum(U_i[:, 0], U_j[:, 0]), 1e-300)
+    speed = np.maximum(np.linalg.norm(U_i[:, 1:], axis=1) / np.maximum(U_i[:, 0], 1e-300) * (U_i[:, 0] > 0),
+                       np.linalg.norm(U_j[:, 1:], axis=1) / np.maximum(U_j[:, 0], 1e-300) * (U_j[:, 0] > 0))
+    scale = np.linalg.norm(c, axis=1) * (speed + np.sqrt(params.gravity * h))
+    err = np.abs(got - ref) / np.maximum(scale, 1e-300)
+    assert err.max() <= 1e-12, (err.max(), int(err.argmax()))
