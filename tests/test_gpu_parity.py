@@ -1090,6 +1090,36 @@ def test_riemann_newton_iterations_and_tau_max(oracle):
             m.step(old, [], [], new, 0.0, -1.0)       # AssertThrow at :573-576
 
 
+@pytest.mark.parametrize("gamma", [1.3, 5.0 / 3.0, 2.0])
+def test_step_parity_other_ratios_of_specific_heats(oracle, gamma):
+    """The Riemann sweep evaluates p_star_two_rarefaction's exponent 2 gamma / (gamma - 1) by multiplications
+    when it is integral (7/5 -> 7, 5/3 -> 5, 2 -> 4) and with pow otherwise (1.3 -> 8.67: the general kernel,
+    split from the indicator sweep). Every path against the oracle, developed flow in 2-D and 3-D."""
+    from ryujin_amd.initial_states import euler_from_primitive
+
+    def edit(p):
+        p.gamma = gamma
+
+    spec = offline.mach3_step_2d(30)
+    off0 = offline.SyntheticOffline(spec)
+
+    def prim(pos):   # Mach 3 for this gamma
+        n = len(pos)
+        v = np.zeros((n, pos.shape[1]))
+        v[:, 0] = 3.0
+        return euler_from_primitive(np.full(n, gamma), v, np.ones(n), gamma=gamma)
+    U0 = _perturbed(prim(off0.positions))
+    dirichlet = prim(off0.b_positions)
+    off, mods = _both(spec, U0, oracle, n_warm=10, dirichlet=dirichlet, params_edit=edit)
+    _compare_step(off, mods, dirichlet)
+
+    spec3 = offline.box_3d(10)
+    off3 = offline.SyntheticOffline(spec3)
+    U3 = euler_radial_contrast(off3.positions, radius=0.4, gamma=gamma)
+    off, mods = _both(spec3, U3, oracle, n_warm=4, params_edit=edit)
+    _compare_step(off, mods)
+
+
 @pytest.mark.parametrize("kinetic,square", [(1, 0), (1, 1), (0, 0)])
 def test_sw_limiter_options(oracle, kinetic, square):
     """Shallow-water limiter with 'limit on kinetic energy' / 'limit on square velocity' in the three
