@@ -384,6 +384,13 @@ enum {
 };
 int ryujin_hip_debug_function(int device, const ryujin_hip_params *params, int which, const double *in,
                               double *out, size_t n);
+/* Host logic of ryujin_hip_time_step, exposed for the CPU test-suite: what the end-of-step flags mean.
+ * restart_accum / tau_invalid_accum: 0 = never raised, else 100 - (index of the first RK stage that raised it).
+ * Returns RYUJIN_ERR_TAU, RYUJIN_RESTART, RYUJIN_WARN or RYUJIN_OK. Under raise_exception the reference throws
+ * Restart at the end of the offending stage (hyperbolic_module.template.h:1194-1207) and never evaluates tau_max
+ * of a later stage (:573-576); here all stages are enqueued before the flags are read, so an invalid tau_max of a
+ * stage LATER than the first Restart must not turn the recoverable Restart into the fatal error. */
+int ryujin_hip_debug_rk_outcome(int restart_accum, int tau_invalid_accum, int id_violation_strategy);
 const char *ryujin_hip_last_error(void);
 const char *ryujin_hip_version(void);
 

@@ -159,7 +159,7 @@ HIP_SYMBOLS = [
     "ryujin_hip_get_alpha", "ryujin_hip_get_counters", "ryujin_hip_debug_fetch",
     "ryujin_hip_set_timers", "ryujin_hip_get_timers", "ryujin_hip_synchronize",
     "ryujin_hip_event_record", "ryujin_hip_event_elapsed_ms", "ryujin_hip_last_error",
-    "ryujin_hip_version", "ryujin_hip_debug_layout", "ryujin_hip_debug_pow", "ryujin_hip_debug_function",
+    "ryujin_hip_version", "ryujin_hip_debug_layout", "ryujin_hip_debug_pow", "ryujin_hip_debug_function", "ryujin_hip_debug_rk_outcome",
 ]
 
 
@@ -227,6 +227,7 @@ def load_hip():
         lib.ryujin_hip_debug_layout.argtypes = [C.POINTER(Offline), c_u64_p, c_u32_p, c_u64_p,
                                                 c_double_p, C.c_uint32, c_double_p]
         lib.ryujin_hip_debug_pow.argtypes = [C.c_int, c_double_p, c_double_p, c_double_p, C.c_size_t]
+        lib.ryujin_hip_debug_rk_outcome.argtypes = [C.c_int, C.c_int, C.c_int]
         lib.ryujin_hip_debug_function.argtypes = [C.c_int, C.POINTER(Params), C.c_int, c_double_p, c_double_p,
                                                   C.c_size_t]
         _hip = lib

@@ -1437,12 +1437,10 @@ int ryujin_hip_ctx::time_step(int scheme, int h_state, int n_tmp, const int *h_t
    * evaluates tau_max of a later one (hyperbolic_module.template.h:1194-1207), whereas here all stages are
    * already enqueued and run on the inadmissible state: an invalid tau_max only counts ("We crashed",
    * :573-576) if it was found in a stage not later than the first Restart. */
-  {
-    const int t = h_scalars->tau_invalid_accum, r = h_scalars->restart_accum;
-    const bool restart_wins = params.id_violation_strategy == RYUJIN_IDV_RAISE_EXCEPTION && r > t;
-    if (t > 0 && !restart_wins)
-      return RYUJIN_ERR_TAU;
-  }
+  const int first_outcome = ryujin_hip_debug_rk_outcome(h_scalars->restart_accum, h_scalars->tau_invalid_accum,
+                                                         params.id_violation_strategy);
+  if (first_outcome == RYUJIN_ERR_TAU)
+    return RYUJIN_ERR_TAU;
   int status = RYUJIN_OK;
   if (h_scalars->restart_accum) {
     if (params.id_violation_strategy == RYUJIN_IDV_RAISE_EXCEPTION) {
@@ -1700,7 +1698,7 @@ int ryujin_hip_state_alloc(ryujin_hip_ctx *ctx, int *handle)
       if (ctx->params.equation == RYUJIN_EQ_EULER)
         ctx->states[h]->rrec.alloc((size_t)ctx->L.n_relevant * ((6 + ctx->dim + 1) / 2 * 2));
       else if (ctx->params.equation == RYUJIN_EQ_SHALLOW_WATER)
-        ctx->states[h]->rrec.alloc((size_t)ctx->L.n_relevant * ((3 + ctx->dim + 1) / 2 * 2));
+        ctx->states[h]->rrec.alloc((size_t)ctx->L.n_relevant * ((2 + ctx->dim + 1) / 2 * 2));
     }
     ctx->states[h]->used = true;
     *handle = h;
@@ -2148,6 +2146,19 @@ int ryujin_hip_debug_function(int device, const ryujin_hip_params *params, int w
     HIP_CHECK(hipMemcpy(out, dout.ptr, n * n_out * sizeof(double), hipMemcpyDeviceToHost));
     return RYUJIN_OK;
   });
+}
+
+/* The decision at the end of a device-resident RK step from the two accumulated flags
+ * (0 = never raised, otherwise kStageCode - index of the first stage that raised it; see time_step) */
+int ryujin_hip_debug_rk_outcome(int restart_accum, int tau_invalid_accum, int id_violation_strategy)
+{
+  const int t = tau_invalid_accum, r = restart_accum;
+  const bool restart_wins = id_violation_strategy == RYUJIN_IDV_RAISE_EXCEPTION && r > t;
+  if (t > 0 && !restart_wins)
+    return RYUJIN_ERR_TAU;
+  if (r > 0)
+    return id_violation_strategy == RYUJIN_IDV_RAISE_EXCEPTION ? RYUJIN_RESTART : RYUJIN_WARN;
+  return RYUJIN_OK;
 }
 
 int ryujin_hip_set_timers(ryujin_hip_ctx *ctx, int enable)

@@ -381,20 +381,19 @@ namespace ryujin_hip
      * stored roots. phi(x_0 h_max) is evaluated on its shock branch only: x_0 = (2 sqrt 2 - 1)^2 > 1, so
      * x_0 h_max > h_Z for both states and rs_f never takes the rarefaction branch there.
      * 5 divisions + 5 square roots per pair instead of 9 + 12; results within a few ulp (1e-12 contract on d_ij).
-     * record = (h, a, sqrt(h), v[DIM]) padded to an even number of doubles */
-    static constexpr int RS = (3 + DIM + 1) / 2 * 2;
+     * record = (h, a, v[DIM]) padded to an even number of doubles (32 bytes); sqrt(h) = a / sqrt(g) */
+    static constexpr int RS = (2 + DIM + 1) / 2 * 2;
 
     static RYUJIN_DEV void riemann_record(const Params &P, const double (&U)[K], double (&rec)[RS])
     {
       const double h = water_depth_sharp(P, U);
       rec[0] = h;
       rec[1] = sqrt(h * P.gravity);
-      rec[2] = sqrt(h);
 #pragma unroll
       for (int d = 0; d < DIM; ++d)
-        rec[3 + d] = U[1 + d] / h;
+        rec[2 + d] = U[1 + d] / h;
 #pragma unroll
-      for (int d = 3 + DIM; d < RS; ++d)
+      for (int d = 2 + DIM; d < RS; ++d)
         rec[d] = 0.;
     }
 
@@ -403,12 +402,12 @@ namespace ryujin_hip
                                               const double (&c)[DIM])
     {
       double norm2 = c[0] * c[0];
-      double vc_i = ri[3] * c[0], vc_j = rj[3] * c[0];
+      double vc_i = ri[2] * c[0], vc_j = rj[2] * c[0];
 #pragma unroll
       for (int d = 1; d < DIM; ++d) {
         norm2 += c[d] * c[d];
-        vc_i += ri[3 + d] * c[d];
-        vc_j += rj[3 + d] * c[d];
+        vc_i += ri[2 + d] * c[d];
+        vc_j += rj[2 + d] * c[d];
       }
       const double norm = sqrt(norm2);
       const double inverse_norm = 1. / norm;
@@ -419,8 +418,9 @@ namespace ryujin_hip
       const bool i_is_min = h_i <= h_j;
       const double h_min = i_is_min ? h_i : h_j, h_max = i_is_min ? h_j : h_i;
       const double a_min = i_is_min ? a_i : a_j, a_max = i_is_min ? a_j : a_i;
-      const double sq_min = i_is_min ? ri[2] : rj[2], sq_max = i_is_min ? rj[2] : ri[2];
       const double sqrt_two = 1.4142135623730951;
+      const double inverse_sqrt_g = sqrt(1. / P.gravity); /* wave-uniform */
+      const double sq_min = a_min * inverse_sqrt_g, sq_max = a_max * inverse_sqrt_g; /* sqrt(h) */
       const double x0 = 9. - 4. * sqrt_two;
       double phi_value_max;
       {
@@ -432,7 +432,7 @@ namespace ryujin_hip
       const double sq_min_max = sq_min * sq_max; /* sqrt(h_min h_max) */
       const double h_star_middle = sq_min_max * (1. + sqrt_two * (u_i - u_j) / (a_min + a_max));
       const double left_radicand = 3. * h_min + 2. * sqrt_two * sq_min_max;
-      const double right_radicand = sqrt_two * (sq_min * sqrt(1. / P.gravity)) * (u_i - u_j);
+      const double right_radicand = sqrt_two * (sq_min * inverse_sqrt_g) * (u_i - u_j);
       double tmp = sqrt(positive_part(left_radicand + right_radicand));
       tmp -= sqrt_two * sq_min;
       const double h_star_right = tmp * tmp;

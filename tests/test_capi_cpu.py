@@ -203,3 +203,28 @@ def test_headers_are_plain_c_and_match_the_ctypes_mirror(tmp_path):
                     str(src), "-o", str(exe)], check=True, capture_output=True)
     sizes = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
     assert sizes == [C.sizeof(capi.Params), C.sizeof(capi.Offline), C.sizeof(capi.SynthSpec)]
+
+
+def test_restart_takes_precedence_over_a_later_invalid_tau():
+    """ryujin_hip_time_step enqueues all RK stages before it reads the flags. The reference throws Restart at the
+    end of the offending stage and never runs the next one (hyperbolic_module.template.h:1194-1207), so an
+    invalid tau_max found in a LATER stage (on the inadmissible state) must not turn the recoverable Restart
+    into the fatal "We crashed" (:573-576) -- while an invalid tau_max in the same or an earlier stage must
+    (tau_max is checked in step 3, the Restart is raised at the end of the step). Flags are coded
+    100 - (first stage that raised them), 0 = never."""
+    lib = capi.load_hip()
+    code = lambda stage: 100 - stage  # noqa: E731
+    RAISE, WARN = capi.IDV_RAISE_EXCEPTION, capi.IDV_WARN
+    f = lib.ryujin_hip_debug_rk_outcome
+    assert f(0, 0, RAISE) == capi.RYUJIN_OK and f(0, 0, WARN) == capi.RYUJIN_OK
+    assert f(code(0), 0, RAISE) == capi.RYUJIN_RESTART and f(code(2), 0, WARN) == capi.RYUJIN_WARN
+    assert f(0, code(1), RAISE) == capi.RYUJIN_ERR_TAU
+    # Restart in stage 0, tau invalid in stage 1 or 2: the bang-bang retry has to run
+    assert f(code(0), code(1), RAISE) == capi.RYUJIN_RESTART
+    assert f(code(0), code(2), RAISE) == capi.RYUJIN_RESTART
+    assert f(code(1), code(2), RAISE) == capi.RYUJIN_RESTART
+    # same stage, or tau first: fatal
+    assert f(code(1), code(1), RAISE) == capi.RYUJIN_ERR_TAU
+    assert f(code(2), code(0), RAISE) == capi.RYUJIN_ERR_TAU
+    # under `warn` (the retry at cfl_min) the reference keeps going: a later invalid tau is a genuine crash
+    assert f(code(0), code(1), WARN) == capi.RYUJIN_ERR_TAU
