@@ -10,7 +10,10 @@ _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if _ROOT not in sys.path:
     sys.path.insert(0, _ROOT)
 
-from ryujin_amd import _build, capi  # noqa: E402
+from ryujin_amd import capi  # noqa: E402
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import build_oracle as _build_oracle  # noqa: E402
 
 EXCHANGE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_int)
 
@@ -22,9 +25,9 @@ def load(path: str | None = None):
     if _lib is not None and path is None:
         return _lib
     if path is None:
-        path = _build.ORACLE_SO
+        path = _build_oracle.ORACLE_SO
         if not os.path.exists(path):
-            _build.build_oracle()
+            _build_oracle.build_oracle()
     lib = C.CDLL(path)
     capi._declare_module_api(lib, "ryujin_oracle_")
     dp = capi.c_double_p
@@ -57,7 +60,7 @@ def load(path: str | None = None):
     lib.ryujin_oracle_scalar_riemann.argtypes = [pp, C.c_double, C.c_double, dp, dp, dp]
     lib.ryujin_oracle_scalar_flux.argtypes = [pp, C.c_double, dp]
     lib.ryujin_oracle_scalar_limit.argtypes = [pp, C.c_int, dp, C.c_double, C.c_double, dp, capi.c_int_p]
-    if path == _build.ORACLE_SO:
+    if path == _build_oracle.ORACLE_SO:
         _lib = lib
     return lib
 

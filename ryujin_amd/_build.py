@@ -2,7 +2,6 @@
 
   ryujin_amd/lib/libryujin_synth.so   g++    synthetic OfflineData generator (host)
   ryujin_amd/lib/libryujin_hip.so     hipcc  HIP kernels + C ABI (gfx950)
-  oracle/build/libryujin_oracle.so    g++    CPU restatement (test infrastructure)
 
 The .so files are git-ignored but travel to the GPU box with the snapshot.
 """
@@ -17,11 +16,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "ryujin_amd", "csrc")
 LIBDIR = os.path.join(ROOT, "ryujin_amd", "lib")
 INCLUDE = os.path.join(ROOT, "include")
-ORACLE = os.path.join(ROOT, "oracle")
 
 SYNTH_SO = os.path.join(LIBDIR, "libryujin_synth.so")
 HIP_SO = os.path.join(LIBDIR, "libryujin_hip.so")
-ORACLE_SO = os.path.join(ORACLE, "build", "libryujin_oracle.so")
 
 
 def _newer(target: str, sources: list[str]) -> bool:
@@ -90,19 +87,8 @@ def build_hip(force: bool = False, defines: tuple = (), out: str | None = None) 
     return HIP_SO
 
 
-def build_oracle(force: bool = False) -> str:
-    src = [os.path.join(ORACLE, "oracle_capi.cc")]
-    deps = src + _sources(ORACLE, (".hpp", ".h", ".cc")) + _headers()
-    if force or not _newer(ORACLE_SO, deps):
-        os.makedirs(os.path.dirname(ORACLE_SO), exist_ok=True)
-        _run(["g++", "-O3", "-std=c++17", "-fPIC", "-shared", "-fopenmp",
-              "-ffp-contract=off", "-Wall", "-I" + INCLUDE, "-I" + ORACLE, *src, "-o", ORACLE_SO])
-    return ORACLE_SO
-
-
 def build_all(force: bool = False) -> None:
     build_synth(force)
-    build_oracle(force)
     build_hip(force)
 
 

@@ -138,14 +138,13 @@ def test_layout_roundtrip_on_renumbered_mesh(oracle):
 
 
 def test_oracle_is_not_reachable_from_the_product():
-    """The product package must not import, link or load anything under oracle/."""
+    """The product package must not import, link, load -- or build -- anything under oracle/ (the checker's
+    build recipe lives in oracle/build_oracle.py)."""
     pkg = os.path.join(ROOT, "ryujin_amd")
     for base, _, files in os.walk(pkg):
         for f in files:
             if f.endswith((".py", ".hpp", ".h", ".hip", ".cc")):
                 text = open(os.path.join(base, f)).read()
-                if f == "_build.py":
-                    continue  # build recipe of the checker, not a use of it
                 assert "oracle_py" not in text and "libryujin_oracle" not in text and \
                     "oracle/" not in text.replace("the CPU oracle", ""), f
 
