@@ -25,9 +25,9 @@ def _n_gpus():
     import ctypes as C
     try:
         from ryujin_amd import capi
-        capi.load_hip()
         n = C.c_int(0)
-        if C.CDLL("libamdhip64.so").hipGetDeviceCount(C.byref(n)) != 0:
+        # dlsym on the library's handle also searches its dependencies: the very runtime it is linked against
+        if capi.load_hip().hipGetDeviceCount(C.byref(n)) != 0:
             return 0
         return n.value
     except Exception:
