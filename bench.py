@@ -468,7 +468,10 @@ def main():
     dom_gbs = alg[dom] * n_q_local / (per_sweep[dom] * 1e-3) / 1e9
     upd_gbs = b_alg * n_q_local / (ev_ms.value / args.steps * 1e-3) / 1e9
 
-    traffic, traffic_file = pmc_traffic_bytes(dom, args.workload)
+    # the committed PMC passes were taken on the default problem of each workload: do not attach them to a run
+    # of another size or with a perturbed state
+    default_problem = (args.cells_per_unit == 995 and args.size == 0 and args.perturbation == 0.0 and n_gpus == 1)
+    traffic, traffic_file = pmc_traffic_bytes(dom, args.workload) if default_problem else (None, None)
     out = {
         "metric": "MDoF-updates/s per Euler forward step; achieved HBM GB/s vs roofline",
         "value": k * n_q_total * args.steps / wall / 1e6,

@@ -528,7 +528,7 @@ namespace ryujin_hip
      * normal velocity does not depend on the direction n_ij: |m|^2 = (m.n)^2 + |m - (m.n) n|^2 for |n| = 1,
      * hence p = (gamma - 1)(E - |m|^2 / (2 rho)) and a = sqrt(gamma p / rho). A row recomputes these for
      * itself and every neighbour, ~4 (2-D) to ~13 (3-D) times per node. They are therefore computed ONCE per
-     * node next to the precomputed values (k_precompute) together with p^((gamma-1)/(2 gamma)), which turns
+     * node next to the precomputed values (k_precompute_records) together with p^((gamma-1)/(2 gamma)), which turns
      *   (p_i / p_j)^(-(gamma-1)/(2 gamma))  into  pw_j / pw_i        (p_star_two_rarefaction, :296-313),
      * and the second pow of that formula has the exponent 2 gamma / (gamma - 1) = 7 for gamma = 7/5.
      * phi(p_max) (:134-148) shares its square roots with p_star_failsafe (:348-368):

@@ -7,12 +7,14 @@
 // lanes gather consecutive j). No MFMA: the path is a bandwidth-bound stencil sweep.
 //
 // Sweeps follow the reference one to one (source/hyperbolic_module.template.h):
-//   k_apply_bc + k_precompute      step 1  :96-193
-//   k_dij_alpha                    step 2  :341-424
-//   k_dij_boundary + k_dij_diag    step 3  :432-564
-//   k_low_order                    step 4  :597-884
-//   k_pij_lij                      step 5  :892-1041
-//   k_high_order<false/true>       step 6/7 :1053-1182
+//   k_apply_bc + k_precompute_records              step 1  :96-193
+//   k_dij_alpha_records (k_alpha + k_dij_records,  step 2  :341-424
+//     k_dij_alpha for rows wider than 32)
+//   k_dij_boundary + k_dij_diag[_unrolled]         step 3  :432-564
+//   k_low_order (finalize_tau)                     step 4  :597-884
+//   k_pij_lij[_recompute]                          step 5  :892-1041
+//   k_high_order_next_cached / k_high_order<false> step 6  :1053-1182
+//   k_high_order_last_cached / k_high_order<true>  step 7  :1053-1182
 
 #pragma once
 
@@ -309,25 +311,8 @@ namespace ryujin_hip
       store_state<K>(U, i, U_i);
   }
 
-  /* precomputation_loop: source/euler/hyperbolic_system.h:702-737 */
-  template <typename E>
-  __global__ void __launch_bounds__(kBlock)
-  k_precompute(const typename E::Params P, const DeviceMesh M, const double *__restrict__ U,
-               double *__restrict__ prec)
-  {
-    constexpr int K = E::K;
-    const uint32_t i = M.slice_begin * 64 + blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= M.n_owned || i >= M.slice_end * 64)
-      return;
-    if (M.row_len[i] == 1)
-      return;
-    double U_i[K];
-    load_state<K>(U, i, U_i);
-    reinterpret_cast<double2 *>(prec)[i] = E::precompute(P, U_i);
-  }
-
-  /* Euler, shallow water: precomputed values AND the per-node Riemann record (E::riemann_record) in one
-   * pass over the owned rows */
+  /* precomputation_loop (source/euler/hyperbolic_system.h:702-737, shallow_water/hyperbolic_system.h:676-716):
+   * the precomputed values AND the per-node Riemann record (E::riemann_record) in one pass over the owned rows */
   template <typename E>
   __global__ void __launch_bounds__(kBlock)
   k_precompute_records(const typename E::Params P, const DeviceMesh M, const double *__restrict__ U,

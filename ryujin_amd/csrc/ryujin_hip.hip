@@ -398,7 +398,7 @@ struct ryujin_hip_ctx {
   void begin_exchange(bool after_split_sweep);
   void end_exchange();
   template <typename F>
-  void sweep(F &&launch, bool followed_by_exchange);
+  void sweep(F &&launch, bool followed_by_exchange, bool join_comm = true);
   template <typename E>
   void prepare_state_vector(int h, const double *dirichlet);
   template <typename E>
@@ -710,8 +710,10 @@ void ryujin_hip_ctx::end_exchange()
   comm_pending = true;
 }
 
+/* join_comm = false: the sweep touches no ghost data and nothing a pending exchange writes, so it need not wait
+ * for it (the pre-pass after the U exchange: it reads owned U only while RCCL fills the ghost range of U) */
 template <typename F>
-void ryujin_hip_ctx::sweep(F &&launch, bool followed_by_exchange)
+void ryujin_hip_ctx::sweep(F &&launch, bool followed_by_exchange, bool join_comm)
 {
   auto run = [&](uint32_t s0, uint32_t s1, hipStream_t on) {
     if (s1 <= s0)
@@ -725,7 +727,8 @@ void ryujin_hip_ctx::sweep(F &&launch, bool followed_by_exchange)
     launch(mm, grid);
     launch_stream = stream;
   };
-  wait_comm();
+  if (join_comm)
+    wait_comm();
   if (n_nbr == 0 || !followed_by_exchange) {
     run(0, L.n_slices, stream);
     return;
@@ -925,22 +928,23 @@ void ryujin_hip_ctx::prepare_state_vector(int h, const double *dirichlet)
                          s.prec.ptr);
     }, true);
     exchange_vector(s.prec.ptr, E::NPREC, true);
-  } else if constexpr (std::is_same<typename E::Params, EulerParams>::value ||
-                       std::is_same<typename E::Params, ShallowWaterParams>::value) {
-    /* sweep() has joined the U exchange: the ghost states are valid, their records are computed locally */
+  } else {
+    static_assert(std::is_same<typename E::Params, EulerParams>::value ||
+                      std::is_same<typename E::Params, ShallowWaterParams>::value,
+                  "Descriptions with node records");
+    /* The pre-pass reads owned U only: it overlaps with the ghost exchange of U (round 1 joined the exchange
+     * first, so that exchange hid behind nothing). The records of the ghost rows are computed locally from the
+     * exchanged ghost states (a function of U_j alone: nothing to exchange), behind both exchanges. */
     sweep([&](const DeviceMesh &mm, dim3 grid) {
       hipLaunchKernelGGL(k_precompute_records<E>, grid, block, 0, launch_stream, eparams, mm, s.U.ptr,
                          s.prec.ptr, s.rrec.ptr);
-    }, true);
+    }, true, /*join_comm=*/false);
     exchange_vector(s.prec.ptr, 2, true); /* :157-160 */
-    if (L.n_relevant > L.n_owned)
+    if (L.n_relevant > L.n_owned) {
+      wait_comm();
       hipLaunchKernelGGL(k_riemann_record_rows<E>, dim3(grid_for(L.n_relevant - L.n_owned)), block, 0, stream,
                          eparams, L.n_owned, L.n_relevant, s.U.ptr, s.rrec.ptr);
-  } else {
-    sweep([&](const DeviceMesh &mm, dim3 grid) {
-      hipLaunchKernelGGL(k_precompute<E>, grid, block, 0, launch_stream, eparams, mm, s.U.ptr, s.prec.ptr);
-    }, true);
-    exchange_vector(s.prec.ptr, 2, true); /* :157-160 */
+    }
   }
   HIP_CHECK(hipGetLastError());
 }

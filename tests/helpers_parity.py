@@ -239,7 +239,16 @@ def compare_step(off, mods, dirichlet=None, tau=0.0, *, oracle=None, params=None
     flipped_rows = set()
     n_flips = {}
     for name, dl in (("lij", dl_first), ("lij_next", dl_next)):
-        assert np.median(dl) == 0.0 or np.median(dl) < 1e-14, name
+        # no systematic difference: the typical |dl| is round-off. (Where P_ij is negligible -- quiescent water,
+        # uniform flow -- l_ij is a quotient of two round-off sized numbers in the reference itself and says
+        # nothing; the median is taken over the pairs with a non-negligible P_ij, as the 1e-10 bound below.)
+        if not (np.median(dl) == 0.0 or np.median(dl) < 1e-14):
+            if "pij" not in c:
+                c["pij"] = mc.debug_fetch("pij")
+            relevant = (np.abs(c["pij"].reshape(-1, k)) / scale).max(axis=1) > 1e-3
+            med = np.median(dl[relevant]) if relevant.any() else 0.0
+            _stat(label, what=name + "_median", all=float(np.median(dl)), relevant=float(med))
+            assert med < 1e-14, (name, float(med))
         idx = np.nonzero(dl > L_TOL)[0]
         if idx.size and "pij" not in c:   # full-size run: P_ij of the oracle only, and only now
             c["pij"] = mc.debug_fetch("pij")
