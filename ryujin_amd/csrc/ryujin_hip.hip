@@ -721,8 +721,8 @@ void ryujin_hip_ctx::sweep(F &&launch, bool followed_by_exchange, bool join_comm
     DeviceMesh mm = mesh;
     mm.slice_begin = s0;
     mm.slice_end = s1;
-    /* one wave per slice, 4 slices per block; rounded up to a multiple of 8 for the XCD remap */
-    const dim3 grid(((s1 - s0 + kWavesPerBlock - 1) / kWavesPerBlock + 7) / 8 * 8);
+    /* one wave per slice, 4 slices per block (waves beyond slice_end return at once) */
+    const dim3 grid((s1 - s0 + kWavesPerBlock - 1) / kWavesPerBlock);
     launch_stream = on;
     launch(mm, grid);
     launch_stream = stream;
