@@ -247,6 +247,12 @@ int ryujin_hip_comm_init(ryujin_hip_comm **comm, const char id[RYUJIN_HIP_UNIQUE
 /* Test facility: n_ranks communicators of ONE process (one host thread per rank, all on `device`)
  * that exchange ghost data with device-to-device copies instead of RCCL. comms: [n_ranks]. */
 int ryujin_hip_comm_init_local(ryujin_hip_comm **comms, int n_ranks, int device);
+/* Measurement facility: a communicator for ONE rank of an n_ranks slab partition that is run alone; every
+ * neighbour is replaced by the rank itself (what it packs for the opposite neighbour arrives in its ghost range,
+ * i.e. a periodic channel). All launches, pack kernels, copies, events and reductions of a middle rank of a real
+ * run, without the network: what the multi-rank choreography costs per rank (scripts/overhead_loopback.py). The
+ * offline data must have two neighbours with equally sized send / ghost ranges (uniform cross-section). */
+int ryujin_hip_comm_init_loopback(ryujin_hip_comm **comm, int rank, int n_ranks, int device);
 void ryujin_hip_comm_destroy(ryujin_hip_comm *comm);
 
 /* ---- lifecycle ----------------------------------------------------------- */

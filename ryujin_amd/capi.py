@@ -149,6 +149,7 @@ def load_synth():
 
 HIP_SYMBOLS = [
     "ryujin_hip_comm_unique_id", "ryujin_hip_comm_init", "ryujin_hip_comm_init_local",
+    "ryujin_hip_comm_init_loopback",
     "ryujin_hip_comm_destroy",
     "ryujin_hip_default_params", "ryujin_hip_create", "ryujin_hip_destroy",
     "ryujin_hip_state_alloc", "ryujin_hip_state_free", "ryujin_hip_state_upload",
@@ -211,6 +212,7 @@ def load_hip():
         lib.ryujin_hip_comm_unique_id.argtypes = [C.c_char_p]
         lib.ryujin_hip_comm_init.argtypes = [C.POINTER(vp), C.c_char_p, C.c_int, C.c_int, C.c_int]
         lib.ryujin_hip_comm_init_local.argtypes = [C.POINTER(vp), C.c_int, C.c_int]
+        lib.ryujin_hip_comm_init_loopback.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int]
         lib.ryujin_hip_comm_destroy.argtypes = [vp]
         lib.ryujin_hip_comm_destroy.restype = None
         lib.ryujin_hip_set_timers.argtypes = [vp, C.c_int]

@@ -184,6 +184,11 @@ struct LocalGroup {
   std::vector<double> scratch_vec;                          /* [n_ranks][8] vector sums (host) */
   int refs = 0;
   int device = 0;
+  /* Measurement facility: ONE rank of an n-rank slab partition run alone, every neighbour replaced by the rank
+   * itself (the segment packed for the opposite neighbour is pulled into the ghost range: a periodic channel).
+   * Same launches, pack kernels, copies, events and reductions as a middle rank of a real run, on an unshared
+   * GPU -- what the choreography costs per rank, without the network (scripts/overhead_loopback.py). */
+  bool loopback = false;
 
   LocalGroup(int n, int dev)
       : n_ranks(n)
@@ -754,9 +759,10 @@ void ryujin_hip_ctx::local_before_pack()
   if (x == 0)
     return;
   for (int q = 0; q < n_nbr; ++q) {
-    g.await(g.pulled, nbr_rank[q], x);
-    HIP_CHECK(hipStreamWaitEvent(
-        comm_stream, g.ev_pulled[(size_t)nbr_rank[q] * LocalGroup::kRing + (x - 1) % LocalGroup::kRing], 0));
+    const int peer = g.loopback ? comm->rank : nbr_rank[q];
+    g.await(g.pulled, peer, x);
+    HIP_CHECK(hipStreamWaitEvent(comm_stream,
+                                 g.ev_pulled[(size_t)peer * LocalGroup::kRing + (x - 1) % LocalGroup::kRing], 0));
   }
 }
 
@@ -775,12 +781,14 @@ void ryujin_hip_ctx::local_exchange(double *base, const std::vector<size_t> &sen
   HIP_CHECK(hipEventRecord(g.ev_packed[(size_t)me * LocalGroup::kRing + slot], comm_stream));
   g.publish(g.packed, me, x + 1);
   for (int q = 0; q < n_nbr; ++q) {
-    g.await(g.packed, nbr_rank[q], x + 1);
-    HIP_CHECK(hipStreamWaitEvent(comm_stream,
-                                 g.ev_packed[(size_t)nbr_rank[q] * LocalGroup::kRing + slot], 0));
+    const int peer = g.loopback ? me : nbr_rank[q];
+    g.await(g.packed, peer, x + 1);
+    HIP_CHECK(hipStreamWaitEvent(comm_stream, g.ev_packed[(size_t)peer * LocalGroup::kRing + slot], 0));
+    /* loopback: what the neighbour on the other side would have received from me */
+    const double *src = g.loopback ? g.mail[me][nbr_rank[n_nbr - 1 - q]] : g.mail[nbr_rank[q]][me];
     if (recv_count[q])
-      HIP_CHECK(hipMemcpyAsync(base + recv_offset[q], g.mail[nbr_rank[q]][me],
-                               recv_count[q] * sizeof(double), hipMemcpyDeviceToDevice, comm_stream));
+      HIP_CHECK(hipMemcpyAsync(base + recv_offset[q], src, recv_count[q] * sizeof(double),
+                               hipMemcpyDeviceToDevice, comm_stream));
   }
   HIP_CHECK(hipEventRecord(g.ev_pulled[(size_t)me * LocalGroup::kRing + slot], comm_stream));
   g.publish(g.pulled, me, x + 1);
@@ -809,13 +817,16 @@ void ryujin_hip_ctx::allreduce_scalar(void *dev_ptr, int op, int count)
   hipLaunchKernelGGL(k_slot_write, dim3(1), dim3(1), 0, stream, dev_ptr, op, count, slots + (size_t)me * 2);
   HIP_CHECK(hipEventRecord(g.ev_reduced[(size_t)me * LocalGroup::kRing + par], stream));
   g.publish(g.reduced, me, a + 1);
-  for (int q = 0; q < g.n_ranks; ++q) {
+  for (int q = 0; q < g.n_ranks && !g.loopback; ++q) {
     if (q == me)
       continue;
     g.await(g.reduced, q, a + 1);
     HIP_CHECK(hipStreamWaitEvent(stream, g.ev_reduced[(size_t)q * LocalGroup::kRing + par], 0));
   }
-  hipLaunchKernelGGL(k_slot_reduce, dim3(1), dim3(1), 0, stream, slots, g.n_ranks, op, count, dev_ptr);
+  if (g.loopback) /* reduce over my own slot only */
+    hipLaunchKernelGGL(k_slot_reduce, dim3(1), dim3(1), 0, stream, slots + (size_t)me * 2, 1, op, count, dev_ptr);
+  else
+    hipLaunchKernelGGL(k_slot_reduce, dim3(1), dim3(1), 0, stream, slots, g.n_ranks, op, count, dev_ptr);
   ++local_reduces;
 }
 
@@ -1649,6 +1660,24 @@ int ryujin_hip_comm_init_local(ryujin_hip_comm **comms, int n_ranks, int device)
   });
 }
 
+int ryujin_hip_comm_init_loopback(ryujin_hip_comm **comm, int rank, int n_ranks, int device)
+{
+  return guarded([&]() {
+    if (!comm || n_ranks < 2 || rank < 0 || rank >= n_ranks)
+      throw HipError(RYUJIN_ERR_ARG, "loopback communicator: 0 <= rank < n_ranks, n_ranks >= 2");
+    auto *group = new LocalGroup(n_ranks, device);
+    group->refs = 1;
+    group->loopback = true;
+    auto *c = new ryujin_hip_comm;
+    c->rank = rank;
+    c->n_ranks = n_ranks;
+    c->device = device;
+    c->local = group;
+    *comm = c;
+    return RYUJIN_OK;
+  });
+}
+
 void ryujin_hip_comm_destroy(ryujin_hip_comm *comm)
 {
   if (!comm)
@@ -1925,7 +1954,7 @@ int ryujin_hip_state_integrals(ryujin_hip_ctx *ctx, int handle, double *out)
     double host[8] = {0.};
     HIP_CHECK(hipMemcpyAsync(host, result, sizeof(double) * K, hipMemcpyDeviceToHost, ctx->stream));
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    if (cm && cm->n_ranks > 1 && cm->local) {
+    if (cm && cm->n_ranks > 1 && cm->local && !cm->local->loopback) {
       LocalGroup &g = *cm->local;
       for (int q = 0; q < K; ++q)
         g.scratch_vec[(size_t)cm->rank * 8 + q] = host[q];
