@@ -8,6 +8,7 @@
 //
 // Sweeps follow the reference one to one (source/hyperbolic_module.template.h):
 //   k_apply_bc + k_precompute_records              step 1  :96-193
+//     (+ k_ghost_precompute_records on the ghost rows)
 //   k_dij_alpha_records (k_alpha + k_dij_records,  step 2  :341-424
 //     k_dij_alpha for rows wider than 32)
 //   k_dij_boundary + k_dij_diag[_unrolled]         step 3  :432-564
@@ -338,12 +339,15 @@ namespace ryujin_hip
     }
   }
 
-  /* the same record for the ghost rows [first, last): computed locally from the exchanged ghost states
-   * (nothing to exchange: the record is a function of U_j alone) */
+  /* the same pair for the ghost rows [first, last): computed locally from the exchanged ghost states (both
+   * are functions of U_j alone, so the reference's update_ghost_values() on the precomputed vector,
+   * hyperbolic_module.template.h:157-160, moves nothing that is not already here -- one exchange less per
+   * update) */
   template <typename E>
   __global__ void __launch_bounds__(kBlock)
-  k_riemann_record_rows(const typename E::Params P, const uint32_t first, const uint32_t last,
-                        const double *__restrict__ U, double *__restrict__ rec)
+  k_ghost_precompute_records(const typename E::Params P, const uint32_t first, const uint32_t last,
+                             const double *__restrict__ U, double *__restrict__ prec,
+                             double *__restrict__ rec)
   {
     constexpr int K = E::K, RS = E::RS;
     const uint32_t i = first + blockIdx.x * blockDim.x + threadIdx.x;
@@ -351,6 +355,7 @@ namespace ryujin_hip
       return;
     double U_i[K], r[RS];
     load_state<K>(U, i, U_i);
+    reinterpret_cast<double2 *>(prec)[i] = E::precompute(P, U_i);
     E::riemann_record(P, U_i, r);
 #pragma unroll
     for (int g = 0; g < RS; ++g)

@@ -153,6 +153,11 @@ namespace
     return q;
   }
 
+  /* Events that order two streams of ONE device: no timing, and no system-scope fence when they complete (the
+   * kernels on either side carry their own device-scope release/acquire; a system-scope fence per event writes
+   * back and invalidates the L2s under the interior launch that runs next to it). */
+  constexpr unsigned kDeviceEventFlags = hipEventDisableTiming | hipEventDisableSystemFence;
+
   int grid_for(size_t n, int block = kBlock) { return (int)std::max<size_t>(1, (n + block - 1) / block); }
 } // namespace
 
@@ -205,7 +210,7 @@ struct LocalGroup {
     HIP_CHECK(hipSetDevice(dev));
     for (auto *set : {&ev_packed, &ev_pulled, &ev_reduced})
       for (auto &e : *set)
-        HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&e, kDeviceEventFlags)); /* one GPU by construction */
     HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&slots), sizeof(unsigned long long) * 4 * n));
     HIP_CHECK(hipMemset(slots, 0, sizeof(unsigned long long) * 4 * n));
     HIP_CHECK(hipDeviceSynchronize());
@@ -263,12 +268,15 @@ struct ryujin_hip_ctx {
   ryujin_hip_comm *comm = nullptr;
   hipStream_t stream = nullptr;      /* compute */
   hipStream_t comm_stream = nullptr; /* ghost exchange, overlapped with the interior rows */
-  hipEvent_t ev_export = nullptr, ev_comm = nullptr;
-  hipStream_t export_stream = nullptr; /* export slices of a split sweep, concurrent with the interior */
-  hipStream_t launch_stream = nullptr; /* the stream the sweep lambdas launch on (stream or export_stream) */
+  hipEvent_t ev_comm = nullptr;
+  hipStream_t launch_stream = nullptr; /* the stream the sweep lambdas launch on (stream or comm_stream) */
   FusedSadd pending_sadd{0., 0., nullptr}; /* set by time_step for the SSPRK stages, consumed by step */
-  hipEvent_t ev_prev = nullptr;
-  bool comm_pending = false;
+  hipEvent_t ev_prev = nullptr; /* compute stream -> comm_stream: everything enqueued so far */
+  hipEvent_t ev_exp = nullptr;  /* comm_stream -> compute stream: the latest export part (not its exchange) */
+  bool comm_pending = false;    /* comm_stream holds work the compute stream has not joined */
+  bool exp_pending = false;     /* ... of which an export part later kernels on the compute stream depend on */
+  bool exchange_after_exp = false; /* an exchange was enqueued behind the latest export part (ev_exp misses it) */
+  bool interior_reads_ghosts = false; /* asymmetric stencil: every sweep joins the exchanges (no overlap) */
   uint32_t n_export_slices = 0;
   uint32_t bounds_stride = 0; /* SoA stride of the limiter bounds: covers the ghost range (dG reads bounds_j) */
 
@@ -357,14 +365,10 @@ struct ryujin_hip_ctx {
       (void)hipStreamSynchronize(comm_stream);
       (void)hipStreamDestroy(comm_stream);
     }
-    if (ev_export)
-      (void)hipEventDestroy(ev_export);
-    if (export_stream) {
-      (void)hipStreamSynchronize(export_stream);
-      (void)hipStreamDestroy(export_stream);
-    }
     if (ev_prev)
       (void)hipEventDestroy(ev_prev);
+    if (ev_exp)
+      (void)hipEventDestroy(ev_exp);
     if (ev_comm)
       (void)hipEventDestroy(ev_comm);
     for (auto &e : ev)
@@ -399,11 +403,12 @@ struct ryujin_hip_ctx {
                       const std::vector<size_t> &recv_offset, const std::vector<size_t> &recv_count);
   void allreduce_scalar(void *dev_ptr, int op, int count = 1);
   void wait_comm();
+  void join_export();
   void finish();
   void begin_exchange(bool after_split_sweep);
   void end_exchange();
   template <typename F>
-  void sweep(F &&launch, bool followed_by_exchange, bool join_comm = true);
+  void sweep(F &&launch);
   template <typename E>
   void prepare_state_vector(int h, const double *dirichlet);
   template <typename E>
@@ -469,11 +474,10 @@ void ryujin_hip_ctx::create(const ryujin_hip_offline &o, const ryujin_hip_params
   HIP_CHECK(hipSetDevice(device));
   HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
   HIP_CHECK(hipStreamCreateWithFlags(&comm_stream, hipStreamNonBlocking));
-  HIP_CHECK(hipEventCreateWithFlags(&ev_export, hipEventDisableTiming));
-  HIP_CHECK(hipStreamCreateWithFlags(&export_stream, hipStreamNonBlocking));
   launch_stream = stream;
-  HIP_CHECK(hipEventCreateWithFlags(&ev_prev, hipEventDisableTiming));
-  HIP_CHECK(hipEventCreateWithFlags(&ev_comm, hipEventDisableTiming));
+  HIP_CHECK(hipEventCreateWithFlags(&ev_prev, kDeviceEventFlags));
+  HIP_CHECK(hipEventCreateWithFlags(&ev_exp, kDeviceEventFlags));
+  HIP_CHECK(hipEventCreateWithFlags(&ev_comm, kDeviceEventFlags));
   for (auto &e : ev)
     HIP_CHECK(hipEventCreate(&e));
   for (auto &set : ev_rk)
@@ -599,6 +603,14 @@ void ryujin_hip_ctx::create(const ryujin_hip_offline &o, const ryujin_hip_params
   mesh.slice_end = L.n_slices;
   /* rows [0, n_export) are the ones other ranks hold as ghosts (offline_data.template.h:213-249) */
   n_export_slices = std::min<uint32_t>(L.n_slices, (o.n_export + kWave - 1) / kWave);
+  /* The overlap of the exchanges with the interior rows rests on: only export rows couple to ghost columns
+   * (true for a symmetric stencil: if i sees the ghost j, the owner of j sees i). Checked, not assumed. */
+  for (uint32_t i = n_export_slices * kWave; i < L.n_owned && !interior_reads_ghosts; ++i)
+    for (uint32_t c = 0; c < L.row_len[i]; ++c)
+      if (L.cols[L.pos(i, c)] >= L.n_owned) {
+        interior_reads_ghosts = true;
+        break;
+      }
   mesh.slice_off = d_slice_off.ptr;
   mesh.row_len = d_row_len.ptr;
   mesh.cols = d_cols.ptr;
@@ -682,17 +694,43 @@ void ryujin_hip_ctx::create(const ryujin_hip_offline &o, const ryujin_hip_params
 }
 
 /* ---- stream choreography of the ghost exchange ------------------------------------------------
- * A sweep that is followed by an exchange runs in two launches: the export slices first, then the
- * interior slices. The exchange (pack + RCCL send/recv) is enqueued on comm_stream behind the export
- * launch (ev_export) and therefore overlaps with the interior launch on the compute stream -- the
- * reference's SynchronizationDispatch idea (source/openmp.h:141-183). The compute stream joins the
- * communication (ev_comm) right before the next kernel: interior rows never touch ghost data, but the
- * exchange is two orders of magnitude shorter than the interior launch, so the join is free. */
+ * Two streams. Every sweep runs as two launches: the few export slices (the rows other ranks hold as
+ * ghosts = the only rows that couple to ghost columns) on comm_stream, the interior slices on the compute
+ * stream. Exchanges (pack + RCCL send/recv, or the in-process copies) follow the export launch that
+ * produced their data in stream order on comm_stream -- the reference's SynchronizationDispatch idea
+ * (source/openmp.h:141-183), taken one step further: NOTHING on the compute stream ever waits for an
+ * exchange. Dependencies:
+ *   export part N      needs interior parts <= N-1 (ev_prev: compute -> comm), export parts and
+ *                      exchanges <= N-1 (stream order on comm_stream)
+ *   interior part N    needs export parts <= N-1 (ev_exp: comm -> compute, recorded BEFORE exchange N-1),
+ *                      interior parts <= N-1 (stream order); never ghost data
+ *   exchange N         needs export part N only (stream order)
+ * so an exchange has the whole interior launch of the NEXT sweep as well to hide behind, and a short sweep
+ * (the pre-pass, 30 us in 2-D) no longer exposes the latency of the exchange in front of it. Kernels outside
+ * sweep() that touch export rows (boundary conditions, boundary d_ij, the scalar all-reduces) call
+ * join_export(); whoever reads the ghost range on the compute stream or on the host calls wait_comm().
+ * (Round 2 started with a third stream for the export part and a join of every exchange in front of the next
+ * sweep: +11 % per update on a middle rank in 2-D without any network in the loop, profiles/r02k_*.) */
 void ryujin_hip_ctx::wait_comm()
 {
   if (comm_pending) {
+    HIP_CHECK(hipEventRecord(ev_comm, comm_stream)); /* the tail of comm_stream as of now */
     HIP_CHECK(hipStreamWaitEvent(stream, ev_comm, 0));
     comm_pending = false;
+    exp_pending = false;
+    exchange_after_exp = false;
+  }
+}
+
+void ryujin_hip_ctx::join_export()
+{
+  if (interior_reads_ghosts) {
+    wait_comm();
+    return;
+  }
+  if (exp_pending) {
+    HIP_CHECK(hipStreamWaitEvent(stream, ev_exp, 0));
+    exp_pending = false;
   }
 }
 
@@ -702,23 +740,24 @@ void ryujin_hip_ctx::finish()
   HIP_CHECK(hipStreamSynchronize(stream));
 }
 
+/* exchange of data the compute stream produced outside a sweep (the state vector behind the boundary
+ * conditions); after a sweep the export part already sits on comm_stream */
 void ryujin_hip_ctx::begin_exchange(bool after_split_sweep)
 {
-  if (!after_split_sweep)
-    HIP_CHECK(hipEventRecord(ev_export, stream)); /* everything enqueued so far */
-  HIP_CHECK(hipStreamWaitEvent(comm_stream, ev_export, 0));
+  if (after_split_sweep)
+    return;
+  HIP_CHECK(hipEventRecord(ev_prev, stream)); /* everything enqueued so far */
+  HIP_CHECK(hipStreamWaitEvent(comm_stream, ev_prev, 0));
 }
 
 void ryujin_hip_ctx::end_exchange()
 {
-  HIP_CHECK(hipEventRecord(ev_comm, comm_stream));
   comm_pending = true;
+  exchange_after_exp = true;
 }
 
-/* join_comm = false: the sweep touches no ghost data and nothing a pending exchange writes, so it need not wait
- * for it (the pre-pass after the U exchange: it reads owned U only while RCCL fills the ghost range of U) */
 template <typename F>
-void ryujin_hip_ctx::sweep(F &&launch, bool followed_by_exchange, bool join_comm)
+void ryujin_hip_ctx::sweep(F &&launch)
 {
   auto run = [&](uint32_t s0, uint32_t s1, hipStream_t on) {
     if (s1 <= s0)
@@ -732,22 +771,19 @@ void ryujin_hip_ctx::sweep(F &&launch, bool followed_by_exchange, bool join_comm
     launch(mm, grid);
     launch_stream = stream;
   };
-  if (join_comm)
-    wait_comm();
-  if (n_nbr == 0 || !followed_by_exchange) {
+  if (n_nbr == 0) {
     run(0, L.n_slices, stream);
     return;
   }
-  /* The few export slices run on their own stream next to the interior slices (a launch of a handful
-   * of blocks would otherwise leave the device idle for the lifetime of one wave): both wait for
-   * everything enqueued so far; the compute stream joins the export part again right away, so that
-   * later kernels see the whole sweep; the exchange only waits for the export part. */
+  join_export();
   HIP_CHECK(hipEventRecord(ev_prev, stream));
-  HIP_CHECK(hipStreamWaitEvent(export_stream, ev_prev, 0));
-  run(0, n_export_slices, export_stream);
-  HIP_CHECK(hipEventRecord(ev_export, export_stream));
+  HIP_CHECK(hipStreamWaitEvent(comm_stream, ev_prev, 0));
+  run(0, n_export_slices, comm_stream);
+  HIP_CHECK(hipEventRecord(ev_exp, comm_stream));
+  exp_pending = true;
+  comm_pending = true;
+  exchange_after_exp = false; /* stream order: ev_exp covers every exchange enqueued so far */
   run(n_export_slices, L.n_slices, stream);
-  HIP_CHECK(hipStreamWaitEvent(stream, ev_export, 0));
 }
 
 /* in-process transport, part 1 (before the pack kernel): the send buffer may only be overwritten once
@@ -800,6 +836,12 @@ void ryujin_hip_ctx::allreduce_scalar(void *dev_ptr, int op, int count)
 {
   if (!comm || comm->n_ranks <= 1)
     return;
+  /* the scalar is written by export parts as well. One RCCL communicator serves both streams: its
+   * collectives are not put next to point-to-point traffic still in flight on comm_stream. */
+  if (comm->local)
+    join_export();
+  else
+    wait_comm();
   if (!comm->local) {
     if (op == 0)
       NCCL_CHECK(ncclAllReduce(dev_ptr, dev_ptr, 1, ncclDouble, ncclMin, comm->comm, stream));
@@ -915,46 +957,57 @@ void ryujin_hip_ctx::prepare_state_vector(int h, const double *dirichlet)
   if (needs_dirichlet && !have_dirichlet)
     throw HipError(RYUJIN_ERR_ARG, "prepare_state_vector: the boundary map holds dirichlet / dynamic / "
                                    "dirichlet_momentum ids but no Dirichlet data was ever passed");
-  wait_comm();
+  /* boundary rows may be export rows: written by the export part of the last sweep -- and read by the pack
+   * kernel of an exchange of this vector that is still in flight (two calls in a row) */
+  if (exchange_after_exp)
+    wait_comm();
+  else
+    join_export();
   if (n_groups)
     hipLaunchKernelGGL(k_apply_bc<E>, dim3(grid_for(n_groups)), block, 0, stream, eparams, n_groups,
                        d_grp_start.ptr, d_b_i.ptr, d_b_normal.ptr, d_b_id.ptr, d_dirichlet.ptr,
                        s.U.ptr);
-  exchange_vector(s.U.ptr, KP, false); /* U.update_ghost_values(), :148 */
+  /* U.update_ghost_values(), :148, is enqueued BEHIND the export part of the first pre-pass sweep, which
+   * reads owned states only: the interior part of step 2 then waits for that export part alone, and the
+   * exchange of U hides behind the interior parts of the pre-pass and of step 2 */
   if constexpr (std::is_same<typename E::Params, EulerAeosParams>::value) {
     /* n_precomputation_cycles = 2 (euler_aeos/hyperbolic_system.h:433), ghost update after each */
     sweep([&](const DeviceMesh &mm, dim3 grid) {
       hipLaunchKernelGGL(k_precompute_aeos0<E::DIMENSION>, grid, block, 0, launch_stream, eparams, mm, s.U.ptr,
                          s.prec.ptr);
-    }, true);
+    });
+    exchange_vector(s.U.ptr, KP, true);
     exchange_vector(s.prec.ptr, 4, true);
     sweep([&](const DeviceMesh &mm, dim3 grid) {
       hipLaunchKernelGGL(k_precompute_aeos1<E::DIMENSION>, grid, block, 0, launch_stream, eparams, mm, s.U.ptr,
                          s.prec.ptr, s.prec.ptr);
-    }, true);
+    });
     exchange_vector(s.prec.ptr, 4, true);
   } else if constexpr (std::is_same<typename E::Params, ScalarParams>::value) {
     sweep([&](const DeviceMesh &mm, dim3 grid) {
       hipLaunchKernelGGL(k_precompute_sc<E::DIMENSION>, grid, block, 0, launch_stream, eparams, mm, s.U.ptr,
                          s.prec.ptr);
-    }, true);
+    });
+    exchange_vector(s.U.ptr, KP, true);
     exchange_vector(s.prec.ptr, E::NPREC, true);
   } else {
     static_assert(std::is_same<typename E::Params, EulerParams>::value ||
                       std::is_same<typename E::Params, ShallowWaterParams>::value,
                   "Descriptions with node records");
-    /* The pre-pass reads owned U only: it overlaps with the ghost exchange of U (round 1 joined the exchange
-     * first, so that exchange hid behind nothing). The records of the ghost rows are computed locally from the
-     * exchanged ghost states (a function of U_j alone: nothing to exchange), behind both exchanges. */
+    /* The pre-pass reads owned U only. Precomputed values and records of the ghost rows are computed locally
+     * from the exchanged ghost states (functions of U_j alone: nothing to exchange, :157-160 moves the same
+     * numbers), behind the exchange of U on comm_stream. */
     sweep([&](const DeviceMesh &mm, dim3 grid) {
       hipLaunchKernelGGL(k_precompute_records<E>, grid, block, 0, launch_stream, eparams, mm, s.U.ptr,
                          s.prec.ptr, s.rrec.ptr);
-    }, true, /*join_comm=*/false);
-    exchange_vector(s.prec.ptr, 2, true); /* :157-160 */
+    });
+    exchange_vector(s.U.ptr, KP, true);
     if (L.n_relevant > L.n_owned) {
-      wait_comm();
-      hipLaunchKernelGGL(k_riemann_record_rows<E>, dim3(grid_for(L.n_relevant - L.n_owned)), block, 0, stream,
-                         eparams, L.n_owned, L.n_relevant, s.U.ptr, s.rrec.ptr);
+      hipLaunchKernelGGL(k_ghost_precompute_records<E>, dim3(grid_for(L.n_relevant - L.n_owned)), block, 0,
+                         n_nbr ? comm_stream : stream, eparams, L.n_owned, L.n_relevant, s.U.ptr, s.prec.ptr,
+                         s.rrec.ptr);
+      if (n_nbr)
+        end_exchange();
     }
   }
   HIP_CHECK(hipGetLastError());
@@ -979,6 +1032,7 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
 
   /* scalars: tau_max := tau_max_in, flags := 0 */
   const bool use_device_tau = deferred && rk_stage > 0;
+  join_export(); /* the flags and tau_max are written by export parts as well */
   hipLaunchKernelGGL(k_step_begin, dim3(1), dim3(1), 0, stream, tau_max_in,
                      (!deferred || rk_stage == 0) ? 1 : 0, (deferred && rk_stage > 0) ? rk_stage - 1 : -1,
                      tau_in, use_device_tau ? 1 : 0, deferred ? rk_stage : 0, d_scalars.ptr);
@@ -995,22 +1049,19 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
     sweep([&](const DeviceMesh &mm, dim3 grid) {
       hipLaunchKernelGGL(k_alpha_aeos<DIM>, grid, block, 0, launch_stream, eparams, mm, old.U.ptr, old.prec.ptr,
                          d_alpha.ptr);
-    }, true);
+    });
     mark(8);
     step2_split = true;
     exchange_vector(d_alpha.ptr, 1, true);
-    const bool pending = comm_pending;
-    comm_pending = false; /* k_dij does not read alpha: do not join the exchange yet */
     sweep([&](const DeviceMesh &mm, dim3 grid) {
       hipLaunchKernelGGL(k_dij_aeos<DIM>, grid, block, 0, launch_stream, eparams, mm, d_lower_mask.ptr,
                          old.U.ptr, old.prec.ptr, d_dij.ptr);
-    }, false);
-    comm_pending = pending;
+    });
   } else if constexpr (is_scalar) {
     sweep([&](const DeviceMesh &mm, dim3 grid) {
       hipLaunchKernelGGL(k_dij_alpha_sc<DIM>, grid, block, 0, launch_stream, eparams, mm, old.U.ptr,
                          old.prec.ptr, d_dij.ptr, d_alpha.ptr);
-    }, true);
+    });
     mark(8);
     step2_split = true;
     exchange_vector(d_alpha.ptr, 1, true);
@@ -1021,7 +1072,7 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
       sweep([&](const DeviceMesh &mm, dim3 grid) {
         hipLaunchKernelGGL((k_dij_alpha_records<E, false>), grid, block, 0, launch_stream, eparams, mm,
                            old.U.ptr, old.prec.ptr, old.rrec.ptr, d_dij.ptr, d_alpha.ptr);
-      }, true);
+      });
       exchange_vector(d_alpha.ptr, 1, true);
     }
   } else if (is_euler && L.max_row_len <= 32) {
@@ -1029,12 +1080,10 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
     sweep([&](const DeviceMesh &mm, dim3 grid) {
       hipLaunchKernelGGL(k_alpha<E>, grid, block, 0, launch_stream, eparams, mm, old.U.ptr, old.prec.ptr,
                          d_alpha.ptr);
-    }, true);
+    });
     mark(8); /* end of the indicator kernel: sweep_ms[0] = k_alpha alone */
     step2_split = true;
     exchange_vector(d_alpha.ptr, 1, true); /* overlaps with the Riemann sweep as well */
-    const bool pending = comm_pending;
-    comm_pending = false; /* k_dij does not read alpha: do not join the exchange yet */
     sweep([&](const DeviceMesh &mm, dim3 grid) {
       if constexpr (is_euler) {
         if (eparams.riemann_newton_max_iterations == 0 && eparams.rarefaction_power > 0)
@@ -1044,19 +1093,20 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
           hipLaunchKernelGGL((k_dij_records<E, true>), grid, block, 0, launch_stream, eparams, mm,
                              d_lower_mask.ptr, old.rrec.ptr, d_dij.ptr);
       }
-    }, false);
-    comm_pending = pending;
+    });
   } else {
     sweep([&](const DeviceMesh &mm, dim3 grid) {
       hipLaunchKernelGGL(k_dij_alpha<E>, grid, block, 0, launch_stream, eparams, mm, old.U.ptr,
                          old.prec.ptr, d_dij.ptr, d_alpha.ptr);
-    }, true);
+    });
     exchange_vector(d_alpha.ptr, 1, true);
   }
   mark(1);
 
   /* Step 3: boundary d_ij, symmetrise, diagonal, tau_max (:432-578) */
   if (n_pairs) {
+    join_export(); /* boundary pairs may sit in export rows, whose d_ij the export part wrote on comm_stream
+                    * (and may point to ghost columns: the U exchange precedes that export part in stream order) */
     if constexpr (is_aeos)
       hipLaunchKernelGGL(k_dij_boundary_aeos<DIM>, dim3(grid_for(n_pairs)), block, 0, stream, eparams,
                          n_pairs, d_p_i.ptr, d_p_j.ptr, d_p_pos.ptr, d_p_cji.ptr, old.U.ptr,
@@ -1082,7 +1132,7 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
     else
       hipLaunchKernelGGL(k_dij_diag, grid, block, 0, launch_stream, mm, params.cfl, d_dij.ptr,
                          d_scalars.ptr);
-  }, false);
+  });
   /* Utilities::MPI::min(tau_max), :571. Inside a device-resident RK step only the first stage needs the
    * global minimum (it defines tau); later stages use their local tau_max for the validity check only,
    * whose flag is reduced once at the end of the RK step together with the restart flag. */
@@ -1161,7 +1211,7 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
                            d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_Z.ptr, d_alpha.ptr,
                            d_dij.ptr, nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
     }
-  }, true);
+  });
   exchange_vector(d_r.ptr, KP, true);
   if (dg && params.limiter_iterations != 0) {
     /* the bounds are extended over the stencil in step 5: their ghost range has to be current
@@ -1179,7 +1229,7 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
       sweep([&](const DeviceMesh &mm, dim3 grid) {
         hipLaunchKernelGGL(k_bounds_combine_euler, grid, block, 0, launch_stream, mm, d_bounds.ptr,
                            d_bounds_combined.ptr);
-      }, false);
+      });
       std::swap(d_bounds.ptr, d_bounds_combined.ptr);
     }
   }
@@ -1202,7 +1252,7 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
       }
       hipLaunchKernelGGL(k_pij_lij<E>, grid, block, 0, launch_stream, eparams, mm, d_scalars.ptr, nw.U.ptr,
                          d_r.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr);
-    }, true);
+    });
     exchange_matrix(d_lij.ptr, true);
   }
   mark(4);
@@ -1226,7 +1276,7 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
         else
           hipLaunchKernelGGL((k_high_order<E, true>), grid, block, 0, launch_stream, eparams, mm, nw.U.ptr,
                              d_bounds.ptr, d_pij.ptr, d_lij.ptr, d_lij_next.ptr, fused_sadd);
-      }, false);
+      });
     } else {
       /* 3-D: cache all l_ij and the P_ij of the first RYUJIN_HO_CP_3D columns (0: two-pass kernel) */
       constexpr int kCachedP = DIM == 3 ? (RYUJIN_HO_CP_3D > 0 ? RYUJIN_HO_CP_3D : 27) : kCachedWidth;
@@ -1238,7 +1288,7 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
         else
           hipLaunchKernelGGL((k_high_order<E, false>), grid, block, 0, launch_stream, eparams, mm, nw.U.ptr,
                              d_bounds.ptr, d_pij.ptr, d_lij.ptr, d_lij_next.ptr, FusedSadd{0., 0., nullptr});
-      }, true);
+      });
       exchange_matrix(d_lij_next.ptr, true);
     }
     mark(5 + pass);
@@ -1246,7 +1296,7 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
   for (int k = 5 + n_iterations; k <= 7; ++k)
     mark(k);
 
-  wait_comm();
+  join_export(); /* (the exchange of U_new stays in flight: whoever reads its ghost range joins it) */
   if (!deferred)
     allreduce_scalar(&d_scalars.ptr->restart_needed, 1); /* MPI::logical_or(restart_needed), :1194 */
   /* (deferred: the restart flag is folded into its accumulator by the next stage's k_step_begin, or by
@@ -1413,7 +1463,7 @@ int ryujin_hip_ctx::time_step(int scheme, int h_state, int n_tmp, const int *h_t
       }
     }
     /* the only host synchronisation of the RK step */
-    wait_comm();
+    join_export();
     hipLaunchKernelGGL(k_accumulate_flags, dim3(1), dim3(1), 0, stream, rk_stage, d_scalars.ptr);
     /* MPI::logical_or over the ranks of the flags accumulated over all stages (restart_accum and
      * tau_invalid_accum are adjacent ints): one collective per RK step instead of one per stage */

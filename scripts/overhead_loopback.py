@@ -24,6 +24,7 @@ ap.add_argument("--dim", type=int, default=2)
 ap.add_argument("--n", type=int, default=0)
 ap.add_argument("--rk-steps", type=int, default=20)
 ap.add_argument("--develop", type=int, default=30, help="untimed SSPRK33 steps")
+ap.add_argument("--timers", action="store_true", help="also print the per-sweep device times (event pairs)")
 args = ap.parse_args()
 lib = capi.load_hip()
 n = args.n or (1580 if args.dim == 2 else 160)
@@ -59,6 +60,17 @@ def run(off, comm):
     lib.ryujin_hip_synchronize(m._ctx)
     ms = (time.perf_counter() - t0) / (3 * args.rk_steps) * 1e3
     assert np.isfinite(state.download()).all() and m.n_warnings() == 0
+    if args.timers:
+        lib.ryujin_hip_set_timers(m._ctx, 1)
+        acc, cnt = (C.c_double * 8)(), C.c_uint()
+        lib.ryujin_hip_get_timers_accum(m._ctx, acc, C.byref(cnt), 1)
+        for _ in range(args.rk_steps):
+            m.time_step("ssprk 33", state, temps, None)
+        lib.ryujin_hip_synchronize(m._ctx)
+        lib.ryujin_hip_get_timers_accum(m._ctx, acc, C.byref(cnt), 1)
+        lib.ryujin_hip_set_timers(m._ctx, 0)
+        print("  sweeps [ms]: " + " ".join(f"{a / max(cnt.value, 1):.4f}" for a in acc)
+              + f"  sum {sum(acc) / max(cnt.value, 1):.4f} over {cnt.value} updates", flush=True)
     return ms, off.n_owned
 
 
