@@ -7,7 +7,8 @@
 // lanes gather consecutive j). No MFMA: the path is a bandwidth-bound stencil sweep.
 //
 // Sweeps follow the reference one to one (source/hyperbolic_module.template.h):
-//   k_apply_bc + k_precompute_records              step 1  :96-193
+//   k_precompute_records (boundary conditions      step 1  :96-193
+//     folded in: apply_bc_row)
 //     (+ k_ghost_precompute_records on the ghost rows)
 //   k_dij_alpha_records (k_alpha + k_dij_records,  step 2  :341-424
 //     k_dij_alpha for rows wider than 32)
@@ -28,7 +29,23 @@
 
 namespace ryujin_hip
 {
+  struct DeviceScalars;
+
+  /* Start of a step (tau_max := tau_max_in, flags := 0, the restart flag of the previous Runge-Kutta stage
+   * folded into its accumulator, the arguments finalize_tau() needs), carried by the first sweep of step 2 and
+   * executed by the first thread of its launches: the kernels of step 2 do not touch the scalars, a kernel
+   * boundary separates them from the previous step and from step 3. Idempotent (a split sweep runs it in
+   * its export and in its interior launch). A launch of its own cost ~10 us of dependency latency per update. */
+  struct StepBegin {
+    DeviceScalars *scalars; /* NULL: this launch does not begin a step */
+    double tau_max_in, tau_in;
+    int reset_accumulators;
+    int accumulate_stage; /* < 0: nothing to fold */
+    int use_device_tau, stage;
+  };
+
   struct DeviceMesh {
+    StepBegin begin;
     uint32_t n_owned, n_relevant, n_slices;
     uint32_t bounds_stride; /* limiter bounds are SoA [n_bounds][bounds_stride], bounds_stride >= n_relevant */
     uint32_t slice_begin, slice_end; /* slice range of this launch (export rows first, then interior) */
@@ -59,12 +76,33 @@ namespace ryujin_hip
      * that later stage: hyperbolic_module.template.h:1194-1207 throws first) */
     int restart_accum;
     int tau_invalid_accum;
-    /* arguments of the running step, stored by k_step_begin for finalize_tau() */
+    /* arguments of the running step, stored by step_begin() for finalize_tau() */
     double tau_in;
     int use_device_tau;
     int stage;
   };
   constexpr int kStageCode = 100;
+
+  RYUJIN_DEV void step_begin(const DeviceMesh &M)
+  {
+    DeviceScalars *scalars = M.begin.scalars;
+    if (!scalars || blockIdx.x != 0 || threadIdx.x != 0)
+      return;
+    if (M.begin.reset_accumulators) {
+      scalars->restart_accum = 0;
+      scalars->tau_invalid_accum = 0;
+    } else if (M.begin.accumulate_stage >= 0) {
+      if (scalars->restart_needed && scalars->restart_accum < kStageCode - M.begin.accumulate_stage)
+        scalars->restart_accum = kStageCode - M.begin.accumulate_stage;
+    }
+    scalars->tau_max_bits = (unsigned long long)__double_as_longlong(M.begin.tau_max_in);
+    scalars->restart_needed = 0;
+    scalars->tau_invalid = 0;
+    scalars->tau_in = M.begin.tau_in;
+    scalars->use_device_tau = M.begin.use_device_tau;
+    scalars->stage = M.begin.stage;
+  }
+
 
   /* minimum waves per SIMD requested from the register allocator for the heavy sweeps (second
    * __launch_bounds__ argument): 512 registers / waves. Tuned on MI355X, see DESIGN.md. */
@@ -272,36 +310,43 @@ namespace ryujin_hip
 
   /* ------------------------------------------------------------------ step 1 */
 
-  /* One thread per boundary DoF; its boundary_map entries are applied in the reference's
-   * (serial) order. grp_start[g]..grp_start[g+1] index the entry arrays sorted by DoF. */
+  /* Boundary conditions (hyperbolic_module.template.h:102-146), folded into the first pre-pass sweep: the thread
+   * of a boundary row applies the row's boundary_map entries in the reference's (serial) order before anything
+   * else reads U_i. slice_mask[s] bit l <=> row 64 s + l is a boundary DoF; its entries are those of group
+   * slice_first[s] + (number of boundary rows below it in the slice), groups being sorted by DoF. (A launch of
+   * its own costs ~10 us of dependency latency per update -- a tenth of the update on the 43 k gridpoint mesh;
+   * used below kBcFoldMaxSlices, k_apply_bc above.) */
+  struct BcFold {
+    const unsigned long long *slice_mask; /* NULL: no boundary DoFs */
+    const uint32_t *slice_first;
+    const uint32_t *grp_start;
+    const double *b_normal;
+    const uint8_t *b_id;
+    const double *dirichlet;
+  };
+
+  /* the boundary_map entries of group g (DoF i), in the reference's serial order */
   template <typename E>
-  __global__ void __launch_bounds__(kBlock)
-  k_apply_bc(const typename E::Params P, const uint32_t n_groups, const uint32_t *__restrict__ grp_start,
-             const uint32_t *__restrict__ b_i, const double *__restrict__ b_normal,
-             const uint8_t *__restrict__ b_id, const double *__restrict__ dirichlet,
-             double *__restrict__ U)
+  RYUJIN_DEV void apply_bc_group(const typename E::Params &P, const BcFold &B, const uint32_t g, const uint32_t i,
+                                 double *U)
   {
     constexpr int K = E::K;
     constexpr int DIM = E::DIMENSION;
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= n_groups)
-      return;
-    const uint32_t e0 = grp_start[g], e1 = grp_start[g + 1];
-    const uint32_t i = b_i[e0];
+    const uint32_t e0 = B.grp_start[g], e1 = B.grp_start[g + 1];
     double U_i[K];
     load_state<K>(U, i, U_i);
     bool touched = false;
     for (uint32_t e = e0; e < e1; ++e) {
-      const int id = b_id[e];
+      const int id = B.b_id[e];
       if (id == RYUJIN_BC_DO_NOTHING)
         continue;
       double normal[DIM], U_D[K], result[K];
 #pragma unroll
       for (int d = 0; d < DIM; ++d)
-        normal[d] = b_normal[(size_t)e * DIM + d];
+        normal[d] = B.b_normal[(size_t)e * DIM + d];
 #pragma unroll
       for (int q = 0; q < K; ++q)
-        U_D[q] = dirichlet ? dirichlet[(size_t)e * K + q] : 0.;
+        U_D[q] = B.dirichlet ? B.dirichlet[(size_t)e * K + q] : 0.;
       E::apply_boundary_conditions(P, id, U_i, normal, U_D, result);
 #pragma unroll
       for (int q = 0; q < K; ++q)
@@ -312,17 +357,46 @@ namespace ryujin_hip
       store_state<K>(U, i, U_i);
   }
 
-  /* precomputation_loop (source/euler/hyperbolic_system.h:702-737, shallow_water/hyperbolic_system.h:676-716):
-   * the precomputed values AND the per-node Riemann record (E::riemann_record) in one pass over the owned rows */
+  /* folded form: called by the thread of row i at the top of the first pre-pass kernel */
+  template <typename E>
+  RYUJIN_DEV void apply_bc_row(const typename E::Params &P, const BcFold &B, const uint32_t i, double *U)
+  {
+    if (!B.slice_mask)
+      return;
+    const unsigned long long m = B.slice_mask[i >> 6];
+    const uint32_t lane = i & 63u;
+    if (!((m >> lane) & 1ull))
+      return;
+    apply_bc_group<E>(P, B, B.slice_first[i >> 6] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), i, U);
+  }
+
+  /* launch of its own (large meshes: the boundary-condition code would cost the streaming pre-pass kernel half
+   * of its occupancy -- 108 instead of 40 registers for Euler -- and a ~5 us launch is invisible there): one
+   * thread per boundary DoF */
   template <typename E>
   __global__ void __launch_bounds__(kBlock)
-  k_precompute_records(const typename E::Params P, const DeviceMesh M, const double *__restrict__ U,
+  k_apply_bc(const typename E::Params P, const uint32_t n_groups, const uint32_t *__restrict__ b_i,
+             const BcFold B, double *U)
+  {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_groups)
+      return;
+    apply_bc_group<E>(P, B, g, b_i[B.grp_start[g]], U);
+  }
+
+  /* precomputation_loop (source/euler/hyperbolic_system.h:702-737, shallow_water/hyperbolic_system.h:676-716):
+   * the precomputed values AND the per-node Riemann record (E::riemann_record) in one pass over the owned rows */
+  template <typename E, bool WITH_BC>
+  __global__ void __launch_bounds__(kBlock)
+  k_precompute_records(const typename E::Params P, const DeviceMesh M, const BcFold B, double *U,
                        double *__restrict__ prec, double *__restrict__ rec)
   {
     constexpr int K = E::K, RS = E::RS;
     const uint32_t i = M.slice_begin * 64 + blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M.n_owned || i >= M.slice_end * 64)
       return;
+    if constexpr (WITH_BC)
+      apply_bc_row<E>(P, B, i, U);
     if (M.row_len[i] == 1)
       return;
     double U_i[K], r[RS];
@@ -371,6 +445,7 @@ namespace ryujin_hip
   {
     constexpr int K = E::K;
     constexpr int DIM = E::DIMENSION;
+    step_begin(M);
     const RowCtx r = row_context(M);
     if (!r.valid)
       return;
@@ -419,6 +494,7 @@ namespace ryujin_hip
   {
     constexpr int K = E::K;
     constexpr int DIM = E::DIMENSION;
+    step_begin(M);
     const RowCtx r = row_context(M);
     if (!r.valid)
       return;
@@ -523,6 +599,7 @@ namespace ryujin_hip
                       double *__restrict__ dij, double *__restrict__ alpha)
   {
     constexpr int K = E::K, RS = E::RS, DIM = E::DIMENSION;
+    step_begin(M);
     const RowCtx r = row_context(M);
     if (!r.valid)
       return;
@@ -697,29 +774,6 @@ namespace ryujin_hip
       tau = cfl * M.mi[r.row] / (-2. * d_sum);
     }
     publish_tau_min(scalars, wave_min(tau), r.lane);
-  }
-
-  /* Start of a step (one thread): fold the restart flag of the PREVIOUS stage of a device-resident RK step
-   * into its accumulator, then tau_max := tau_max_in, per-step flags := 0, and remember the arguments that
-   * finalize_tau() needs. (Three single-thread kernels per step -- reset, finalize tau, accumulate flags -- were
-   * three dependent launches of ~5-8 us each; on small meshes that was a fifth of the update.) */
-  __global__ void k_step_begin(const double tau_max_in, const int reset_accumulators,
-                               const int accumulate_stage /* < 0: nothing to fold */, const double tau_in,
-                               const int use_device_tau, const int stage, DeviceScalars *__restrict__ scalars)
-  {
-    if (reset_accumulators) {
-      scalars->restart_accum = 0;
-      scalars->tau_invalid_accum = 0;
-    } else if (accumulate_stage >= 0) {
-      if (scalars->restart_needed && scalars->restart_accum < kStageCode - accumulate_stage)
-        scalars->restart_accum = kStageCode - accumulate_stage;
-    }
-    scalars->tau_max_bits = (unsigned long long)__double_as_longlong(tau_max_in);
-    scalars->restart_needed = 0;
-    scalars->tau_invalid = 0;
-    scalars->tau_in = tau_in;
-    scalars->use_device_tau = use_device_tau;
-    scalars->stage = stage;
   }
 
   /* tau = (tau_in == 0 ? tau_max : tau_in) with the validity check of :571-578, evaluated by EVERY thread of

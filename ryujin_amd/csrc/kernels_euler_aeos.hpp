@@ -14,9 +14,9 @@ namespace ryujin_hip
 {
   /* precomputation_loop cycle 0 (hyperbolic_system.h:919-938): p_i from the equation of state,
    * surrogate gamma_i */
-  template <int DIM>
+  template <int DIM, bool WITH_BC>
   __global__ void __launch_bounds__(kBlock)
-  k_precompute_aeos0(const EulerAeosParams P, const DeviceMesh M, const double *__restrict__ U,
+  k_precompute_aeos0(const EulerAeosParams P, const DeviceMesh M, const BcFold B, double *U,
                      double *__restrict__ prec)
   {
     using E = EulerAeos<DIM>;
@@ -24,6 +24,8 @@ namespace ryujin_hip
     const uint32_t i = M.slice_begin * 64 + blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M.n_owned || i >= M.slice_end * 64)
       return;
+    if constexpr (WITH_BC)
+      apply_bc_row<E>(P, B, i, U);
     if (M.row_len[i] == 1)
       return;
     double U_i[K];
@@ -76,6 +78,7 @@ namespace ryujin_hip
   {
     using E = EulerAeos<DIM>;
     constexpr int K = E::K;
+    step_begin(M);
     const RowCtx r = row_context(M);
     if (!r.valid)
       return;

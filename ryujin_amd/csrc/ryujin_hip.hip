@@ -158,6 +158,9 @@ namespace
    * back and invalidates the L2s under the interior launch that runs next to it). */
   constexpr unsigned kDeviceEventFlags = hipEventDisableTiming | hipEventDisableSystemFence;
 
+  /* boundary conditions ride on the pre-pass kernel up to this many slices (262 k gridpoints), see BcFold */
+  constexpr uint32_t kBcFoldMaxSlices = 4096;
+
   int grid_for(size_t n, int block = kBlock) { return (int)std::max<size_t>(1, (n + block - 1) / block); }
 } // namespace
 
@@ -276,6 +279,7 @@ struct ryujin_hip_ctx {
   bool comm_pending = false;    /* comm_stream holds work the compute stream has not joined */
   bool exp_pending = false;     /* ... of which an export part later kernels on the compute stream depend on */
   bool exchange_after_exp = false; /* an exchange was enqueued behind the latest export part (ev_exp misses it) */
+  StepBegin pending_begin{}; /* set by step(), carried by its first sweep (step_begin) */
   bool interior_reads_ghosts = false; /* asymmetric stencil: every sweep joins the exchanges (no overlap) */
   uint32_t n_export_slices = 0;
   uint32_t bounds_stride = 0; /* SoA stride of the limiter bounds: covers the ghost range (dG reads bounds_j) */
@@ -311,7 +315,8 @@ struct ryujin_hip_ctx {
   /* boundary data */
   uint32_t n_bdry = 0, n_groups = 0;
   std::vector<uint32_t> bdry_perm; /* sorted entry -> original entry */
-  DeviceBuffer<uint32_t> d_grp_start, d_b_i;
+  DeviceBuffer<uint32_t> d_grp_start, d_b_i, d_bc_first;
+  DeviceBuffer<unsigned long long> d_bc_mask; /* BcFold: boundary rows of every slice */
   DeviceBuffer<double> d_b_normal, d_dirichlet;
   DeviceBuffer<uint8_t> d_b_id;
   bool have_dirichlet = false, needs_dirichlet = false;
@@ -649,6 +654,16 @@ void ryujin_hip_ctx::create(const ryujin_hip_offline &o, const ryujin_hip_params
         grp_start.push_back(e);
     }
     n_groups = (uint32_t)grp_start.size();
+    /* which rows of a slice are boundary DoFs, and the group of the first one (BcFold) */
+    std::vector<unsigned long long> bc_mask(L.n_slices, 0ull);
+    std::vector<uint32_t> bc_first(L.n_slices, 0u);
+    for (uint32_t g = n_groups; g-- > 0;) {
+      const uint32_t row = b_i[grp_start[g]];
+      bc_mask[row / kWave] |= 1ull << (row % kWave);
+      bc_first[row / kWave] = g; /* descending loop: the smallest group of the slice wins */
+    }
+    d_bc_mask.upload(bc_mask);
+    d_bc_first.upload(bc_first);
     grp_start.push_back(n_bdry);
     d_grp_start.upload(grp_start);
     d_b_i.upload(b_i);
@@ -763,6 +778,7 @@ void ryujin_hip_ctx::sweep(F &&launch)
     if (s1 <= s0)
       return;
     DeviceMesh mm = mesh;
+    mm.begin = pending_begin;
     mm.slice_begin = s0;
     mm.slice_end = s1;
     /* one wave per slice, 4 slices per block (waves beyond slice_end return at once) */
@@ -771,6 +787,10 @@ void ryujin_hip_ctx::sweep(F &&launch)
     launch(mm, grid);
     launch_stream = stream;
   };
+  struct Consume { /* the start of a step rides on one sweep only */
+    StepBegin &b;
+    ~Consume() { b = StepBegin{}; }
+  } consume{pending_begin};
   if (n_nbr == 0) {
     run(0, L.n_slices, stream);
     return;
@@ -957,23 +977,34 @@ void ryujin_hip_ctx::prepare_state_vector(int h, const double *dirichlet)
   if (needs_dirichlet && !have_dirichlet)
     throw HipError(RYUJIN_ERR_ARG, "prepare_state_vector: the boundary map holds dirichlet / dynamic / "
                                    "dirichlet_momentum ids but no Dirichlet data was ever passed");
-  /* boundary rows may be export rows: written by the export part of the last sweep -- and read by the pack
-   * kernel of an exchange of this vector that is still in flight (two calls in a row) */
-  if (exchange_after_exp)
-    wait_comm();
-  else
-    join_export();
-  if (n_groups)
-    hipLaunchKernelGGL(k_apply_bc<E>, dim3(grid_for(n_groups)), block, 0, stream, eparams, n_groups,
-                       d_grp_start.ptr, d_b_i.ptr, d_b_normal.ptr, d_b_id.ptr, d_dirichlet.ptr,
-                       s.U.ptr);
+  /* Boundary conditions (:102-146). Small meshes: applied by the first pre-pass sweep itself (apply_bc_row; a
+   * launch less per update). Boundary rows may be export rows -- read by the pack kernel of an exchange of this
+   * vector that is still in flight (two calls in a row): the export part runs behind it in stream order on
+   * comm_stream, the interior part never writes them. Large meshes: a launch of its own in front of the sweep
+   * (the streaming pre-pass kernel keeps its occupancy); it writes export rows from the compute stream and
+   * therefore joins whatever comm_stream still holds for them. */
+  const BcFold bc{n_groups ? d_bc_mask.ptr : nullptr, d_bc_first.ptr, d_grp_start.ptr, d_b_normal.ptr,
+                  d_b_id.ptr,   d_dirichlet.ptr};
+  const bool fold_bc = L.n_slices <= kBcFoldMaxSlices;
+  if (!fold_bc && n_groups) {
+    if (exchange_after_exp)
+      wait_comm();
+    else
+      join_export();
+    hipLaunchKernelGGL(k_apply_bc<E>, dim3(grid_for(n_groups)), block, 0, stream, eparams, n_groups, d_b_i.ptr,
+                       bc, s.U.ptr);
+  }
   /* U.update_ghost_values(), :148, is enqueued BEHIND the export part of the first pre-pass sweep, which
    * reads owned states only: the interior part of step 2 then waits for that export part alone, and the
    * exchange of U hides behind the interior parts of the pre-pass and of step 2 */
   if constexpr (std::is_same<typename E::Params, EulerAeosParams>::value) {
     /* n_precomputation_cycles = 2 (euler_aeos/hyperbolic_system.h:433), ghost update after each */
     sweep([&](const DeviceMesh &mm, dim3 grid) {
-      hipLaunchKernelGGL(k_precompute_aeos0<E::DIMENSION>, grid, block, 0, launch_stream, eparams, mm, s.U.ptr,
+      if (fold_bc)
+        hipLaunchKernelGGL((k_precompute_aeos0<E::DIMENSION, true>), grid, block, 0, launch_stream, eparams, mm, bc, s.U.ptr,
+                         s.prec.ptr);
+      else
+        hipLaunchKernelGGL((k_precompute_aeos0<E::DIMENSION, false>), grid, block, 0, launch_stream, eparams, mm, bc, s.U.ptr,
                          s.prec.ptr);
     });
     exchange_vector(s.U.ptr, KP, true);
@@ -985,7 +1016,11 @@ void ryujin_hip_ctx::prepare_state_vector(int h, const double *dirichlet)
     exchange_vector(s.prec.ptr, 4, true);
   } else if constexpr (std::is_same<typename E::Params, ScalarParams>::value) {
     sweep([&](const DeviceMesh &mm, dim3 grid) {
-      hipLaunchKernelGGL(k_precompute_sc<E::DIMENSION>, grid, block, 0, launch_stream, eparams, mm, s.U.ptr,
+      if (fold_bc)
+        hipLaunchKernelGGL((k_precompute_sc<E::DIMENSION, true>), grid, block, 0, launch_stream, eparams, mm, bc, s.U.ptr,
+                         s.prec.ptr);
+      else
+        hipLaunchKernelGGL((k_precompute_sc<E::DIMENSION, false>), grid, block, 0, launch_stream, eparams, mm, bc, s.U.ptr,
                          s.prec.ptr);
     });
     exchange_vector(s.U.ptr, KP, true);
@@ -998,7 +1033,11 @@ void ryujin_hip_ctx::prepare_state_vector(int h, const double *dirichlet)
      * from the exchanged ghost states (functions of U_j alone: nothing to exchange, :157-160 moves the same
      * numbers), behind the exchange of U on comm_stream. */
     sweep([&](const DeviceMesh &mm, dim3 grid) {
-      hipLaunchKernelGGL(k_precompute_records<E>, grid, block, 0, launch_stream, eparams, mm, s.U.ptr,
+      if (fold_bc)
+        hipLaunchKernelGGL((k_precompute_records<E, true>), grid, block, 0, launch_stream, eparams, mm, bc, s.U.ptr,
+                         s.prec.ptr, s.rrec.ptr);
+      else
+        hipLaunchKernelGGL((k_precompute_records<E, false>), grid, block, 0, launch_stream, eparams, mm, bc, s.U.ptr,
                          s.prec.ptr, s.rrec.ptr);
     });
     exchange_vector(s.U.ptr, KP, true);
@@ -1030,12 +1069,19 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
 
   const dim3 block(kBlock);
 
-  /* scalars: tau_max := tau_max_in, flags := 0 */
+  /* scalars: tau_max := tau_max_in, flags := 0 -- carried by the first sweep of step 2 (step_begin) */
   const bool use_device_tau = deferred && rk_stage > 0;
-  join_export(); /* the flags and tau_max are written by export parts as well */
-  hipLaunchKernelGGL(k_step_begin, dim3(1), dim3(1), 0, stream, tau_max_in,
-                     (!deferred || rk_stage == 0) ? 1 : 0, (deferred && rk_stage > 0) ? rk_stage - 1 : -1,
-                     tau_in, use_device_tau ? 1 : 0, deferred ? rk_stage : 0, d_scalars.ptr);
+  struct ClearBegin { /* a step that throws before its first sweep must not leave it armed */
+    StepBegin &b;
+    ~ClearBegin() { b = StepBegin{}; }
+  } clear_begin{pending_begin};
+  pending_begin = StepBegin{d_scalars.ptr,
+                            tau_max_in,
+                            tau_in,
+                            (!deferred || rk_stage == 0) ? 1 : 0,
+                            (deferred && rk_stage > 0) ? rk_stage - 1 : -1,
+                            use_device_tau ? 1 : 0,
+                            deferred ? rk_stage : 0};
 
   bool euler_fast_riemann = false;
   if constexpr (is_euler)
@@ -1299,7 +1345,7 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
   join_export(); /* (the exchange of U_new stays in flight: whoever reads its ghost range joins it) */
   if (!deferred)
     allreduce_scalar(&d_scalars.ptr->restart_needed, 1); /* MPI::logical_or(restart_needed), :1194 */
-  /* (deferred: the restart flag is folded into its accumulator by the next stage's k_step_begin, or by
+  /* (deferred: the restart flag is folded into its accumulator by the next stage's step_begin(), or by
    * time_step() behind the last stage) */
 
   HIP_CHECK(hipGetLastError());

@@ -184,15 +184,17 @@ namespace ryujin_hip
 
 
   /* ------------------------------------------------------------------ step 1: precomputation_loop */
-  template <int DIM>
+  template <int DIM, bool WITH_BC>
   __global__ void __launch_bounds__(kBlock)
-  k_precompute_sc(const ScalarParams P, const DeviceMesh M, const double *__restrict__ U,
+  k_precompute_sc(const ScalarParams P, const DeviceMesh M, const BcFold B, double *U,
                   double *__restrict__ prec)
   {
     using E = ScalarConservation<DIM>;
     const uint32_t i = M.slice_begin * 64 + blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M.n_owned || i >= M.slice_end * 64)
       return;
+    if constexpr (WITH_BC)
+      apply_bc_row<E>(P, B, i, U);
     if (M.row_len[i] == 1)
       return;
     const double u = U[(size_t)i * 2];
@@ -211,6 +213,7 @@ namespace ryujin_hip
   {
     using E = ScalarConservation<DIM>;
     constexpr int NP = E::NPREC;
+    step_begin(M);
     const RowCtx r = row_context(M);
     if (!r.valid)
       return;
