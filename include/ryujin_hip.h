@@ -259,7 +259,12 @@ void ryujin_hip_comm_destroy(ryujin_hip_comm *comm);
 void ryujin_hip_default_params(ryujin_hip_params *params, int equation, int dim);
 
 /* HyperbolicModule ctor + prepare() (hyperbolic_module.template.h:28-86).
- * `comm` may be NULL for a single rank. `device` is the HIP device ordinal. */
+ * `comm` may be NULL for a single rank. `device` is the HIP device ordinal.
+ * Two environment variables, read here, exist for the test suite only (they select code branches that the
+ * mesh would otherwise select, results are identical): RYUJIN_HIP_JOIN_EXCHANGES=1 (every sweep joins the
+ * ghost exchanges: the choreography of a non-symmetric stencil), RYUJIN_HIP_BC_FOLD_MAX_SLICES=<n> (boundary
+ * conditions ride on the pre-pass kernel up to n slices of 64 rows; default 4096, 0 = always a launch of
+ * their own). */
 int ryujin_hip_create(ryujin_hip_ctx **ctx, const ryujin_hip_offline *offline,
                       const ryujin_hip_params *params, ryujin_hip_comm *comm, int device);
 void ryujin_hip_destroy(ryujin_hip_ctx *ctx);

@@ -249,14 +249,22 @@ def test_device_pow_accuracy():
     assert out[5] == 1.0
 
 
-@pytest.mark.parametrize("n_ranks", [2, 3])
-def test_partitioned_hip_matches_single_rank(n_ranks):
+@pytest.mark.parametrize("n_ranks,mode", [(2, ""), (3, ""), (3, "join_exchanges"), (3, "bc_launch")])
+def test_partitioned_hip_matches_single_rank(n_ranks, mode, monkeypatch):
     """Multi-rank code path of the library on ONE GPU: n contexts (one host thread each) own x-slabs of
     the mesh and exchange ghosts through the in-process transport (ryujin_hip_comm_init_local), which
     shares pack kernels, send/receive offsets and the ghost-row layout with the RCCL transport. The
-    partitioned run must reproduce the single-rank run (same tau; U to round-off)."""
+    partitioned run must reproduce the single-rank run (same tau; U to round-off).
+    mode: the branches small meshes do not take by themselves -- "join_exchanges": the fallback
+    choreography of an asymmetric stencil (every sweep joins the exchanges); "bc_launch": boundary
+    conditions as a launch of their own in front of the pre-pass (large meshes)."""
     import ctypes as C
     import threading
+
+    if mode == "join_exchanges":
+        monkeypatch.setenv("RYUJIN_HIP_JOIN_EXCHANGES", "1")
+    elif mode == "bc_launch":
+        monkeypatch.setenv("RYUJIN_HIP_BC_FOLD_MAX_SLICES", "0")
 
     lib = capi.load_hip()
     cpu, n_updates = 40, 6
