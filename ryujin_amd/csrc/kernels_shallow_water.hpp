@@ -136,7 +136,8 @@ namespace ryujin_hip
     load_state<K>(U, j_n, U_n);
     double alpha_n = alpha[j_n];
     double Z_n = Z[j_n];
-    double h_star_n = prec[(size_t)j_n * 2 + 1];
+    const bool friction = P.manning != 0.; /* h_star_j only enters the friction term */
+    double h_star_n = friction ? prec[(size_t)j_n * 2 + 1] : 1.;
     for (uint32_t c = 0; c < r.width; ++c) {
       const uint64_t colbase = (uint64_t)r.base + c;
       const bool active = row_active && c < r.len;
@@ -157,7 +158,7 @@ namespace ryujin_hip
         load_state<K>(U, j_n, U_n);
         alpha_n = alpha[j_n];
         Z_n = Z[j_n];
-        h_star_n = prec[(size_t)j_n * 2 + 1];
+        h_star_n = friction ? prec[(size_t)j_n * 2 + 1] : 1.;
         j_nn = (c + 2 < r.width) ? ld_stream(cols + ((colbase + 2) * 64 + r.lane)) : i;
       }
       if (!active)

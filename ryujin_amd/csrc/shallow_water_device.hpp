@@ -203,6 +203,15 @@ namespace ryujin_hip
     static RYUJIN_DEV void manning_friction(const Params &P, const double (&U)[K],
                                             const double h_star, const double tau, double (&r)[K])
     {
+      /* n = 0 (the reference's default and BASELINE configs[4]): factor = 0 and the source is -0 * x = (-)0 for
+       * every finite x -- return the zeros without the division and the square root (uniform branch on a kernel
+       * argument; exact up to the sign of a zero that is only ever added to something) */
+      if (P.manning == 0.) {
+#pragma unroll
+        for (int q = 0; q < K; ++q)
+          r[q] = 0.;
+        return;
+      }
       const double h_inverse = inverse_water_depth_mollified(P, U);
       double v2;
       {
