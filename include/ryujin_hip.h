@@ -264,7 +264,8 @@ void ryujin_hip_default_params(ryujin_hip_params *params, int equation, int dim)
  * mesh would otherwise select, results are identical): RYUJIN_HIP_JOIN_EXCHANGES=1 (every sweep joins the
  * ghost exchanges: the choreography of a non-symmetric stencil), RYUJIN_HIP_BC_FOLD_MAX_SLICES=<n> (boundary
  * conditions ride on the pre-pass kernel up to n slices of 64 rows; default 4096, 0 = always a launch of
- * their own). */
+ * their own), RYUJIN_HIP_SMALL_MESH_SPLIT=0 (meshes that do not fill the device run the same step-5/6 kernels as
+ * large ones instead of the variants that spread the columns of a slice over several waves). */
 int ryujin_hip_create(ryujin_hip_ctx **ctx, const ryujin_hip_offline *offline,
                       const ryujin_hip_params *params, ryujin_hip_comm *comm, int device);
 void ryujin_hip_destroy(ryujin_hip_ctx *ctx);

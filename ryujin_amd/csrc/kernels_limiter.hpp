@@ -152,7 +152,7 @@ namespace ryujin_hip
   /* Step 5 for Euler, stages == 0, fused with the first part of P_ij of step 4 (:769-813): instead of
    * loading P_ij it is recomputed from U_i, U_j, alpha, d_ij, c_ij in exactly the operation order of
    * k_low_order, then the mass-matrix correction and the limiter follow as in k_pij_lij. */
-  template <int DIM>
+  template <int DIM, int NY = 1>
   __global__ void __launch_bounds__(kBlock, RYUJIN_OCC_PIJ)
   k_pij_lij_recompute(const EulerParams P, const DeviceMesh M, DeviceScalars *__restrict__ scalars,
                       const double weight, const double *__restrict__ old_U,
@@ -193,22 +193,26 @@ namespace ryujin_hip
     bool all_ok = true;
     unsigned long long undecided_mask = 0;
 
-    /* software pipeline: loads of column c+1 are in flight while column c is processed */
-    uint32_t j_n = r.width > 1 ? ld_stream(cols + (((uint64_t)r.base + 1) * 64 + r.lane)) : i;
-    uint32_t j_nn = r.width > 2 ? ld_stream(cols + (((uint64_t)r.base + 2) * 64 + r.lane)) : i;
+    /* NY > 1 (small meshes, less than two waves per SIMD: the sweep is one wave's latency chain): the pairs of
+     * a row are independent in this sweep, so NY waves (blockIdx.y) share a slice, wave y taking the columns
+     * 1 + y, 1 + y + NY, ... -- a chain NY times shorter, the per-row data read NY times from L2 */
+    const uint32_t c0 = 1 + (NY > 1 ? blockIdx.y : 0);
+    /* software pipeline: loads of the next column are in flight while column c is processed */
+    uint32_t j_n = r.width > c0 ? ld_stream(cols + (((uint64_t)r.base + c0) * 64 + r.lane)) : i;
+    uint32_t j_nn = r.width > c0 + NY ? ld_stream(cols + (((uint64_t)r.base + c0 + NY) * 64 + r.lane)) : i;
     double c_n[DIM], U_n[K], F_n[K];
     double mjinv_n = 0., mij_n = 0., d_n = 0., alpha_n = 0.;
-    if (r.width > 1) {
-      load_entry<DIM>(cij, (uint64_t)r.base + 1, r.lane, c_n);
-      d_n = dij[((uint64_t)r.base + 1) * 64 + r.lane];
-      mij_n = ld_stream(mij + (((uint64_t)r.base + 1) * 64 + r.lane));
+    if (r.width > c0) {
+      load_entry<DIM>(cij, (uint64_t)r.base + c0, r.lane, c_n);
+      d_n = dij[((uint64_t)r.base + c0) * 64 + r.lane];
+      mij_n = ld_stream(mij + (((uint64_t)r.base + c0) * 64 + r.lane));
       load_state<K>(old_U, j_n, U_n);
       load_state<K>(r_in, j_n, F_n);
       mjinv_n = mi_inv[j_n];
       alpha_n = alpha[j_n];
     }
 
-    for (uint32_t c = 1; c < r.width; ++c) {
+    for (uint32_t c = c0; c < r.width; c += NY) {
       const uint64_t colbase = (uint64_t)r.base + c;
       const uint64_t pos = colbase * 64 + r.lane;
       const bool active = row_active && c < r.len;
@@ -222,16 +226,16 @@ namespace ryujin_hip
         F_jH[q] = F_n[q];
       }
       const double m_j_inv = mjinv_n, m_ij = mij_n, d_ij = d_n, alpha_j = alpha_n;
-      if (c + 1 < r.width) {
+      if (c + NY < r.width) {
         j_n = j_nn;
-        load_entry<DIM>(cij, colbase + 1, r.lane, c_n);
-        d_n = dij[(colbase + 1) * 64 + r.lane];
-        mij_n = ld_stream(mij + ((colbase + 1) * 64 + r.lane));
+        load_entry<DIM>(cij, colbase + NY, r.lane, c_n);
+        d_n = dij[(colbase + NY) * 64 + r.lane];
+        mij_n = ld_stream(mij + ((colbase + NY) * 64 + r.lane));
         load_state<K>(old_U, j_n, U_n);
         load_state<K>(r_in, j_n, F_n);
         mjinv_n = mi_inv[j_n];
         alpha_n = alpha[j_n];
-        j_nn = (c + 2 < r.width) ? ld_stream(cols + ((colbase + 2) * 64 + r.lane)) : i;
+        j_nn = (c + 2 * NY < r.width) ? ld_stream(cols + ((colbase + 2 * NY) * 64 + r.lane)) : i;
       }
       if (!active)
         continue;
@@ -478,7 +482,10 @@ namespace ryujin_hip
    * and all loads of a row are independent and issued up front.
    * CP < MAXW (3-D Q1: 27 columns of 5 components do not fit the register file at a useful occupancy):
    * all l_ij but only the P_ij of columns < CP are cached, the others are fetched a second time. */
-  template <typename E, int MAXW, int CP = MAXW>
+  /* SPLIT (small meshes, the sweep is one wave's latency chain): the four waves of a block share ONE slice; all
+   * of them form the new U_i (bitwise the same sum), the first one stores it -- behind a block barrier, the update
+   * is in place -- and wave w runs the second limiter pass for the columns 1 + w, 5 + w, ... only. */
+  template <typename E, int MAXW, int CP = MAXW, bool SPLIT = false>
   __global__ void __launch_bounds__(kBlock, (MAXW > 9 ? (CP < MAXW ? RYUJIN_OCC_HO_3D : 1) : RYUJIN_OCC_HO))
   k_high_order_next_cached(const typename E::Params P, const DeviceMesh M, double *__restrict__ new_U,
                            const double *__restrict__ bounds, const double *__restrict__ pij,
@@ -486,9 +493,24 @@ namespace ryujin_hip
   {
     constexpr int K = E::K;
     constexpr int NB = E::NB;
-    const RowCtx r = row_context(M);
-    if (!r.valid)
-      return;
+    static_assert(!SPLIT || CP == MAXW, "the split variant caches the whole row");
+    RowCtx r;
+    const uint32_t group = SPLIT ? (threadIdx.x >> 6) : 0u;
+    if constexpr (SPLIT) { /* one slice per block (uniform over the block: the barrier below is safe) */
+      r.lane = threadIdx.x & 63;
+      r.slice = M.slice_begin + blockIdx.x;
+      r.valid = r.slice < M.slice_end;
+      if (!r.valid)
+        return;
+      r.row = r.slice * 64 + r.lane;
+      r.len = M.row_len[r.row];
+      r.base = M.slice_off[r.slice];
+      r.width = M.slice_off[r.slice + 1] - r.base;
+    } else {
+      r = row_context(M);
+      if (!r.valid)
+        return;
+    }
     const bool row_active = r.len > 1;
     const uint32_t i = row_active ? r.row : (r.row < M.n_owned ? r.row : M.n_owned - 1);
     const uint32_t *__restrict__ idx_t = M.idx_t;
@@ -540,13 +562,21 @@ namespace ryujin_hip
         }
       }
     }
-    if (row_active)
-      store_state<K>(new_U, i, U_i_new);
+    if constexpr (SPLIT) {
+      __syncthreads(); /* every wave of the block has read the old new_U[i] */
+      if (row_active && group == 0)
+        store_state<K>(new_U, i, U_i_new);
+    } else {
+      if (row_active)
+        store_state<K>(new_U, i, U_i_new);
+    }
 
     unsigned long long undecided_mask = 0;
 #pragma unroll
     for (int c = 1; c < MAXW; ++c) {
       if ((uint32_t)c >= r.width)
+        continue;
+      if (SPLIT && (uint32_t)(c - 1) % kWavesPerBlock != group)
         continue;
       {
         const bool lane_on = row_active && (uint32_t)c < r.len;

@@ -159,6 +159,11 @@ namespace
    * back and invalidates the L2s under the interior launch that runs next to it). */
   constexpr unsigned kDeviceEventFlags = hipEventDisableTiming | hipEventDisableSystemFence;
 
+  /* waves of k_pij_lij_recompute an MI355X holds at once (256 CUs x 4 SIMDs x 2): below that step 5 splits the
+   * columns of a slice over several waves */
+  constexpr uint32_t kResidentWavesStep5 = 2048;
+  /* the same for the first of the two high-order sweeps (4 waves per SIMD) */
+  constexpr uint32_t kResidentWavesStep6 = 4096;
   /* boundary conditions ride on the pre-pass kernel up to this many slices (262 k gridpoints), see BcFold */
   constexpr uint32_t kBcFoldMaxSlices = 4096;
 
@@ -282,6 +287,7 @@ struct ryujin_hip_ctx {
   bool exchange_after_exp = false; /* an exchange was enqueued behind the latest export part (ev_exp misses it) */
   StepBegin pending_begin{}; /* set by step(), carried by its first sweep (step_begin) */
   uint32_t bc_fold_max_slices = kBcFoldMaxSlices;
+  uint32_t resident_waves_step5 = kResidentWavesStep5, resident_waves_step6 = kResidentWavesStep6;
   bool interior_reads_ghosts = false; /* asymmetric stencil: every sweep joins the exchanges (no overlap) */
   uint32_t n_export_slices = 0;
   uint32_t bounds_stride = 0; /* SoA stride of the limiter bounds: covers the ghost range (dG reads bounds_j) */
@@ -624,6 +630,9 @@ void ryujin_hip_ctx::create(const ryujin_hip_offline &o, const ryujin_hip_params
     interior_reads_ghosts = interior_reads_ghosts || std::atoi(e) != 0;
   if (const char *e = std::getenv("RYUJIN_HIP_BC_FOLD_MAX_SLICES"))
     bc_fold_max_slices = (uint32_t)std::strtoul(e, nullptr, 10);
+  if (const char *e = std::getenv("RYUJIN_HIP_SMALL_MESH_SPLIT"))
+    if (std::atoi(e) == 0)
+      resident_waves_step5 = resident_waves_step6 = 0; /* small meshes run the kernels of the large ones */
   mesh.slice_off = d_slice_off.ptr;
   mesh.row_len = d_row_len.ptr;
   mesh.cols = d_cols.ptr;
@@ -1291,9 +1300,23 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
     sweep([&](const DeviceMesh &mm, dim3 grid) {
       if constexpr (is_euler) {
         if (recompute_p) {
-          hipLaunchKernelGGL(k_pij_lij_recompute<DIM>, grid, block, 0, launch_stream, eparams, mm,
-                             d_scalars.ptr, weight, old.U.ptr, d_alpha.ptr, d_dij.ptr, nw.U.ptr,
-                             d_r.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr);
+          /* small meshes: up to four waves per slice, each taking a share of the columns (see the kernel), as
+           * long as all of them are resident at once (256 CUs x 4 SIMDs x 2 waves of this kernel) */
+          const uint32_t groups = std::min<uint32_t>(4u, resident_waves_step5 / std::max<uint32_t>(1u, grid.x * kWavesPerBlock));
+          auto launch5 = [&](auto ny) {
+            constexpr int NY = decltype(ny)::value;
+            hipLaunchKernelGGL((k_pij_lij_recompute<DIM, NY>), dim3(grid.x, NY), block, 0, launch_stream, eparams,
+                               mm, d_scalars.ptr, weight, old.U.ptr, d_alpha.ptr, d_dij.ptr, nw.U.ptr, d_r.ptr,
+                               d_bounds.ptr, d_pij.ptr, d_lij.ptr);
+          };
+          if (groups >= 4)
+            launch5(std::integral_constant<int, 4>{});
+          else if (groups == 3)
+            launch5(std::integral_constant<int, 3>{});
+          else if (groups == 2)
+            launch5(std::integral_constant<int, 2>{});
+          else
+            launch5(std::integral_constant<int, 1>{});
           return;
         }
       }
@@ -1335,6 +1358,16 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
       /* 3-D: cache all l_ij and the P_ij of the first RYUJIN_HO_CP_3D columns (0: two-pass kernel) */
       constexpr int kCachedP = DIM == 3 ? (RYUJIN_HO_CP_3D > 0 ? RYUJIN_HO_CP_3D : 27) : kCachedWidth;
       sweep([&](const DeviceMesh &mm, dim3 grid) {
+        if constexpr (DIM <= 2) {
+          /* small meshes: the four waves of a block share one slice (see the kernel) while all of them fit */
+          const uint32_t n_launch = mm.slice_end - mm.slice_begin;
+          if (L.max_row_len <= (uint32_t)kCachedWidth && n_launch * kWavesPerBlock <= resident_waves_step6) {
+            hipLaunchKernelGGL((k_high_order_next_cached<E, kCachedWidth, kCachedWidth, true>), dim3(n_launch),
+                               block, 0, launch_stream, eparams, mm, nw.U.ptr, d_bounds.ptr, d_pij.ptr,
+                               d_lij.ptr, d_lij_next.ptr);
+            return;
+          }
+        }
         if ((DIM <= 2 || RYUJIN_HO_CP_3D > 0) && L.max_row_len <= (uint32_t)kCachedWidth)
           hipLaunchKernelGGL((k_high_order_next_cached<E, kCachedWidth, kCachedP>), grid, block, 0,
                              launch_stream, eparams, mm, nw.U.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr,

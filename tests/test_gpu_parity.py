@@ -1516,3 +1516,22 @@ def test_unstructured_p1_mesh_scalar_conservation(oracle):
             p.sc_use_averaged_entropy = averaged
         mods = _scalar_both(off, U0, oracle, edit, n_warm=15, dirichlet=dirichlet)
         _scalar_compare(off, mods, dirichlet)
+
+
+@pytest.mark.parametrize("which", ["euler_2d", "euler_1d", "euler_erk33", "sw_2d", "sw_1d", "aeos_2d", "scalar_2d"])
+def test_step_parity_with_the_kernels_of_large_meshes(oracle, monkeypatch, which):
+    """The meshes of this file do not fill an MI355X, so they take the small-mesh branches of the library
+    (boundary conditions folded into the pre-pass, steps 5 and 6 with the columns of a slice spread over several
+    waves). Re-run one case per Description with those branches switched off: the kernels BASELINE-sized meshes
+    run (also covered at full size for Euler and shallow water in test_gpu_parity_fullsize.py)."""
+    monkeypatch.setenv("RYUJIN_HIP_SMALL_MESH_SPLIT", "0")
+    monkeypatch.setenv("RYUJIN_HIP_BC_FOLD_MAX_SLICES", "0")
+    {
+        "euler_2d": lambda: test_step_parity_2d_step_geometry(oracle),
+        "euler_1d": lambda: test_step_parity_1d(oracle),
+        "euler_erk33": lambda: test_multistage_parity_erk33(oracle),
+        "sw_2d": lambda: test_sw_step_parity_2d_dam_break_over_bathymetry(oracle),
+        "sw_1d": lambda: test_sw_step_parity_1d(oracle),
+        "aeos_2d": lambda: test_aeos_step_parity_2d_step_geometry(oracle, False),
+        "scalar_2d": lambda: test_scalar_parity_2d(oracle, "kpp"),
+    }[which]()
