@@ -159,6 +159,16 @@ namespace
    * back and invalidates the L2s under the interior launch that runs next to it). */
   constexpr unsigned kDeviceEventFlags = hipEventDisableTiming | hipEventDisableSystemFence;
 
+  /* (a runtime that does not know the flag -- the process may run on the ROCm runtime its host application
+   * bundles -- gets the plain synchronisation event) */
+  void create_device_event(hipEvent_t *e)
+  {
+    if (hipEventCreateWithFlags(e, kDeviceEventFlags) != hipSuccess) {
+      (void)hipGetLastError();
+      HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    }
+  }
+
   /* waves of k_pij_lij_recompute an MI355X holds at once (256 CUs x 4 SIMDs x 2): below that step 5 splits the
    * columns of a slice over several waves */
   constexpr uint32_t kResidentWavesStep5 = 2048;
@@ -219,7 +229,7 @@ struct LocalGroup {
     HIP_CHECK(hipSetDevice(dev));
     for (auto *set : {&ev_packed, &ev_pulled, &ev_reduced})
       for (auto &e : *set)
-        HIP_CHECK(hipEventCreateWithFlags(&e, kDeviceEventFlags)); /* one GPU by construction */
+        create_device_event(&e); /* one GPU by construction */
     HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&slots), sizeof(unsigned long long) * 4 * n));
     HIP_CHECK(hipMemset(slots, 0, sizeof(unsigned long long) * 4 * n));
     HIP_CHECK(hipDeviceSynchronize());
@@ -488,9 +498,9 @@ void ryujin_hip_ctx::create(const ryujin_hip_offline &o, const ryujin_hip_params
   HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
   HIP_CHECK(hipStreamCreateWithFlags(&comm_stream, hipStreamNonBlocking));
   launch_stream = stream;
-  HIP_CHECK(hipEventCreateWithFlags(&ev_prev, kDeviceEventFlags));
-  HIP_CHECK(hipEventCreateWithFlags(&ev_exp, kDeviceEventFlags));
-  HIP_CHECK(hipEventCreateWithFlags(&ev_comm, kDeviceEventFlags));
+  create_device_event(&ev_prev);
+  create_device_event(&ev_exp);
+  create_device_event(&ev_comm);
   for (auto &e : ev)
     HIP_CHECK(hipEventCreate(&e));
   for (auto &set : ev_rk)
