@@ -42,11 +42,32 @@ def _free_port():
     return p
 
 
-def _launch(world, script_args, timeout=900):
+_hung = []  # a launch that had to be killed: the remaining cases would hang the same way, skip them
+
+
+def _run_group(cmd, env=None, timeout=420):
+    """Run `cmd` in its own process group; on a timeout kill the whole group (launcher AND its rank processes,
+    which would otherwise keep their GPUs) and remember that the RCCL path hung."""
+    import signal
+    if _hung:
+        pytest.skip(f"an earlier multi-GPU launch hung ({_hung[0]})")
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                            start_new_session=True)
+    try:
+        out, err = proc.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        os.killpg(proc.pid, signal.SIGKILL)  # the group this call created, nothing else
+        out, err = proc.communicate()
+        _hung.append(" ".join(cmd[-4:]))
+        pytest.fail(f"multi-GPU launch timed out after {timeout} s: {' '.join(cmd)}\n{err[-4000:]}")
+    return subprocess.CompletedProcess(cmd, proc.returncode, out, err)
+
+
+def _launch(world, script_args, timeout=420):
     env = dict(os.environ, OMP_NUM_THREADS="4", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), *script_args]
-    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    return _run_group(cmd, env, timeout)
 
 
 @pytest.mark.parametrize("world,case", [(2, "step2d:40"), (4, "step2d:40"), (8, "step2d:60"), (2, "cylinder3d:16"),
@@ -83,9 +104,8 @@ def test_bench_self_launches_its_ranks(n):
     JSON line with n_gpus == N."""
     if _n_gpus() < n:
         pytest.skip(f"needs {n} GPUs")
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "6",
-                          "--warmup", "3", "--develop", "30", "--cells-per-unit", "200"],
-                         capture_output=True, text=True, timeout=900)
+    res = _run_group([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "6",
+                      "--warmup", "3", "--develop", "30", "--cells-per-unit", "200", "--watchdog", "360"])
     assert res.returncode == 0, res.stderr[-4000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, res.stdout
