@@ -10,8 +10,6 @@ import os
 import sys
 
 import numpy as np
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -53,6 +51,11 @@ def run(off, comm, device, n_updates):
 
 
 def main():
+    # torch only here: the parent test imports this module for run() / make_spec() into a process that has
+    # libryujin_hip.so loaded already, and torch coming second would bring a second ROCm runtime along
+    # (heap corruption at exit). In the worker torch comes FIRST, as in bench.py.
+    import torch
+    import torch.distributed as dist
     out_path, case, n_updates = sys.argv[1], sys.argv[2], int(sys.argv[3])
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     dist.init_process_group("gloo")
