@@ -83,6 +83,29 @@ def test_riemann_solver_default(oracle, golden_dir):
         assert np.isclose(out[4], lam, rtol=RTOL, atol=0)
 
 
+def test_riemann_solver_simd_baseline_is_the_tolerance_model(oracle, golden_dir):
+    """tests/euler/riemann_solver-simd.output: the reference's own SIMD evaluation of the same ten cases (SURVEY
+    8c: "expected last-digit spread between scalar and SIMD evaluation -> tolerance model"). Two statements:
+    the oracle is as close to the SIMD baseline as the scalar baseline is (so RTOL is the reference's own
+    spread, not a number of ours), and phi(p*), a difference of O(1) terms, is where the spread is absolute."""
+    params = oracle.default_params(capi.EQ_EULER, 1)
+    scalar = _blocks(os.path.join(golden_dir, "euler_riemann_solver.output"))
+    simd = _blocks(os.path.join(golden_dir, "euler_riemann_solver-simd.output"))
+    assert len(scalar) == len(simd) == len(RIEMANN_CASES)
+    labels = ["p_star_two_rarefaction =", "p_star_failsafe =", "p^*_tilde  =", "-> lambda_max ="]
+    spread = 0.0
+    for (left, right), b_scalar, b_simd in zip(RIEMANN_CASES, scalar, simd):
+        _, _, out, _ = _run_riemann(oracle, params, left, right)
+        for label, ours in zip(labels, (out[0], out[1], out[2], out[4])):
+            a, b = _grab(b_scalar, label)[0], _grab(b_simd, label)[0]
+            spread = max(spread, abs(a - b) / abs(a))
+            assert np.isclose(ours, b, rtol=RTOL, atol=0), (label, ours, b)
+        a, b = _grab(b_scalar, "phi(p_*_t) =")[0], _grab(b_simd, "phi(p_*_t) =")[0]
+        assert abs(a - b) <= 1e-13 and abs(out[3] - b) <= 1e-13 + 1e-12 * abs(b)
+    # the reference's two evaluations differ in the last digits, and by less than the tolerance used above
+    assert 0.0 < spread <= RTOL
+
+
 @pytest.mark.parametrize("n_newton", [2, 10])
 def test_riemann_solver_iterated(oracle, golden_dir, n_newton):
     """tests/euler/riemann_solver-iterated-{2,10}.output: Newton path incl. per-iteration values."""
