@@ -217,6 +217,15 @@ def main():
     ap.add_argument("--probe-launch", action="store_true",
                     help="(test hook) initialise torch.distributed, print the rank layout as the JSON line and exit "
                          "before anything touches a GPU")
+    ap.add_argument("--reps", type=int, default=5,
+                    help="timed passes of exactly --steps steps each (barrier + synchronise on both sides of "
+                         "every pass); the JSON line reports the median pass and the min/max spread")
+    ap.add_argument("--system-events", action="store_true",
+                    help="create the events between the compute and the exchange stream with the system-scope "
+                         "fence (ryujin_hip_params::system_scope_events)")
+    ap.add_argument("--no-events-check", action="store_true",
+                    help="N > 1: skip the bitwise comparison of a few updates run with device-scope and with "
+                         "system-scope events before the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--watchdog", type=int, default=1500,
                     help="abort the process after this many seconds (a hung collective must not hang the box)")
@@ -369,8 +378,15 @@ def main():
         rc = lib.ryujin_hip_comm_init(C.byref(comm), uid, rank, world, device)
         assert rc == 0, lib.ryujin_hip_last_error()
 
-    m = HyperbolicModule(off, equation=equation, backend="hip", comm=comm, device=device)
-    m.cfl = 0.9
+    def make_module(system_events: bool):
+        p = capi.Params()
+        lib.ryujin_hip_default_params(C.byref(p), equation, off.dim)
+        p.system_scope_events = 1 if system_events else 0
+        mod = HyperbolicModule(off, p, backend="hip", comm=comm, device=device)
+        mod.cfl = 0.9
+        return mod
+
+    m = make_module(args.system_events)
     drv = Ssprk33Stages(m, U0, dirichlet)
     ctx = m._ctx
 
@@ -382,6 +398,35 @@ def main():
     for _ in range(args.develop):  # untimed: let the flow develop
         drv.update()
     U_developed = drv.U.download() if (n_gpus == 1 and not args.no_cpu_baseline) else None
+
+    # ---- N > 1: device-scope against system-scope events, before anything is timed. The events that tie the
+    # compute and the exchange stream carry no system-scope fence by default; whether that
+    # is enough when a REMOTE GPU wrote the ghost data is decided here by the hardware: the same six updates from
+    # the same developed state with either kind of event must agree bit for bit on every rank. If they do not,
+    # the run continues on system-scope events and says so in the JSON line.
+    events = {"kind": "system" if args.system_events else "device", "check": None}
+    if n_gpus > 1 and not args.no_events_check and not args.system_events:
+        import torch
+        while drv.stage != 0:
+            drv.update()
+        U_start = drv.U.download()
+        m_sys = make_module(True)
+        drv_sys = Ssprk33Stages(m_sys, U_start, dirichlet)
+        drv_dev = Ssprk33Stages(m, U_start, dirichlet)
+        for _ in range(2):
+            drv_dev.rk_step()
+            drv_sys.rk_step()
+        same = bool(np.array_equal(drv_dev.U.download(), drv_sys.U.download()))
+        flag = torch.tensor([0 if same else 1], dtype=torch.int64)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag[0]) == 0:
+            events["check"] = "2 SSPRK33 steps with device-scope and with system-scope events: bitwise equal on every rank"
+            m_sys.close()
+        else:
+            events = {"kind": "system", "check": "device-scope events gave DIFFERENT results on some rank "
+                                                 "(stale ghost data): timed on system-scope events"}
+            m, ctx = m_sys, m_sys._ctx
+            drv = Ssprk33Stages(m, U_start, dirichlet)
     for _ in range(args.warmup):
         drv.update()
 
@@ -399,18 +444,35 @@ def main():
                 drv.update()
                 n_done += 1
 
-    # ---- pass 1, the reported value: exactly K steps, no per-sweep instrumentation (the hipEvent pairs
-    # around every sweep cost a few per cent: each record is a barrier packet between two kernels)
+    # ---- pass 1, the reported value: --reps passes of exactly K steps each, no per-sweep instrumentation (the
+    # hipEvent pairs around every sweep cost a few per cent: each record is a barrier packet between two kernels).
+    # Every pass is bracketed by barrier + synchronise on both sides; the MEDIAN pass is the reported one
+    # (SURVEY.md section 8d), min and max travel with it.
     lib.ryujin_hip_set_timers(ctx, 0)
-    barrier()
-    t0 = time.perf_counter()
-    lib.ryujin_hip_event_record(ctx, 0)
-    run_steps(args.steps)
-    lib.ryujin_hip_event_record(ctx, 1)
-    barrier()
-    wall = time.perf_counter() - t0
-    ev_ms = C.c_double()
-    lib.ryujin_hip_event_elapsed_ms(ctx, C.byref(ev_ms))
+    walls, evs = [], []
+    for _ in range(max(1, args.reps)):
+        while drv.stage != 0:  # every pass starts at an SSPRK33 step boundary
+            drv.update()
+        barrier()
+        t0 = time.perf_counter()
+        lib.ryujin_hip_event_record(ctx, 0)
+        run_steps(args.steps)
+        lib.ryujin_hip_event_record(ctx, 1)
+        barrier()
+        w = time.perf_counter() - t0
+        e = C.c_double()
+        lib.ryujin_hip_event_elapsed_ms(ctx, C.byref(e))
+        if dist is not None:
+            import torch
+            tt = torch.tensor([w], dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)  # MAX over ranks, per pass
+            w = float(tt[0])
+        walls.append(w)
+        evs.append(e.value)
+    order = sorted(range(len(walls)), key=lambda q: walls[q])
+    median_pass = order[(len(order) - 1) // 2]
+    wall = walls[median_pass]
+    ev_ms = C.c_double(evs[median_pass])
 
     # ---- pass 2, the roofline breakdown: the same K steps again with hipEvent pairs around every sweep
     while drv.stage != 0:
@@ -418,10 +480,12 @@ def main():
     lib.ryujin_hip_set_timers(ctx, 1)
     lib.ryujin_hip_get_timers_accum(ctx, tmp, C.byref(n_upd), 1)  # reset the accumulators
     barrier()
+    xinfo0 = m.exchange_info()
     lib.ryujin_hip_event_record(ctx, 0)
     run_steps(args.steps)
     lib.ryujin_hip_event_record(ctx, 1)
     barrier()
+    xinfo1 = m.exchange_info()
     ev_ms_instrumented = C.c_double()
     lib.ryujin_hip_event_elapsed_ms(ctx, C.byref(ev_ms_instrumented))
     lib.ryujin_hip_get_timers_accum(ctx, tmp, C.byref(n_upd), 0)
@@ -431,14 +495,30 @@ def main():
     n_q_local = off.n_owned
     if dist is not None:
         import torch
-        tt = torch.tensor([wall], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        wall = float(tt[0])
         nn = torch.tensor([n_q_local], dtype=torch.int64)
         dist.all_reduce(nn, op=dist.ReduceOp.SUM)
         n_q_total = int(nn[0])
     else:
         n_q_total = n_q_local
+
+    # what RCCL and the library themselves report about the multi-rank run (rank 0's view + neighbour counts
+    # of all ranks): "RCCL saw N ranks" can be read off the JSON line
+    rccl = None
+    if comm is not None:
+        v = [C.c_int(-1) for _ in range(5)]
+        lib.ryujin_hip_comm_info(comm, *[C.byref(x) for x in v])
+        info = xinfo1
+        nb = [len(info["neighbours"])]
+        if dist is not None:
+            gathered = [None] * world
+            dist.all_gather_object(gathered, nb[0])
+            nb = gathered
+        rccl = {"ranks": v[3].value, "rank": v[2].value, "device": v[4].value,
+                "neighbours_of_rank0": info["neighbours"], "n_neighbours_per_rank": nb,
+                # counted by the library over the K steps of the instrumented pass (5 ghost exchanges per update:
+                # U, alpha, r, l_ij, l'_ij; 2 all-reduces per SSPRK33 step: tau_max of the first stage, the flags)
+                "exchanges_per_update": (xinfo1["n_exchanges"] - xinfo0["n_exchanges"]) / args.steps,
+                "allreduces_per_update": (xinfo1["n_allreduces"] - xinfo0["n_allreduces"]) / args.steps}
 
     if rank != 0:
         return
@@ -478,6 +558,8 @@ def main():
         "unit": "MDoF-updates/s",
         "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": wall / args.steps * 1e3,
+        "reps": len(walls), "ms_per_step_min": min(walls) / args.steps * 1e3,
+        "ms_per_step_max": max(walls) / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": workload_name,
@@ -500,7 +582,10 @@ def main():
                             "device_ms_per_update_instrumented": ev_ms_instrumented.value / args.steps},
         "sweep_ms": {n: round(v, 4) for n, v in sorted(per_sweep.items())},
         "n_warnings": m.n_warnings(),
+        "events": events,
     }
+    if rccl is not None:
+        out["rccl"] = rccl
     if not args.no_cpu_baseline and n_gpus == 1:
         try:
             out["cpu_baseline"] = cpu_baseline(spec, U_developed, dirichlet, args.cpu_budget, equation)

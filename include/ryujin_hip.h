@@ -144,6 +144,22 @@ typedef struct ryujin_hip_params {
   int sc_use_greedy_wavespeed;                /* 0 */
   int sc_use_averaged_entropy;                /* 0 */
   int sc_random_entropies;                    /* 0; > 0 is not reproducible in the reference: rejected */
+
+  /* Run-time switches of the library itself (no ParameterAcceptor counterpart; all default to 0).
+   * system_scope_events: the events that tie the compute stream and the exchange stream of ONE device are
+   *   created without the system-scope fence by default (the RCCL kernels carry their own system-scope
+   *   semantics); nonzero selects plain hipEventDisableTiming events -- the conservative choice, selectable
+   *   without a rebuild should a multi-GPU run ever show stale ghost data (bench.py --gpus N runs both and
+   *   compares bitwise before it times anything).
+   * debug_*: test hooks that select code branches the mesh would otherwise select (results are identical):
+   *   debug_join_exchanges != 0: every sweep joins the ghost exchanges (the choreography of a non-symmetric
+   *   stencil); debug_bc_fold_max_slices: boundary conditions ride on the pre-pass kernel up to n slices of
+   *   64 rows (0 = default 4096, < 0 = always a launch of their own); debug_no_small_mesh_split != 0: meshes
+   *   that do not fill the device run the same step-5/6 kernels as large ones. */
+  int system_scope_events;
+  int debug_join_exchanges;
+  int debug_bc_fold_max_slices;
+  int debug_no_small_mesh_split;
 } ryujin_hip_params;
 
 /* ---- offline data (input contract) ------------------------------------- */
@@ -223,7 +239,8 @@ typedef struct ryujin_hip_offline {
    * section 8 f-4). When nonzero the step uses the incidence matrix in the high-order viscosity
    * (hyperbolic_module.template.h:733-737), the full block-diagonal inverse mass matrix instead of the
    * Neumann series (:976-986) and extends the limiter bounds over the stencil (:938-948).
-   * Both matrices in the storage scheme of mij. Single rank, Euler only, in this version.
+   * Both matrices in the storage scheme of mij. Any number of ranks (the limiter bounds are exchanged,
+   * :601-613); Euler and shallow water (the other Descriptions are refused with RYUJIN_ERR_UNSUPPORTED).
    */
   int discontinuous_ansatz;
   const double *incidence;           /* [nnz] OfflineData::incidence_matrix() */
@@ -254,20 +271,25 @@ int ryujin_hip_comm_init_local(ryujin_hip_comm **comms, int n_ranks, int device)
  * offline data must have two neighbours with equally sized send / ghost ranges (uniform cross-section). */
 int ryujin_hip_comm_init_loopback(ryujin_hip_comm **comm, int rank, int n_ranks, int device);
 void ryujin_hip_comm_destroy(ryujin_hip_comm *comm);
+/* What the communicator itself reports: rank / n_ranks as passed to comm_init and -- RCCL communicators only,
+ * -1 otherwise -- ncclCommUserRank / ncclCommCount / ncclCommCuDevice as RCCL sees them (bench.py prints them
+ * so that "RCCL saw N ranks" can be read off the JSON line). Any pointer may be NULL. */
+int ryujin_hip_comm_info(const ryujin_hip_comm *comm, int *rank, int *n_ranks, int *rccl_rank,
+                         int *rccl_count, int *rccl_device);
 
 /* ---- lifecycle ----------------------------------------------------------- */
 void ryujin_hip_default_params(ryujin_hip_params *params, int equation, int dim);
 
 /* HyperbolicModule ctor + prepare() (hyperbolic_module.template.h:28-86).
- * `comm` may be NULL for a single rank. `device` is the HIP device ordinal.
- * Two environment variables, read here, exist for the test suite only (they select code branches that the
- * mesh would otherwise select, results are identical): RYUJIN_HIP_JOIN_EXCHANGES=1 (every sweep joins the
- * ghost exchanges: the choreography of a non-symmetric stencil), RYUJIN_HIP_BC_FOLD_MAX_SLICES=<n> (boundary
- * conditions ride on the pre-pass kernel up to n slices of 64 rows; default 4096, 0 = always a launch of
- * their own), RYUJIN_HIP_SMALL_MESH_SPLIT=0 (meshes that do not fill the device run the same step-5/6 kernels as
- * large ones instead of the variants that spread the columns of a slice over several waves). */
+ * `comm` may be NULL for a single rank. `device` is the HIP device ordinal. The library reads no
+ * environment variables; its run-time switches are the last four fields of ryujin_hip_params. */
 int ryujin_hip_create(ryujin_hip_ctx **ctx, const ryujin_hip_offline *offline,
                       const ryujin_hip_params *params, ryujin_hip_comm *comm, int device);
+/* The exchange pattern of a context and what it has done so far: neighbour ranks (at most max_nbr written),
+ * number of point-to-point ghost exchanges (vector or matrix; one grouped send/recv set per neighbour each)
+ * and of scalar all-reduces enqueued since create(). Any pointer may be NULL. */
+int ryujin_hip_exchange_info(ryujin_hip_ctx *ctx, int *n_nbr, int *nbr_rank, int max_nbr,
+                             unsigned long long *n_exchanges, unsigned long long *n_allreduces);
 void ryujin_hip_destroy(ryujin_hip_ctx *ctx);
 
 /* ---- state vectors (StateVector = U + precomputed, source/state_vector.h:47-51) */
@@ -347,7 +369,10 @@ int ryujin_hip_get_counters(ryujin_hip_ctx *ctx, unsigned *n_restarts, unsigned 
 /* Module-owned intermediates of the LAST step() in the reference's logical
  * (row, col_idx) order as plain CSR over owned rows (nnz_owned entries):
  * what: 0 d_ij, 1 l_ij (after the last pass = lij_matrix_), 2 p_ij (k comps),
- *       3 bounds (n_bounds per row), 4 r_i (k per row), 5 lij_next */
+ *       3 bounds (n_bounds per row), 4 r_i (k per row), 5 lij_next;
+ * over ALL locally relevant rows -- the ghost rows / ghost range a rank received included (multi-rank parity
+ * tests): 6 d_ij, 7 l_ij, 8 lij_next (plain CSR over n_relevant rows; d_ij is never exchanged, its ghost rows
+ * stay zero as in the reference), 9 r_i (k per row, n_relevant rows) */
 int ryujin_hip_debug_fetch(ryujin_hip_ctx *ctx, int what, double *out, size_t n_doubles);
 /* device time [ms] of the sweeps of the last step (hipEvent pairs; ms[n] = the reference's Scope timer
  * "time step [H] n", n = 2..7; ms[1] unused (step 1 is a separate call); ms[0] = the indicator kernel

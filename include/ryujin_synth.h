@@ -51,6 +51,14 @@ const double *ryujin_synth_positions(const ryujin_synth *s);   /* [n_relevant*di
 const uint64_t *ryujin_synth_global_ids(const ryujin_synth *s); /* [n_relevant] lexicographic id of the node in the full grid */
 const double *ryujin_synth_bdry_positions(const ryujin_synth *s); /* [n_bdry*dim] */
 
+/* exported instance of ryujin_ghost_row_send_entries() (include/ryujin_exchange_lists.h): the ghost-row
+ * send-list rule of sparse_matrix_simd.template.h:196-264, the function the generator itself calls; bound by
+ * the test partitioner and pinned against the reference's 4-rank baseline (tests/test_send_lists_golden.py) */
+size_t ryujin_synth_ghost_row_send_entries(const uint64_t *row_starts, const uint32_t *columns,
+                                           const uint32_t *exported_rows, size_t n_exported,
+                                           uint32_t ghost_begin, uint32_t ghost_end, uint32_t *out_row,
+                                           uint32_t *out_col);
+
 #ifdef __cplusplus
 }
 #endif

@@ -518,6 +518,11 @@ namespace oracle
       case 3: src = &bounds; count = (size_t)n_owned * NB; break;
       case 4: src = &r; count = (size_t)n_owned * K; break;
       case 5: src = &lij_next; count = nnz_owned; break;
+      /* over all locally relevant rows (ghost rows / ghost range included): multi-rank parity tests */
+      case 6: src = &dij; count = csr.ptr[n_relevant]; break;
+      case 7: src = &lij; count = csr.ptr[n_relevant]; break;
+      case 8: src = &lij_next; count = csr.ptr[n_relevant]; break;
+      case 9: src = &r; count = (size_t)n_relevant * K; break;
       default: return RYUJIN_ERR_ARG;
       }
       if (n < count)

@@ -56,6 +56,9 @@ class Params(C.Structure):
         ("sc_flux", C.c_int), ("sc_flux_polynomial", (C.c_double * 4) * 3),
         ("sc_derivative_approximation_delta", C.c_double), ("sc_use_greedy_wavespeed", C.c_int),
         ("sc_use_averaged_entropy", C.c_int), ("sc_random_entropies", C.c_int),
+        # run-time switches of the library (no ParameterAcceptor counterpart; 0 = default)
+        ("system_scope_events", C.c_int), ("debug_join_exchanges", C.c_int),
+        ("debug_bc_fold_max_slices", C.c_int), ("debug_no_small_mesh_split", C.c_int),
     ]
 
 
@@ -123,6 +126,9 @@ def load_synth():
         lib.ryujin_synth_global_ids.argtypes = [C.c_void_p]
         lib.ryujin_synth_bdry_positions.restype = c_double_p
         lib.ryujin_synth_bdry_positions.argtypes = [C.c_void_p]
+        lib.ryujin_synth_ghost_row_send_entries.restype = C.c_size_t
+        lib.ryujin_synth_ghost_row_send_entries.argtypes = [c_u64_p, c_u32_p, c_u32_p, C.c_size_t, C.c_uint32,
+                                                            C.c_uint32, c_u32_p, c_u32_p]
         # OfflineData dumps (include/ryujin_offline_io.h)
         lib.ryujin_offline_write.restype = C.c_int
         lib.ryujin_offline_write.argtypes = [C.c_char_p, C.POINTER(Offline), C.c_int, C.c_int, c_double_p,
@@ -150,7 +156,7 @@ def load_synth():
 HIP_SYMBOLS = [
     "ryujin_hip_comm_unique_id", "ryujin_hip_comm_init", "ryujin_hip_comm_init_local",
     "ryujin_hip_comm_init_loopback",
-    "ryujin_hip_comm_destroy",
+    "ryujin_hip_comm_destroy", "ryujin_hip_comm_info", "ryujin_hip_exchange_info",
     "ryujin_hip_default_params", "ryujin_hip_create", "ryujin_hip_destroy",
     "ryujin_hip_state_alloc", "ryujin_hip_state_free", "ryujin_hip_state_upload",
     "ryujin_hip_state_download", "ryujin_hip_state_download_precomputed", "ryujin_hip_state_integrals",
@@ -215,6 +221,9 @@ def load_hip():
         lib.ryujin_hip_comm_init_loopback.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int]
         lib.ryujin_hip_comm_destroy.argtypes = [vp]
         lib.ryujin_hip_comm_destroy.restype = None
+        lib.ryujin_hip_comm_info.argtypes = [vp, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p]
+        lib.ryujin_hip_exchange_info.argtypes = [vp, c_int_p, c_int_p, C.c_int, C.POINTER(C.c_ulonglong),
+                                                 C.POINTER(C.c_ulonglong)]
         lib.ryujin_hip_set_timers.argtypes = [vp, C.c_int]
         lib.ryujin_hip_get_timers.argtypes = [vp, c_double_p]
         lib.ryujin_hip_get_timers_accum.argtypes = [vp, c_double_p, C.POINTER(C.c_uint), C.c_int]

@@ -4,6 +4,7 @@
 // reference's deal.II assembly.
 
 #include "ryujin_synth.h"
+#include "ryujin_exchange_lists.h"
 
 #include <algorithm>
 #include <array>
@@ -598,20 +599,18 @@ bool ryujin_synth::build()
       send_idx.push_back(i);
     send_off.push_back((uint32_t)send_idx.size());
     recv_off.push_back(ghost_end);
-    /* matrix rows: diagonal + entries whose column is a ghost owned by p
-     * (sparse_matrix_simd.template.h:247-259) */
-    for (uint32_t i = exp_begin; i < exp_end; ++i) {
-      const uint64_t rs = row_starts[i], re = row_starts[i + 1];
-      row_send_row.push_back(i);
-      row_send_col.push_back(0);
-      for (uint64_t e = rs + 1; e < re; ++e) {
-        const uint32_t j = columns[e];
-        if (j >= ghost_begin && j < ghost_end) {
-          row_send_row.push_back(i);
-          row_send_col.push_back((uint32_t)(e - rs));
-        }
-      }
-    }
+    /* matrix rows: diagonal + entries whose column is a ghost owned by p -- the one statement of the rule of
+     * sparse_matrix_simd.template.h:196-264 (include/ryujin_exchange_lists.h) */
+    const std::vector<uint32_t> exported(send_idx.end() - (exp_end - exp_begin), send_idx.end());
+    const size_t n_entries = ryujin_ghost_row_send_entries(row_starts.data(), columns.data(), exported.data(),
+                                                           exported.size(), ghost_begin, ghost_end, nullptr,
+                                                           nullptr);
+    const size_t first = row_send_row.size();
+    row_send_row.resize(first + n_entries);
+    row_send_col.resize(first + n_entries);
+    ryujin_ghost_row_send_entries(row_starts.data(), columns.data(), exported.data(), exported.size(),
+                                  ghost_begin, ghost_end, row_send_row.data() + first,
+                                  row_send_col.data() + first);
     row_send_off.push_back((uint32_t)row_send_row.size());
   };
 
@@ -715,6 +714,15 @@ const uint64_t *ryujin_synth_global_ids(const ryujin_synth *s)
 const double *ryujin_synth_bdry_positions(const ryujin_synth *s)
 {
   return s->b_pos.data();
+}
+
+size_t ryujin_synth_ghost_row_send_entries(const uint64_t *row_starts, const uint32_t *columns,
+                                           const uint32_t *exported_rows, size_t n_exported,
+                                           uint32_t ghost_begin, uint32_t ghost_end, uint32_t *out_row,
+                                           uint32_t *out_col)
+{
+  return ryujin_ghost_row_send_entries(row_starts, columns, exported_rows, n_exported, ghost_begin, ghost_end,
+                                       out_row, out_col);
 }
 
 } /* extern "C" */

@@ -160,10 +160,11 @@ namespace
   constexpr unsigned kDeviceEventFlags = hipEventDisableTiming | hipEventDisableSystemFence;
 
   /* (a runtime that does not know the flag -- the process may run on the ROCm runtime its host application
-   * bundles -- gets the plain synchronisation event) */
-  void create_device_event(hipEvent_t *e)
+   * bundles -- gets the plain synchronisation event; so does a context created with
+   * ryujin_hip_params::system_scope_events != 0) */
+  void create_device_event(hipEvent_t *e, const bool system_scope = false)
   {
-    if (hipEventCreateWithFlags(e, kDeviceEventFlags) != hipSuccess) {
+    if (system_scope || hipEventCreateWithFlags(e, kDeviceEventFlags) != hipSuccess) {
       (void)hipGetLastError();
       HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
     }
@@ -208,6 +209,7 @@ struct LocalGroup {
   std::vector<double> scratch_vec;                          /* [n_ranks][8] vector sums (host) */
   int refs = 0;
   int device = 0;
+  bool aborted = false; /* a rank failed: the others must not wait for it (guarded_ctx sets it) */
   /* Measurement facility: ONE rank of an n-rank slab partition run alone, every neighbour replaced by the rank
    * itself (the segment packed for the opposite neighbour is pulled into the ghost range: a periodic channel).
    * Same launches, pack kernels, copies, events and reductions as a middle rank of a real run, on an unshared
@@ -237,6 +239,9 @@ struct LocalGroup {
 
   ~LocalGroup()
   {
+    /* contexts of the group may still have waits on these events enqueued */
+    (void)hipSetDevice(device);
+    (void)hipDeviceSynchronize();
     for (auto *set : {&ev_packed, &ev_pulled, &ev_reduced})
       for (auto &e : *set)
         if (e)
@@ -257,7 +262,17 @@ struct LocalGroup {
   void await(const std::vector<unsigned long> &counter, int rank, unsigned long value)
   {
     std::unique_lock<std::mutex> lock(mtx);
-    cv.wait(lock, [&] { return counter[rank] >= value; });
+    cv.wait(lock, [&] { return aborted || counter[rank] >= value; });
+    if (aborted && counter[rank] < value)
+      throw HipError(RYUJIN_ERR_COMM, "in-process transport: another rank of the group failed");
+  }
+  void abort()
+  {
+    {
+      std::lock_guard<std::mutex> lock(mtx);
+      aborted = true;
+    }
+    cv.notify_all();
   }
 
   void barrier() /* host rendezvous for the host-valued reductions (state_integrals) */
@@ -269,7 +284,9 @@ struct LocalGroup {
       ++generation;
       cv.notify_all();
     } else {
-      cv.wait(lock, [&] { return generation != gen; });
+      cv.wait(lock, [&] { return aborted || generation != gen; });
+      if (aborted && generation == gen)
+        throw HipError(RYUJIN_ERR_COMM, "in-process transport: another rank of the group failed");
     }
   }
 };
@@ -366,6 +383,7 @@ struct ryujin_hip_ctx {
   DeviceBuffer<double> d_send_buf;
 
   unsigned n_restarts = 0, n_warnings = 0;
+  unsigned long long n_exchanges = 0, n_allreduces = 0; /* ryujin_hip_exchange_info */
 
   /* profiling */
   bool timers_enabled = false;
@@ -498,9 +516,9 @@ void ryujin_hip_ctx::create(const ryujin_hip_offline &o, const ryujin_hip_params
   HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
   HIP_CHECK(hipStreamCreateWithFlags(&comm_stream, hipStreamNonBlocking));
   launch_stream = stream;
-  create_device_event(&ev_prev);
-  create_device_event(&ev_exp);
-  create_device_event(&ev_comm);
+  create_device_event(&ev_prev, p.system_scope_events != 0);
+  create_device_event(&ev_exp, p.system_scope_events != 0);
+  create_device_event(&ev_comm, p.system_scope_events != 0);
   for (auto &e : ev)
     HIP_CHECK(hipEventCreate(&e));
   for (auto &set : ev_rk)
@@ -634,15 +652,14 @@ void ryujin_hip_ctx::create(const ryujin_hip_offline &o, const ryujin_hip_params
         interior_reads_ghosts = true;
         break;
       }
-  /* test hooks (tests/test_gpu_parity.py runs the partitioned cases through both branches of each): force
-   * the fallback choreography / move the mesh size below which boundary conditions ride on the pre-pass */
-  if (const char *e = std::getenv("RYUJIN_HIP_JOIN_EXCHANGES"))
-    interior_reads_ghosts = interior_reads_ghosts || std::atoi(e) != 0;
-  if (const char *e = std::getenv("RYUJIN_HIP_BC_FOLD_MAX_SLICES"))
-    bc_fold_max_slices = (uint32_t)std::strtoul(e, nullptr, 10);
-  if (const char *e = std::getenv("RYUJIN_HIP_SMALL_MESH_SPLIT"))
-    if (std::atoi(e) == 0)
-      resident_waves_step5 = resident_waves_step6 = 0; /* small meshes run the kernels of the large ones */
+  /* test hooks (ryujin_hip_params::debug_*; tests/test_gpu_parity.py runs the partitioned cases through both
+   * branches of each): force the fallback choreography / move the mesh size below which boundary conditions
+   * ride on the pre-pass / small meshes run the kernels of the large ones */
+  interior_reads_ghosts = interior_reads_ghosts || p.debug_join_exchanges != 0;
+  if (p.debug_bc_fold_max_slices != 0)
+    bc_fold_max_slices = p.debug_bc_fold_max_slices < 0 ? 0u : (uint32_t)p.debug_bc_fold_max_slices;
+  if (p.debug_no_small_mesh_split != 0)
+    resident_waves_step5 = resident_waves_step6 = 0;
   mesh.slice_off = d_slice_off.ptr;
   mesh.row_len = d_row_len.ptr;
   mesh.cols = d_cols.ptr;
@@ -740,8 +757,8 @@ void ryujin_hip_ctx::create(const ryujin_hip_offline &o, const ryujin_hip_params
  * ghosts = the only rows that couple to ghost columns) on comm_stream, the interior slices on the compute
  * stream. Exchanges (pack + RCCL send/recv, or the in-process copies) follow the export launch that
  * produced their data in stream order on comm_stream -- the reference's SynchronizationDispatch idea
- * (source/openmp.h:141-183), taken one step further: NOTHING on the compute stream ever waits for an
- * exchange. Dependencies:
+ * (source/openmp.h:141-183), taken one step further: no SWEEP on the compute stream ever waits for an
+ * exchange (the scalar all-reduces do, see allreduce_scalar). Dependencies:
  *   export part N      needs interior parts <= N-1 (ev_prev: compute -> comm), export parts and
  *                      exchanges <= N-1 (stream order on comm_stream)
  *   interior part N    needs export parts <= N-1 (ev_exp: comm -> compute, recorded BEFORE exchange N-1),
@@ -749,8 +766,9 @@ void ryujin_hip_ctx::create(const ryujin_hip_offline &o, const ryujin_hip_params
  *   exchange N         needs export part N only (stream order)
  * so an exchange has the whole interior launch of the NEXT sweep as well to hide behind, and a short sweep
  * (the pre-pass, 30 us in 2-D) no longer exposes the latency of the exchange in front of it. Kernels outside
- * sweep() that touch export rows (boundary conditions, boundary d_ij, the scalar all-reduces) call
- * join_export(); whoever reads the ghost range on the compute stream or on the host calls wait_comm().
+ * sweep() that touch export rows (boundary conditions, boundary d_ij) call join_export(); whoever reads the
+ * ghost range on the compute stream or on the host, and the scalar all-reduces (one communicator: RCCL orders
+ * them behind the exchanges anyway), call wait_comm().
  * (Round 2 started with a third stream for the export part and a join of every exchange in front of the next
  * sweep: +11 % per update on a middle rank in 2-D without any network in the loop, profiles/r02k_*.) */
 void ryujin_hip_ctx::wait_comm()
@@ -794,6 +812,7 @@ void ryujin_hip_ctx::begin_exchange(bool after_split_sweep)
 
 void ryujin_hip_ctx::end_exchange()
 {
+  ++n_exchanges;
   comm_pending = true;
   exchange_after_exp = true;
 }
@@ -883,12 +902,16 @@ void ryujin_hip_ctx::allreduce_scalar(void *dev_ptr, int op, int count)
 {
   if (!comm || comm->n_ranks <= 1)
     return;
-  /* the scalar is written by export parts as well. One RCCL communicator serves both streams: its
-   * collectives are not put next to point-to-point traffic still in flight on comm_stream. */
-  if (comm->local)
-    join_export();
-  else
-    wait_comm();
+  /* The scalar is written by export parts as well, and ONE communicator serves both streams: RCCL orders the
+   * operations of a communicator in issue order whatever stream they are enqueued on, so an all-reduce on the
+   * compute stream implicitly waits for the point-to-point exchanges issued before it. The join is therefore
+   * made explicit -- for BOTH transports, so that the in-process transport the partitioned parity tests (and
+   * scripts/overhead_loopback.py) run has exactly the dependency graph of the RCCL leg. This is the one place
+   * where the compute stream waits for an exchange: the exchange of alpha in front of the tau_max reduction
+   * of the first stage, enqueued behind the export part of step 2 and long finished when step 3 retires (two
+   * interior launches later), and whatever is in flight at the end of a step / of a Runge-Kutta step. */
+  wait_comm();
+  ++n_allreduces;
   if (!comm->local) {
     if (op == 0)
       NCCL_CHECK(ncclAllReduce(dev_ptr, dev_ptr, 1, ncclDouble, ncclMin, comm->comm, stream));
@@ -1072,8 +1095,10 @@ void ryujin_hip_ctx::prepare_state_vector(int h, const double *dirichlet)
       hipLaunchKernelGGL(k_ghost_precompute_records<E>, dim3(grid_for(L.n_relevant - L.n_owned)), block, 0,
                          n_nbr ? comm_stream : stream, eparams, L.n_owned, L.n_relevant, s.U.ptr, s.prec.ptr,
                          s.rrec.ptr);
-      if (n_nbr)
-        end_exchange();
+      if (n_nbr) { /* work on comm_stream behind the latest export part, as an exchange (not counted as one) */
+        comm_pending = true;
+        exchange_after_exp = true;
+      }
     }
   }
   HIP_CHECK(hipGetLastError());
@@ -1655,12 +1680,16 @@ namespace
   template <typename F>
   int guarded_ctx(ryujin_hip_ctx *ctx, F &&f)
   {
-    return guarded([&]() {
+    const int status = guarded([&]() {
       if (!ctx)
         throw HipError(RYUJIN_ERR_ARG, "null context");
       HIP_CHECK(hipSetDevice(ctx->device));
       return f();
     });
+    /* in-process transport: a rank that failed must not leave the rank threads of its group waiting for it */
+    if (status < 0 && status != RYUJIN_ERR_TAU && ctx && ctx->comm && ctx->comm->local)
+      ctx->comm->local->abort();
+    return status;
   }
 
   template <typename E>
@@ -1757,6 +1786,10 @@ void ryujin_hip_default_params(ryujin_hip_params *p, int equation, int dim)
   p->sc_use_greedy_wavespeed = 0;
   p->sc_use_averaged_entropy = 0;
   p->sc_random_entropies = 0;
+  p->system_scope_events = 0;
+  p->debug_join_exchanges = 0;
+  p->debug_bc_fold_max_slices = 0;
+  p->debug_no_small_mesh_split = 0;
 }
 
 int ryujin_hip_comm_unique_id(char id[RYUJIN_HIP_UNIQUE_ID_BYTES])
@@ -1841,6 +1874,51 @@ void ryujin_hip_comm_destroy(ryujin_hip_comm *comm)
   if (comm->comm)
     (void)ncclCommDestroy(comm->comm);
   delete comm;
+}
+
+int ryujin_hip_comm_info(const ryujin_hip_comm *comm, int *rank, int *n_ranks, int *rccl_rank, int *rccl_count,
+                         int *rccl_device)
+{
+  return guarded([&]() {
+    if (!comm)
+      throw HipError(RYUJIN_ERR_ARG, "null communicator");
+    int r = -1, n = -1, d = -1;
+    if (comm->comm) {
+      NCCL_CHECK(ncclCommUserRank(comm->comm, &r));
+      NCCL_CHECK(ncclCommCount(comm->comm, &n));
+      NCCL_CHECK(ncclCommCuDevice(comm->comm, &d));
+    }
+    if (rank)
+      *rank = comm->rank;
+    if (n_ranks)
+      *n_ranks = comm->n_ranks;
+    if (rccl_rank)
+      *rccl_rank = r;
+    if (rccl_count)
+      *rccl_count = n;
+    if (rccl_device)
+      *rccl_device = d;
+    return RYUJIN_OK;
+  });
+}
+
+int ryujin_hip_exchange_info(ryujin_hip_ctx *ctx, int *n_nbr, int *nbr_rank, int max_nbr,
+                             unsigned long long *n_exchanges, unsigned long long *n_allreduces)
+{
+  return guarded([&]() {
+    if (!ctx)
+      throw HipError(RYUJIN_ERR_ARG, "null context");
+    if (n_nbr)
+      *n_nbr = ctx->n_nbr;
+    if (nbr_rank)
+      for (int q = 0; q < ctx->n_nbr && q < max_nbr; ++q)
+        nbr_rank[q] = ctx->nbr_rank[q];
+    if (n_exchanges)
+      *n_exchanges = ctx->n_exchanges;
+    if (n_allreduces)
+      *n_allreduces = ctx->n_allreduces;
+    return RYUJIN_OK;
+  });
 }
 
 int ryujin_hip_create(ryujin_hip_ctx **ctx, const ryujin_hip_offline *offline,
@@ -2144,6 +2222,29 @@ int ryujin_hip_debug_fetch(ryujin_hip_ctx *ctx, int what, double *out, size_t n_
     case 1: fetch_matrix(ctx->d_lij.ptr, 1); break;
     case 2: fetch_matrix(ctx->d_pij.ptr, (uint32_t)ctx->K); break;
     case 5: fetch_matrix(ctx->d_lij_next.ptr, 1); break;
+    case 6:
+    case 7:
+    case 8: { /* plain CSR over ALL locally relevant rows: owned rows, then the ghost rows as received */
+      const double *dev = what == 6 ? ctx->d_dij.ptr : (what == 7 ? ctx->d_lij.ptr : ctx->d_lij_next.ptr);
+      const uint64_t n_ghost_entries = L.nnz_total - L.nnz_sell;
+      if (n_doubles < L.nnz_owned_logical + n_ghost_entries)
+        throw HipError(RYUJIN_ERR_ARG, "output buffer too small");
+      std::vector<double> tmp(L.nnz_total);
+      HIP_CHECK(hipMemcpy(tmp.data(), dev, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+      L.gather_logical(tmp, 1, out);
+      std::copy(tmp.begin() + L.nnz_sell, tmp.end(), out + L.nnz_owned_logical);
+      break;
+    }
+    case 9: {
+      if (n_doubles < (size_t)L.n_relevant * ctx->K)
+        throw HipError(RYUJIN_ERR_ARG, "output buffer too small");
+      std::vector<double> tmp((size_t)L.n_relevant * ctx->KP);
+      HIP_CHECK(hipMemcpy(tmp.data(), ctx->d_r.ptr, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+      for (uint32_t i = 0; i < L.n_relevant; ++i)
+        for (int q = 0; q < ctx->K; ++q)
+          out[(size_t)i * ctx->K + q] = tmp[(size_t)i * ctx->KP + q];
+      break;
+    }
     case 3: {
       if (n_doubles < (size_t)L.n_owned * ctx->NB)
         throw HipError(RYUJIN_ERR_ARG, "output buffer too small");

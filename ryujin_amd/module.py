@@ -60,6 +60,11 @@ class StateVector:
 
 
 class HyperbolicModule:
+    # run-time switches of the library (ryujin_hip_params::system_scope_events / debug_*) applied to every module
+    # constructed while set: the parity suite re-runs whole test functions through the branches a small mesh does
+    # not take by itself (monkeypatch.setattr(HyperbolicModule, "library_switches", {...}))
+    library_switches: dict = {}
+
     def __init__(self, offline, params: capi.Params | None = None, *, equation=capi.EQ_EULER,
                  backend="hip", comm=None, device: int = 0):
         if backend == "hip":
@@ -70,6 +75,8 @@ class HyperbolicModule:
         self.dim = offline.dim
         if params is None:
             params = self.default_params(equation, self.dim)
+        for name, value in type(self).library_switches.items():
+            setattr(params, name, value)
         self.params = params
         self.equation = params.equation
         # problem_dimension, n_precomputed_values, Limiter::n_bounds of the Description
@@ -216,13 +223,27 @@ class HyperbolicModule:
         return self._counters()[1]
 
     # ------------------------------------------------------------------ introspection
+    def exchange_info(self) -> dict:
+        """Neighbour ranks of this context and the number of ghost exchanges / scalar all-reduces it has
+        enqueued so far (ryujin_hip_exchange_info; device backend only)."""
+        n_nbr, nx, nr = C.c_int(0), C.c_ulonglong(0), C.c_ulonglong(0)
+        nbr = (C.c_int * 64)()
+        self._check(self._f("exchange_info")(self._ctx, C.byref(n_nbr), nbr, 64, C.byref(nx), C.byref(nr)))
+        return dict(neighbours=[nbr[q] for q in range(min(n_nbr.value, 64))], n_exchanges=nx.value,
+                    n_allreduces=nr.value)
+
     def debug_fetch(self, what: str) -> np.ndarray:
-        codes = {"dij": 0, "lij": 1, "pij": 2, "bounds": 3, "r": 4, "lij_next": 5}
+        """`*_all`: over all locally relevant rows, i.e. including the ghost rows / ghost range received from
+        the neighbour ranks."""
+        codes = {"dij": 0, "lij": 1, "pij": 2, "bounds": 3, "r": 4, "lij_next": 5,
+                 "dij_all": 6, "lij_all": 7, "lij_next_all": 8, "r_all": 9}
         rs = self.offline.row_starts
         nnz_owned = int(rs[self.n_owned])
+        nnz_all = int(rs[self.n_relevant])
         sizes = {"dij": nnz_owned, "lij": nnz_owned, "pij": nnz_owned * self.k,
                  "bounds": self.n_owned * self.n_bounds, "r": self.n_owned * self.k,
-                 "lij_next": nnz_owned}
+                 "lij_next": nnz_owned, "dij_all": nnz_all, "lij_all": nnz_all, "lij_next_all": nnz_all,
+                 "r_all": self.n_relevant * self.k}
         out = np.empty(sizes[what], dtype=np.float64)
         self._check(self._f("debug_fetch")(self._ctx, codes[what], capi.as_ptr(out, capi.c_double_p),
                                            out.size))

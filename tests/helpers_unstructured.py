@@ -216,18 +216,25 @@ def ghost_row_send_entries(local_rows, exported_rows, ghost_range):
     exported to that rank, in export order, the diagonal and then the entries whose column lies in the ghost
     range RECEIVED from the same rank -- a ghost row only holds the transposes of owned entries (:61-74).
     ghost_range = (begin, end) in local indices, or None if that rank sends us nothing: then nothing is sent
-    to it either (:229-247, the unmatched import target). Pinned against the reference's
+    to it either (:229-247, the unmatched import target).
+    This is a binding of THE C function that states the rule (include/ryujin_exchange_lists.h, exported by
+    libryujin_synth.so): the same code builds the lists of the mesh generator (bench.py --gpus N, rccl_worker.py),
+    of every partitioned test and of the deal.II-side adapter. Pinned against the reference's
     tests/common/sparsity_pattern_simd_01.mpirun=4.output in tests/test_send_lists_golden.py."""
-    out = []
     if ghost_range is None:
-        return out
-    lo, hi = ghost_range
-    for i in exported_rows:
-        out.append((i, 0))
-        for c in range(1, len(local_rows[i])):
-            if lo <= local_rows[i][c] < hi:
-                out.append((i, c))
-    return out
+        return []
+    lib = capi.load_synth()
+    ptr = np.zeros(len(local_rows) + 1, dtype=np.uint64)
+    ptr[1:] = np.cumsum([len(r) for r in local_rows])
+    cols = np.array([c for r in local_rows for c in r], dtype=np.uint32)
+    rows = np.ascontiguousarray(exported_rows, dtype=np.uint32)
+    args = (capi.as_ptr(ptr, capi.c_u64_p), capi.as_ptr(cols, capi.c_u32_p), capi.as_ptr(rows, capi.c_u32_p),
+            rows.size, int(ghost_range[0]), int(ghost_range[1]))
+    n = lib.ryujin_synth_ghost_row_send_entries(*args, None, None)
+    out_row, out_col = np.zeros(max(n, 1), dtype=np.uint32), np.zeros(max(n, 1), dtype=np.uint32)
+    lib.ryujin_synth_ghost_row_send_entries(*args, capi.as_ptr(out_row, capi.c_u32_p),
+                                            capi.as_ptr(out_col, capi.c_u32_p))
+    return [(int(out_row[q]), int(out_col[q])) for q in range(n)]
 
 
 def run_partitioned_oracle(oracle, views, params, U0_global, n_updates, dirichlet_fn=None):

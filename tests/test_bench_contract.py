@@ -20,7 +20,22 @@ def test_algorithmic_bytes_match_the_survey():
     assert list(bench.algorithmic_bytes(2, 4, 9).values()) == [48, 316, 224, 700, 860, 556, 460]
 
 
-@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(ROOT, "profiles", "r02[e-z]_bench*.json"))))
+def _committed_bench_lines():
+    """every bench line committed from round 2 (second half) on; earlier ones predate the contract fields"""
+    import re
+    paths = []
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench*.json"))):
+        tag = re.match(r"r(\d+)([a-z]?)_", os.path.basename(path))
+        if tag and (int(tag.group(1)), tag.group(2)) >= (2, "e"):
+            paths.append(path)
+    return paths
+
+
+def test_there_are_committed_bench_lines_to_check():
+    assert len(_committed_bench_lines()) >= 1
+
+
+@pytest.mark.parametrize("path", _committed_bench_lines())
 def test_committed_bench_lines_follow_the_contract(path):
     lines = [ln for ln in open(path).read().splitlines() if ln.strip()]
     assert len(lines) == 1                                     # ONE JSON line
@@ -37,6 +52,8 @@ def test_committed_bench_lines_follow_the_contract(path):
     # value is consistent with the time per step and the size of the job
     dofs = d["config"]["dofs_total"]
     assert abs(d["value"] - dofs / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * d["value"]
+    if "reps" in d:   # round 3 on: median of `reps` passes of exactly `steps` steps, spread reported
+        assert d["reps"] >= 1 and d["ms_per_step_min"] <= d["ms_per_step"] <= d["ms_per_step_max"]
     if "cpu_baseline" in d:
         c = d["cpu_baseline"]
         assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["unit"] == d["unit"] and c["sample"]

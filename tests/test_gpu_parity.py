@@ -249,7 +249,8 @@ def test_device_pow_accuracy():
     assert out[5] == 1.0
 
 
-@pytest.mark.parametrize("n_ranks,mode", [(2, ""), (3, ""), (3, "join_exchanges"), (3, "bc_launch")])
+@pytest.mark.parametrize("n_ranks,mode", [(2, ""), (3, ""), (3, "join_exchanges"), (3, "bc_launch"),
+                                          (3, "system_events")])
 def test_partitioned_hip_matches_single_rank(n_ranks, mode, monkeypatch):
     """Multi-rank code path of the library on ONE GPU: n contexts (one host thread each) own x-slabs of
     the mesh and exchange ghosts through the in-process transport (ryujin_hip_comm_init_local), which
@@ -257,14 +258,17 @@ def test_partitioned_hip_matches_single_rank(n_ranks, mode, monkeypatch):
     partitioned run must reproduce the single-rank run (same tau; U to round-off).
     mode: the branches small meshes do not take by themselves -- "join_exchanges": the fallback
     choreography of an asymmetric stencil (every sweep joins the exchanges); "bc_launch": boundary
-    conditions as a launch of their own in front of the pre-pass (large meshes)."""
+    conditions as a launch of their own in front of the pre-pass (large meshes); "system_events": the events
+    between the two streams created with the system-scope fence (ryujin_hip_params::system_scope_events)."""
     import ctypes as C
     import threading
 
     if mode == "join_exchanges":
-        monkeypatch.setenv("RYUJIN_HIP_JOIN_EXCHANGES", "1")
+        monkeypatch.setattr(HyperbolicModule, "library_switches", {"debug_join_exchanges": 1})
     elif mode == "bc_launch":
-        monkeypatch.setenv("RYUJIN_HIP_BC_FOLD_MAX_SLICES", "0")
+        monkeypatch.setattr(HyperbolicModule, "library_switches", {"debug_bc_fold_max_slices": -1})
+    elif mode == "system_events":
+        monkeypatch.setattr(HyperbolicModule, "library_switches", {"system_scope_events": 1})
 
     lib = capi.load_hip()
     cpu, n_updates = 40, 6
@@ -1524,8 +1528,8 @@ def test_step_parity_with_the_kernels_of_large_meshes(oracle, monkeypatch, which
     (boundary conditions folded into the pre-pass, steps 5 and 6 with the columns of a slice spread over several
     waves). Re-run one case per Description with those branches switched off: the kernels BASELINE-sized meshes
     run (also covered at full size for Euler and shallow water in test_gpu_parity_fullsize.py)."""
-    monkeypatch.setenv("RYUJIN_HIP_SMALL_MESH_SPLIT", "0")
-    monkeypatch.setenv("RYUJIN_HIP_BC_FOLD_MAX_SLICES", "0")
+    monkeypatch.setattr(HyperbolicModule, "library_switches",
+                        {"debug_no_small_mesh_split": 1, "debug_bc_fold_max_slices": -1})
     {
         "euler_2d": lambda: test_step_parity_2d_step_geometry(oracle),
         "euler_1d": lambda: test_step_parity_1d(oracle),

@@ -61,3 +61,39 @@ def test_send_targets_match_the_reference_baseline(golden_dir):
         assert got == golden[rank], (rank, got, golden[rank])
     # what the baseline says in words: rank 0 only imports, rank 3 only exports, 1 <-> 2 swap 4 and 2 entries
     assert golden == [[], [(0, 0), (2, 4)], [(0, 0), (1, 2)], []]
+
+
+def _rule_restated_in_python(local_rows, exported_rows, ghost_range):
+    """Independent restatement of sparse_matrix_simd.template.h:249-261 (the C function is the one under test)."""
+    if ghost_range is None:
+        return []
+    out = []
+    for i in exported_rows:
+        out.append((i, 0))
+        out += [(i, c) for c in range(1, len(local_rows[i])) if ghost_range[0] <= local_rows[i][c] < ghost_range[1]]
+    return out
+
+
+def test_the_generator_builds_its_lists_with_the_pinned_rule():
+    """The mesh generator (csrc/offline_synthetic.cc: bench.py --gpus N, tests/rccl_worker.py, every slab
+    partition of the suite) calls the same C function; its row_send_row / row_send_col must be what the rule
+    gives for its own stencil, export lists and ghost ranges -- on a 2-D step mesh and on the 3-D cylinder."""
+    import numpy as np
+
+    from ryujin_amd import offline
+    for spec_of in (lambda r: offline.mach3_step_2d(20, n_ranks=3, rank=r),
+                    lambda r: offline.cylinder_channel_3d(6, n_ranks=3, rank=r)):
+        for rank in range(3):
+            off = offline.SyntheticOffline(spec_of(rank))
+            o = off.c.contents
+            rs = off.row_starts.astype(np.int64)
+            cols = off.columns.astype(np.int64)
+            local_rows = [cols[rs[i]:rs[i + 1]].tolist() for i in range(off.n_relevant)]
+            assert o.n_nbr == (1 if rank in (0, 2) else 2)
+            for q in range(o.n_nbr):
+                exported = [o.send_idx[e] for e in range(o.send_off[q], o.send_off[q + 1])]
+                ghost_range = (o.recv_off[q], o.recv_off[q + 1])
+                want = _rule_restated_in_python(local_rows, exported, ghost_range)
+                got = [(o.row_send_row[e], o.row_send_col[e]) for e in range(o.row_send_off[q], o.row_send_off[q + 1])]
+                assert got == want, (rank, q)
+                assert ghost_row_send_entries(local_rows, exported, ghost_range) == want
