@@ -417,7 +417,11 @@ enum {
   RYUJIN_DEBUG_EULER_DIJ_RECORDS_2D = 5, /* the same through the per-node Riemann records the sweep uses */
   RYUJIN_DEBUG_EULER_DIJ_RECORDS_3D = 6,
   RYUJIN_DEBUG_SW_DIJ_2D = 7,          /* in: U_i[3], U_j[3], c_ij[2]   out: d_ij (shallow water, dim = 2) */
-  RYUJIN_DEBUG_SW_DIJ_RECORDS_2D = 8   /* the same through the per-node Riemann records the sweep uses */
+  RYUJIN_DEBUG_SW_DIJ_RECORDS_2D = 8,  /* the same through the per-node Riemann records the sweep uses */
+  /* the production evaluation path of the sweeps -- per-node Riemann records, dij_from_records -- fed with the
+   * reference's 1-D Riemann data: in as RYUJIN_DEBUG_EULER_RIEMANN / RYUJIN_DEBUG_SW_RIEMANN, out: lambda_max */
+  RYUJIN_DEBUG_EULER_RIEMANN_RECORDS = 9,
+  RYUJIN_DEBUG_SW_RIEMANN_RECORDS = 10
 };
 int ryujin_hip_debug_function(int device, const ryujin_hip_params *params, int which, const double *in,
                               double *out, size_t n);

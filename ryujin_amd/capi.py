@@ -31,6 +31,7 @@ UNIQUE_ID_BYTES = 128
 DEBUG_EULER_RIEMANN, DEBUG_EULER_LIMIT_1D, DEBUG_SW_RIEMANN, DEBUG_EULER_DIJ_2D, DEBUG_EULER_DIJ_3D = range(5)
 DEBUG_EULER_DIJ_RECORDS_2D, DEBUG_EULER_DIJ_RECORDS_3D = 5, 6
 DEBUG_SW_DIJ_2D, DEBUG_SW_DIJ_RECORDS_2D = 7, 8
+DEBUG_EULER_RIEMANN_RECORDS, DEBUG_SW_RIEMANN_RECORDS = 9, 10
 
 
 class Params(C.Structure):

@@ -542,12 +542,11 @@ namespace ryujin_hip
      * record = (rho, p, a, pw, a / pw, 1 / p, v[DIM]), padded to an even number of doubles */
     static constexpr int RS = (6 + DIM + 1) / 2 * 2;
 
-    static RYUJIN_DEV void riemann_record(const EulerParams &P, const double (&U)[K], double (&rec)[RS])
+    /* the record of a node with density rho, pressure p, speed of sound a, velocity v */
+    static RYUJIN_DEV void riemann_record_from_primitive(const EulerParams &P, const double rho, const double p,
+                                                         const double a, const double (&v)[DIM],
+                                                         double (&rec)[RS])
     {
-      const double rho = U[0];
-      const double rho_inverse = 1. / rho;
-      const double p = (P.gamma - 1.) * internal_energy(U);
-      const double a = sqrt(P.gamma * p * rho_inverse);
       const double pw = dev_pow(p, (P.gamma - 1.) * 0.5 * P.gamma_inverse);
       rec[0] = rho;
       rec[1] = p;
@@ -557,10 +556,23 @@ namespace ryujin_hip
       rec[5] = 1. / p;
 #pragma unroll
       for (int d = 0; d < DIM; ++d)
-        rec[6 + d] = U[1 + d] * rho_inverse;
+        rec[6 + d] = v[d];
 #pragma unroll
       for (int d = 6 + DIM; d < RS; ++d)
         rec[d] = 0.;
+    }
+
+    static RYUJIN_DEV void riemann_record(const EulerParams &P, const double (&U)[K], double (&rec)[RS])
+    {
+      const double rho = U[0];
+      const double rho_inverse = 1. / rho;
+      const double p = (P.gamma - 1.) * internal_energy(U);
+      const double a = sqrt(P.gamma * p * rho_inverse);
+      double v[DIM];
+#pragma unroll
+      for (int d = 0; d < DIM; ++d)
+        v[d] = U[1 + d] * rho_inverse;
+      riemann_record_from_primitive(P, rho, p, a, v, rec);
     }
 
     /* GENERAL = false: Newton iterations off and integral rarefaction exponent (the defaults with

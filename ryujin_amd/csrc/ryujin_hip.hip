@@ -2383,6 +2383,21 @@ namespace
       out[q] = PE.riemann_newton_max_iterations == 0 && PE.rarefaction_power > 0
                    ? Euler<3>::dij_from_records<false>(PE, r_i, r_j, c)
                    : Euler<3>::dij_from_records<true>(PE, r_i, r_j, c);
+    } else if (which == RYUJIN_DEBUG_EULER_RIEMANN_RECORDS) {
+      /* the PRODUCTION evaluation path (per-node records, dij_from_records) on the reference's Riemann data */
+      const double *v = in + q * 8;
+      double r_i[Euler<1>::RS], r_j[Euler<1>::RS];
+      const double u_i[1] = {v[1]}, u_j[1] = {v[5]}, n[1] = {1.};
+      Euler<1>::riemann_record_from_primitive(PE, v[0], v[2], v[3], u_i, r_i);
+      Euler<1>::riemann_record_from_primitive(PE, v[4], v[6], v[7], u_j, r_j);
+      out[q] = PE.riemann_newton_max_iterations == 0 && PE.rarefaction_power > 0
+                   ? Euler<1>::dij_from_records<false>(PE, r_i, r_j, n)
+                   : Euler<1>::dij_from_records<true>(PE, r_i, r_j, n);
+    } else if (which == RYUJIN_DEBUG_SW_RIEMANN_RECORDS) {
+      const double *v = in + q * 6;
+      const double r_i[ShallowWater<1>::RS] = {v[0], v[2], v[1], 0.}, r_j[ShallowWater<1>::RS] = {v[3], v[5], v[4], 0.};
+      const double n[1] = {1.};
+      out[q] = ShallowWater<1>::dij_from_records<false>(PS, r_i, r_j, n);
     } else if (which == RYUJIN_DEBUG_SW_DIJ_2D || which == RYUJIN_DEBUG_SW_DIJ_RECORDS_2D) {
       const double *v = in + q * 8;
       const double U_i[3] = {v[0], v[1], v[2]}, U_j[3] = {v[3], v[4], v[5]}, c[2] = {v[6], v[7]};
@@ -2406,7 +2421,9 @@ int ryujin_hip_debug_function(int device, const ryujin_hip_params *params, int w
       throw HipError(RYUJIN_ERR_ARG, "null argument");
     size_t n_in, n_out;
     switch (which) {
-    case RYUJIN_DEBUG_EULER_RIEMANN: n_in = 8; n_out = 1; break;
+    case RYUJIN_DEBUG_EULER_RIEMANN:
+    case RYUJIN_DEBUG_EULER_RIEMANN_RECORDS: n_in = 8; n_out = 1; break;
+    case RYUJIN_DEBUG_SW_RIEMANN_RECORDS: n_in = 6; n_out = 1; break;
     case RYUJIN_DEBUG_EULER_LIMIT_1D: n_in = 9; n_out = 3; break;
     case RYUJIN_DEBUG_SW_RIEMANN: n_in = 6; n_out = 2; break;
     case RYUJIN_DEBUG_EULER_DIJ_2D:

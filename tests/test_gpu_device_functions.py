@@ -56,6 +56,29 @@ def test_device_riemann_solver_against_the_reference_baselines(oracle, golden_di
         np.testing.assert_allclose(lam, expected, rtol=1e-13, atol=0)
 
 
+def test_production_riemann_path_against_the_reference_baselines(oracle, golden_dir):
+    """The evaluation path the sweeps RUN by default -- per-node Riemann records, dij_from_records<false>: no pow,
+    another operation order than the reference (euler_device.hpp) -- on the reference's own ten states
+    (tests/euler/riemann_solver.cc:79-98, incl. the Leblanc state with p_R = 6.7e-11 and pressure ratios of 1e9)
+    against riemann_solver.output: 1e-12 relative, the d_ij contract."""
+    params = oracle.default_params(capi.EQ_EULER, 1)
+    assert params.riemann_newton_max_iterations == 0     # the default configuration = the records fast path
+    blocks = _blocks(os.path.join(golden_dir, "euler_riemann_solver.output"))
+    items = [np.concatenate([_riemann_data(left, params.gamma), _riemann_data(right, params.gamma)])
+             for left, right in RIEMANN_CASES]
+    lam = _device(params, capi.DEBUG_EULER_RIEMANN_RECORDS, items, 1)[:, 0]
+    for got, block in zip(lam, blocks):
+        ref = _grab(block, "-> lambda_max =")[0]
+        assert abs(got - ref) <= 1e-12 * abs(ref), (got, ref)
+    # and with Newton iterations switched on the records path hands over to the reference's riemann_compute
+    for n_newton, golden in ((2, "euler_riemann_solver-iterated-2.output"), (10, "euler_riemann_solver-iterated-10.output")):
+        params.riemann_newton_max_iterations = n_newton
+        lam = _device(params, capi.DEBUG_EULER_RIEMANN_RECORDS, items, 1)[:, 0]
+        for got, block in zip(lam, _blocks(os.path.join(golden_dir, golden))):
+            ref = _grab(block, "-> lambda_max =")[0]
+            assert abs(got - ref) <= 1e-12 * abs(ref) + 1e-15, (n_newton, got, ref)
+
+
 def test_device_limiter_against_the_reference_baseline(oracle, golden_dir):
     """limiter.output is the EXPENSIVE_BOUNDS_CHECK build (limiter.cc:10); the device runs the production
     control flow (limiter.template.h:183-217). For the six in-bounds cases both return the same l up to the
@@ -104,23 +127,29 @@ def test_device_sw_riemann_solver_against_the_reference_baseline(oracle, golden_
     for (h_star, l), h_ref, l_ref in zip(out, hst, lam):
         assert abs(h_star - h_ref) <= 1e-13 * abs(h_ref), (h_star, h_ref)
         assert abs(l - l_ref) <= 1e-13 * abs(l_ref), (l, l_ref)
+    # the evaluation path the sweeps run (per-node records, ShallowWater::dij_from_records) on the same three
+    # states: 1e-12 relative
+    lam_rec = _device(params, capi.DEBUG_SW_RIEMANN_RECORDS, [riemann_data(a) + riemann_data(b) for a, b in cases], 1)[:, 0]
+    for l, l_ref in zip(lam_rec, lam):
+        assert abs(l - l_ref) <= 1e-12 * abs(l_ref), (l, l_ref)
 
 
 @pytest.mark.parametrize("records", [False, True])
-@pytest.mark.parametrize("dim", [2, 3])
-def test_device_dij_against_the_oracle_on_random_states(oracle, dim, records):
+@pytest.mark.parametrize("dim,decades", [(2, (4, 6)), (3, (4, 6)), (2, (10, 10))])
+def test_device_dij_against_the_oracle_on_random_states(oracle, dim, decades, records):
     """d_ij = |c_ij| lambda_max(U_i, U_j, c_ij/|c_ij|) for 200 k random admissible state pairs and directions,
-    Mach numbers up to 5, pressure ratios up to 1e6: 1e-12 relative (the stated d_ij contract) -- through
-    dij_from_states (the reference's operation order) and through the per-node Riemann records of the sweep
-    (k_dij_records: a different but equivalent evaluation, see euler_device.hpp)."""
+    Mach numbers up to 5, density / pressure ratios up to 1e4 / 1e6 -- and up to 1e10 / 1e10, beyond the Leblanc
+    state of the reference's unit test: 1e-12 relative (the stated d_ij contract) -- through dij_from_states
+    (the reference's operation order) and through the per-node Riemann records of the sweep (k_dij_records: a
+    different but equivalent evaluation, see euler_device.hpp)."""
     rng = np.random.default_rng(7)
     n = 200_000
     params = oracle.default_params(capi.EQ_EULER, dim)
     k = dim + 2
 
     def states():
-        rho = 10.0 ** rng.uniform(-3, 1, n)
-        p = 10.0 ** rng.uniform(-4, 2, n)
+        rho = 10.0 ** rng.uniform(1 - decades[0], 1, n)
+        p = 10.0 ** rng.uniform(2 - decades[1], 2, n)
         a = np.sqrt(params.gamma * p / rho)
         v = rng.normal(size=(n, dim))
         v *= (rng.uniform(0, 5, n) * a / np.linalg.norm(v, axis=1))[:, None]

@@ -54,7 +54,7 @@ def _both(spec, U0, oracle, n_warm=0, dirichlet=None, params_edit=None, equation
     return off, mods
 
 
-def _compare_step(off, mods, dirichlet=None, tau=0.0):
+def _compare_step(off, mods, dirichlet=None, tau=0.0, stage_vectors=None, stage_weights=()):
     """One update on both backends, every intermediate array compared: tests/helpers_parity.py states the
     tolerances and classifies every l_ij outlier as a psi_r = 0 branch flip (no quota)."""
     import inspect
@@ -62,7 +62,8 @@ def _compare_step(off, mods, dirichlet=None, tau=0.0):
     from helpers_parity import compare_step
     label = next((f.function for f in inspect.stack() if f.function.startswith("test_")), "")
     return compare_step(off, mods, dirichlet, tau, oracle=getattr(mods, "oracle", None),
-                        params=getattr(mods, "params", None), label=label)
+                        params=getattr(mods, "params", None), label=label, stage_vectors=stage_vectors,
+                        stage_weights=stage_weights)
 
 
 def test_step_parity_2d_step_geometry(oracle):
@@ -701,27 +702,47 @@ def test_device_integrals_conservation_monitor():
 
 @pytest.mark.parametrize("scheme", ["erk 43", "erk 54"])
 def test_erk43_erk54_parity_with_the_oracle(oracle, scheme):
-    """step<3> and step<4> (four stage vectors with the ERK54 weights, time_integrator.template.h:405-510):
-    three Runge-Kutta steps on the GPU and with the oracle from the same developed state."""
+    """step<1> ... step<4> with the ERK43 / ERK54 stage vectors and weights (time_integrator.template.h:405-510):
+    the flow is developed by two Runge-Kutta steps on the GPU, then every stage of the third one is compared with
+    the oracle ON IDENTICAL INPUTS through compare_step -- all intermediates, the stated per-update contract, l_ij
+    outliers classified -- and the oracle's stage result is handed to both backends for the next stage."""
     spec = offline.mach3_step_2d(20)
-    off = offline.SyntheticOffline(spec)
-    dirichlet = euler_uniform(off.b_positions)
-    U_start = _perturbed(euler_uniform(off.positions))
-    res = []
-    for backend in ("hip", oracle.backend()):
-        m = HyperbolicModule(off, equation=capi.EQ_EULER, backend=backend)
-        sv = m.new_state_vector(U_start)
-        ti = TimeIntegrator(m, scheme, cfl_min=0.9, cfl_max=0.9, cfl_recovery_strategy="none",
-                            dirichlet_fn=lambda t: dirichlet)
-        t = 0.0
-        for _ in range(3):
-            sv, tau = ti.step(sv, t)
-            t += tau
-        res.append((t, sv.download()[: off.n_owned]))
-    assert abs(res[0][0] - res[1][0]) <= 1e-12 * res[1][0]
-    scale = np.abs(res[1][1]).max(axis=0)
-    err = np.abs(res[0][1] - res[1][1]) / scale
-    assert (err > 1e-10).sum() <= max(2, int(1e-4 * err.size)) and err.max() < 1e-8
+    dirichlet = euler_uniform(offline.SyntheticOffline(spec).b_positions)
+    off, mods = _both(spec, _perturbed(euler_uniform(offline.SyntheticOffline(spec).positions)), oracle,
+                      dirichlet=dirichlet)
+    (mg, og, ng), (mc, oc, nc) = mods
+    ti = TimeIntegrator(mg, scheme, cfl_min=0.9, cfl_max=0.9, cfl_recovery_strategy="none",
+                        dirichlet_fn=lambda t: dirichlet)
+    sv, t = og, 0.0
+    for _ in range(2):
+        sv, tau = ti.step(sv, t)
+        t += tau
+    U_start = sv.download()
+    # stage table: (indices of the stage vectors among [U, T0, T1, ...], weights) -- TimeIntegrator._erk43/_erk54
+    a = TimeIntegrator.ERK54
+    c54 = a["c"]
+    table = {"erk 43": [((), ()), ((0,), (-1.0,)), ((1,), (-1.0,)), ((1, 2), (5.0 / 3.0, -10.0 / 3.0))],
+             "erk 54": [((), ()), ((0,), ((a["a_31"] - a["a_21"]) / c54,)),
+                        ((0, 1), ((a["a_41"] - a["a_31"]) / c54, (a["a_42"] - a["a_32"]) / c54)),
+                        ((0, 1, 2), ((a["a_51"] - a["a_41"]) / c54, (a["a_52"] - a["a_42"]) / c54,
+                                     (a["a_53"] - a["a_43"]) / c54)),
+                        ((0, 1, 2, 3), ((a["a_61"] - a["a_51"]) / c54, (a["a_62"] - a["a_52"]) / c54,
+                                        (a["a_63"] - a["a_53"]) / c54, (a["a_64"] - a["a_54"]) / c54))]}[scheme]
+    vec = {id(mg): [mg.new_state_vector(U_start)], id(mc): [mc.new_state_vector(U_start)]}
+    tau = 0.0
+    for stage, (idx, weights) in enumerate(table):
+        for m in (mg, mc):
+            vec[id(m)].append(m.new_state_vector())
+            for q in idx:   # stage vectors must be prepared state vectors (hyperbolic_module.h:207-213)
+                m.prepare_state_vector(vec[id(m)][q], 0.0, dirichlet)
+        step_mods = _Mods([(mg, vec[id(mg)][stage], vec[id(mg)][stage + 1]),
+                           (mc, vec[id(mc)][stage], vec[id(mc)][stage + 1])])
+        step_mods.oracle, step_mods.params = mods.oracle, mods.params
+        g, c = _compare_step(off, step_mods, dirichlet, tau,
+                             stage_vectors=([vec[id(mg)][q] for q in idx], [vec[id(mc)][q] for q in idx]),
+                             stage_weights=weights)
+        tau = c["tau"]
+        vec[id(mg)][stage + 1].upload(vec[id(mc)][stage + 1].download())   # identical inputs for the next stage
 
 
 # ------------------------------------------------------------------ scalar conservation equations
@@ -771,21 +792,27 @@ def _scalar_compare(off, mods, dirichlet=None, stages=(), weights=(), tau=0.0, n
     n = off.n_owned
     active = np.diff(np.asarray(off._keep["row_starts"] if hasattr(off, "_keep") else off.row_starts).astype(np.int64))[:n] > 1
     scale = np.abs(c["U"][:n]).max()
+    rs_diag = np.asarray(off._keep["row_starts"] if hasattr(off, "_keep") else off.row_starts).astype(np.int64)[:n]
     assert g["status"] == c["status"]
     np.testing.assert_allclose(g["prec"][:n][active], c["prec"][:n][active], rtol=1e-13, atol=1e-15 * scale)
-    np.testing.assert_allclose(g["alpha"][:n][active], c["alpha"][:n][active], rtol=1e-9, atol=1e-10)
+    assert np.abs(g["alpha"][:n][active] - c["alpha"][:n][active]).max() <= (1e-9 if noisy_flux else 1e-12)
     np.testing.assert_allclose(g["dij"], c["dij"], rtol=1e-12,
                                atol=1e-4 * np.abs(c["dij"]).max() if noisy_flux else 1e-300)
     assert abs(g["tau"] - c["tau"]) <= 1e-12 * c["tau"]
     np.testing.assert_allclose(g["bounds"].reshape(n, -1)[active], c["bounds"].reshape(n, -1)[active], rtol=1e-12,
                                atol=1e-14 * scale)
-    np.testing.assert_allclose(g["r"], c["r"], rtol=1e-9, atol=1e-11 * max(np.abs(c["r"]).max(), 1e-300))
-    np.testing.assert_allclose(g["pij"], c["pij"], rtol=1e-8, atol=1e-12 * max(np.abs(c["pij"]).max(), 1e-300))
+    # r_i, P_ij: 1e-12 of the largest entry (the contract of helpers_parity.py; the never-read diagonal P_ii aside)
+    assert np.abs(g["r"] - c["r"]).max() <= 1e-12 * max(np.abs(c["r"]).max(), 1e-300)
+    g["pij"][rs_diag] = c["pij"][rs_diag]
+    assert np.abs(g["pij"] - c["pij"]).max() <= 1e-12 * max(np.abs(c["pij"]).max(), 1e-300)
+    # l_ij of the scalar limiter is a quotient (u_max - u) / P_ij: where P_ij is round-off sized it is undefined in
+    # the reference itself. Every pair beyond 1e-10 must be inert: |dl| lambda |P_ij| below the U_new contract.
+    rs_ = np.asarray(off._keep["row_starts"] if hasattr(off, "_keep") else off.row_starts).astype(np.int64)[: n + 1]
+    lam = np.repeat(1.0 / np.maximum(np.diff(rs_) - 1, 1), np.diff(rs_))
     for name in ("lij", "lij_next"):
         dl = np.abs(g[name] - c[name])
-        p_rel = np.abs(c["pij"]) / scale
-        bad = (dl > 1e-10) & (p_rel > 1e-6)
-        assert bad.sum() <= max(2, int(1e-4 * dl.size)), (name, int(bad.sum()))
+        effect = dl * lam * np.abs(c["pij"]) / scale
+        assert effect[dl > 1e-10].max(initial=0.0) <= 1e-12, (name, float(effect[dl > 1e-10].max(initial=0.0)))
     err = np.abs(g["U"][:n] - c["U"][:n]) / scale
     assert err.max() <= 1e-12, err.max()
     return g, c
@@ -1064,16 +1091,7 @@ def test_limiter_iterations_0_and_1(oracle, iterations):
     def edit(p):
         p.limiter_iterations = iterations
     off, mods = _both(spec, U0, oracle, n_warm=8, dirichlet=dirichlet, params_edit=edit)
-    res = []
-    for m, old, new in mods:
-        m.prepare_state_vector(old, 0.0, dirichlet)
-        tau = m.step(old, [], [], new)
-        res.append((tau, new.download()[: off.n_owned], m.debug_fetch("bounds")))
-    assert abs(res[0][0] - res[1][0]) <= 1e-12 * res[1][0]
-    scale = np.abs(res[1][1]).max(axis=0)
-    err = np.abs(res[0][1] - res[1][1]) / scale
-    assert (err > 1e-11).sum() <= max(2, int(1e-4 * err.size)) and err.max() < 1e-9
-    np.testing.assert_allclose(res[0][2], res[1][2], rtol=1e-12)
+    _compare_step(off, mods, dirichlet)   # the stated contract, l_ij outliers classified, no quota
 
 
 def test_riemann_newton_iterations_and_tau_max(oracle):
@@ -1441,7 +1459,34 @@ def test_unstructured_arbitrary_partition_on_gpu(oracle, equation):
         np.testing.assert_allclose(out[r][1], taus, rtol=1e-13)
         np.testing.assert_allclose(out[r][2], integ, rtol=1e-11, atol=1e-12 * np.abs(integ).max())
         U[views[r].global_ids[: views[r].n_owned]] = out[r][0]
-    assert (np.abs(U - U_ref).max(axis=0) / np.abs(U_ref).max(axis=0)).max() < 1e-9
+    # Partitioned against single-rank HIP after 24 updates of a blast wave. A partition renumbers the rows, which
+    # changes the order of every stencil sum: the two runs differ by round-off from the first update on and the
+    # flow amplifies it. The yardstick is what the SAME renumbering does to the reference algorithm itself -- the
+    # partitioned oracle against the single-rank oracle over the same sequence of updates: the HIP pair may not
+    # drift apart more than 4x as far (plus the per-update contract, 1e-11 each; the one-update comparison of every
+    # rank against the oracle, ghost rows included, is tests/test_partitioned_vs_oracle.py).
+    from helpers_partitioned import run_oracle_ranks
+
+    def oracle_sequence(m, part, r, U_init=None):
+        a, b = m.new_state_vector(U0[part.global_ids] if U_init is None else U_init), m.new_state_vector()
+        for _ in range(n_updates):
+            m.prepare_state_vector(a, 0.0)
+            m.step(a, [], [], b)
+            a, b = b, a
+        ti = TimeIntegrator(m, "ssprk 33", cfl_min=p.cfl, cfl_max=p.cfl, cfl_recovery_strategy="none")
+        for _ in range(n_rk):
+            a, _tau = ti.step(a, 0.0)
+        return a.download()[: part.n_owned]
+    parts_U = run_oracle_ranks(oracle, views, lambda: p, oracle_sequence)
+    U_oracle_part = np.empty_like(U0)
+    for r in range(n_ranks):
+        U_oracle_part[views[r].global_ids[: views[r].n_owned]] = parts_U[r]
+    m_single = HyperbolicModule(off, p, backend=oracle.backend())
+    U_oracle_single = oracle_sequence(m_single, off, 0, U_init=U0)
+    drift_oracle = (np.abs(U_oracle_part - U_oracle_single).max(axis=0) / np.abs(U_ref).max(axis=0)).max()
+    drift_hip = (np.abs(U - U_ref).max(axis=0) / np.abs(U_ref).max(axis=0)).max()
+    n_total = n_updates + 3 * n_rk
+    assert drift_hip <= 4.0 * drift_oracle + 1e-11 * n_total, (drift_hip, drift_oracle)
     for r in range(n_ranks):
         lib.ryujin_hip_comm_destroy(C.c_void_p(comms[r]))
 

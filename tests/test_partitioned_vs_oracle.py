@@ -14,7 +14,7 @@ the unstructured P1 disk cut into 4 sectors (up to 3 neighbours per rank, nodes 
 import numpy as np
 import pytest
 
-from helpers_partitioned import (compare_ghost_rows, compare_rank, one_update_with_intermediates, run_hip_ranks,
+from helpers_partitioned import (compare_ghost_rows, compare_rank, global_scales, one_update_with_intermediates, run_hip_ranks,
                                  run_oracle_ranks)
 from ryujin_amd import capi, offline
 from ryujin_amd.initial_states import euler_radial_contrast, euler_uniform
@@ -88,7 +88,9 @@ def _compare_partitioned(oracle, parts, equation, dim, U_init, dirichlet_of, n_w
     body = one_update_with_intermediates(states, dirichlet_of)
     hip = run_hip_ranks(parts, make, body)
     ref = run_oracle_ranks(oracle, parts, make, body)
-    accepted = [compare_rank(part, hip[r], ref[r], k, label=f"rank {r}") for r, part in enumerate(parts)]
+    scales = global_scales(parts, ref, k)
+    accepted = [compare_rank(part, hip[r], ref[r], k, label=f"rank {r}", scales=scales)
+                for r, part in enumerate(parts)]
     assert compare_ghost_rows(parts, hip, ref, accepted) > 0
     # the comparison of the ghost rows of l_ij is not vacuous: some ghost-row entry was actually limited
     ghost_l = np.concatenate([ref[r]["lij_next"][int(parts[r].row_starts[parts[r].n_owned]):] for r in range(len(parts))])
