@@ -261,6 +261,8 @@ typedef struct ryujin_hip_comm ryujin_hip_comm;
 int ryujin_hip_comm_unique_id(char id[RYUJIN_HIP_UNIQUE_ID_BYTES]);
 int ryujin_hip_comm_init(ryujin_hip_comm **comm, const char id[RYUJIN_HIP_UNIQUE_ID_BYTES],
                          int rank, int n_ranks, int device);
+/* number of HIP devices visible to this process (a host application picks rank % count) */
+int ryujin_hip_device_count(int *n_devices);
 /* Test facility: n_ranks communicators of ONE process (one host thread per rank, all on `device`)
  * that exchange ghost data with device-to-device copies instead of RCCL. comms: [n_ranks]. */
 int ryujin_hip_comm_init_local(ryujin_hip_comm **comms, int n_ranks, int device);
@@ -330,8 +332,8 @@ int ryujin_hip_sadd(ryujin_hip_ctx *ctx, int h_dst, double s, double b, int h_sr
  * schemes built from prepare_state_vector + step<s> + sadd. One host synchronisation per RK step: the
  * tau of the first stage and the restart flags of all stages stay on the device. h_state names the
  * solution before and after the call (state_vector.swap(temp) is done on the handles); h_tmp are three
- * scratch state vectors (temp_[0..2]). dirichlet_aos as in prepare_state_vector (time independent; use
- * the per-stage API for time-dependent Dirichlet data). tau_max = t_final - t. With
+ * scratch state vectors (temp_[0..2]). dirichlet_aos as in prepare_state_vector (time independent;
+ * ryujin_hip_time_step_fn below takes time-dependent Dirichlet data). tau_max = t_final - t. With
  * RYUJIN_CFL_RECOVERY_BANG_BANG the reference's bang-bang control (:250-274) is applied internally.
  * *tau_out = the time increment of the whole RK step (3 tau for ERK33). */
 enum {
@@ -351,6 +353,18 @@ int ryujin_hip_time_step(ryujin_hip_ctx *ctx, int scheme, int h_state, const int
 int ryujin_hip_time_step_n(ryujin_hip_ctx *ctx, int scheme, int h_state, int n_tmp, const int *h_tmp,
                            const double *dirichlet_aos, double tau_max, int cfl_recovery,
                            double cfl_min, double cfl_max, double *tau_out);
+
+/* The same with TIME-DEPENDENT Dirichlet data: the reference evaluates initial_state(position, t + c_s tau) for
+ * every stage (hyperbolic_module.template.h:137-139 called with the stage times of
+ * time_integrator.template.h:279-510). `dirichlet_fn(user, time, values)` fills values[n_bdry * k] (the layout of
+ * prepare_state_vector's dirichlet_aos; entries whose boundary id does not read Dirichlet data may be left
+ * untouched) and is called once per stage from the calling thread: for the first stage at `t` before anything is
+ * enqueued, for the later stages as soon as tau exists on the host -- behind step 3 of the first stage, while its
+ * remaining sweeps run. NULL: no boundary id reads Dirichlet data, or the data of an earlier call is kept. */
+typedef void (*ryujin_hip_dirichlet_fn)(void *user, double time, double *dirichlet_aos);
+int ryujin_hip_time_step_fn(ryujin_hip_ctx *ctx, int scheme, int h_state, int n_tmp, const int *h_tmp, double t,
+                            ryujin_hip_dirichlet_fn dirichlet_fn, void *user, double tau_max, int cfl_recovery,
+                            double cfl_min, double cfl_max, double *tau_out);
 
 /* Conservation monitor on the device (the interior integrals of ryujin::Quantities,
  * source/quantities.template.h): out[q] = sum over ALL ranks of

@@ -366,6 +366,14 @@ struct ryujin_hip_ctx {
   DeviceBuffer<DeviceScalars> d_scalars;
   DeviceBuffer<double> d_integrals; /* ryujin_hip_state_integrals: block partials + result */
   DeviceScalars *h_scalars = nullptr; /* pinned */
+  /* time-dependent Dirichlet data inside a device-resident RK step (ryujin_hip_time_step_fn): the tau of the
+   * first stage is copied to the host as soon as it exists (behind step 3 of the first stage), the later stages'
+   * boundary data is evaluated at t + c_s tau while the rest of the first stage runs */
+  static constexpr int kMaxRkStages = 5;
+  unsigned long long *h_tau_early = nullptr; /* pinned */
+  hipEvent_t ev_tau = nullptr;
+  bool want_tau_early = false;
+  double *h_dirichlet_stage[kMaxRkStages] = {}; /* pinned staging, one per RK stage */
 
   struct State {
     DeviceBuffer<double> U, prec;
@@ -424,6 +432,13 @@ struct ryujin_hip_ctx {
         (void)hipEventDestroy(e);
     if (h_scalars)
       (void)hipHostFree(h_scalars);
+    if (h_tau_early)
+      (void)hipHostFree(h_tau_early);
+    if (ev_tau)
+      (void)hipEventDestroy(ev_tau);
+    for (auto *b : h_dirichlet_stage)
+      if (b)
+        (void)hipHostFree(b);
     if (stream)
       (void)hipStreamDestroy(stream);
   }
@@ -457,7 +472,8 @@ struct ryujin_hip_ctx {
            double tau_max_in, double *tau_out);
   template <typename E>
   int time_step(int scheme, int h_state, int n_tmp, const int *h_tmp, const double *dirichlet,
-                double tau_max, int cfl_recovery, double cfl_min, double cfl_max, double *tau_out);
+                double tau_max, int cfl_recovery, double cfl_min, double cfl_max, double *tau_out,
+                double t = 0., ryujin_hip_dirichlet_fn dirichlet_fn = nullptr, void *dirichlet_user = nullptr);
   void mark(int k)
   {
     if (timers_enabled)
@@ -1016,12 +1032,26 @@ void ryujin_hip_ctx::prepare_state_vector(int h, const double *dirichlet)
   const dim3 block(kBlock);
   if (dirichlet && n_bdry) {
     /* permute into the grouped order, then upload */
-    std::vector<double> tmp((size_t)n_bdry * K);
-    for (uint32_t e = 0; e < n_bdry; ++e)
-      std::memcpy(&tmp[(size_t)e * K], &dirichlet[(size_t)bdry_perm[e] * K], sizeof(double) * K);
-    HIP_CHECK(hipMemcpyAsync(d_dirichlet.ptr, tmp.data(), tmp.size() * sizeof(double),
-                             hipMemcpyHostToDevice, stream));
-    HIP_CHECK(hipStreamSynchronize(stream)); /* tmp goes out of scope */
+    if (deferred) {
+      /* inside a device-resident RK step: a pinned staging buffer per stage, no host synchronisation (a buffer
+       * is rewritten in the next RK step at the earliest, i.e. behind the end-of-step synchronisation). The
+       * copy is ordered on the compute stream behind every kernel of the previous stage that read the data. */
+      double *&buf = h_dirichlet_stage[rk_stage];
+      if (!buf)
+        HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&buf), (size_t)n_bdry * K * sizeof(double)));
+      for (uint32_t e = 0; e < n_bdry; ++e)
+        std::memcpy(&buf[(size_t)e * K], &dirichlet[(size_t)bdry_perm[e] * K], sizeof(double) * K);
+      join_export(); /* the export part of the previous pre-pass may have applied boundary conditions */
+      HIP_CHECK(hipMemcpyAsync(d_dirichlet.ptr, buf, (size_t)n_bdry * K * sizeof(double), hipMemcpyHostToDevice,
+                               stream));
+    } else {
+      std::vector<double> tmp((size_t)n_bdry * K);
+      for (uint32_t e = 0; e < n_bdry; ++e)
+        std::memcpy(&tmp[(size_t)e * K], &dirichlet[(size_t)bdry_perm[e] * K], sizeof(double) * K);
+      HIP_CHECK(hipMemcpyAsync(d_dirichlet.ptr, tmp.data(), tmp.size() * sizeof(double),
+                               hipMemcpyHostToDevice, stream));
+      HIP_CHECK(hipStreamSynchronize(stream)); /* tmp goes out of scope */
+    }
     have_dirichlet = true;
   }
   if (needs_dirichlet && !have_dirichlet)
@@ -1236,6 +1266,14 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
    * whose flag is reduced once at the end of the RK step together with the restart flag. */
   if (!(deferred && rk_stage > 0))
     allreduce_scalar(&d_scalars.ptr->tau_max_bits, 0);
+  if (want_tau_early && deferred && rk_stage == 0) {
+    /* tau_max = min(tau_max argument, CFL bound over all ranks) is final here: hand it to the host while
+     * steps 4-7 of this stage run (time-dependent Dirichlet data of the later stages) */
+    join_export();
+    HIP_CHECK(hipMemcpyAsync(h_tau_early, &d_scalars.ptr->tau_max_bits, sizeof(unsigned long long),
+                             hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipEventRecord(ev_tau, stream));
+  }
   /* tau itself is resolved inside the step-4 kernel (finalize_tau) */
   mark(2);
 
@@ -1475,7 +1513,8 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
 template <typename E>
 int ryujin_hip_ctx::time_step(int scheme, int h_state, int n_tmp, const int *h_tmp, const double *dirichlet,
                               double tau_max, int cfl_recovery, double cfl_min, double cfl_max,
-                              double *tau_out)
+                              double *tau_out, double t, ryujin_hip_dirichlet_fn dirichlet_fn,
+                              void *dirichlet_user)
 {
   const int U = h_state;
   int n_stages = 0;
@@ -1543,14 +1582,49 @@ int ryujin_hip_ctx::time_step(int scheme, int h_state, int n_tmp, const int *h_t
     const int none[1] = {0};
     const double no_w[1] = {0.};
 
+    /* Dirichlet data of stage st: time independent (the array, uploaded once), or initial_state(position,
+     * t + c_s tau) per stage (time_integrator.template.h:279-510: SSPRK22 t, t+tau; SSPRK33 t, t+tau, t+tau/2;
+     * ERK stage s at t + s tau) through the caller's function. tau is known on the host as soon as step 3 of
+     * the first stage has run; the first stage's remaining sweeps are already enqueued behind it. */
+    const bool time_dependent = dirichlet_fn != nullptr && n_bdry > 0 && needs_dirichlet;
+    std::vector<double> stage_data;
+    double tau_first = 0.;
+    auto dirichlet_at = [&](int st) -> const double * {
+      if (!time_dependent)
+        return st == 0 ? dirichlet : nullptr;
+      double c = 0.;
+      if (st > 0)
+        c = erk ? (double)st : (scheme == RYUJIN_SCHEME_SSPRK_33 && st == 2 ? 0.5 : 1.);
+      stage_data.assign((size_t)n_bdry * K, 0.);
+      dirichlet_fn(dirichlet_user, t + c * tau_first, stage_data.data());
+      return stage_data.data();
+    };
+    struct EarlyTau {
+      bool &flag;
+      ~EarlyTau() { flag = false; }
+    } early_tau{want_tau_early};
+    if (time_dependent && n_stages > 1) {
+      if (!h_tau_early) {
+        HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&h_tau_early), sizeof(unsigned long long)));
+        HIP_CHECK(hipEventCreateWithFlags(&ev_tau, hipEventDisableTiming));
+      }
+      want_tau_early = true;
+    }
+
     rk_stage = 0;
-    prepare_state_vector<E>(U, dirichlet);
+    prepare_state_vector<E>(U, dirichlet_at(0));
     step<E>(U, 0, none, no_w, T[0], 0., first_tau_max, &dummy);
     result = T[0];
+    if (want_tau_early) {
+      HIP_CHECK(hipEventSynchronize(ev_tau));
+      tau_first = __builtin_bit_cast(double, *h_tau_early);
+      if (!(tau_first > 0.) || std::isinf(tau_first))
+        tau_first = 0.; /* invalid tau_max: the step ends in RYUJIN_ERR_TAU whatever the later stages see */
+    }
     if (erk) {
       for (int st = 1; st < n_stages; ++st) {
         rk_stage = st;
-        prepare_state_vector<E>(T[st - 1], nullptr);
+        prepare_state_vector<E>(T[st - 1], dirichlet_at(st));
         step<E>(T[st - 1], erk_stage[st].n, erk_stage[st].h, erk_stage[st].w, T[st], 1. /*device tau*/,
                 no_limit, &dummy);
         result = T[st];
@@ -1571,7 +1645,7 @@ int ryujin_hip_ctx::time_step(int scheme, int h_state, int n_tmp, const int *h_t
           ryujin_hip_sadd(this, h_new, sa, sb, U);
       };
       rk_stage = 1;
-      prepare_state_vector<E>(T[0], nullptr);
+      prepare_state_vector<E>(T[0], dirichlet_at(1));
       if (scheme == RYUJIN_SCHEME_SSPRK_22)
         stage_with_sadd(T[0], T[1], 1. / 2., 1. / 2.);
       else
@@ -1579,7 +1653,7 @@ int ryujin_hip_ctx::time_step(int scheme, int h_state, int n_tmp, const int *h_t
       result = T[1];
       if (n_stages >= 3) {
         rk_stage = 2;
-        prepare_state_vector<E>(T[1], nullptr);
+        prepare_state_vector<E>(T[1], dirichlet_at(2));
         stage_with_sadd(T[1], T[0], 2. / 3., 1. / 3.);
         result = T[0];
       }
@@ -2075,6 +2149,42 @@ int ryujin_hip_time_step_n(ryujin_hip_ctx *ctx, int scheme, int h_state, int n_t
                                                                    dirichlet_aos, tau_max, cfl_recovery,
                                                                    cfl_min, cfl_max, tau_out);
     });
+  });
+}
+
+int ryujin_hip_time_step_fn(ryujin_hip_ctx *ctx, int scheme, int h_state, int n_tmp, const int *h_tmp, double t,
+                            ryujin_hip_dirichlet_fn dirichlet_fn, void *user, double tau_max, int cfl_recovery,
+                            double cfl_min, double cfl_max, double *tau_out)
+{
+  return guarded_ctx(ctx, [&]() {
+    if (!h_tmp || !tau_out || n_tmp < 1 || n_tmp > 8)
+      throw HipError(RYUJIN_ERR_ARG, "time_step: bad argument");
+    if (std::isnan(tau_max) || !(tau_max > 0.))
+      return RYUJIN_ERR_TAU; /* as in step() */
+    ctx->state(h_state);
+    for (int q = 0; q < n_tmp; ++q) {
+      ctx->state(h_tmp[q]);
+      if (h_tmp[q] == h_state)
+        throw HipError(RYUJIN_ERR_ARG, "time_step: temporary vectors must differ from the state vector");
+      for (int r = 0; r < q; ++r)
+        if (h_tmp[r] == h_tmp[q])
+          throw HipError(RYUJIN_ERR_ARG, "time_step: temporary vectors must be distinct");
+    }
+    return dispatch_equation(ctx->params.equation, ctx->dim, [&](auto tag) {
+      return ctx->template time_step<typename decltype(tag)::type>(scheme, h_state, n_tmp, h_tmp, nullptr, tau_max,
+                                                                   cfl_recovery, cfl_min, cfl_max, tau_out, t,
+                                                                   dirichlet_fn, user);
+    });
+  });
+}
+
+int ryujin_hip_device_count(int *n_devices)
+{
+  return guarded([&]() {
+    if (!n_devices)
+      throw HipError(RYUJIN_ERR_ARG, "null argument");
+    HIP_CHECK(hipGetDeviceCount(n_devices));
+    return RYUJIN_OK;
   });
 }
 

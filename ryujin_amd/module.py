@@ -153,9 +153,13 @@ class HyperbolicModule:
         return tau_out.value
 
     def time_step(self, scheme: str, state: StateVector, temps, dirichlet=None, tau_max=None,
-                  cfl_recovery="none", cfl_min=0.45, cfl_max=0.90) -> float:
+                  cfl_recovery="none", cfl_min=0.45, cfl_max=0.90, t=0.0, dirichlet_fn=None) -> float:
         """Device-resident TimeIntegrator::step (ryujin_hip_time_step): one host synchronisation per
-        RK step. `state` names the solution before and after the call."""
+        RK step. `state` names the solution before and after the call. dirichlet_fn(time) -> [n_bdry, k]:
+        time-dependent Dirichlet data, evaluated by the library at the stage times t + c_s tau
+        (ryujin_hip_time_step_fn)."""
+        if dirichlet_fn is not None:
+            return self._time_step_fn(scheme, state, temps, t, dirichlet_fn, tau_max, cfl_recovery, cfl_min, cfl_max)
         schemes = {"ssprk 22": capi.SCHEME_SSPRK_22, "ssprk 33": capi.SCHEME_SSPRK_33,
                    "erk 11": capi.SCHEME_ERK_11, "erk 22": capi.SCHEME_ERK_22, "erk 33": capi.SCHEME_ERK_33,
                    "erk 43": capi.SCHEME_ERK_43, "erk 54": capi.SCHEME_ERK_54}
@@ -169,6 +173,32 @@ class HyperbolicModule:
                                   float(np.finfo(np.float64).max if tau_max is None else tau_max),
                                   capi.CFL_RECOVERY_BANG_BANG if cfl_recovery == "bang bang control"
                                   else capi.CFL_RECOVERY_NONE, float(cfl_min), float(cfl_max), C.byref(tau))
+        if rc == capi.RYUJIN_ERR_TAU:
+            raise TauError("I'm sorry, Dave. I'm afraid I can't do that. We crashed.")
+        self._check(rc)
+        self.last_status = rc
+        if rc == capi.RYUJIN_RESTART:
+            raise Restart()
+        return tau.value
+
+    SCHEMES = {"ssprk 22": capi.SCHEME_SSPRK_22, "ssprk 33": capi.SCHEME_SSPRK_33, "erk 11": capi.SCHEME_ERK_11,
+               "erk 22": capi.SCHEME_ERK_22, "erk 33": capi.SCHEME_ERK_33, "erk 43": capi.SCHEME_ERK_43,
+               "erk 54": capi.SCHEME_ERK_54}
+
+    def _time_step_fn(self, scheme, state, temps, t, dirichlet_fn, tau_max, cfl_recovery, cfl_min, cfl_max):
+        n = self.offline.n_bdry * self.k
+
+        def callback(user, time, out):
+            values = np.ascontiguousarray(dirichlet_fn(time), dtype=np.float64).reshape(-1)
+            assert values.size == n
+            C.memmove(out, values.ctypes.data, n * 8)
+        cb = capi.DIRICHLET_FN(callback)
+        hs = (C.c_int * len(temps))(*[x.handle for x in temps])
+        tau = C.c_double(0.0)
+        rc = self._f("time_step_fn")(self._ctx, self.SCHEMES[scheme], state.handle, len(temps), hs, float(t), cb,
+                                     None, float(np.finfo(np.float64).max if tau_max is None else tau_max),
+                                     capi.CFL_RECOVERY_BANG_BANG if cfl_recovery == "bang bang control"
+                                     else capi.CFL_RECOVERY_NONE, float(cfl_min), float(cfl_max), C.byref(tau))
         if rc == capi.RYUJIN_ERR_TAU:
             raise TauError("I'm sorry, Dave. I'm afraid I can't do that. We crashed.")
         self._check(rc)
@@ -248,6 +278,26 @@ class HyperbolicModule:
         self._check(self._f("debug_fetch")(self._ctx, codes[what], capi.as_ptr(out, capi.c_double_p),
                                            out.size))
         return out
+
+
+class DeviceResidentTimeIntegrator:
+    """TimeIntegrator::step(state_vector, t, t_final) executed inside the library (ryujin_hip_time_step_fn): the
+    interface of TimeIntegrator below, one host synchronisation per Runge-Kutta step, Dirichlet data evaluated at
+    the stage times by a callback (what contrib/hyperbolic_module_hip.h::time_step does on the ryujin side)."""
+
+    def __init__(self, module: "HyperbolicModule", scheme: str = "erk 33", cfl_min=0.45, cfl_max=0.90,
+                 cfl_recovery_strategy: str = "bang bang control", dirichlet_fn=None):
+        self.m, self.scheme = module, scheme
+        self.cfl_min, self.cfl_max, self.cfl_recovery_strategy = cfl_min, cfl_max, cfl_recovery_strategy
+        self.dirichlet_fn = dirichlet_fn
+        self.temp = [module.new_state_vector() for _ in range({"erk 43": 4, "erk 54": 5}.get(scheme, 3))]
+        module.cfl = cfl_max
+
+    def step(self, state: StateVector, t: float, t_final: float = np.finfo(np.float64).max):
+        tau = self.m.time_step(self.scheme, state, self.temp, tau_max=t_final - t,
+                               cfl_recovery=self.cfl_recovery_strategy, cfl_min=self.cfl_min, cfl_max=self.cfl_max,
+                               t=t, dirichlet_fn=self.dirichlet_fn)
+        return state, tau
 
 
 class TimeIntegrator:

@@ -1301,6 +1301,19 @@ def test_verification_golden_on_gpu(oracle, golden_dir, case):
     fn("hip", oracle.default_params, golden_dir, *args, slack=VERIFICATION_SLACK.get(case, 1.0))
 
 
+@pytest.mark.parametrize("case", ["euler_leblanc_1d", "euler_rarefaction_1d", "euler_aeos_leblanc_1d",
+                                  "sw_steady_incline", "sw_ritter_dam_break"])
+def test_verification_golden_through_the_device_resident_driver(oracle, golden_dir, case):
+    """The same baselines with every Runge-Kutta step executed INSIDE the library (ryujin_hip_time_step_fn: one
+    host synchronisation per step) and the exact solution supplied as time-dependent Dirichlet data at the stage
+    times t + c_s tau (time_integrator.template.h:373-403; hyperbolic_module.template.h:137-139): the tubes have
+    Dirichlet ends that move with the exact solution, the incline has `dynamic` boundaries. Same tolerances as the
+    stage-wise run above."""
+    from test_oracle_golden_verification import CASES
+    fn, args = CASES[case]
+    fn("hip-device", oracle.default_params, golden_dir, *args, slack=VERIFICATION_SLACK.get(case, 1.0))
+
+
 @pytest.mark.parametrize("description,scheme,level", [("euler", "ssprk 33", 6), ("euler", "erk 33", 7),
                                                       ("euler", "ssprk 33", 7), ("euler_aeos", "erk 33", 6),
                                                       ("euler_aeos", "ssprk 33", 7), ("euler_aeos", "erk 33", 7)])

@@ -60,11 +60,17 @@ def run_verification(backend, off, params, exact, components, scheme="erk 33", c
     `exact(positions, t)` is the analytic solution (initial values, Dirichlet data and error reference)."""
     if bathymetry is not None:
         off.set_initial_precomputed(bathymetry)
-    m = HyperbolicModule(off, params, backend=backend)
+    # "hip-device": the whole Runge-Kutta step inside the library (ryujin_hip_time_step_fn), Dirichlet data
+    # evaluated at the stage times t + c_s tau through the callback
+    device_rk = backend == "hip-device"
+    m = HyperbolicModule(off, params, backend="hip" if device_rk else backend)
     sv = m.new_state_vector(exact(off.positions, 0.0))
     bpos = off.b_positions
-    ti = TimeIntegrator(m, scheme, cfl_min=cfl, cfl_max=cfl, cfl_recovery_strategy="none",
-                        dirichlet_fn=(lambda t: exact(bpos, t)) if with_dirichlet else None)
+    integrator = TimeIntegrator
+    if device_rk:
+        from ryujin_amd.module import DeviceResidentTimeIntegrator as integrator
+    ti = integrator(m, scheme, cfl_min=cfl, cfl_max=cfl, cfl_recovery_strategy="none",
+                    dirichlet_fn=(lambda t: exact(bpos, t)) if with_dirichlet else None)
     t, n_steps = 0.0, 0
     while t < t_final:
         sv, tau = ti.step(sv, t)
