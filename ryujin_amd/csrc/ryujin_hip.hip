@@ -1338,7 +1338,26 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
                            d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_alpha.ptr, d_dij.ptr,
                            nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
     } else {
-      if (stages == 0)
+      /* rows of at most 3 / 9 columns (1-D, 2-D Q1): one walk over the stencil, the shift-free part of the
+       * limiter's U_ij_bar parked in LDS (kernels_shallow_water.hpp); wider rows: the two walks of the reference */
+      constexpr int kSwWidth = DIM == 1 ? 3 : 9;
+      const bool single_walk = RYUJIN_SW_SINGLE_WALK && L.max_row_len <= (uint32_t)kSwWidth;
+      auto launch_single_walk = [&](auto has_stages, auto friction) {
+        hipLaunchKernelGGL((k_low_order_sw_single_walk<DIM, decltype(has_stages)::value, kSwWidth,
+                                                       decltype(friction)::value>),
+                           grid, block, 0, launch_stream, eparams, mm, d_scalars.ptr, weight, S, old.U.ptr,
+                           old.prec.ptr, d_Z.ptr, d_alpha.ptr, d_dij.ptr, nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
+      };
+      const bool friction = eparams.manning != 0.;
+      if (single_walk && stages == 0 && friction)
+        launch_single_walk(std::false_type{}, std::true_type{});
+      else if (single_walk && stages == 0)
+        launch_single_walk(std::false_type{}, std::false_type{});
+      else if (single_walk && friction)
+        launch_single_walk(std::true_type{}, std::true_type{});
+      else if (single_walk)
+        launch_single_walk(std::true_type{}, std::false_type{});
+      else if (stages == 0)
         hipLaunchKernelGGL((k_low_order_sw<DIM, false>), grid, block, 0, launch_stream, eparams, mm,
                            d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_Z.ptr, d_alpha.ptr,
                            d_dij.ptr, nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);

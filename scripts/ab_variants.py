@@ -22,16 +22,34 @@ ap.add_argument("--steps", type=int, default=15)
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--dim", type=int, default=2)
 ap.add_argument("--length", type=float, default=1.25, help="3-D: channel length in units")
+ap.add_argument("--workload", default="", help="sw2d: the shallow-water dam break of bench.py (--cells-per-unit = "
+                                               "cells per direction, default 1824); sedov3d: the radial-contrast box "
+                                               "(default 160 cells per direction); default: step2d / cylinder3d by --dim")
 ap.add_argument("variants", nargs="+")
 args = ap.parse_args()
 
-if args.dim == 2:
+equation = capi.EQ_EULER
+if args.workload == "sw2d":
+    from ryujin_amd.initial_states import sw_circular_dam_break
+    n = args.cells_per_unit if args.cells_per_unit != 995 else 1824
+    spec = offline.rectangle_2d(n, (-5.0, -5.0), (5.0, 5.0), ny=n)
+    equation = capi.EQ_SHALLOW_WATER
+elif args.workload == "sedov3d":
+    from ryujin_amd.initial_states import euler_radial_contrast
+    n = args.cells_per_unit if args.cells_per_unit != 995 else 160
+    spec = offline.box_3d(n)
+elif args.dim == 2:
     spec = offline.mach3_step_2d(args.cells_per_unit)
 else:
     spec = offline.cylinder_channel_3d(args.cells_per_unit, length_units=args.length)
 off = offline.SyntheticOffline(spec)
-U0 = euler_uniform(off.positions)
-dirichlet = euler_uniform(off.b_positions)
+if args.workload == "sw2d":
+    U0, dirichlet = sw_circular_dam_break(off.positions), None
+elif args.workload == "sedov3d":
+    U0, dirichlet = euler_radial_contrast(off.positions, inner=(1.0, 0.0, 100.0), outer=(1.0, 0.0, 0.1), radius=0.1), None
+else:
+    U0 = euler_uniform(off.positions)
+    dirichlet = euler_uniform(off.b_positions)
 print(f"n_q={off.n_owned}", flush=True)
 
 mods = {}
@@ -45,7 +63,7 @@ for v in args.variants:
     lib.ryujin_hip_synchronize.argtypes = [C.c_void_p]
     lib.ryujin_hip_event_record.argtypes = [C.c_void_p, C.c_int]
     lib.ryujin_hip_event_elapsed_ms.argtypes = [C.c_void_p, capi.c_double_p]
-    m = HyperbolicModule(off, equation=capi.EQ_EULER, backend=(lib, "ryujin_hip_"))
+    m = HyperbolicModule(off, equation=equation, backend=(lib, "ryujin_hip_"))
     m.cfl = 0.9
     if U_dev is None:
         d = Ssprk33Stages(m, U0, dirichlet)
