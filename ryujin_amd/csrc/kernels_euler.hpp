@@ -139,6 +139,9 @@ namespace ryujin_hip
 #ifndef RYUJIN_OCC_HO
 #define RYUJIN_OCC_HO 2
 #endif
+#ifndef RYUJIN_STAGE0_PIJ
+#define RYUJIN_STAGE0_PIJ 1 /* Euler, stages == 0: P_ij formed on the fly in steps 5-7 (kernels_limiter_stage0.hpp) */
+#endif
 
   constexpr int kBlock = 256;
   constexpr int kWavesPerBlock = kBlock / 64;

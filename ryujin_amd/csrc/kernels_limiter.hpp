@@ -489,7 +489,8 @@ namespace ryujin_hip
   __global__ void __launch_bounds__(kBlock, (MAXW > 9 ? (CP < MAXW ? RYUJIN_OCC_HO_3D : 1) : RYUJIN_OCC_HO))
   k_high_order_next_cached(const typename E::Params P, const DeviceMesh M, double *__restrict__ new_U,
                            const double *__restrict__ bounds, const double *__restrict__ pij,
-                           const double *__restrict__ lij, double *__restrict__ lij_next)
+                           const double *__restrict__ lij, double *__restrict__ lij_next,
+                           const double *__restrict__ V_unlimited = nullptr)
   {
     constexpr int K = E::K;
     constexpr int NB = E::NB;
@@ -526,22 +527,62 @@ namespace ryujin_hip
 
     double l[MAXW];
     double p[CP][K];
+    if (V_unlimited != nullptr) {
+      /* Step 5 left V_i = U_i^low + sum_j lambda P_ij, accumulated exactly as the update below accumulates it
+       * when every l_ij is 1 (k_lij_stage0). If no pair of the slice was limited -- wave-uniform; most of a
+       * developed flow -- that IS the new U_i bit for bit, the second pass stores (1 - l) l' = 0, and P_ij is
+       * not read at all. */
+      bool limited = false;
 #pragma unroll
-    for (int c = 1; c < MAXW; ++c) {
-      l[c] = 0.;
-      if (c < CP) {
+      for (int c = 1; c < MAXW; ++c) {
+        l[c] = 0.;
+        if ((uint32_t)c < r.width) {
+          const uint32_t pos = (uint32_t)(((uint64_t)r.base + c) * 64 + r.lane);
+          const double l_a = lij[pos];
+          const double l_b = lij[idx_t[pos]];
+          l[c] = fmin(l_a, l_b);
+          limited = limited || (row_active && (uint32_t)c < r.len && l[c] != 1.);
+        }
+      }
+      if (!__any(limited)) {
+        if (row_active) {
+          double V_i[K];
+          load_state<K>(V_unlimited, i, V_i);
+          if (!SPLIT || group == 0)
+            store_state<K>(new_U, i, V_i);
+#pragma unroll
+          for (int c = 1; c < MAXW; ++c)
+            if ((uint32_t)c < r.len && (!SPLIT || (uint32_t)(c - 1) % kWavesPerBlock == group))
+              st_stream(lij_next + ((r.base + c) * 64 + r.lane), 0.);
+        }
+        return;
+      }
+#pragma unroll
+      for (int c = 1; c < CP; ++c) {
 #pragma unroll
         for (int q = 0; q < K; ++q)
-          p[c < CP ? c : 0][q] = 0.;
+          p[c][q] = 0.;
+        if ((uint32_t)c < r.width)
+          load_entry<K>(pij, (uint64_t)r.base + c, r.lane, p[c]);
       }
-      if ((uint32_t)c < r.width) {
-        const uint64_t colbase = (uint64_t)r.base + c;
-        const uint32_t pos = (uint32_t)(colbase * 64 + r.lane);
-        const double l_a = lij[pos];
-        const double l_b = lij[idx_t[pos]];
-        l[c] = fmin(l_a, l_b);
-        if (c < CP)
-          load_entry<K>(pij, colbase, r.lane, p[c < CP ? c : 0]);
+    } else {
+#pragma unroll
+      for (int c = 1; c < MAXW; ++c) {
+        l[c] = 0.;
+        if (c < CP) {
+#pragma unroll
+          for (int q = 0; q < K; ++q)
+            p[c < CP ? c : 0][q] = 0.;
+        }
+        if ((uint32_t)c < r.width) {
+          const uint64_t colbase = (uint64_t)r.base + c;
+          const uint32_t pos = (uint32_t)(colbase * 64 + r.lane);
+          const double l_a = lij[pos];
+          const double l_b = lij[idx_t[pos]];
+          l[c] = fmin(l_a, l_b);
+          if (c < CP)
+            load_entry<K>(pij, colbase, r.lane, p[c < CP ? c : 0]);
+        }
       }
     }
 #pragma unroll

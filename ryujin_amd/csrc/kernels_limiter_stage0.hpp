@@ -1,0 +1,180 @@
+// Step 5 of HyperbolicModule::step (source/hyperbolic_module.template.h:892-1041) without stage vectors
+// (stages == 0: every update of SSPRK22/33, the first stage of the ERK schemes), for the Descriptions whose
+// P_ij has no source terms (Euler): P_ij IS FORMED HERE, ONCE, instead of being started in step 4 and
+// finished in step 5.
+//
+// Without stage vectors the weight of the current flux is 1 - sum_s omega_s = 1, and the first part of P_ij,
+//   P_ij = -flux_ij + (d_ij^H - d_ij)(U_j - U_i) + 1 * flux_ij                          (:795-846)
+// is (d_ij^H - d_ij)(U_j - U_i) up to the rounding of the two flux terms that cancel. The reference stores that
+// first part in step 4 (8 k S bytes per row) and reads, corrects and stores it again in step 5 -- in 3-D a
+// third of all bytes an update moves. Here step 4 does not touch P_ij, and step 5 forms
+//   P_ij = tau / m_i * (S - 1) * [ (d_ij^H - d_ij)(U_j - U_i) + b_ij F_j - b_ji F_i ],
+//   b_ij = -m_ij / m_j,  b_ji = -m_ij / m_i                                              (:987-1001)
+// in registers from what it streams (d_ij, m_ij) and gathers from the per-node vectors (U_j, F_j, alpha_j,
+// 1/m_j: they stay in L2 / Infinity Cache between neighbouring rows), limits it and stores it for the two
+// high-order passes. Neither c_ij nor a flux is evaluated (the 2-D kernel of rounds 1-2 recomputed the first part
+// in the reference's operation order: c_ij stream + one flux evaluation per pair). Against the reference this
+// P_ij differs by the cancellation residue of its flux terms, eps * |flux_ij|: ~1e-15 of the largest entry, three
+// orders inside the 1e-12 contract on P_ij (tests/helpers_parity.py); its first part is antisymmetric bit for
+// bit (d_ij = d_ji, alpha_i + alpha_j symmetric), which the reference's is only to round-off.
+//
+// The sweep also leaves, per row, V_i = U_i^low + sum_j lambda P_ij accumulated exactly as step 6 accumulates
+// U_i^low + sum_j l_ij lambda P_ij when every l_ij is 1: in slices where nothing was limited step 6 takes V_i
+// and never reads P_ij (kernels_limiter.hpp) -- bit-identical, and most of a developed flow.
+//
+// (Measured and dropped, profiles/r03f_ab_variants_*: forming P_ij on the fly in steps 6 and 7 as well, so that it
+// is never stored. Step 5 gained what is kept here, but the two high-order sweeps lost more than the P_ij stream
+// costs them -- six dependent gathers per column through the texture addresser against two coalesced 16-byte
+// streams: 2-D step 6 0.227 -> 0.332 ms, 3-D 1.61 -> 2.06 ms.)
+
+#pragma once
+
+#include "kernels_limiter.hpp"
+
+namespace ryujin_hip
+{
+#ifndef RYUJIN_OCC_LIJ0
+#define RYUJIN_OCC_LIJ0 3 /* waves per SIMD asked of the register allocator */
+#endif
+#ifndef RYUJIN_OCC_LIJ0_3D
+#define RYUJIN_OCC_LIJ0_3D 2 /* A/B on MI355X (4.2 M gridpoints): 2.15 ms at 3 waves (28 B/lane of scratch), 1.85 at 2 */
+#endif
+
+  /* what a row needs of a neighbour to form P_ij */
+  template <int K>
+  struct PairData {
+    double U_j[K], F_j[K];
+    double d_ij, m_ij, alpha_j, m_j_inv;
+  };
+
+  /* per-row constants */
+  template <int K>
+  struct RowData {
+    double U_i[K], F_i[K];
+    double alpha_i, m_i_inv, factor; /* factor = tau / m_i * (row_length - 1) */
+  };
+
+  template <int K>
+  RYUJIN_DEV void load_pair(const DeviceMesh &M, const double *__restrict__ old_U,
+                            const double *__restrict__ r_in, const double *__restrict__ alpha,
+                            const double *__restrict__ dij, const uint64_t pos, const uint32_t j, PairData<K> &p)
+  {
+    p.d_ij = dij[pos];
+    p.m_ij = ld_stream(M.mij + pos);
+    load_state<K>(old_U, j, p.U_j);
+    load_state<K>(r_in, j, p.F_j);
+    p.alpha_j = alpha[j];
+    p.m_j_inv = M.mi_inv[j];
+  }
+
+  /* P_ij for stages == 0 (see the header comment) */
+  template <int K>
+  RYUJIN_DEV void pij_stage0(const RowData<K> &row, const PairData<K> &p, double (&P_ij)[K])
+  {
+    const double d_ijH = p.d_ij * ((row.alpha_i + p.alpha_j) * .5);
+    const double dd = d_ijH - p.d_ij;
+    /* Neumann series: b_ij = delta_ij - m_ij/m_j, b_ji = delta_ij - m_ij/m_i (:987-996) */
+    const double b_ij = 0. - p.m_ij * p.m_j_inv;
+    const double b_ji = 0. - p.m_ij * row.m_i_inv;
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+      double v = dd * (p.U_j[q] - row.U_i[q]);
+      v += b_ij * p.F_j[q] - b_ji * row.F_i[q];
+      P_ij[q] = v * row.factor;
+    }
+  }
+
+  /* NY > 1 (small meshes): NY waves (blockIdx.y) share a slice, wave y taking the columns 1 + y, 1 + y + NY, ...;
+   * no V_i then (the row's sum is spread over several waves): the caller passes V_out = nullptr */
+  template <typename E, int NY = 1>
+  __global__ void __launch_bounds__(kBlock, (E::DIMENSION == 3 ? RYUJIN_OCC_LIJ0_3D : RYUJIN_OCC_LIJ0))
+  k_lij_stage0(const typename E::Params P, const DeviceMesh M, DeviceScalars *__restrict__ scalars,
+               const double *__restrict__ old_U, const double *__restrict__ alpha,
+               const double *__restrict__ dij, const double *__restrict__ new_U,
+               const double *__restrict__ r_in, const double *__restrict__ bounds, double *__restrict__ pij,
+               double *__restrict__ lij, double *__restrict__ V_out)
+  {
+    constexpr int K = E::K;
+    constexpr int NB = E::NB;
+    const RowCtx r = row_context(M);
+    if (!r.valid)
+      return;
+    const bool row_active = r.len > 1;
+    const uint32_t i = row_active ? r.row : (r.row < M.n_owned ? r.row : M.n_owned - 1);
+    const uint32_t *__restrict__ cols = M.cols;
+
+    const size_t stride = M.bounds_stride;
+    double bnd[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+      bnd[b] = bounds[(size_t)b * stride + i];
+    double U_i_new[K], V_i[K];
+    load_state<K>(new_U, i, U_i_new);
+#pragma unroll
+    for (int q = 0; q < K; ++q)
+      V_i[q] = U_i_new[q];
+    RowData<K> row;
+    load_state<K>(old_U, i, row.U_i);
+    load_state<K>(r_in, i, row.F_i);
+    row.alpha_i = alpha[i];
+    row.m_i_inv = M.mi_inv[i];
+    row.factor = scalars->tau * row.m_i_inv * (double)(r.len - 1);
+    const double lambda = 1. / (double)(r.len - 1);
+    bool all_ok = true;
+    unsigned long long undecided_mask = 0;
+
+    const uint32_t c0 = 1 + (NY > 1 ? blockIdx.y : 0);
+    /* software pipeline: the loads of the next column are in flight while column c is limited */
+    uint32_t j_n = r.width > c0 ? ld_stream(cols + (((uint64_t)r.base + c0) * 64 + r.lane)) : i;
+    uint32_t j_nn = r.width > c0 + NY ? ld_stream(cols + (((uint64_t)r.base + c0 + NY) * 64 + r.lane)) : i;
+    PairData<K> next;
+    if (r.width > c0)
+      load_pair<K>(M, old_U, r_in, alpha, dij, ((uint64_t)r.base + c0) * 64 + r.lane, j_n, next);
+
+    for (uint32_t c = c0; c < r.width; c += NY) {
+      const uint64_t colbase = (uint64_t)r.base + c;
+      const uint64_t pos = colbase * 64 + r.lane;
+      const bool active = row_active && c < r.len;
+      double P_ij[K];
+      pij_stage0<K>(row, next, P_ij);
+      if (c + NY < r.width) {
+        j_n = j_nn;
+        load_pair<K>(M, old_U, r_in, alpha, dij, (colbase + NY) * 64 + r.lane, j_n, next);
+        j_nn = (c + 2 * NY < r.width) ? ld_stream(cols + ((colbase + 2 * NY) * 64 + r.lane)) : i;
+      }
+      if (!active)
+        continue;
+      store_entry<K>(pij, colbase, r.lane, P_ij);
+      if (NY == 1) {
+        /* what the first high-order pass adds when nothing is limited: U += l lambda P with l = 1 (:1107-1131) */
+#pragma unroll
+        for (int q = 0; q < K; ++q)
+          V_i[q] += lambda * P_ij[q];
+      }
+      bool success, undecided;
+      const double l_ij = E::limit_fast(P, bnd, U_i_new, P_ij, success, undecided);
+      if (undecided) {
+        undecided_mask |= 1ull << c;
+      } else {
+        lij[pos] = l_ij;
+        all_ok = all_ok && success;
+      }
+    }
+    if (NY == 1 && V_out != nullptr && row_active)
+      store_state<K>(V_out, i, V_i);
+
+    /* the few pairs that need the Newton iteration */
+    while (undecided_mask) {
+      const uint32_t c = (uint32_t)__builtin_ctzll(undecided_mask);
+      undecided_mask &= undecided_mask - 1;
+      const uint64_t colbase = (uint64_t)r.base + c;
+      double P_ij[K];
+      load_entry<K>(pij, colbase, r.lane, P_ij);
+      bool success;
+      const double l_ij = E::limit(P, bnd, U_i_new, P_ij, success);
+      lij[colbase * 64 + r.lane] = l_ij;
+      all_ok = all_ok && success;
+    }
+    flag_restart(scalars, all_ok, r.lane);
+  }
+} // namespace ryujin_hip

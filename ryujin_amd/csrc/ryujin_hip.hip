@@ -30,6 +30,7 @@
 #include "host_layout.hpp"
 #include "kernels_euler.hpp"
 #include "kernels_limiter.hpp"
+#include "kernels_limiter_stage0.hpp"
 #include "kernels_euler_aeos.hpp"
 #include "kernels_shallow_water.hpp"
 #include "scalar_conservation_device.hpp"
@@ -390,6 +391,15 @@ struct ryujin_hip_ctx {
   DeviceBuffer<uint32_t> d_send_idx, d_row_send_pos;
   DeviceBuffer<double> d_send_buf;
 
+  /* step 5 of the running step left V_i = U_i^low + sum_j lambda P_ij (k_lij_stage0): step 6 may take it */
+  DeviceBuffer<double> d_V;
+  bool stage0_V = false;
+  void ensure_pij()
+  {
+    if (d_pij.n == 0)
+      d_pij.alloc(L.nnz_total * (size_t)K);
+  }
+
   unsigned n_restarts = 0, n_warnings = 0;
   unsigned long long n_exchanges = 0, n_allreduces = 0; /* ryujin_hip_exchange_info */
 
@@ -741,7 +751,7 @@ void ryujin_hip_ctx::create(const ryujin_hip_offline &o, const ryujin_hip_params
   d_dij.alloc(L.nnz_total);
   d_lij.alloc(L.nnz_total);
   d_lij_next.alloc(L.nnz_total);
-  d_pij.alloc(L.nnz_total * (size_t)K);
+  /* (p_ij is allocated by the first step: ensure_pij) */
   d_scalars.alloc(1);
 
   /* ---- exchange pattern ---- */
@@ -1297,6 +1307,15 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
    * to 1.34 ms on 4.2 M gridpoints but step 5 grows from 2.16 to 2.77-2.94 ms (27 flux evaluations per row at
    * 240 registers): -0.7 % ... +1.5 % per update, inside the run-to-run spread -- so only for dim <= 2. */
   const bool recompute_p = is_euler && DIM <= 2 && stages == 0 && params.limiter_iterations != 0 && !dg;
+  /* Euler, stages == 0, Q1 stencil widths: P_ij is never materialised, steps 5-7 form it on the fly from
+   * d_ij, m_ij and the per-node vectors (kernels_limiter_stage0.hpp) -- any dimension */
+  constexpr int kStage0Width = DIM == 1 ? 3 : (DIM == 2 ? 9 : 27);
+  const bool stage0_pij = RYUJIN_STAGE0_PIJ && is_euler && stages == 0 && params.limiter_iterations != 0 && !dg &&
+                          L.max_row_len <= (uint32_t)kStage0Width;
+  stage0_V = false;
+  ensure_pij();
+  if (stage0_pij && d_V.n == 0)
+    d_V.alloc((size_t)L.n_relevant * KP);
   sweep([&](const DeviceMesh &mm, dim3 grid) {
     if constexpr (is_euler) {
       if (dg && stages == 0)
@@ -1307,7 +1326,7 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
         hipLaunchKernelGGL((k_low_order<DIM, true, true, true>), grid, block, 0, launch_stream, eparams, mm,
                            d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_alpha.ptr, d_dij.ptr,
                            nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
-      else if (recompute_p)
+      else if (recompute_p || stage0_pij)
         hipLaunchKernelGGL((k_low_order<DIM, false, false>), grid, block, 0, launch_stream, eparams, mm,
                            d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_alpha.ptr, d_dij.ptr,
                            nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
@@ -1391,6 +1410,28 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
   if (n_iterations != 0) {
     sweep([&](const DeviceMesh &mm, dim3 grid) {
       if constexpr (is_euler) {
+        if (stage0_pij) {
+          /* small meshes: up to four waves per slice, each taking a share of the columns (decided for the whole
+           * mesh, not per launch: the export and the interior part of a split sweep must agree on whether V_i exists) */
+          const uint32_t n_blocks = (L.n_slices + kWavesPerBlock - 1) / kWavesPerBlock;
+          const uint32_t groups = std::min<uint32_t>(4u, resident_waves_step5 / std::max<uint32_t>(1u, n_blocks * kWavesPerBlock));
+          auto launch5 = [&](auto ny) {
+            constexpr int NY = decltype(ny)::value;
+            hipLaunchKernelGGL((k_lij_stage0<E, NY>), dim3(grid.x, NY), block, 0, launch_stream, eparams, mm,
+                               d_scalars.ptr, old.U.ptr, d_alpha.ptr, d_dij.ptr, nw.U.ptr, d_r.ptr, d_bounds.ptr,
+                               d_pij.ptr, d_lij.ptr, NY == 1 ? d_V.ptr : nullptr);
+            stage0_V = NY == 1;
+          };
+          if (groups >= 4)
+            launch5(std::integral_constant<int, 4>{});
+          else if (groups == 3)
+            launch5(std::integral_constant<int, 3>{});
+          else if (groups == 2)
+            launch5(std::integral_constant<int, 2>{});
+          else
+            launch5(std::integral_constant<int, 1>{});
+          return;
+        }
         if (recompute_p) {
           /* small meshes: up to four waves per slice, each taking a share of the columns (see the kernel), as
            * long as all of them are resident at once (256 CUs x 4 SIMDs x 2 waves of this kernel) */
@@ -1456,14 +1497,14 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
           if (L.max_row_len <= (uint32_t)kCachedWidth && n_launch * kWavesPerBlock <= resident_waves_step6) {
             hipLaunchKernelGGL((k_high_order_next_cached<E, kCachedWidth, kCachedWidth, true>), dim3(n_launch),
                                block, 0, launch_stream, eparams, mm, nw.U.ptr, d_bounds.ptr, d_pij.ptr,
-                               d_lij.ptr, d_lij_next.ptr);
+                               d_lij.ptr, d_lij_next.ptr, stage0_V ? d_V.ptr : nullptr);
             return;
           }
         }
         if ((DIM <= 2 || RYUJIN_HO_CP_3D > 0) && L.max_row_len <= (uint32_t)kCachedWidth)
           hipLaunchKernelGGL((k_high_order_next_cached<E, kCachedWidth, kCachedP>), grid, block, 0,
                              launch_stream, eparams, mm, nw.U.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr,
-                             d_lij_next.ptr);
+                             d_lij_next.ptr, stage0_V ? d_V.ptr : nullptr);
         else
           hipLaunchKernelGGL((k_high_order<E, false>), grid, block, 0, launch_stream, eparams, mm, nw.U.ptr,
                              d_bounds.ptr, d_pij.ptr, d_lij.ptr, d_lij_next.ptr, FusedSadd{0., 0., nullptr});
@@ -2349,7 +2390,10 @@ int ryujin_hip_debug_fetch(ryujin_hip_ctx *ctx, int what, double *out, size_t n_
     switch (what) {
     case 0: fetch_matrix(ctx->d_dij.ptr, 1); break;
     case 1: fetch_matrix(ctx->d_lij.ptr, 1); break;
-    case 2: fetch_matrix(ctx->d_pij.ptr, (uint32_t)ctx->K); break;
+    case 2:
+      ctx->ensure_pij();
+      fetch_matrix(ctx->d_pij.ptr, (uint32_t)ctx->K);
+      break;
     case 5: fetch_matrix(ctx->d_lij_next.ptr, 1); break;
     case 6:
     case 7:
