@@ -574,6 +574,10 @@ def main():
                      "traffic": traffic,
                      "traffic_source": (f"{traffic_file} (separate rocprofv3 --pmc passes of this command, "
                                         "bytes per launch)") if traffic_file else None,
+                     "traffic_calibration": ("(2 FETCH_SIZE + WRITE_SIZE) x 1024; factor 2.000 measured for streaming "
+                                             "reads of 4/8/16 B per lane, 1.98-1.99 for stencil-order gathers of "
+                                             "32/64-byte records, WRITE_SIZE 1.000 "
+                                             "(profiles/r03h_counter_calibration.md)") if traffic_file else None,
                      "algorithmic_bytes_per_gridpoint": alg[dom],
                      "mean_launch_ms": per_sweep[dom]},
         "roofline_update": {"bound": "hbm", "achieved": upd_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
