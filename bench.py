@@ -42,7 +42,7 @@ def algorithmic_bytes(dim: int, k: int, S: float, n_prec: int = 2, n_bounds: int
 KERNEL_OF_SWEEP = {  # sweep name -> kernel-name prefixes in the rocprof summaries
     "2 dij_alpha": ("k_dij_alpha",), "2a alpha (k_alpha)": ("k_alpha",), "2b dij (k_dij)": ("k_dij<",),
     "3 dij_diag_tau": ("k_dij_diag",), "4 low_order": ("k_low_order",),
-    "5 pij_lij": ("k_pij_lij",), "6 high_order_next_lij": ("k_high_order_next_cached", "k_high_order<"),
+    "5 pij_lij": ("k_lij_stage0", "k_pij_lij"), "6 high_order_next_lij": ("k_high_order_next_cached", "k_high_order<"),
     "7 high_order": ("k_high_order<",),
 }
 

@@ -407,6 +407,9 @@ int ryujin_hip_event_elapsed_ms(ryujin_hip_ctx *ctx, double *ms);
  * device layout and gathered back into out [nnz*n_comp] (AoS per entry). Any pointer may be NULL. */
 int ryujin_hip_debug_layout(const ryujin_hip_offline *offline, uint64_t *ptr, uint32_t *col,
                             uint64_t *transposed, const double *data, uint32_t n_comp, double *out);
+/* Device addresses of the stencil streams of a context (cols, c_ij, m_ij, d_ij, l_ij, l'_ij, p_ij, idx_t): for
+ * the placement study of scripts/placement_probe.py (how the kernel times depend on where the allocator put them). */
+int ryujin_hip_debug_addresses(ryujin_hip_ctx *ctx, uint64_t out[8]);
 /* Evaluate the device implementation of ryujin::pow (source/simd.template.h:196-272) on n pairs:
  * out[i] = pow(x[i], y[i]). Needs a GPU; used by the parity tests only. */
 int ryujin_hip_debug_pow(int device, const double *x, const double *y, double *out, size_t n);

@@ -67,6 +67,7 @@ namespace
   template <typename T>
   struct DeviceBuffer {
     T *ptr = nullptr;
+    void *base = nullptr;
     size_t n = 0;
     DeviceBuffer() = default;
     DeviceBuffer(const DeviceBuffer &) = delete;
@@ -74,9 +75,10 @@ namespace
     ~DeviceBuffer() { release(); }
     void release()
     {
-      if (ptr)
-        (void)hipFree(ptr);
+      if (base)
+        (void)hipFree(base);
       ptr = nullptr;
+      base = nullptr;
       n = 0;
     }
     void alloc(size_t count, bool zero = true)
@@ -85,7 +87,10 @@ namespace
       n = count;
       if (count == 0)
         count = 1;
-      HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&ptr), count * sizeof(T)));
+      /* (the allocator hands out 2 MiB aligned blocks; shifting the streams of a context against each other by
+       * 4.25 KiB or 260 KiB per stream changed no kernel time: profiles/r03i_placement_*.log) */
+      HIP_CHECK(hipMalloc(&base, count * sizeof(T)));
+      ptr = static_cast<T *>(base);
       if (zero) {
         /* hipMemset on device memory is asynchronous and ordered on the NULL stream, which does not
          * synchronise with the non-blocking streams of the context: a kernel launched right after the
@@ -2442,6 +2447,20 @@ int ryujin_hip_debug_fetch(ryujin_hip_ctx *ctx, int what, double *out, size_t n_
     }
     default: throw HipError(RYUJIN_ERR_ARG, "unknown debug_fetch selector");
     }
+    return RYUJIN_OK;
+  });
+}
+
+int ryujin_hip_debug_addresses(ryujin_hip_ctx *ctx, uint64_t out[8])
+{
+  return guarded([&]() {
+    if (!ctx || !out)
+      throw HipError(RYUJIN_ERR_ARG, "null argument");
+    ctx->ensure_pij();
+    const void *p[8] = {ctx->d_cols.ptr, ctx->d_cij.ptr, ctx->d_mij.ptr, ctx->d_dij.ptr,
+                        ctx->d_lij.ptr,  ctx->d_lij_next.ptr, ctx->d_pij.ptr, ctx->d_idx_t.ptr};
+    for (int q = 0; q < 8; ++q)
+      out[q] = (uint64_t)(uintptr_t)p[q];
     return RYUJIN_OK;
   });
 }
