@@ -760,6 +760,9 @@ namespace oracle
     int n_prec() const override { return 2; }
     int n_bounds() const override { return NB; }
 
+    bool discontinuous_ansatz = false;
+    std::vector<double> incidence, mass_matrix_inverse;
+
     ShallowWaterModule(const ryujin_hip_offline &o, const ryujin_hip_params &p)
         : view(p)
     {
@@ -778,6 +781,14 @@ namespace oracle
         Z.assign(o.initial_precomputed, o.initial_precomputed + n_relevant);
       else
         Z.assign(n_relevant, 0.);
+      /* discontinuous ansatz (hyperbolic_module.template.h:287-293): incidence matrix, full inverse mass matrix */
+      discontinuous_ansatz = o.discontinuous_ansatz != 0;
+      if (discontinuous_ansatz) {
+        if (!o.incidence || !o.mass_matrix_inverse)
+          throw std::runtime_error("discontinuous ansatz without incidence / inverse mass matrix");
+        incidence = csr.gather(o, o.incidence, 1);
+        mass_matrix_inverse = csr.gather(o, o.mass_matrix_inverse, 1);
+      }
       measure_of_omega = o.measure_of_omega;
       b_i.assign(o.b_i, o.b_i + o.n_bdry);
       b_normal.assign(o.b_normal, o.b_normal + (size_t)o.n_bdry * dim);
@@ -1010,7 +1021,9 @@ namespace oracle
             const auto U_j = get_state(old_U, j);
             const double Z_j = Z[j];
             const double d_ij = dij[e];
-            const double factor = (alpha_i + alpha[j]) * .5;
+            double factor = (alpha_i + alpha[j]) * .5;
+            if (discontinuous_ansatz) /* :733-737 */
+              factor = std::max(factor, incidence[e]);
             const double d_ijH = d_ij * factor;
             const auto c_ij = get_c(e);
             const double denom = std::max(d_ij, 100. * std::numeric_limits<double>::min());
@@ -1078,9 +1091,38 @@ namespace oracle
         }
       }
       do_exchange(EX_R, r.data(), K);
+      if (discontinuous_ansatz) /* the bounds are extended over the stencil below: ghost range (:603-612) */
+        do_exchange(EX_BOUNDS, bounds.data(), NB);
 
       /* Step 5 */
       const int n_iterations = params.limiter_iterations;
+      if (n_iterations != 0 && discontinuous_ansatz) {
+        /* Extend the bounds over the stencil (:938-948) with Limiter::combine_bounds AS WRITTEN
+         * (shallow_water/limiter.h:386-397): (min h_min, max h_max, min h_small, max(k_max_l, H_MAX_r) -- sic: the
+         * fourth entry takes the water-depth bound of the right argument, not its kinetic-energy bound --,
+         * max v2_max). The left argument is the running result, the right one a neighbour's ORIGINAL bounds (the
+         * reference combines in place while other threads read; see hyperbolic_module.hpp). */
+        const std::vector<double> original(bounds);
+#pragma omp parallel for schedule(static)
+        for (uint32_t i = 0; i < n_owned; ++i) {
+          const uint64_t rs = csr.ptr[i], re = csr.ptr[i + 1];
+          if (re - rs == 1)
+            continue;
+          double b[NB];
+          for (int q = 0; q < NB; ++q)
+            b[q] = original[(size_t)i * NB + q];
+          for (uint64_t e = rs + 1; e < re; ++e) {
+            const double *right = &original[(size_t)csr.col[e] * NB];
+            b[0] = std::min(b[0], right[0]);
+            b[1] = std::max(b[1], right[1]);
+            b[2] = std::min(b[2], right[2]);
+            b[3] = std::max(b[3], right[1]); /* sic */
+            b[4] = std::max(b[4], right[4]);
+          }
+          for (int q = 0; q < NB; ++q)
+            bounds[(size_t)i * NB + q] = b[q];
+        }
+      }
       if (n_iterations != 0) {
 #pragma omp parallel
         {
@@ -1101,8 +1143,14 @@ namespace oracle
             for (uint64_t e = rs + 1; e < re; ++e) {
               const uint32_t j = csr.col[e];
               const auto F_jH = get_state(r, j);
-              const double b_ij = 0. - mij[e] * mi_inv[j];
-              const double b_ji = 0. - mij[e] * m_i_inv;
+              double b_ij, b_ji;
+              if (discontinuous_ansatz) { /* full consistent mass matrix inverse (:976-986) */
+                b_ij = mi[i] * mass_matrix_inverse[e] - 0.;
+                b_ji = mi[j] * mass_matrix_inverse[e] - 0.;
+              } else { /* Neumann series (:988-996) */
+                b_ij = 0. - mij[e] * mi_inv[j];
+                b_ji = 0. - mij[e] * m_i_inv;
+              }
               state_type P_ij;
               for (int q = 0; q < K; ++q) {
                 P_ij[q] = pij[e * K + q];

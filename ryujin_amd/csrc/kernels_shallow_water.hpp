@@ -18,7 +18,8 @@
 
 namespace ryujin_hip
 {
-  template <int DIM, bool HAS_STAGES>
+  /* DG: discontinuous ansatz, the incidence matrix enters the high-order viscosity (:733-737) */
+  template <int DIM, bool HAS_STAGES, bool DG = false>
   __global__ void __launch_bounds__(kBlock, RYUJIN_OCC_LOW)
   k_low_order_sw(const ShallowWaterParams P, const DeviceMesh M,
                  DeviceScalars *scalars, const double weight,
@@ -171,7 +172,9 @@ namespace ryujin_hip
       if (!active)
         continue;
 
-      const double factor = (alpha_i + alpha_j) * .5;
+      double factor = (alpha_i + alpha_j) * .5;
+      if constexpr (DG)
+        factor = fmax(factor, M.incidence[colbase * 64 + r.lane]);
       const double d_ijH = d_ij * factor;
       const double denom = fmax(d_ij, 100. * DBL_MIN);
       double scaled_c_ij[DIM];
@@ -660,5 +663,40 @@ namespace ryujin_hip
     bounds[2 * stride + i] = h_small;
     bounds[3 * stride + i] = kin_max_r;
     bounds[4 * stride + i] = v2_max_r;
+  }
+  /* Discontinuous ansatz: extend the limiter bounds over the stencil (hyperbolic_module.template.h:938-948) with
+   * Limiter::combine_bounds AS WRITTEN in shallow_water/limiter.h:386-397:
+   *   (min h_min, max h_max, min h_small, max(k_max_l, H_MAX_r) [sic], max v2_max)
+   * -- the kinetic-energy bound of the running result is combined with the water-depth bound of the neighbour.
+   * Reads the ORIGINAL bounds of the neighbours and writes a second buffer (as k_bounds_combine_euler). */
+  __global__ void __launch_bounds__(kBlock)
+  k_bounds_combine_sw(const DeviceMesh M, const double *__restrict__ in, double *__restrict__ out)
+  {
+    const RowCtx r = row_context(M);
+    if (!r.valid)
+      return;
+    const bool row_active = r.len > 1;
+    const uint32_t i = row_active ? r.row : (r.row < M.n_owned ? r.row : M.n_owned - 1);
+    const size_t stride = M.bounds_stride;
+    double b[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q)
+      b[q] = in[(size_t)q * stride + i];
+    for (uint32_t c = 1; c < r.width; ++c) {
+      const uint32_t j = M.cols[((uint64_t)r.base + c) * 64 + r.lane];
+      if (row_active && c < r.len) {
+        const double h_max_r = in[stride + j];
+        b[0] = fmin(b[0], in[j]);
+        b[1] = fmax(b[1], h_max_r);
+        b[2] = fmin(b[2], in[2 * stride + j]);
+        b[3] = fmax(b[3], h_max_r); /* sic */
+        b[4] = fmax(b[4], in[4 * stride + j]);
+      }
+    }
+    if (row_active) {
+#pragma unroll
+      for (int q = 0; q < 5; ++q)
+        out[(size_t)q * stride + i] = b[q];
+    }
   }
 } // namespace ryujin_hip

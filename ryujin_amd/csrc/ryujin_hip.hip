@@ -637,8 +637,9 @@ void ryujin_hip_ctx::create(const ryujin_hip_offline &o, const ryujin_hip_params
     d_mij.upload(mij);
     dg = o.discontinuous_ansatz != 0;
     if (dg) {
-      if (p.equation != RYUJIN_EQ_EULER)
-        throw HipError(RYUJIN_ERR_UNSUPPORTED, "discontinuous ansatz: Euler equations only in this version");
+      if (p.equation != RYUJIN_EQ_EULER && p.equation != RYUJIN_EQ_SHALLOW_WATER)
+        throw HipError(RYUJIN_ERR_UNSUPPORTED,
+                       "discontinuous ansatz: Euler and shallow-water equations only in this version");
       if (!o.incidence || !o.mass_matrix_inverse)
         throw HipError(RYUJIN_ERR_ARG, "discontinuous ansatz without incidence / inverse mass matrix");
       d_incidence.upload(L.scatter(o, o.incidence, 1));
@@ -1365,7 +1366,7 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
       /* rows of at most 3 / 9 columns (1-D, 2-D Q1): one walk over the stencil, the shift-free part of the
        * limiter's U_ij_bar parked in LDS (kernels_shallow_water.hpp); wider rows: the two walks of the reference */
       constexpr int kSwWidth = DIM == 1 ? 3 : 9;
-      const bool single_walk = RYUJIN_SW_SINGLE_WALK && L.max_row_len <= (uint32_t)kSwWidth;
+      const bool single_walk = RYUJIN_SW_SINGLE_WALK && !dg && L.max_row_len <= (uint32_t)kSwWidth;
       auto launch_single_walk = [&](auto has_stages, auto friction) {
         hipLaunchKernelGGL((k_low_order_sw_single_walk<DIM, decltype(has_stages)::value, kSwWidth,
                                                        decltype(friction)::value>),
@@ -1381,6 +1382,14 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
         launch_single_walk(std::true_type{}, std::true_type{});
       else if (single_walk)
         launch_single_walk(std::true_type{}, std::false_type{});
+      else if (dg && stages == 0)
+        hipLaunchKernelGGL((k_low_order_sw<DIM, false, true>), grid, block, 0, launch_stream, eparams, mm,
+                           d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_Z.ptr, d_alpha.ptr,
+                           d_dij.ptr, nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
+      else if (dg)
+        hipLaunchKernelGGL((k_low_order_sw<DIM, true, true>), grid, block, 0, launch_stream, eparams, mm,
+                           d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_Z.ptr, d_alpha.ptr,
+                           d_dij.ptr, nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
       else if (stages == 0)
         hipLaunchKernelGGL((k_low_order_sw<DIM, false>), grid, block, 0, launch_stream, eparams, mm,
                            d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_Z.ptr, d_alpha.ptr,
@@ -1402,12 +1411,17 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
 
   /* Step 5: second part of p_ij, first l_ij; ghost rows of l_ij (:892-1041) */
   const int n_iterations = params.limiter_iterations;
-  if constexpr (is_euler) {
+  if constexpr (is_euler || is_sw) {
     if (dg && n_iterations != 0) {
-      /* bounds over the stencil (:938-948); steps 5-7 read the extended bounds */
+      /* bounds over the stencil (:938-948) with the Description's Limiter::combine_bounds; steps 5-7 read the
+       * extended bounds */
       sweep([&](const DeviceMesh &mm, dim3 grid) {
-        hipLaunchKernelGGL(k_bounds_combine_euler, grid, block, 0, launch_stream, mm, d_bounds.ptr,
-                           d_bounds_combined.ptr);
+        if constexpr (is_euler)
+          hipLaunchKernelGGL(k_bounds_combine_euler, grid, block, 0, launch_stream, mm, d_bounds.ptr,
+                             d_bounds_combined.ptr);
+        else
+          hipLaunchKernelGGL(k_bounds_combine_sw, grid, block, 0, launch_stream, mm, d_bounds.ptr,
+                             d_bounds_combined.ptr);
       });
       std::swap(d_bounds.ptr, d_bounds_combined.ptr);
     }
@@ -1458,7 +1472,7 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
           return;
         }
       }
-      if constexpr (is_euler) {
+      if constexpr (is_euler || is_sw) {
         if (dg) {
           hipLaunchKernelGGL((k_pij_lij<E, true>), grid, block, 0, launch_stream, eparams, mm, d_scalars.ptr,
                              nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr);

@@ -162,3 +162,136 @@ def test_dg_q1_partitioned_hip_matches_single_rank():
     assert (np.abs(U - U_ref) / np.abs(U_ref).max(axis=0)).max() < 1e-12
     for r in range(n_ranks):
         lib.ryujin_hip_comm_destroy(C.c_void_p(comms[r]))
+
+
+# ------------------------------------------------------------------ shallow water on the dG-Q1 stencil
+
+def _sw_params(oracle, dim):
+    p = oracle.default_params(capi.EQ_SHALLOW_WATER, dim)
+    p.cfl = 0.4
+    return p
+
+
+def _sw_hump(positions, centre, radius=0.18, Z=None):
+    """water at rest with a smooth compact hump of the free surface: (h, q)"""
+    dim = positions.shape[1]
+    r2 = ((positions - np.asarray(centre)) ** 2).sum(1) / radius ** 2
+    bump = np.where(r2 < 1.0, np.exp(1.0 - 1.0 / np.maximum(1.0 - r2, 1e-300)), 0.0)
+    U = np.zeros((len(positions), dim + 1))
+    U[:, 0] = 1.0 + 0.4 * bump - (0.0 if Z is None else Z)
+    return U
+
+
+@pytest.mark.parametrize("n_cells,h", [((64,), 1.0 / 64), ((28, 28), 1.0 / 28)])
+def test_sw_oracle_conserves_on_a_dg_q1_stencil(oracle, n_cells, h):
+    """Shallow water with the discontinuous ansatz in the oracle: incidence matrix in the high-order viscosity,
+    full inverse mass matrix, bounds extended over the stencil with Limiter::combine_bounds AS WRITTEN
+    (shallow_water/limiter.h:386-397: the kinetic-energy bound is combined with the neighbour's water-depth bound).
+    Flat bed: mass and momentum are conserved to round-off while the waves stay away from the boundary."""
+    off, info = dg_q1_offline(n_cells, h)
+    dim = len(n_cells)
+    p = _sw_params(oracle, dim)
+    m = HyperbolicModule(off, p, backend=oracle.backend())
+    U0 = _sw_hump(off.positions, [0.5] * dim, radius=0.15)
+    a, b = m.new_state_vector(U0), m.new_state_vector()
+    before = (off.mi[:, None] * U0).sum(0)
+    for _ in range(10 if dim == 1 else 6):
+        m.prepare_state_vector(a, 0.0)
+        m.step(a, [], [], b)
+        a, b = b, a
+    U = a.download()
+    assert np.isfinite(U).all() and U[:, 0].min() > 0.5
+    assert np.abs(U - U0).max() > 1e-3
+    assert np.abs(U - U0)[info["is_bdry"]].max() < 1e-12
+    after = (off.mi[:, None] * U).sum(0)
+    scale = (off.mi[:, None] * np.abs(U)).sum(0).max()
+    assert np.abs(after - before).max() <= 1e-13 * scale, (after - before) / scale
+
+
+def test_sw_oracle_lake_at_rest_on_a_dg_q1_stencil(oracle):
+    """well-balancedness survives the dG branch: h + Z = const, q = 0 over a smooth bathymetry stays at rest"""
+    off, info = dg_q1_offline((24, 24), 1.0 / 24)
+    x = off.positions
+    Z = 0.3 * np.exp(-20.0 * ((x - 0.5) ** 2).sum(1))
+    off.set_initial_precomputed(Z)
+    p = _sw_params(oracle, 2)
+    m = HyperbolicModule(off, p, backend=oracle.backend())
+    U0 = np.zeros((off.n_owned, 3))
+    U0[:, 0] = 1.0 - Z
+    a, b = m.new_state_vector(U0), m.new_state_vector()
+    for _ in range(5):
+        m.prepare_state_vector(a, 0.0)
+        m.step(a, [], [], b)
+        a, b = b, a
+    U = a.download()
+    assert np.abs(U[:, 0] + Z - 1.0).max() < 1e-13
+    assert np.abs(U[:, 1:]).max() < 1e-13
+
+
+def test_sw_partitioned_oracle_dg_matches_single_rank(oracle):
+    from helpers_unstructured import partition, run_partitioned_oracle
+    n_cells, h = (18, 10), 1.0 / 18
+    off, info = dg_q1_offline(n_cells, h)
+    x = off.positions
+    Z = 0.2 * np.cos(5.0 * x[:, 0]) ** 2
+    off.set_initial_precomputed(Z)
+    p = _sw_params(oracle, 2)
+    U0 = _sw_hump(off.positions, [0.5, 0.28], radius=0.2, Z=Z)
+    m = HyperbolicModule(off, p, backend=oracle.backend())
+    a, b = m.new_state_vector(U0), m.new_state_vector()
+    taus = []
+    for _ in range(6):
+        m.prepare_state_vector(a, 0.0)
+        taus.append(m.step(a, [], [], b))
+        a, b = b, a
+    U_ref = a.download()
+    views = partition(off, info, _owner_by_cells(n_cells, info["n_per_cell"], 3), bathymetry=Z)
+    U, taus_p = run_partitioned_oracle(oracle, views, p, U0, 6)
+    for t in taus_p:
+        assert np.allclose(t, taus, rtol=1e-13, atol=0)
+    scale = np.abs(U_ref).max(axis=0)
+    assert (np.abs(U - U_ref) / np.maximum(scale, 1e-3 * scale.max())).max() < 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_cells,h", [((96,), 1.0 / 96), ((24, 24), 1.0 / 24)])
+def test_sw_dg_q1_hip_against_the_oracle(oracle, n_cells, h):
+    from helpers_parity import compare_step
+    off, info = dg_q1_offline(n_cells, h)
+    dim = len(n_cells)
+    x = off.positions
+    Z = 0.15 * np.cos(4.0 * x[:, 0]) ** 2
+    off.set_initial_precomputed(Z)
+    p = _sw_params(oracle, dim)
+    mg = HyperbolicModule(off, p, backend="hip")
+    a, b = mg.new_state_vector(_sw_hump(off.positions, [0.45] * dim, Z=Z)), mg.new_state_vector()
+    for _ in range(12):
+        mg.prepare_state_vector(a, 0.0)
+        mg.step(a, [], [], b)
+        a, b = b, a
+    mc = HyperbolicModule(off, p, backend=oracle.backend())
+    mods = [(mg, a, b), (mc, mc.new_state_vector(a.download()), mc.new_state_vector())]
+    g, c = compare_step(off, mods, oracle=oracle, params=p, label="sw_dg_q1_%dd" % dim)
+    assert (g["U"][:, 0] > 0).all()
+
+
+@pytest.mark.gpu
+def test_sw_dg_q1_partitioned_hip_rank_by_rank_against_the_oracle(oracle):
+    """three ranks, FIVE bound vectors exchanged before they are combined over the stencil"""
+    from helpers_partitioned import (compare_ghost_rows, compare_rank, global_scales, one_update_with_intermediates,
+                                     run_hip_ranks, run_oracle_ranks)
+    from helpers_unstructured import partition
+    n_cells, h = (24, 12), 1.0 / 24
+    off, info = dg_q1_offline(n_cells, h)
+    x = off.positions
+    Z = 0.15 * np.cos(4.0 * x[:, 0]) ** 2
+    off.set_initial_precomputed(Z)
+    U0 = _sw_hump(off.positions, [0.5, 0.25], radius=0.2, Z=Z)
+    views = partition(off, info, _owner_by_cells(n_cells, info["n_per_cell"], 3), bathymetry=Z)
+    make = lambda: _sw_params(oracle, 2)  # noqa: E731
+    body = one_update_with_intermediates([U0[v.global_ids] for v in views])
+    hip = run_hip_ranks(views, make, body)
+    ref = run_oracle_ranks(oracle, views, make, body)
+    scales = global_scales(views, ref, 3)
+    accepted = [compare_rank(v, hip[r], ref[r], 3, label=f"rank {r}", scales=scales) for r, v in enumerate(views)]
+    assert compare_ghost_rows(views, hip, ref, accepted) > 0
