@@ -1316,7 +1316,7 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
   /* Euler, stages == 0, Q1 stencil widths: P_ij is never materialised, steps 5-7 form it on the fly from
    * d_ij, m_ij and the per-node vectors (kernels_limiter_stage0.hpp) -- any dimension */
   constexpr int kStage0Width = DIM == 1 ? 3 : (DIM == 2 ? 9 : 27);
-  const bool stage0_pij = RYUJIN_STAGE0_PIJ && is_euler && stages == 0 && params.limiter_iterations != 0 && !dg &&
+  const bool stage0_pij = RYUJIN_STAGE0_PIJ && (is_euler || is_aeos) && stages == 0 && params.limiter_iterations != 0 && !dg &&
                           L.max_row_len <= (uint32_t)kStage0Width;
   stage0_V = false;
   ensure_pij();
@@ -1354,7 +1354,11 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
                            d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_alpha.ptr, d_dij.ptr,
                            nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
     } else if constexpr (is_aeos) {
-      if (stages == 0)
+      if (stage0_pij)
+        hipLaunchKernelGGL((k_low_order_aeos<DIM, false, false>), grid, block, 0, launch_stream, eparams, mm,
+                           d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_alpha.ptr, d_dij.ptr,
+                           nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
+      else if (stages == 0)
         hipLaunchKernelGGL((k_low_order_aeos<DIM, false>), grid, block, 0, launch_stream, eparams, mm,
                            d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_alpha.ptr, d_dij.ptr,
                            nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
@@ -1428,7 +1432,7 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
   }
   if (n_iterations != 0) {
     sweep([&](const DeviceMesh &mm, dim3 grid) {
-      if constexpr (is_euler) {
+      if constexpr (is_euler || is_aeos) {
         if (stage0_pij) {
           /* small meshes: up to four waves per slice, each taking a share of the columns (decided for the whole
            * mesh, not per launch: the export and the interior part of a split sweep must agree on whether V_i exists) */
@@ -1451,6 +1455,8 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
             launch5(std::integral_constant<int, 1>{});
           return;
         }
+      }
+      if constexpr (is_euler) {
         if (recompute_p) {
           /* small meshes: up to four waves per slice, each taking a share of the columns (see the kernel), as
            * long as all of them are resident at once (256 CUs x 4 SIMDs x 2 waves of this kernel) */
