@@ -42,7 +42,8 @@ namespace ryujin_hip
   __global__ void __launch_bounds__(kBlock, RYUJIN_OCC_PIJ)
   k_pij_lij(const typename E::Params P, const DeviceMesh M, DeviceScalars *__restrict__ scalars,
             const double *__restrict__ new_U, const double *__restrict__ r_in,
-            const double *__restrict__ bounds, double *pij, double *__restrict__ lij)
+            const double *__restrict__ bounds, double *pij, double *__restrict__ lij,
+            double *__restrict__ V_out = nullptr)
   {
     constexpr int K = E::K;
     constexpr int NB = E::NB;
@@ -70,6 +71,13 @@ namespace ryujin_hip
     load_state<K>(r_in, i, F_iH);
     const double lambda_inv = (double)(r.len - 1);
     const double factor = tau * m_i_inv * lambda_inv;
+    /* V_i = U_i^low + sum_j lambda P_ij, accumulated as the first high-order pass accumulates it when every l_ij
+     * is 1: in slices where nothing was limited that pass takes V_i and skips P_ij (k_high_order_next_cached) */
+    const double lambda = 1. / (double)(r.len - 1);
+    double V_i[K];
+#pragma unroll
+    for (int q = 0; q < K; ++q)
+      V_i[q] = U_i_new[q];
     bool all_ok = true;
     unsigned long long undecided_mask = 0;
 
@@ -122,6 +130,9 @@ namespace ryujin_hip
         P_ij[q] *= factor;
       }
       store_entry<K>(pij, colbase, r.lane, P_ij);
+#pragma unroll
+      for (int q = 0; q < K; ++q)
+        V_i[q] += lambda * P_ij[q];
 
       bool success, undecided;
       const double l_ij =
@@ -133,6 +144,8 @@ namespace ryujin_hip
         all_ok = all_ok && success;
       }
     }
+    if (V_out != nullptr && row_active)
+      store_state<K>(V_out, i, V_i);
 
     /* the few pairs that need the Newton iteration */
     while (undecided_mask) {

@@ -396,7 +396,7 @@ struct ryujin_hip_ctx {
   DeviceBuffer<uint32_t> d_send_idx, d_row_send_pos;
   DeviceBuffer<double> d_send_buf;
 
-  /* step 5 of the running step left V_i = U_i^low + sum_j lambda P_ij (k_lij_stage0): step 6 may take it */
+  /* step 5 of the running step left V_i = U_i^low + sum_j lambda P_ij (k_lij_stage0, k_pij_lij): step 6 may take it */
   DeviceBuffer<double> d_V;
   bool stage0_V = false;
   void ensure_pij()
@@ -1320,7 +1320,7 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
                           L.max_row_len <= (uint32_t)kStage0Width;
   stage0_V = false;
   ensure_pij();
-  if (stage0_pij && d_V.n == 0)
+  if (params.limiter_iterations == 2 && d_V.n == 0)
     d_V.alloc((size_t)L.n_relevant * KP);
   sweep([&](const DeviceMesh &mm, dim3 grid) {
     if constexpr (is_euler) {
@@ -1443,7 +1443,7 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
             hipLaunchKernelGGL((k_lij_stage0<E, NY>), dim3(grid.x, NY), block, 0, launch_stream, eparams, mm,
                                d_scalars.ptr, old.U.ptr, d_alpha.ptr, d_dij.ptr, nw.U.ptr, d_r.ptr, d_bounds.ptr,
                                d_pij.ptr, d_lij.ptr, NY == 1 ? d_V.ptr : nullptr);
-            stage0_V = NY == 1;
+            stage0_V = NY == 1 && d_V.ptr != nullptr;
           };
           if (groups >= 4)
             launch5(std::integral_constant<int, 4>{});
@@ -1481,12 +1481,14 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
       if constexpr (is_euler || is_sw) {
         if (dg) {
           hipLaunchKernelGGL((k_pij_lij<E, true>), grid, block, 0, launch_stream, eparams, mm, d_scalars.ptr,
-                             nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr);
+                             nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr, d_V.ptr);
+          stage0_V = d_V.ptr != nullptr;
           return;
         }
       }
       hipLaunchKernelGGL(k_pij_lij<E>, grid, block, 0, launch_stream, eparams, mm, d_scalars.ptr, nw.U.ptr,
-                         d_r.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr);
+                         d_r.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr, d_V.ptr);
+      stage0_V = d_V.ptr != nullptr;
     });
     exchange_matrix(d_lij.ptr, true);
   }
