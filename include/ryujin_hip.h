@@ -438,7 +438,14 @@ enum {
   /* the production evaluation path of the sweeps -- per-node Riemann records, dij_from_records -- fed with the
    * reference's 1-D Riemann data: in as RYUJIN_DEBUG_EULER_RIEMANN / RYUJIN_DEBUG_SW_RIEMANN, out: lambda_max */
   RYUJIN_DEBUG_EULER_RIEMANN_RECORDS = 9,
-  RYUJIN_DEBUG_SW_RIEMANN_RECORDS = 10
+  RYUJIN_DEBUG_SW_RIEMANN_RECORDS = 10,
+  /* EulerAEOS (params->eos etc. select the equation of state):
+   *   RYUJIN_DEBUG_AEOS_RIEMANN  in: rd_i[5], rd_j[5] = (rho, u, p, gamma, a)   out: lambda_max
+   *                              (euler_aeos/riemann_solver.template.h:443-560; tests/euler_aeos/riemann_solver*.cc)
+   *   RYUJIN_DEBUG_AEOS_LIMIT_1D in: bounds[4], U[3], P[3] (dim = 1)            out: l, success, took the Newton tail
+   *                              (euler_aeos/limiter.template.h:15-360; tests/euler_aeos/limiter*.cc) */
+  RYUJIN_DEBUG_AEOS_RIEMANN = 11,
+  RYUJIN_DEBUG_AEOS_LIMIT_1D = 12
 };
 int ryujin_hip_debug_function(int device, const ryujin_hip_params *params, int which, const double *in,
                               double *out, size_t n);

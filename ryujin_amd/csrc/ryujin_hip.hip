@@ -143,6 +143,45 @@ namespace
     return q;
   }
 
+  EulerAeosParams make_aeos_params(const ryujin_hip_params &p)
+  {
+    EulerAeosParams aeosparams{};
+  aeosparams.eos = p.eos;
+    aeosparams.strict = p.compute_strict_bounds != 0;
+    aeosparams.gamma = p.gamma;
+    aeosparams.eos_b = p.eos_covolume_b;
+    aeosparams.eos_q = p.eos_q;
+    aeosparams.eos_pinf = p.eos_pinf;
+    aeosparams.vdw_a = p.eos_vdw_a;
+    aeosparams.jwl_A = p.jwl_A;
+    aeosparams.jwl_B = p.jwl_B;
+    aeosparams.jwl_R1 = p.jwl_R1;
+    aeosparams.jwl_R2 = p.jwl_R2;
+    aeosparams.jwl_omega = p.jwl_omega;
+    aeosparams.jwl_rho_0 = p.jwl_rho_0;
+    aeosparams.jwl_q_0 = p.jwl_q_0;
+    /* interpolation parameters of the surrogate (equation_of_state_noble_abel_stiffened_gas.h:52-56,
+     * equation_of_state_van_der_waals.h:46-52; zero for the other equations of state) */
+    aeosparams.b = aeosparams.pinf = aeosparams.q = 0.;
+    if (p.eos == RYUJIN_EOS_NOBLE_ABEL_STIFFENED_GAS) {
+      aeosparams.b = p.eos_covolume_b;
+      aeosparams.pinf = p.eos_pinf;
+      aeosparams.q = p.eos_q;
+    } else if (p.eos == RYUJIN_EOS_VAN_DER_WAALS) {
+      aeosparams.b = p.eos_covolume_b;
+      if (p.eos_covolume_b > 0.)
+        aeosparams.pinf = p.eos_vdw_a / (p.eos_covolume_b * p.eos_covolume_b);
+    }
+    aeosparams.reference_density = p.reference_density;
+    aeosparams.vacuum_small = p.vacuum_state_relaxation_small;
+    aeosparams.vacuum_large = p.vacuum_state_relaxation_large;
+    aeosparams.evc_factor = p.indicator_evc_factor;
+    aeosparams.lim_newton_tolerance = p.limiter_newton_tolerance;
+    aeosparams.lim_relaxation_factor = p.limiter_relaxation_factor;
+    aeosparams.lim_newton_max_iterations = p.limiter_newton_max_iterations;
+    return aeosparams;
+  }
+
   ShallowWaterParams make_sw_params(const ryujin_hip_params &p)
   {
     ShallowWaterParams q{};
@@ -560,39 +599,7 @@ void ryujin_hip_ctx::create(const ryujin_hip_offline &o, const ryujin_hip_params
   HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&h_scalars), sizeof(DeviceScalars)));
 
   eparams = make_euler_params(p);
-  aeosparams.eos = p.eos;
-  aeosparams.strict = p.compute_strict_bounds != 0;
-  aeosparams.gamma = p.gamma;
-  aeosparams.eos_b = p.eos_covolume_b;
-  aeosparams.eos_q = p.eos_q;
-  aeosparams.eos_pinf = p.eos_pinf;
-  aeosparams.vdw_a = p.eos_vdw_a;
-  aeosparams.jwl_A = p.jwl_A;
-  aeosparams.jwl_B = p.jwl_B;
-  aeosparams.jwl_R1 = p.jwl_R1;
-  aeosparams.jwl_R2 = p.jwl_R2;
-  aeosparams.jwl_omega = p.jwl_omega;
-  aeosparams.jwl_rho_0 = p.jwl_rho_0;
-  aeosparams.jwl_q_0 = p.jwl_q_0;
-  /* interpolation parameters of the surrogate (equation_of_state_noble_abel_stiffened_gas.h:52-56,
-   * equation_of_state_van_der_waals.h:46-52; zero for the other equations of state) */
-  aeosparams.b = aeosparams.pinf = aeosparams.q = 0.;
-  if (p.eos == RYUJIN_EOS_NOBLE_ABEL_STIFFENED_GAS) {
-    aeosparams.b = p.eos_covolume_b;
-    aeosparams.pinf = p.eos_pinf;
-    aeosparams.q = p.eos_q;
-  } else if (p.eos == RYUJIN_EOS_VAN_DER_WAALS) {
-    aeosparams.b = p.eos_covolume_b;
-    if (p.eos_covolume_b > 0.)
-      aeosparams.pinf = p.eos_vdw_a / (p.eos_covolume_b * p.eos_covolume_b);
-  }
-  aeosparams.reference_density = p.reference_density;
-  aeosparams.vacuum_small = p.vacuum_state_relaxation_small;
-  aeosparams.vacuum_large = p.vacuum_state_relaxation_large;
-  aeosparams.evc_factor = p.indicator_evc_factor;
-  aeosparams.lim_newton_tolerance = p.limiter_newton_tolerance;
-  aeosparams.lim_relaxation_factor = p.limiter_relaxation_factor;
-  aeosparams.lim_newton_max_iterations = p.limiter_newton_max_iterations;
+  aeosparams = make_aeos_params(p);
 
   scparams.flux = p.sc_flux;
   scparams.use_greedy_wavespeed = p.sc_use_greedy_wavespeed != 0;
@@ -2543,12 +2550,31 @@ int ryujin_hip_debug_pow(int device, const double *x, const double *y, double *o
 namespace
 {
   __global__ void __launch_bounds__(kBlock)
-  k_debug_function(const EulerParams PE, const ShallowWaterParams PS, const int which, const size_t n,
-                   const double *__restrict__ in, double *__restrict__ out)
+  k_debug_function(const EulerParams PE, const ShallowWaterParams PS, const EulerAeosParams PA, const int which,
+                   const size_t n, const double *__restrict__ in, double *__restrict__ out)
   {
     const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n)
       return;
+    if (which == RYUJIN_DEBUG_AEOS_RIEMANN) {
+      const double *v = in + q * 10;
+      const EulerAeos<1>::RiemannData rd_i{v[0], v[1], v[2], v[3], v[4]}, rd_j{v[5], v[6], v[7], v[8], v[9]};
+      out[q] = EulerAeos<1>::riemann_compute(PA, rd_i, rd_j);
+      return;
+    }
+    if (which == RYUJIN_DEBUG_AEOS_LIMIT_1D) {
+      /* the composition the sweeps use: limit_fast(), and limit() for the undecided pairs */
+      const double *v = in + q * 10;
+      const double bnd[4] = {v[0], v[1], v[2], v[3]}, U[3] = {v[4], v[5], v[6]}, Pij[3] = {v[7], v[8], v[9]};
+      bool success, undecided;
+      double l = EulerAeos<1>::limit_fast(PA, bnd, U, Pij, success, undecided);
+      if (undecided)
+        l = EulerAeos<1>::limit(PA, bnd, U, Pij, success);
+      out[q * 3 + 0] = l;
+      out[q * 3 + 1] = success ? 1. : 0.;
+      out[q * 3 + 2] = undecided ? 1. : 0.;
+      return;
+    }
     if (which == RYUJIN_DEBUG_EULER_RIEMANN) {
       const double *v = in + q * 8;
       const Euler<1>::RiemannData rd_i{v[0], v[1], v[2], v[3]}, rd_j{v[4], v[5], v[6], v[7]};
@@ -2638,6 +2664,8 @@ int ryujin_hip_debug_function(int device, const ryujin_hip_params *params, int w
     case RYUJIN_DEBUG_EULER_RIEMANN:
     case RYUJIN_DEBUG_EULER_RIEMANN_RECORDS: n_in = 8; n_out = 1; break;
     case RYUJIN_DEBUG_SW_RIEMANN_RECORDS: n_in = 6; n_out = 1; break;
+    case RYUJIN_DEBUG_AEOS_RIEMANN: n_in = 10; n_out = 1; break;
+    case RYUJIN_DEBUG_AEOS_LIMIT_1D: n_in = 10; n_out = 3; break;
     case RYUJIN_DEBUG_EULER_LIMIT_1D: n_in = 9; n_out = 3; break;
     case RYUJIN_DEBUG_SW_RIEMANN: n_in = 6; n_out = 2; break;
     case RYUJIN_DEBUG_EULER_DIJ_2D:
@@ -2653,7 +2681,8 @@ int ryujin_hip_debug_function(int device, const ryujin_hip_params *params, int w
     din.upload(in, n * n_in);
     dout.alloc(n * n_out);
     hipLaunchKernelGGL(k_debug_function, dim3(grid_for(n)), dim3(kBlock), 0, nullptr,
-                       make_euler_params(*params), make_sw_params(*params), which, n, din.ptr, dout.ptr);
+                       make_euler_params(*params), make_sw_params(*params), make_aeos_params(*params), which, n,
+                       din.ptr, dout.ptr);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemcpy(out, dout.ptr, n * n_out * sizeof(double), hipMemcpyDeviceToHost));
     return RYUJIN_OK;

@@ -206,3 +206,70 @@ def test_device_sw_dij_against_the_oracle_on_random_states(oracle, records):
     scale = np.linalg.norm(c, axis=1) * (speed + np.sqrt(params.gravity * h))
     err = np.abs(got - ref) / np.maximum(scale, 1e-300)
     assert err.max() <= 1e-12, (err.max(), int(err.argmax()))
+
+
+# ----------------------------------------------------------------------------- EulerAEOS
+
+@pytest.mark.parametrize("variant", ["", "-strict", "-strict-NASG"])
+def test_device_aeos_riemann_solver_against_the_reference_baselines(oracle, golden_dir, variant):
+    """The device Riemann solver of the EulerAEOS Description on the 22 (21) problems of
+    tests/euler_aeos/riemann_solver{,-strict,-strict-NASG}.cc -- constant and varying surrogate gamma, covolume,
+    NASG reference pressure, gamma up to 118 and down to 1.00005 -- against the lambda_max of the reference's
+    baselines. The pressure estimates are powers with exponent 2 gamma / (gamma - 1) (4e4 for gamma = 1.00005):
+    their condition number scales the tolerance, as for the oracle (tests/test_oracle_golden_aeos.py)."""
+    from test_oracle_golden_aeos import RIEMANN_CASES as AEOS_CASES
+    from test_oracle_golden_aeos import _params, _riemann_blocks
+    blocks = _riemann_blocks(os.path.join(golden_dir, f"euler_aeos_riemann_solver{variant}.output"))
+    cases = list(AEOS_CASES)
+    nasg = variant.endswith("NASG")
+    if nasg:
+        del cases[17]
+    assert len(blocks) == len(cases)
+    for n, ((left, right, cov), (ins, tr, lam_ref)) in enumerate(zip(cases, blocks)):
+        if cov is None:
+            p = _params(oracle, strict=(variant != ""))
+        elif nasg:
+            p = _params(oracle, eos=capi.EOS_NOBLE_ABEL_STIFFENED_GAS, b=cov, pinf=0.5, strict=True)
+        else:
+            p = _params(oracle, eos=capi.EOS_VAN_DER_WAALS, b=cov, strict=(variant != ""))
+        item = []
+        for rho, u, pr, gamma in (left, right):
+            x = 1. - cov * rho if cov else 1. - 0. * rho
+            item += [rho, u, pr, gamma, np.sqrt(gamma * pr / (rho * x))]
+        lam = _device(p, capi.DEBUG_AEOS_RIEMANN, [item], 1)[0, 0]
+        g_min = min(left[3], right[3])
+        rel = 2e-12 + 1e-15 * 2. * g_min / (g_min - 1.)
+        scale = max(abs(left[2]), abs(right[2]), abs(left[1]), abs(right[1]), 1e-300)
+        assert abs(lam - lam_ref) <= rel * max(abs(lam), abs(lam_ref)) + 1e-13 * scale, (n, lam, lam_ref)
+
+
+@pytest.mark.parametrize("nasg", [False, True])
+def test_device_aeos_limiter_against_the_reference_baselines(oracle, golden_dir, nasg):
+    """limiter{,-NASG}.output are EXPENSIVE_BOUNDS_CHECK builds (limiter.cc:10); the device runs the production
+    control flow. Cases whose low-order state violates the bounds report failure on both; for the others l agrees
+    up to the Newton tolerance with the baseline and to round-off with the oracle's production flow."""
+    from test_oracle_golden_aeos import _limiter_cases, _limiter_golden, _params
+    if nasg:
+        _, eos, components, compress = _limiter_cases(True)
+        cases = ([(dict(), c) for c in components(2.0, 1.8, 1.82, None)] +
+                 [(eos(1.0e-1), c) for c in components(2.0, 1.5, 1.7448913582358123, None, s0_first=1.7)] +
+                 [(eos(0.2), c) for c in compress(0.2)])
+        gold = _limiter_golden(os.path.join(golden_dir, "euler_aeos_limiter-NASG.output"))
+    else:
+        cases = _limiter_cases(False)
+        gold = _limiter_golden(os.path.join(golden_dir, "euler_aeos_limiter.output"))
+    assert len(cases) == len(gold)
+    lib = oracle.lib()
+    dbl = lambda *v: (C.c_double * len(v))(*v)  # noqa: E731
+    for n, ((eos_kw, (U, P, bounds)), ref) in enumerate(zip(cases, gold)):
+        p = _params(oracle, **eos_kw)
+        l, success, _ = _device(p, capi.DEBUG_AEOS_LIMIT_1D, [list(bounds) + list(U) + list(P)], 3)[0]
+        lo, so = C.c_double(), C.c_int()
+        trace = (C.c_double * 40)()
+        assert lib.ryujin_oracle_aeos_limit(C.byref(p), 0, dbl(*bounds), dbl(*U), dbl(*P), C.byref(lo), C.byref(so),
+                                            trace, 40) == 0    # the oracle's PRODUCTION flow
+        assert bool(success) == bool(so.value), n
+        assert abs(l - lo.value) <= 1e-13, (n, l, lo.value)
+        if ref["success"]:
+            assert bool(success), n
+            assert abs(l - ref["l"]) <= 1e-10, (n, l, ref["l"])
