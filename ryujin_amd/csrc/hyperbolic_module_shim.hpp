@@ -12,6 +12,7 @@
 
 #pragma once
 
+#include <algorithm>
 #include <array>
 #include <functional>
 #include <limits>
@@ -164,27 +165,24 @@ namespace ryujin_hip_shim
      * explicit schemes, executed device-resident with one host synchronisation per Runge-Kutta step
      * (ryujin_hip_time_step). `scheme` is a RYUJIN_SCHEME_* id, `temp` the integrator's temp_[0..2].
      * With cfl_recovery == RYUJIN_CFL_RECOVERY_BANG_BANG the reference's retry loop (:250-274) runs
-     * inside the library; otherwise a Restart propagates as in step(). Dirichlet data is evaluated at
-     * time t (time independent during the step, as in the benchmark configurations). */
+     * inside the library; otherwise a Restart propagates as in step(). Dirichlet data is evaluated by the
+     * dirichlet function at every stage time. */
     template <std::size_t n_temp>
     double time_step(int scheme, StateVector &state_vector, std::array<StateVector, n_temp> &temp, double t,
                      double t_final = std::numeric_limits<double>::max(),
                      int cfl_recovery = RYUJIN_CFL_RECOVERY_NONE, double cfl_min = 0.45,
                      double cfl_max = 0.9) const
     {
-      const double *ptr = nullptr;
-      if (dirichlet_) {
-        dirichlet_values_.resize((size_t)offline_.n_bdry * k_);
-        dirichlet_(t, dirichlet_values_);
-        ptr = dirichlet_values_.data();
-      }
       int h_tmp[n_temp]; /* temp_[0..n): 3 for SSPRK22/33 and ERK11/22/33, 4 for ERK43, 5 for ERK54 */
       for (std::size_t q = 0; q < n_temp; ++q)
         h_tmp[q] = temp[q].handle_;
       double tau_out = 0.;
-      const int status =
-          ryujin_hip_time_step_n(ctx_, scheme, state_vector.handle_, (int)n_temp, h_tmp, ptr, t_final - t,
-                                 cfl_recovery, cfl_min, cfl_max, &tau_out);
+      /* Dirichlet data at the stage times t + c_s tau (time_integrator.template.h:373-403): the library calls
+       * back once per stage, for the later stages as soon as tau exists on the host */
+      const int status = ryujin_hip_time_step_fn(ctx_, scheme, state_vector.handle_, (int)n_temp, h_tmp, t,
+                                                 dirichlet_ ? &dirichlet_trampoline : nullptr,
+                                                 const_cast<HyperbolicModule *>(this), t_final - t, cfl_recovery,
+                                                 cfl_min, cfl_max, &tau_out);
       if (status == RYUJIN_ERR_TAU)
         throw std::runtime_error("I'm sorry, Dave. I'm afraid I can't do that.\nWe crashed.");
       check(status);
@@ -219,6 +217,14 @@ namespace ryujin_hip_shim
     ryujin_hip_ctx *context() const { return ctx_; }
 
   private:
+    static void dirichlet_trampoline(void *user, double time, double *values)
+    {
+      const auto *self = static_cast<const HyperbolicModule *>(user);
+      self->dirichlet_values_.resize((size_t)self->offline_.n_bdry * self->k_);
+      self->dirichlet_(time, self->dirichlet_values_);
+      std::copy(self->dirichlet_values_.begin(), self->dirichlet_values_.end(), values);
+    }
+
     static void check(int status)
     {
       if (status < 0)

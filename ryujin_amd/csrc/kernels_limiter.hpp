@@ -25,7 +25,11 @@ namespace ryujin_hip
    * Both tests are wave-uniform (__any over the 64 rows of the slice, per column), so nothing diverges.
    * Away from shocks the first pass returns l == 1 exactly (t_r stays t_max and psi_r > 0,
    * limiter.template.h:88-108,188-216) and the second pass therefore stores exact zeros: in a developed
-   * Mach-3 flow the large majority of (slice, column) tiles take the shortcut. */
+   * Mach-3 flow the large majority of (slice, column) tiles take the shortcut.
+   * Assumption: finite inputs. Where U_i or P_ij is NaN / inf (an update that has already left the admissible
+   * set) the reference stores (1 - l) l' = 0 * NaN = NaN and adds 0 * inf = NaN, the shortcuts store / add 0: the
+   * device result looks clean in that one entry where the reference propagates the NaN. Such a state raises the
+   * restart flag in step 5 of the same update (the limiter reports failure on it), which is what the caller acts on. */
   RYUJIN_DEV void flag_restart(DeviceScalars *scalars, const bool all_ok, const uint32_t lane)
   {
     if (__any(!all_ok)) {

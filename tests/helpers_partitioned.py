@@ -217,3 +217,19 @@ def compare_ghost_rows(parts, hip, ref, accepted):
                     assert int(src[e]) in accepted[p][name], (r, p, name, int(e), float(d[e]))
             n_checked += g1 - g0
     return n_checked
+
+
+def compare_rank_files(oracle, parts, prefix, make_params, dirichlet_of, k):
+    """Parent side of the multi-process runs (tests/rccl_worker.py `intermediates`): every rank stored
+    <prefix>.rank<r>.npz -- its local state before and its arrays after one update; the partitioned ORACLE is run
+    from the same states and compared rank by rank, ghost rows included."""
+    hip = [dict(np.load(f"{prefix}.rank{r}.npz")) for r in range(len(parts))]
+    for h in hip:
+        h["tau"], h["status"] = float(h["tau"]), int(h["status"])
+    ref = run_oracle_ranks(oracle, parts, make_params,
+                           one_update_with_intermediates([h["U_local"] for h in hip], dirichlet_of))
+    scales = global_scales(parts, ref, k)
+    accepted = [compare_rank(part, hip[r], ref[r], k, label=f"rank {r}", scales=scales) for r, part in enumerate(parts)]
+    n = compare_ghost_rows(parts, hip, ref, accepted)
+    assert n > 0
+    return hip, ref

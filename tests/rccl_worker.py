@@ -4,7 +4,10 @@ rank 0 broadcasts over gloo) and runs (a) stage-wise forward-Euler updates, (b) 
 with the deferred collectives, on the 2-D Mach-3 step and on the 3-D cylinder channel. Rank 0 stores the
 gathered owned entries; the parent test compares them with a single-GPU run of the same problem.
 
-usage: rccl_worker.py <out.npz> <case> <n_updates>     case: step2d:<cells per unit> | cylinder3d:<cells per unit>"""
+usage: rccl_worker.py <out.npz> <case> <n_updates>     case: step2d:<cells per unit> | cylinder3d:<cells per unit>
+       rccl_worker.py <prefix> <case> <n_warm> intermediates[:system]
+           every rank stores <prefix>.rank<r>.npz: its arrays after one update incl. ghost range / ghost rows, for the
+           rank-by-rank comparison with the partitioned oracle (":system": system-scope events)"""
 import ctypes as C
 import os
 import sys
@@ -50,6 +53,32 @@ def run(off, comm, device, n_updates):
             integrals)
 
 
+def intermediates(off, comm, device, n_warm, out_prefix, rank, switches=None):
+    """Develop the flow for n_warm updates, then run ONE update and store every array the rank holds afterwards --
+    ghost range and ghost rows included (tests/helpers_partitioned.py) -- together with the rank's local state
+    before that update: the parent runs the partitioned ORACLE from those states and compares rank by rank."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers_partitioned import one_update_with_intermediates
+    p = capi.Params()
+    capi.load_hip().ryujin_hip_default_params(C.byref(p), capi.EQ_EULER, off.dim)
+    p.cfl = 0.9
+    for name, value in (switches or {}).items():
+        setattr(p, name, value)
+    m = HyperbolicModule(off, p, backend="hip", comm=comm, device=device)
+    dirichlet = euler_uniform(off.b_positions) if off.n_bdry else None
+    a, b = m.new_state_vector(initial(off)), m.new_state_vector()
+    for _ in range(n_warm):
+        m.prepare_state_vector(a, 0.0, dirichlet)
+        m.step(a, [], [], b)
+        a, b = b, a
+    U_local = a.download()
+    res = one_update_with_intermediates([U_local], lambda part: dirichlet)(m, off, 0)
+    np.savez(f"{out_prefix}.rank{rank}.npz", U_local=U_local, **res)
+    info = m.exchange_info()
+    m.close()
+    return info
+
+
 def main():
     # torch only here: the parent test imports this module for run() / make_spec() into a process that has
     # libryujin_hip.so loaded already, and torch coming second would bring a second ROCm runtime along
@@ -81,6 +110,17 @@ def main():
     assert rc == 0, lib.ryujin_hip_last_error()
 
     off = offline.SyntheticOffline(make_spec(case, world, rank))
+    if len(sys.argv) > 4 and sys.argv[4].startswith("intermediates"):
+        # rccl_worker.py <prefix> <case> <n_warm> intermediates[:system]  -- rank-by-rank comparison with the oracle
+        switches = {"system_scope_events": 1} if sys.argv[4].endswith(":system") else None
+        info = intermediates(off, comm, device, n_updates, out_path, rank, switches)
+        v = [C.c_int(-1) for _ in range(5)]
+        lib.ryujin_hip_comm_info(comm, *[C.byref(x) for x in v])
+        assert v[3].value == world, ("ncclCommCount", v[3].value, world)
+        assert info["n_exchanges"] >= 5 * (n_updates + 1), info
+        dist.barrier()
+        lib.ryujin_hip_comm_destroy(comm)
+        return
     gid, U, taus, alpha, integrals = run(off, comm, device, n_updates)
 
     def gather(x):

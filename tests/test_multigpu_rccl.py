@@ -98,6 +98,37 @@ def test_rccl_partitioned_run_matches_single_gpu(tmp_path, world, case):
     assert np.allclose(d["integrals"], integrals[None, :], rtol=1e-12)
 
 
+@pytest.mark.parametrize("world,case,events", [(2, "step2d:30", "device"), (3, "step2d:30", "device"),
+                                               (3, "step2d:30", "system"), (4, "cylinder3d:8", "device"),
+                                               (8, "cylinder3d:16", "device")])
+def test_rccl_ranks_against_the_partitioned_oracle(oracle, tmp_path, world, case, events):
+    """The decisive check for the RCCL leg: every rank of a real multi-process run against THE SAME rank of the
+    partitioned oracle after one update on identical inputs -- d_ij on ghost columns, alpha and r on the ghost
+    range, l_ij / l'_ij including the ghost rows received over xGMI (which must be bitwise the entries the sender
+    holds at its send positions) -- with device-scope and with system-scope events between the two streams. The same
+    comparison runs on one GPU with the in-process transport (tests/test_partitioned_vs_oracle.py); the worker also
+    asserts ncclCommCount == world and at least 5 exchanges per update."""
+    if _n_gpus() < world:
+        pytest.skip(f"needs {world} GPUs (RCCL refuses several ranks on one device)")
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import rccl_worker
+    from helpers_partitioned import compare_rank_files
+    from ryujin_amd import capi, offline
+    from ryujin_amd.initial_states import euler_uniform
+    prefix = str(tmp_path / "ranks")
+    mode = "intermediates" + (":system" if events == "system" else "")
+    res = _launch(world, [os.path.join(ROOT, "tests", "rccl_worker.py"), prefix, case, "12", mode])
+    assert res.returncode == 0, res.stderr[-4000:]
+    parts = [offline.SyntheticOffline(rccl_worker.make_spec(case, world, r)) for r in range(world)]
+
+    def make_params():
+        p = oracle.default_params(capi.EQ_EULER, parts[0].dim)
+        p.cfl = 0.9
+        return p
+    compare_rank_files(oracle, parts, prefix, make_params,
+                       lambda part: euler_uniform(part.b_positions) if part.n_bdry else None, parts[0].dim + 2)
+
+
 @pytest.mark.parametrize("n", [2, 8])
 def test_bench_self_launches_its_ranks(n):
     """`python bench.py --gpus N` invoked like the single-GPU line: launches N ranks itself and prints ONE
@@ -111,3 +142,6 @@ def test_bench_self_launches_its_ranks(n):
     assert len(lines) == 1, res.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == n and d["scaling"] == "weak" and d["value"] > 0 and d["n_warnings"] == 0
+    # what RCCL itself saw, and the verdict of the events self-check
+    assert d["rccl"]["ranks"] == n and len(d["rccl"]["n_neighbours_per_rank"]) == n
+    assert d["rccl"]["exchanges_per_update"] == 5.0 and d["events"]["check"] is not None

@@ -140,3 +140,44 @@ def test_partitioned_unstructured_sectors_rank_by_rank_against_the_oracle(oracle
     assert max(v.c.contents.n_nbr for v in views) >= 2
     U_init = [U0[v.global_ids] for v in views]
     _compare_partitioned(oracle, views, eq, 2, U_init, None, n_warm=10, cfl=0.5)
+
+
+@pytest.mark.gpu
+def test_the_rank_file_plumbing_of_the_rccl_test_on_one_gpu(oracle, tmp_path):
+    """tests/test_multigpu_rccl.py::test_rccl_ranks_against_the_partitioned_oracle needs several GPUs. Its worker
+    function (rccl_worker.intermediates: develop, one update, store the rank's arrays) and its parent side
+    (helpers_partitioned.compare_rank_files) run here on ONE GPU with the in-process transport, so that the first
+    multi-GPU box exercises nothing but RCCL itself for the first time."""
+    import ctypes as C
+    import threading
+
+    import rccl_worker
+    from helpers_partitioned import compare_rank_files
+    lib = capi.load_hip()
+    world, case = 3, "step2d:30"
+    parts = [offline.SyntheticOffline(rccl_worker.make_spec(case, world, r)) for r in range(world)]
+    comms = (C.c_void_p * world)()
+    assert lib.ryujin_hip_comm_init_local(comms, world, 0) == 0
+    prefix, out = str(tmp_path / "ranks"), {}
+
+    def worker(r):
+        try:
+            out[r] = rccl_worker.intermediates(parts[r], C.c_void_p(comms[r]), 0, 12, prefix, r)
+        except BaseException as e:  # noqa: BLE001
+            out[r] = e
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+        assert not t.is_alive()
+    for r in range(world):
+        assert not isinstance(out[r], BaseException), out[r]
+        assert out[r]["n_exchanges"] >= 5 * 13 and len(out[r]["neighbours"]) == (1 if r in (0, world - 1) else 2)
+        lib.ryujin_hip_comm_destroy(C.c_void_p(comms[r]))
+
+    def make_params():
+        p = oracle.default_params(capi.EQ_EULER, 2)
+        p.cfl = 0.9
+        return p
+    compare_rank_files(oracle, parts, prefix, make_params, _mach3_dirichlet, 4)
