@@ -10,6 +10,8 @@
 #include <array>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <map>
@@ -234,13 +236,40 @@ bool ryujin_synth::build()
   }
   const uint32_t n_export = next;
 
-  for (int64_t iz = 0; iz < nn[2]; ++iz)
-    for (int64_t iy = 0; iy < nn[1]; ++iy)
-      for (int64_t ix = x0; ix < x1; ++ix) {
-        const size_t b = box_index(ix, iy, iz);
-        if (node_id[b] == kInvalid && node_active(ix, iy, iz))
-          node_id[b] = next++;
-      }
+  /* Remaining owned nodes: lexicographic (x fastest), or -- experiment knob of the measurement scripts,
+   * RYUJIN_SYNTH_TILE=tx,ty,tz -- tile by tile, lexicographic inside a tile: the library is numbering agnostic, a
+   * numbering whose stencil neighbours stay within a few dozen slices keeps the per-node gathers in L2. */
+  int64_t tile[3] = {nn[0], 1, 1};
+  bool tiled = false;
+  if (const char *e = std::getenv("RYUJIN_SYNTH_TILE")) {
+    long long a = 0, b = 0, c = 0;
+    if (std::sscanf(e, "%lld,%lld,%lld", &a, &b, &c) == 3 && a > 0 && b > 0 && c > 0) {
+      tile[0] = a;
+      tile[1] = b;
+      tile[2] = c;
+      tiled = true;
+    }
+  }
+  if (!tiled) {
+    for (int64_t iz = 0; iz < nn[2]; ++iz)
+      for (int64_t iy = 0; iy < nn[1]; ++iy)
+        for (int64_t ix = x0; ix < x1; ++ix) {
+          const size_t b = box_index(ix, iy, iz);
+          if (node_id[b] == kInvalid && node_active(ix, iy, iz))
+            node_id[b] = next++;
+        }
+  } else {
+    for (int64_t tz = 0; tz < nn[2]; tz += tile[2])
+      for (int64_t ty = 0; ty < nn[1]; ty += tile[1])
+        for (int64_t tx = x0; tx < x1; tx += tile[0])
+          for (int64_t iz = tz; iz < std::min(nn[2], tz + tile[2]); ++iz)
+            for (int64_t iy = ty; iy < std::min(nn[1], ty + tile[1]); ++iy)
+              for (int64_t ix = tx; ix < std::min(x1, tx + tile[0]); ++ix) {
+                const size_t b = box_index(ix, iy, iz);
+                if (node_id[b] == kInvalid && node_active(ix, iy, iz))
+                  node_id[b] = next++;
+              }
+  }
   const uint32_t n_owned = next;
 
   uint32_t n_ghost_left = 0, n_ghost_right = 0;
