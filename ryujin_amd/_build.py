@@ -71,7 +71,7 @@ def build_hip(force: bool = False, defines: tuple = (), out: str | None = None) 
         hipcc = hipcc_path()
         os.makedirs(os.path.dirname(out), exist_ok=True)
         _run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-              "-ffp-contract=off", *["-D" + d for d in defines], "-I" + INCLUDE, "-I" + CSRC, *src,
+              "-ffp-contract=" + os.environ.get("RYUJIN_FP_CONTRACT", "off"), *["-D" + d for d in defines], "-I" + INCLUDE, "-I" + CSRC, *src,
               "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib", "-o", out])
         return out
     if force or not _newer(HIP_SO, deps):
