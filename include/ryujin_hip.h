@@ -440,12 +440,17 @@ enum {
   RYUJIN_DEBUG_EULER_RIEMANN_RECORDS = 9,
   RYUJIN_DEBUG_SW_RIEMANN_RECORDS = 10,
   /* EulerAEOS (params->eos etc. select the equation of state):
-   *   RYUJIN_DEBUG_AEOS_RIEMANN  in: rd_i[5], rd_j[5] = (rho, u, p, gamma, a)   out: lambda_max
+   *   RYUJIN_DEBUG_AEOS_RIEMANN  in: rd_i[5], rd_j[5] = (rho, u, p, gamma, a)   out: lambda_max, evaluated through
+   *                              the per-node records of the sweep (EulerAeos::dij_from_records with n = 1)
    *                              (euler_aeos/riemann_solver.template.h:443-560; tests/euler_aeos/riemann_solver*.cc)
    *   RYUJIN_DEBUG_AEOS_LIMIT_1D in: bounds[4], U[3], P[3] (dim = 1)            out: l, success, took the Newton tail
    *                              (euler_aeos/limiter.template.h:15-360; tests/euler_aeos/limiter*.cc) */
   RYUJIN_DEBUG_AEOS_RIEMANN = 11,
-  RYUJIN_DEBUG_AEOS_LIMIT_1D = 12
+  RYUJIN_DEBUG_AEOS_LIMIT_1D = 12,
+  /* EulerAEOS d_ij from two states (dim = 2; p from the equation of state): in U_i[4], U_j[4], c_ij[2], out d_ij --
+   * in the reference's operation order and through the per-node Riemann records the sweep uses */
+  RYUJIN_DEBUG_AEOS_DIJ_2D = 13,
+  RYUJIN_DEBUG_AEOS_DIJ_RECORDS_2D = 14
 };
 int ryujin_hip_debug_function(int device, const ryujin_hip_params *params, int which, const double *in,
                               double *out, size_t n);

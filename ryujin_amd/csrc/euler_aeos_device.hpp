@@ -116,6 +116,13 @@ namespace ryujin_hip
       return (gamma - 1.) * (rho_e - rho * P.q) / covolume - gamma * P.pinf;
     }
 
+    /* (1 - b rho)^x. Without a covolume (b == 0 is a kernel argument: a scalar branch) the base is exactly 1
+     * and pow(1, x) == 1 exactly: the polytropic gas skips one of its two powers per entropy evaluation */
+    static RYUJIN_DEV double covolume_pow(const Params &P, const double covolume, const double exponent)
+    {
+      return P.b == 0. ? 1. : dev_pow(covolume, exponent);
+    }
+
     /* hyperbolic_system.h:1073-1088 */
     static RYUJIN_DEV double surrogate_specific_entropy(const Params &P, const double (&U)[K],
                                                         const double gamma_min)
@@ -136,7 +143,7 @@ namespace ryujin_hip
       const double rho_rho_e_q = rho * E - 0.5 * momentum_norm_square(U) - rho * rho * P.q;
       const double exponent = 1. / (gamma_min + 1.);
       const double covolume = 1. - P.b * rho;
-      const double covolume_term = dev_pow(covolume, gamma_min - 1.);
+      const double covolume_term = covolume_pow(P, covolume, gamma_min - 1.);
       const double rho_pinfcov = rho * P.pinf * covolume;
       return dev_pow((rho_rho_e_q - rho_pinfcov) * covolume_term, exponent);
     }
@@ -273,8 +280,10 @@ namespace ryujin_hip
 
     /* ------------------------------------------------------------------ Riemann solver */
 
+    /* alpha = rs_alpha(rho, gamma, a) (:39-50) and alpha_hat = rs_c(gamma) alpha (:21-36) depend on one state only:
+     * carried along instead of being re-derived inside every pressure estimate */
     struct RiemannData {
-      double rho, u, p, gamma, a;
+      double rho, u, p, gamma, a, alpha, alpha_hat;
     };
 
     /* riemann_solver.template.h:21-36 */
@@ -310,7 +319,63 @@ namespace ryujin_hip
       const double gamma = surrogate_gamma(P, U, p);
       const double x = 1. - P.b * rho;
       const double a = sqrt(gamma * (p + P.pinf) / (rho * x));
-      return {rho, proj_m * rho_inverse, p, gamma, a};
+      return make_riemann_data(P, rho, proj_m * rho_inverse, p, gamma, a);
+    }
+
+    static RYUJIN_DEV RiemannData make_riemann_data(const Params &P, const double rho, const double u,
+                                                    const double p, const double gamma, const double a)
+    {
+      const double alpha = rs_alpha(P, rho, gamma, a);
+      return {rho, u, p, gamma, a, alpha, rs_c(gamma) * alpha};
+    }
+
+    /* ---- per-node Riemann record (as Euler<DIM>::riemann_record): everything riemann_data_from_state derives
+     * from one state and its EOS pressure except the normal velocity -- rho, p, gamma, a, alpha, alpha_hat -- and
+     * the velocity vector; per pair this removes 2 x (3 divisions + 1 square root) of the state conversion and
+     * the 2-3 x (division, square root, division) of rs_alpha / rs_c. The normal velocity becomes v . n instead
+     * of (m . n) / rho: a few ulp, inside the 1e-12 contract on d_ij (pinned on random pairs and in every sweep
+     * comparison, as for Euler). record = (rho, p, gamma, a, alpha, alpha_hat, v[DIM]) padded to even. */
+    static constexpr int RS = (6 + DIM + 1) / 2 * 2;
+
+    static RYUJIN_DEV void riemann_record(const Params &P, const double (&U)[K], const double p,
+                                          double (&rec)[RS])
+    {
+      const double rho = U[0];
+      const double rho_inverse = 1.0 / rho;
+      const double gamma = surrogate_gamma(P, U, p);
+      const double x = 1. - P.b * rho;
+      const double a = sqrt(gamma * (p + P.pinf) / (rho * x));
+      const double alpha = rs_alpha(P, rho, gamma, a);
+      rec[0] = rho;
+      rec[1] = p;
+      rec[2] = gamma;
+      rec[3] = a;
+      rec[4] = alpha;
+      rec[5] = rs_c(gamma) * alpha;
+#pragma unroll
+      for (int d = 0; d < DIM; ++d)
+        rec[6 + d] = U[1 + d] * rho_inverse;
+#pragma unroll
+      for (int d = 6 + DIM; d < RS; ++d)
+        rec[d] = 0.;
+    }
+
+    static RYUJIN_DEV double dij_from_records(const Params &P, const double (&ri)[RS], const double (&rj)[RS],
+                                              const double (&c)[DIM])
+    {
+      double norm2 = c[0] * c[0];
+      double vc_i = ri[6] * c[0], vc_j = rj[6] * c[0];
+#pragma unroll
+      for (int d = 1; d < DIM; ++d) {
+        norm2 += c[d] * c[d];
+        vc_i += ri[6 + d] * c[d];
+        vc_j += rj[6 + d] * c[d];
+      }
+      const double norm = sqrt(norm2);
+      const double inverse_norm = 1. / norm;
+      const RiemannData rd_i{ri[0], vc_i * inverse_norm, ri[1], ri[2], ri[3], ri[4], ri[5]};
+      const RiemannData rd_j{rj[0], vc_j * inverse_norm, rj[1], rj[2], rj[3], rj[4], rj[5]};
+      return norm * riemann_compute(P, rd_i, rd_j);
     }
 
     /* :161-198 */
@@ -333,13 +398,12 @@ namespace ryujin_hip
     /* :53-120 */
     static RYUJIN_DEV double p_star_RS_full(const Params &P, const RiemannData &i, const RiemannData &j)
     {
-      const double alpha_i = rs_alpha(P, i.rho, i.gamma, i.a);
-      const double alpha_j = rs_alpha(P, j.rho, j.gamma, j.a);
+      const double alpha_i = i.alpha;
+      const double alpha_j = j.alpha;
       const double p_min = fmin(i.p, j.p);
       const double p_max = fmax(i.p, j.p);
       const double gamma_min = i.p < j.p ? i.gamma : j.gamma;
-      const double alpha_min = i.p < j.p ? alpha_i : alpha_j;
-      const double alpha_hat_min = rs_c(gamma_min) * alpha_min;
+      const double alpha_hat_min = i.p < j.p ? i.alpha_hat : j.alpha_hat; /* rs_c(gamma_min) alpha_min */
       const double alpha_max = i.p >= j.p ? alpha_i : alpha_j;
       const double gamma_m = fmin(i.gamma, j.gamma);
       const double gamma_M = fmax(i.gamma, j.gamma);
@@ -365,8 +429,8 @@ namespace ryujin_hip
     static RYUJIN_DEV double p_star_SS_full(const Params &P, const RiemannData &i, const RiemannData &j)
     {
       const double gamma_m = fmin(i.gamma, j.gamma);
-      const double alpha_hat_i = rs_c(i.gamma) * rs_alpha(P, i.rho, i.gamma, i.a);
-      const double alpha_hat_j = rs_c(j.gamma) * rs_alpha(P, j.rho, j.gamma, j.a);
+      const double alpha_hat_i = i.alpha_hat;
+      const double alpha_hat_j = j.alpha_hat;
       const double exponent = (gamma_m - 1.) / (2. * gamma_m);
       const double exponent_inverse = 1. / exponent;
       const double numerator = positive_part(alpha_hat_i + alpha_hat_j - (j.u - i.u));
@@ -381,16 +445,14 @@ namespace ryujin_hip
     /* :201-255 */
     static RYUJIN_DEV double p_star_interpolated(const Params &P, const RiemannData &i, const RiemannData &j)
     {
-      const double alpha_i = rs_alpha(P, i.rho, i.gamma, i.a);
-      const double alpha_j = rs_alpha(P, j.rho, j.gamma, j.a);
+      const double alpha_i = i.alpha;
+      const double alpha_j = j.alpha;
       const double p_min = fmin(i.p, j.p) + P.pinf;
       const double p_max = fmax(i.p, j.p) + P.pinf;
       const double gamma_min = i.p < j.p ? i.gamma : j.gamma;
-      const double alpha_min = i.p < j.p ? alpha_i : alpha_j;
-      const double alpha_hat_min = rs_c(gamma_min) * alpha_min;
-      const double gamma_max = i.p >= j.p ? i.gamma : j.gamma;
+      const double alpha_hat_min = i.p < j.p ? i.alpha_hat : j.alpha_hat; /* rs_c(gamma_min) alpha_min */
       const double alpha_max = i.p >= j.p ? alpha_i : alpha_j;
-      const double alpha_hat_max = rs_c(gamma_max) * alpha_max;
+      const double alpha_hat_max = i.p >= j.p ? i.alpha_hat : j.alpha_hat; /* rs_c(gamma_max) alpha_max */
       const double gamma_m = fmin(i.gamma, j.gamma);
       const double gamma_M = fmax(i.gamma, j.gamma);
       const double p_ratio = p_min / p_max;
@@ -484,7 +546,7 @@ namespace ryujin_hip
       r.rho_e = internal_energy(V);
       const double shift = r.rho_e - r.rho * P.q - P.pinf * r.covolume;
       r.psi = relax_small * r.rho * shift -
-              s_min * r.rho * r.rho_gamma * dev_pow(r.covolume, -(gamma - 1.));
+              s_min * r.rho * r.rho_gamma * covolume_pow(P, r.covolume, -(gamma - 1.));
       return r;
     }
 
@@ -586,7 +648,7 @@ namespace ryujin_hip
         const Psi L = psi_of(P, U_l, s_min, gamma, relax_small);
 
         const double lower_bound =
-            (1. - relax) * s_min * L.rho * L.rho_gamma * dev_pow(L.covolume, -gm1);
+            (1. - relax) * s_min * L.rho * L.rho_gamma * covolume_pow(P, L.covolume, -gm1);
         if (n == 0 && !(fmin(0., L.psi - lower_bound) == 0.))
           success = false;
 

@@ -17,10 +17,10 @@ namespace ryujin_hip
   template <int DIM, bool WITH_BC>
   __global__ void __launch_bounds__(kBlock)
   k_precompute_aeos0(const EulerAeosParams P, const DeviceMesh M, const BcFold B, double *U,
-                     double *__restrict__ prec)
+                     double *__restrict__ prec, double *__restrict__ rec)
   {
     using E = EulerAeos<DIM>;
-    constexpr int K = E::K;
+    constexpr int K = E::K, RS = E::RS;
     const uint32_t i = M.slice_begin * 64 + blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M.n_owned || i >= M.slice_end * 64)
       return;
@@ -28,22 +28,50 @@ namespace ryujin_hip
       apply_bc_row<E>(P, B, i, U);
     if (M.row_len[i] == 1)
       return;
-    double U_i[K];
+    double U_i[K], rr[RS];
     load_state<K>(U, i, U_i);
-    E::store_prec(prec, i, E::precompute_cycle0(P, U_i));
+    const auto prec_i = E::precompute_cycle0(P, U_i);
+    E::store_prec(prec, i, prec_i);
+    /* the node's Riemann record for step 2 (EulerAeos::riemann_record) */
+    E::riemann_record(P, U_i, prec_i.p, rr);
+#pragma unroll
+    for (int g = 0; g < RS; ++g)
+      rec[(size_t)i * RS + g] = rr[g];
   }
 
-  /* cycle 1 (:942-975): gamma_min over the stencil, then s_i and eta_i for that gamma_min. The
-   * neighbours' gamma_j are recomputed from (U_j, p_j) as in the reference (slot 1 of a neighbour may
-   * already hold its minimum), so a row only ever reads slot 0 of its neighbours and writes slots 1-3
-   * of its own entry: the sweep runs in place (prec_out == prec_in) without a race. */
+  /* Riemann records of the ghost rows, from the exchanged ghost states and pressures (functions of (U_j, p_j)
+   * alone): behind the exchange of the precomputed values of cycle 0, on the stream of the exchange */
+  template <int DIM>
+  __global__ void __launch_bounds__(kBlock)
+  k_ghost_records_aeos(const EulerAeosParams P, const uint32_t first, const uint32_t last,
+                       const double *__restrict__ U, const double *__restrict__ prec, double *__restrict__ rec)
+  {
+    using E = EulerAeos<DIM>;
+    constexpr int K = E::K, RS = E::RS;
+    const uint32_t i = first + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= last)
+      return;
+    double U_i[K], rr[RS];
+    load_state<K>(U, i, U_i);
+    E::riemann_record(P, U_i, prec[(size_t)i * 4], rr);
+#pragma unroll
+    for (int g = 0; g < RS; ++g)
+      rec[(size_t)i * RS + g] = rr[g];
+  }
+
+  /* cycle 1 (:942-975): gamma_min over the stencil, then s_i and eta_i for that gamma_min. The reference
+   * recomputes the neighbours' gamma_j from (U_j, p_j) (slot 1 of a neighbour may already hold its minimum);
+   * here gamma_j = surrogate_gamma(U_j, p_j) is slot 2 of the neighbour's Riemann record, written by cycle 0 (and
+   * by k_ghost_records_aeos for the ghost rows) with the same function on the same arguments: one 8-byte gather
+   * per neighbour instead of two 32-byte ones and a division. A row writes slots 1-3 of its own entry only:
+   * the sweep runs in place (prec_out == prec_in). */
   template <int DIM>
   __global__ void __launch_bounds__(kBlock)
   k_precompute_aeos1(const EulerAeosParams P, const DeviceMesh M, const double *__restrict__ U,
-                     const double *prec_in, double *prec_out)
+                     const double *__restrict__ rec, const double *prec_in, double *prec_out)
   {
     using E = EulerAeos<DIM>;
-    constexpr int K = E::K;
+    constexpr int K = E::K, RS = E::RS;
     const RowCtx r = row_context(M);
     if (!r.valid)
       return;
@@ -53,14 +81,21 @@ namespace ryujin_hip
     load_state<K>(U, i, U_i);
     typename E::Prec prec_i = E::load_prec(prec_in, i);
     double gamma_min_i = prec_i.gamma_min;
-    for (uint32_t c = 1; c < r.width; ++c) {
-      const uint64_t pos = ((uint64_t)r.base + c) * 64 + r.lane;
-      const uint32_t j = ld_stream(M.cols + pos);
-      double U_j[K];
-      load_state<K>(U, j, U_j);
-      const double p_j = prec_in[(size_t)j * 4];
-      if (row_active && c < r.len)
-        gamma_min_i = fmin(gamma_min_i, E::surrogate_gamma(P, U_j, p_j));
+    /* four columns at a time: the index loads, then the dependent gathers, are in flight together (one column
+     * after the other the sweep was bound by 2 x 8 memory latencies per wave) */
+    for (uint32_t c = 1; c < r.width; c += 4) {
+      uint32_t j[4];
+      double gamma_j[4];
+#pragma unroll
+      for (uint32_t u = 0; u < 4; ++u)
+        j[u] = c + u < r.width ? ld_stream(M.cols + (((uint64_t)r.base + c + u) * 64 + r.lane)) : i;
+#pragma unroll
+      for (uint32_t u = 0; u < 4; ++u)
+        gamma_j[u] = rec[(size_t)j[u] * RS + 2];
+#pragma unroll
+      for (uint32_t u = 0; u < 4; ++u)
+        if (row_active && c + u < r.len)
+          gamma_min_i = fmin(gamma_min_i, gamma_j[u]);
     }
     if (!row_active)
       return;
@@ -117,14 +152,14 @@ namespace ryujin_hip
       alpha[i] = indicator.alpha(P, M.mi[i] * M.measure_of_omega_inverse);
   }
 
-  /* step 2b: upper-triangular d_ij */
+  /* step 2b: upper-triangular d_ij from the per-node Riemann records (EulerAeos::dij_from_records) */
   template <int DIM>
   __global__ void __launch_bounds__(kBlock, RYUJIN_OCC_DIJ)
   k_dij_aeos(const EulerAeosParams P, const DeviceMesh M, const uint32_t *__restrict__ lower_mask,
-             const double *__restrict__ U, const double *__restrict__ prec, double *__restrict__ dij)
+             const double *__restrict__ rec, double *__restrict__ dij)
   {
     using E = EulerAeos<DIM>;
-    constexpr int K = E::K;
+    constexpr int RS = E::RS;
     const RowCtx r = row_context(M);
     if (!r.valid)
       return;
@@ -133,9 +168,8 @@ namespace ryujin_hip
     const uint32_t upper =
         row_active ? (~lower_mask[r.row] & (r.len >= 32 ? 0xFFFFFFFFu : ((1u << r.len) - 1u)) & ~1u) : 0u;
 
-    double U_i[K];
-    load_state<K>(U, i, U_i);
-    const double p_i = prec[(size_t)i * 4];
+    double rec_i[RS];
+    load_state<RS>(rec, i, rec_i);
     for (uint32_t c = 1; c < r.width; ++c) {
       const bool mine = (upper >> c) & 1u;
       if (!__any(mine))
@@ -143,12 +177,11 @@ namespace ryujin_hip
       const uint64_t colbase = (uint64_t)r.base + c;
       const uint64_t pos = colbase * 64 + r.lane;
       const uint32_t j = ld_stream(M.cols + pos);
-      double c_ij[DIM], U_j[K];
+      double c_ij[DIM], rec_j[RS];
       load_entry<DIM>(M.cij, colbase, r.lane, c_ij);
-      load_state<K>(U, j, U_j);
-      const double p_j = prec[(size_t)j * 4];
+      load_state<RS>(rec, j, rec_j);
       if (mine)
-        dij[pos] = E::dij_from_states(P, U_i, p_i, U_j, p_j, c_ij);
+        dij[pos] = E::dij_from_records(P, rec_i, rec_j, c_ij);
     }
   }
 
@@ -157,25 +190,23 @@ namespace ryujin_hip
   __global__ void __launch_bounds__(kBlock)
   k_dij_boundary_aeos(const EulerAeosParams P, const uint32_t n_pairs, const uint32_t *__restrict__ p_i,
                       const uint32_t *__restrict__ p_j, const uint32_t *__restrict__ p_pos,
-                      const double *__restrict__ cji, const double *__restrict__ U,
-                      const double *__restrict__ prec, double *__restrict__ dij)
+                      const double *__restrict__ cji, const double *__restrict__ rec, double *__restrict__ dij)
   {
     using E = EulerAeos<DIM>;
-    constexpr int K = E::K;
+    constexpr int RS = E::RS;
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n_pairs)
       return;
     const uint32_t i = p_i[q], j = p_j[q];
     if (j < i)
       return;
-    double U_i[K], U_j[K], c_ji[DIM];
-    load_state<K>(U, i, U_i);
-    load_state<K>(U, j, U_j);
+    double rec_i[RS], rec_j[RS], c_ji[DIM];
+    load_state<RS>(rec, i, rec_i);
+    load_state<RS>(rec, j, rec_j);
 #pragma unroll
     for (int d = 0; d < DIM; ++d)
       c_ji[d] = cji[(size_t)q * DIM + d];
-    const double d_ji =
-        E::dij_from_states(P, U_j, prec[(size_t)j * 4], U_i, prec[(size_t)i * 4], c_ji);
+    const double d_ji = E::dij_from_records(P, rec_j, rec_i, c_ji);
     const uint32_t pos = p_pos[q];
     dij[pos] = fmax(dij[pos], d_ji);
   }

@@ -40,6 +40,18 @@ namespace ryujin_hip
 #define RYUJIN_OCC_LIJ0_3D 2 /* A/B on MI355X (4.2 M gridpoints): 2.15 ms at 3 waves (28 B/lane of scratch), 1.85 at 2 */
 #endif
 
+#ifndef RYUJIN_OCC_LIJ0_AEOS
+#define RYUJIN_OCC_LIJ0_AEOS 2 /* EulerAEOS (a fourth bound, gamma_min, powers in psi): 52 B/lane of scratch at 3 waves */
+#endif
+  struct EulerAeosParams;
+  template <typename E>
+  constexpr int lij0_waves_per_simd()
+  {
+    if (std::is_same<typename E::Params, EulerAeosParams>::value)
+      return RYUJIN_OCC_LIJ0_AEOS;
+    return E::DIMENSION == 3 ? RYUJIN_OCC_LIJ0_3D : RYUJIN_OCC_LIJ0;
+  }
+
   /* what a row needs of a neighbour to form P_ij */
   template <int K>
   struct PairData {
@@ -87,7 +99,7 @@ namespace ryujin_hip
   /* NY > 1 (small meshes): NY waves (blockIdx.y) share a slice, wave y taking the columns 1 + y, 1 + y + NY, ...;
    * no V_i then (the row's sum is spread over several waves): the caller passes V_out = nullptr */
   template <typename E, int NY = 1>
-  __global__ void __launch_bounds__(kBlock, (E::DIMENSION == 3 ? RYUJIN_OCC_LIJ0_3D : RYUJIN_OCC_LIJ0))
+  __global__ void __launch_bounds__(kBlock, lij0_waves_per_simd<E>())
   k_lij_stage0(const typename E::Params P, const DeviceMesh M, DeviceScalars *__restrict__ scalars,
                const double *__restrict__ old_U, const double *__restrict__ alpha,
                const double *__restrict__ dij, const double *__restrict__ new_U,

@@ -422,7 +422,7 @@ struct ryujin_hip_ctx {
 
   struct State {
     DeviceBuffer<double> U, prec;
-    DeviceBuffer<double> rrec; /* Euler, shallow water: per-node Riemann records (E::riemann_record) */
+    DeviceBuffer<double> rrec; /* Euler, EulerAEOS, shallow water: per-node Riemann records (E::riemann_record) */
     bool used = false;
   };
   std::vector<std::unique_ptr<State>> states;
@@ -1105,16 +1105,26 @@ void ryujin_hip_ctx::prepare_state_vector(int h, const double *dirichlet)
     sweep([&](const DeviceMesh &mm, dim3 grid) {
       if (fold_bc)
         hipLaunchKernelGGL((k_precompute_aeos0<E::DIMENSION, true>), grid, block, 0, launch_stream, eparams, mm, bc, s.U.ptr,
-                         s.prec.ptr);
+                         s.prec.ptr, s.rrec.ptr);
       else
         hipLaunchKernelGGL((k_precompute_aeos0<E::DIMENSION, false>), grid, block, 0, launch_stream, eparams, mm, bc, s.U.ptr,
-                         s.prec.ptr);
+                         s.prec.ptr, s.rrec.ptr);
     });
     exchange_vector(s.U.ptr, KP, true);
     exchange_vector(s.prec.ptr, 4, true);
+    if (L.n_relevant > L.n_owned) {
+      /* Riemann records of the ghost rows from the exchanged (U_j, p_j): on comm_stream behind the two exchanges */
+      hipLaunchKernelGGL(k_ghost_records_aeos<E::DIMENSION>, dim3(grid_for(L.n_relevant - L.n_owned)), block, 0,
+                         n_nbr ? comm_stream : stream, eparams, L.n_owned, L.n_relevant, s.U.ptr, s.prec.ptr,
+                         s.rrec.ptr);
+      if (n_nbr) {
+        comm_pending = true;
+        exchange_after_exp = true;
+      }
+    }
     sweep([&](const DeviceMesh &mm, dim3 grid) {
       hipLaunchKernelGGL(k_precompute_aeos1<E::DIMENSION>, grid, block, 0, launch_stream, eparams, mm, s.U.ptr,
-                         s.prec.ptr, s.prec.ptr);
+                         s.rrec.ptr, s.prec.ptr, s.prec.ptr);
     });
     exchange_vector(s.prec.ptr, 4, true);
   } else if constexpr (std::is_same<typename E::Params, ScalarParams>::value) {
@@ -1206,7 +1216,7 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
     exchange_vector(d_alpha.ptr, 1, true);
     sweep([&](const DeviceMesh &mm, dim3 grid) {
       hipLaunchKernelGGL(k_dij_aeos<DIM>, grid, block, 0, launch_stream, eparams, mm, d_lower_mask.ptr,
-                         old.U.ptr, old.prec.ptr, d_dij.ptr);
+                         old.rrec.ptr, d_dij.ptr);
     });
   } else if constexpr (is_scalar) {
     sweep([&](const DeviceMesh &mm, dim3 grid) {
@@ -1260,8 +1270,7 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
                     * (and may point to ghost columns: the U exchange precedes that export part in stream order) */
     if constexpr (is_aeos)
       hipLaunchKernelGGL(k_dij_boundary_aeos<DIM>, dim3(grid_for(n_pairs)), block, 0, stream, eparams,
-                         n_pairs, d_p_i.ptr, d_p_j.ptr, d_p_pos.ptr, d_p_cji.ptr, old.U.ptr,
-                         old.prec.ptr, d_dij.ptr);
+                         n_pairs, d_p_i.ptr, d_p_j.ptr, d_p_pos.ptr, d_p_cji.ptr, old.rrec.ptr, d_dij.ptr);
     else if constexpr (is_scalar)
       hipLaunchKernelGGL(k_dij_boundary_sc<DIM>, dim3(grid_for(n_pairs)), block, 0, stream, eparams,
                          n_pairs, d_p_i.ptr, d_p_j.ptr, d_p_pos.ptr, d_p_cji.ptr, old.U.ptr,
@@ -2121,7 +2130,7 @@ int ryujin_hip_state_alloc(ryujin_hip_ctx *ctx, int *handle)
       h = (int)ctx->states.size() - 1;
       ctx->states[h]->U.alloc((size_t)ctx->L.n_relevant * ctx->KP);
       ctx->states[h]->prec.alloc((size_t)ctx->L.n_relevant * ctx->NPREC);
-      if (ctx->params.equation == RYUJIN_EQ_EULER)
+      if (ctx->params.equation == RYUJIN_EQ_EULER || ctx->params.equation == RYUJIN_EQ_EULER_AEOS)
         ctx->states[h]->rrec.alloc((size_t)ctx->L.n_relevant * ((6 + ctx->dim + 1) / 2 * 2));
       else if (ctx->params.equation == RYUJIN_EQ_SHALLOW_WATER)
         ctx->states[h]->rrec.alloc((size_t)ctx->L.n_relevant * ((2 + ctx->dim + 1) / 2 * 2));
@@ -2557,9 +2566,30 @@ namespace
     if (q >= n)
       return;
     if (which == RYUJIN_DEBUG_AEOS_RIEMANN) {
+      /* through the PRODUCTION evaluation path: per-node records, dij_from_records with n = (1) */
+      using A = EulerAeos<1>;
       const double *v = in + q * 10;
-      const EulerAeos<1>::RiemannData rd_i{v[0], v[1], v[2], v[3], v[4]}, rd_j{v[5], v[6], v[7], v[8], v[9]};
-      out[q] = EulerAeos<1>::riemann_compute(PA, rd_i, rd_j);
+      const A::RiemannData rd_i = A::make_riemann_data(PA, v[0], v[1], v[2], v[3], v[4]),
+                           rd_j = A::make_riemann_data(PA, v[5], v[6], v[7], v[8], v[9]);
+      const double r_i[A::RS] = {rd_i.rho, rd_i.p, rd_i.gamma, rd_i.a, rd_i.alpha, rd_i.alpha_hat, rd_i.u, 0.},
+                   r_j[A::RS] = {rd_j.rho, rd_j.p, rd_j.gamma, rd_j.a, rd_j.alpha, rd_j.alpha_hat, rd_j.u, 0.};
+      const double n[1] = {1.};
+      out[q] = A::dij_from_records(PA, r_i, r_j, n);
+      return;
+    }
+    if (which == RYUJIN_DEBUG_AEOS_DIJ_2D || which == RYUJIN_DEBUG_AEOS_DIJ_RECORDS_2D) {
+      using A = EulerAeos<2>;
+      const double *v = in + q * 10;
+      const double U_i[4] = {v[0], v[1], v[2], v[3]}, U_j[4] = {v[4], v[5], v[6], v[7]}, c[2] = {v[8], v[9]};
+      const double p_i = A::precompute_cycle0(PA, U_i).p, p_j = A::precompute_cycle0(PA, U_j).p;
+      if (which == RYUJIN_DEBUG_AEOS_DIJ_2D) {
+        out[q] = A::dij_from_states(PA, U_i, p_i, U_j, p_j, c);
+      } else {
+        double r_i[A::RS], r_j[A::RS];
+        A::riemann_record(PA, U_i, p_i, r_i);
+        A::riemann_record(PA, U_j, p_j, r_j);
+        out[q] = A::dij_from_records(PA, r_i, r_j, c);
+      }
       return;
     }
     if (which == RYUJIN_DEBUG_AEOS_LIMIT_1D) {
@@ -2664,7 +2694,9 @@ int ryujin_hip_debug_function(int device, const ryujin_hip_params *params, int w
     case RYUJIN_DEBUG_EULER_RIEMANN:
     case RYUJIN_DEBUG_EULER_RIEMANN_RECORDS: n_in = 8; n_out = 1; break;
     case RYUJIN_DEBUG_SW_RIEMANN_RECORDS: n_in = 6; n_out = 1; break;
-    case RYUJIN_DEBUG_AEOS_RIEMANN: n_in = 10; n_out = 1; break;
+    case RYUJIN_DEBUG_AEOS_RIEMANN:
+    case RYUJIN_DEBUG_AEOS_DIJ_2D:
+    case RYUJIN_DEBUG_AEOS_DIJ_RECORDS_2D: n_in = 10; n_out = 1; break;
     case RYUJIN_DEBUG_AEOS_LIMIT_1D: n_in = 10; n_out = 3; break;
     case RYUJIN_DEBUG_EULER_LIMIT_1D: n_in = 9; n_out = 3; break;
     case RYUJIN_DEBUG_SW_RIEMANN: n_in = 6; n_out = 2; break;

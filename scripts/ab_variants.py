@@ -24,7 +24,8 @@ ap.add_argument("--dim", type=int, default=2)
 ap.add_argument("--length", type=float, default=1.25, help="3-D: channel length in units")
 ap.add_argument("--workload", default="", help="sw2d: the shallow-water dam break of bench.py (--cells-per-unit = "
                                                "cells per direction, default 1824); sedov3d: the radial-contrast box "
-                                               "(default 160 cells per direction); default: step2d / cylinder3d by --dim")
+                                               "(default 160 cells per direction); step2d_aeos: step2d through EulerAEOS; "
+                                               "default: step2d / cylinder3d by --dim")
 ap.add_argument("variants", nargs="+")
 args = ap.parse_args()
 
@@ -40,6 +41,8 @@ elif args.workload == "sedov3d":
     spec = offline.box_3d(n)
 elif args.dim == 2:
     spec = offline.mach3_step_2d(args.cells_per_unit)
+    if args.workload == "step2d_aeos":  # the same problem through the EulerAEOS Description
+        equation = capi.EQ_EULER_AEOS
 else:
     spec = offline.cylinder_channel_3d(args.cells_per_unit, length_units=args.length)
 off = offline.SyntheticOffline(spec)

@@ -273,3 +273,41 @@ def test_device_aeos_limiter_against_the_reference_baselines(oracle, golden_dir,
         if ref["success"]:
             assert bool(success), n
             assert abs(l - ref["l"]) <= 1e-10, (n, l, ref["l"])
+
+
+@pytest.mark.parametrize("records", [False, True])
+@pytest.mark.parametrize("eos", ["polytropic", "covolume", "nasg"])
+def test_device_aeos_dij_against_the_oracle_on_random_states(oracle, eos, records):
+    """EulerAEOS d_ij = |c_ij| lambda_max for 20 k random admissible state pairs and directions (density over 3.6
+    decades, internal energy over 2.7, Mach numbers up to 3; polytropic gas, covolume b = 0.1, NASG with b = 0.1 and
+    p_infty = 0.5): in the reference's operation order (dij_from_states) and through the per-node Riemann records
+    the sweeps use (k_dij_aeos: rho, p, gamma, a, alpha, alpha_hat and the velocity per node, normal velocity
+    v . n instead of (m . n) / rho) against the oracle's pipeline from states, 1e-12 relative."""
+    from test_oracle_golden_aeos import _params
+    kw = {"polytropic": dict(), "covolume": dict(eos=capi.EOS_VAN_DER_WAALS, b=0.1),
+          "nasg": dict(eos=capi.EOS_NOBLE_ABEL_STIFFENED_GAS, b=0.1, pinf=0.5)}[eos]
+    params = _params(oracle, dim=2, **kw)
+    rng = np.random.default_rng(11)
+    n = 20_000
+
+    def states():
+        rho = 10.0 ** rng.uniform(-3, 0.6, n)
+        rho_e = 10.0 ** rng.uniform(0.3, 3, n)
+        a = np.sqrt(1.4 * 0.4 * rho_e / rho)
+        v = rng.normal(size=(n, 2))
+        v *= (rng.uniform(0, 3, n) * a / np.linalg.norm(v, axis=1))[:, None]
+        return np.column_stack([rho, rho[:, None] * v, rho_e + 0.5 * rho * (v ** 2).sum(1)])
+
+    U_i, U_j = states(), states()
+    c = rng.normal(size=(n, 2)) * 10.0 ** rng.uniform(-4, 0, n)[:, None]
+    got = _device(params, capi.DEBUG_AEOS_DIJ_RECORDS_2D if records else capi.DEBUG_AEOS_DIJ_2D,
+                  np.hstack([U_i, U_j, c]), 1)[:, 0]
+    lib = oracle.lib()
+    norm = np.linalg.norm(c, axis=1)
+    nrm = np.ascontiguousarray(c / norm[:, None])
+    U_i, U_j = np.ascontiguousarray(U_i), np.ascontiguousarray(U_j)
+    dp = capi.c_double_p
+    ref = np.array([lib.ryujin_oracle_aeos_lambda_max(C.byref(params), capi.as_ptr(U_i[q], dp), capi.as_ptr(U_j[q], dp),
+                                                      capi.as_ptr(nrm[q], dp)) for q in range(n)]) * norm
+    rel = np.abs(got - ref) / np.abs(ref)
+    assert rel.max() <= 1e-12, (rel.max(), int(rel.argmax()))
