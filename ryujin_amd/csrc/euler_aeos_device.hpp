@@ -503,9 +503,19 @@ namespace ryujin_hip
             phi_p_max < 0. ? fmin(p_star_tilde, p_star_backup) : fmin(p_max, p_star_tilde);
         return compute_lambda(P, i, j, p_2);
       }
-      const double p_star_RS = p_star_RS_full(P, i, j);
-      const double p_star_SS = p_star_SS_full(P, i, j);
-      const double p_2 = phi_p_max < 0. ? p_star_SS : fmin(p_max, p_star_RS);
+      /* The reference evaluates both estimates (seven powers) and selects by the sign of phi(p_max). Where the
+       * sign is the same over the wave only the selected estimate is evaluated: same value, two or five powers less. */
+      const bool two_shocks = phi_p_max < 0.;
+      double p_2;
+      if (!__any(!two_shocks)) {
+        p_2 = p_star_SS_full(P, i, j);
+      } else if (!__any(two_shocks)) {
+        p_2 = fmin(p_max, p_star_RS_full(P, i, j));
+      } else {
+        const double p_star_RS = p_star_RS_full(P, i, j);
+        const double p_star_SS = p_star_SS_full(P, i, j);
+        p_2 = two_shocks ? p_star_SS : fmin(p_max, p_star_RS);
+      }
       return compute_lambda(P, i, j, p_2);
     }
 

@@ -279,6 +279,10 @@ namespace ryujin_hip
       return out;
     }
 
+    /* the row's own column contributes exact zeros to the indicator sums (eta_j / rho_j - eta_i / rho_i and
+     * f_j - f_i vanish bit for bit for j = i): the sweep skips it */
+    static constexpr bool kIndicatorDiagonalIsZero = true;
+
     /* Indicator (entropy-viscosity commutator): indicator.h:187-258 */
     struct Indicator {
       double rho_i_inverse, eta_i, left;

@@ -651,7 +651,9 @@ namespace ryujin_hip
         j_nn = (c + 2 < r.width) ? ld_stream(cols + ((colbase + 2) * 64 + r.lane)) : i;
       }
       const bool active = row_active && c < r.len;
-      if (active)
+      /* Euler: column 0 is the row itself, eta_j / rho_j = eta_i / rho_i and f_j = f_i bit for bit, its terms are
+       * exact zeros added to sums that start at zero */
+      if (active && (c > 0 || !E::kIndicatorDiagonalIsZero))
         indicator.accumulate(P, U_j, prec_j, c_ij);
       /* upper triangle only (:394-408) */
       const bool mine = active && c > 0 && j > i;
@@ -943,7 +945,9 @@ namespace ryujin_hip
 #pragma unroll
         for (int q = 0; q < K; ++q)
           U_avg[q] = (U_i[q] + U_j[q]) * .5;
-        const double s_interp = E::specific_entropy(P, U_avg);
+        /* column 0 (j = i, wave-uniform): U_avg = U_i exactly and s(U_i) is the precomputed s_i = s_j (the same
+         * function on the same arguments): one power and one division less per row, the same bits */
+        const double s_interp = c == 0 ? s_j : E::specific_entropy(P, U_avg);
         s_interp_max = fmax(s_interp_max, s_interp);
       }
 

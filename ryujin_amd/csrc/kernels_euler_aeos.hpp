@@ -145,7 +145,8 @@ namespace ryujin_hip
         load_entry<DIM>(cij, colbase + 1, r.lane, c_n);
         load_state<K>(U, j_n, U_n);
       }
-      if (row_active && c < r.len)
+      /* column 0 is the row itself: eta_j = eta_i and f_j = f_i bit for bit, its terms are exact zeros */
+      if (row_active && c < r.len && c > 0)
         indicator.accumulate(P, U_j, c_ij);
     }
     if (row_active)
@@ -332,10 +333,13 @@ namespace ryujin_hip
         rho_max = fmax(rho_max, rho_ij_bar);
         rho_relaxation_numerator += 1. * (rho_i + rho_j);
         rho_relaxation_denominator += 1.;
-        const double s_ij_bar = E::surrogate_specific_entropy(P, U_ij_bar, gamma_min);
+        /* column 0 (j = i): U_ij_bar = U_avg = U_j = U_i exactly, and s(U_i, gamma_min) is the precomputed s_i
+         * (cycle 1 of the precomputation evaluates the same function on the same arguments): three powers less
+         * per row, the same bits. c is wave-uniform. */
+        const double s_ij_bar = c == 0 ? prec_i.s : E::surrogate_specific_entropy(P, U_ij_bar, gamma_min);
         if (P.strict) {
-          const double s_j_strict = E::surrogate_specific_entropy(P, U_j, gamma_min);
-          const double s_interp = E::surrogate_specific_entropy(P, U_avg, gamma_min);
+          const double s_j_strict = c == 0 ? prec_i.s : E::surrogate_specific_entropy(P, U_j, gamma_min);
+          const double s_interp = c == 0 ? prec_i.s : E::surrogate_specific_entropy(P, U_avg, gamma_min);
           s_min = fmin(s_min, s_j_strict);
           s_min = fmin(s_min, s_ij_bar);
           s_interp_max = fmax(s_interp_max, s_interp);

@@ -242,6 +242,10 @@ namespace ryujin_hip
       return out;
     }
 
+    /* `left` accumulates (eta_j + p_j) v_j . c_ij, not a difference: the row's own column counts (c_ii != 0 on the
+     * boundary) */
+    static constexpr bool kIndicatorDiagonalIsZero = false;
+
     /* ------------------------------------------------------------------ Indicator */
     struct Indicator {
       double eta_i, left;
