@@ -17,7 +17,7 @@ namespace ryujin_hip
   template <int DIM, bool WITH_BC>
   __global__ void __launch_bounds__(kBlock)
   k_precompute_aeos0(const EulerAeosParams P, const DeviceMesh M, const BcFold B, double *U,
-                     double *__restrict__ prec, double *__restrict__ rec)
+                     double *__restrict__ prec, double *__restrict__ rec, double *__restrict__ gamma)
   {
     using E = EulerAeos<DIM>;
     constexpr int K = E::K, RS = E::RS;
@@ -37,6 +37,7 @@ namespace ryujin_hip
 #pragma unroll
     for (int g = 0; g < RS; ++g)
       rec[(size_t)i * RS + g] = rr[g];
+    gamma[i] = rr[2]; /* once more as a dense vector: cycle 1 gathers it over the stencil */
   }
 
   /* Riemann records of the ghost rows, from the exchanged ghost states and pressures (functions of (U_j, p_j)
@@ -44,7 +45,8 @@ namespace ryujin_hip
   template <int DIM>
   __global__ void __launch_bounds__(kBlock)
   k_ghost_records_aeos(const EulerAeosParams P, const uint32_t first, const uint32_t last,
-                       const double *__restrict__ U, const double *__restrict__ prec, double *__restrict__ rec)
+                       const double *__restrict__ U, const double *__restrict__ prec, double *__restrict__ rec,
+                       double *__restrict__ gamma)
   {
     using E = EulerAeos<DIM>;
     constexpr int K = E::K, RS = E::RS;
@@ -57,21 +59,22 @@ namespace ryujin_hip
 #pragma unroll
     for (int g = 0; g < RS; ++g)
       rec[(size_t)i * RS + g] = rr[g];
+    gamma[i] = rr[2];
   }
 
   /* cycle 1 (:942-975): gamma_min over the stencil, then s_i and eta_i for that gamma_min. The reference
    * recomputes the neighbours' gamma_j from (U_j, p_j) (slot 1 of a neighbour may already hold its minimum);
-   * here gamma_j = surrogate_gamma(U_j, p_j) is slot 2 of the neighbour's Riemann record, written by cycle 0 (and
-   * by k_ghost_records_aeos for the ghost rows) with the same function on the same arguments: one 8-byte gather
-   * per neighbour instead of two 32-byte ones and a division. A row writes slots 1-3 of its own entry only:
-   * the sweep runs in place (prec_out == prec_in). */
+   * here gamma_j = surrogate_gamma(U_j, p_j) was left in a dense vector by cycle 0 (and by k_ghost_records_aeos for
+   * the ghost rows) -- the same function on the same arguments: one coalesced 8-byte gather per neighbour instead
+   * of two 32-byte ones and a division. A row writes slots 1-3 of its own entry only: the sweep runs in place
+   * (prec_out == prec_in). */
   template <int DIM>
   __global__ void __launch_bounds__(kBlock)
   k_precompute_aeos1(const EulerAeosParams P, const DeviceMesh M, const double *__restrict__ U,
-                     const double *__restrict__ rec, const double *prec_in, double *prec_out)
+                     const double *__restrict__ gamma, const double *prec_in, double *prec_out)
   {
     using E = EulerAeos<DIM>;
-    constexpr int K = E::K, RS = E::RS;
+    constexpr int K = E::K;
     const RowCtx r = row_context(M);
     if (!r.valid)
       return;
@@ -91,7 +94,7 @@ namespace ryujin_hip
         j[u] = c + u < r.width ? ld_stream(M.cols + (((uint64_t)r.base + c + u) * 64 + r.lane)) : i;
 #pragma unroll
       for (uint32_t u = 0; u < 4; ++u)
-        gamma_j[u] = rec[(size_t)j[u] * RS + 2];
+        gamma_j[u] = gamma[j[u]];
 #pragma unroll
       for (uint32_t u = 0; u < 4; ++u)
         if (row_active && c + u < r.len)

@@ -408,6 +408,7 @@ struct ryujin_hip_ctx {
 
   /* module-owned vectors and matrices */
   DeviceBuffer<double> d_alpha, d_bounds, d_r, d_dij, d_lij, d_lij_next, d_pij;
+  DeviceBuffer<double> d_gamma; /* EulerAEOS: surrogate gamma_i of cycle 0, one double per node, for the stencil minimum of cycle 1 */
   DeviceBuffer<DeviceScalars> d_scalars;
   DeviceBuffer<double> d_integrals; /* ryujin_hip_state_integrals: block partials + result */
   DeviceScalars *h_scalars = nullptr; /* pinned */
@@ -757,6 +758,8 @@ void ryujin_hip_ctx::create(const ryujin_hip_offline &o, const ryujin_hip_params
 
   /* ---- module-owned storage (prepare(): hyperbolic_module.template.h:52-86) ---- */
   d_alpha.alloc(L.n_relevant);
+  if (params.equation == RYUJIN_EQ_EULER_AEOS)
+    d_gamma.alloc(L.n_relevant);
   d_bounds.alloc((size_t)NB * bounds_stride);
   if (dg)
     d_bounds_combined.alloc((size_t)NB * bounds_stride);
@@ -1105,10 +1108,10 @@ void ryujin_hip_ctx::prepare_state_vector(int h, const double *dirichlet)
     sweep([&](const DeviceMesh &mm, dim3 grid) {
       if (fold_bc)
         hipLaunchKernelGGL((k_precompute_aeos0<E::DIMENSION, true>), grid, block, 0, launch_stream, eparams, mm, bc, s.U.ptr,
-                         s.prec.ptr, s.rrec.ptr);
+                         s.prec.ptr, s.rrec.ptr, d_gamma.ptr);
       else
         hipLaunchKernelGGL((k_precompute_aeos0<E::DIMENSION, false>), grid, block, 0, launch_stream, eparams, mm, bc, s.U.ptr,
-                         s.prec.ptr, s.rrec.ptr);
+                         s.prec.ptr, s.rrec.ptr, d_gamma.ptr);
     });
     exchange_vector(s.U.ptr, KP, true);
     exchange_vector(s.prec.ptr, 4, true);
@@ -1116,7 +1119,7 @@ void ryujin_hip_ctx::prepare_state_vector(int h, const double *dirichlet)
       /* Riemann records of the ghost rows from the exchanged (U_j, p_j): on comm_stream behind the two exchanges */
       hipLaunchKernelGGL(k_ghost_records_aeos<E::DIMENSION>, dim3(grid_for(L.n_relevant - L.n_owned)), block, 0,
                          n_nbr ? comm_stream : stream, eparams, L.n_owned, L.n_relevant, s.U.ptr, s.prec.ptr,
-                         s.rrec.ptr);
+                         s.rrec.ptr, d_gamma.ptr);
       if (n_nbr) {
         comm_pending = true;
         exchange_after_exp = true;
@@ -1124,7 +1127,7 @@ void ryujin_hip_ctx::prepare_state_vector(int h, const double *dirichlet)
     }
     sweep([&](const DeviceMesh &mm, dim3 grid) {
       hipLaunchKernelGGL(k_precompute_aeos1<E::DIMENSION>, grid, block, 0, launch_stream, eparams, mm, s.U.ptr,
-                         s.rrec.ptr, s.prec.ptr, s.prec.ptr);
+                         d_gamma.ptr, s.prec.ptr, s.prec.ptr);
     });
     exchange_vector(s.prec.ptr, 4, true);
   } else if constexpr (std::is_same<typename E::Params, ScalarParams>::value) {
