@@ -20,8 +20,10 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <exception>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "ryujin_hip.h"
@@ -29,6 +31,35 @@
 namespace ryujin_hip
 {
   constexpr uint32_t kWave = 64;
+
+  /* fn(begin, end) over [0, n) in contiguous chunks on up to 16 host threads (setup only: the conversion of a
+   * 200^3 mesh touches 2e8 matrix entries several times); the first exception of a chunk is rethrown */
+  template <typename F>
+  void parallel_chunks(const uint64_t n, F &&fn)
+  {
+    const unsigned hw = std::thread::hardware_concurrency();
+    const uint64_t n_threads = std::min<uint64_t>(std::min<unsigned>(hw ? hw : 1u, 16u), n / 4096 + 1);
+    if (n_threads <= 1) {
+      fn((uint64_t)0, n);
+      return;
+    }
+    std::vector<std::thread> pool;
+    std::vector<std::exception_ptr> errors(n_threads);
+    const uint64_t chunk = (n + n_threads - 1) / n_threads;
+    for (uint64_t t = 0; t < n_threads; ++t)
+      pool.emplace_back([&, t]() {
+        try {
+          fn(std::min(n, t * chunk), std::min(n, (t + 1) * chunk));
+        } catch (...) {
+          errors[t] = std::current_exception();
+        }
+      });
+    for (auto &th : pool)
+      th.join();
+    for (auto &e : errors)
+      if (e)
+        std::rethrow_exception(e);
+  }
 
   /* logical (row, col_idx) view of the reference layout */
   struct RefView {
@@ -140,17 +171,19 @@ namespace ryujin_hip
 
       /* columns; padding -> own row */
       cols.assign(nnz_total, 0);
-      for (uint32_t s = 0; s < n_slices; ++s) {
-        const uint32_t width = slice_off[s + 1] - slice_off[s];
-        for (uint32_t l = 0; l < kWave; ++l) {
-          const uint32_t row = s * kWave + l;
-          const uint32_t self = row < n_owned ? row : (n_owned ? n_owned - 1 : 0);
-          for (uint32_t c = 0; c < width; ++c) {
-            const uint64_t p = ((uint64_t)slice_off[s] + c) * kWave + l;
-            cols[p] = (row < n_owned && c < row_len[row]) ? o.columns[ref.scalar_pos(row, c)] : self;
+      parallel_chunks(n_slices, [&](const uint64_t s0, const uint64_t s1) {
+        for (uint32_t s = (uint32_t)s0; s < (uint32_t)s1; ++s) {
+          const uint32_t width = slice_off[s + 1] - slice_off[s];
+          for (uint32_t l = 0; l < kWave; ++l) {
+            const uint32_t row = s * kWave + l;
+            const uint32_t self = row < n_owned ? row : (n_owned ? n_owned - 1 : 0);
+            for (uint32_t c = 0; c < width; ++c) {
+              const uint64_t p = ((uint64_t)slice_off[s] + c) * kWave + l;
+              cols[p] = (row < n_owned && c < row_len[row]) ? o.columns[ref.scalar_pos(row, c)] : self;
+            }
           }
         }
-      }
+      });
       for (uint32_t i = n_owned; i < n_relevant; ++i) {
         const uint32_t len = ref.row_length(i);
         for (uint32_t c = 0; c < len; ++c)
@@ -181,36 +214,40 @@ namespace ryujin_hip
         return -1;
       };
       idx_t.assign(nnz_total, 0);
-      for (uint32_t i = 0; i < n_relevant; ++i) {
-        const uint32_t len = logical_len(i);
-        for (uint32_t c = 0; c < len; ++c) {
-          const uint64_t p = pos(i, c);
-          const uint32_t j = cols[p];
-          if (c == 0 || j == i) {
-            idx_t[p] = (uint32_t)pos(i, 0);
-            continue;
+      parallel_chunks(n_relevant, [&](const uint64_t i0, const uint64_t i1) {
+        for (uint32_t i = (uint32_t)i0; i < (uint32_t)i1; ++i) {
+          const uint32_t len = logical_len(i);
+          for (uint32_t c = 0; c < len; ++c) {
+            const uint64_t p = pos(i, c);
+            const uint32_t j = cols[p];
+            if (c == 0 || j == i) {
+              idx_t[p] = (uint32_t)pos(i, 0);
+              continue;
+            }
+            const int64_t ct = find_in_row(j, i);
+            if (ct < 0) {
+              if (i < n_owned)
+                throw std::invalid_argument("sparsity pattern is not structurally symmetric");
+              idx_t[p] = (uint32_t)p;
+              continue;
+            }
+            idx_t[p] = (uint32_t)pos(j, (uint32_t)ct);
           }
-          const int64_t ct = find_in_row(j, i);
-          if (ct < 0) {
-            if (i < n_owned)
-              throw std::invalid_argument("sparsity pattern is not structurally symmetric");
-            idx_t[p] = (uint32_t)p;
-            continue;
-          }
-          idx_t[p] = (uint32_t)pos(j, (uint32_t)ct);
         }
-      }
+      });
       /* padding entries: transpose -> themselves */
-      for (uint32_t s = 0; s < n_slices; ++s) {
-        const uint32_t width = slice_off[s + 1] - slice_off[s];
-        for (uint32_t l = 0; l < kWave; ++l) {
-          const uint32_t row = s * kWave + l;
-          for (uint32_t c = (row < n_owned ? row_len[row] : 0); c < width; ++c) {
-            const uint64_t p = ((uint64_t)slice_off[s] + c) * kWave + l;
-            idx_t[p] = (uint32_t)p;
+      parallel_chunks(n_slices, [&](const uint64_t s0, const uint64_t s1) {
+        for (uint32_t s = (uint32_t)s0; s < (uint32_t)s1; ++s) {
+          const uint32_t width = slice_off[s + 1] - slice_off[s];
+          for (uint32_t l = 0; l < kWave; ++l) {
+            const uint32_t row = s * kWave + l;
+            for (uint32_t c = (row < n_owned ? row_len[row] : 0); c < width; ++c) {
+              const uint64_t p = ((uint64_t)slice_off[s] + c) * kWave + l;
+              idx_t[p] = (uint32_t)p;
+            }
           }
         }
-      }
+      });
     }
 
     /* reference layout -> device layout (padding = 0) */
@@ -218,26 +255,30 @@ namespace ryujin_hip
     {
       const RefView ref(o);
       std::vector<double> out(nnz_total * n_comp, 0.);
-      for (uint32_t i = 0; i < n_relevant; ++i) {
-        const uint32_t len = ref.row_length(i);
-        for (uint32_t c = 0; c < len; ++c) {
-          const uint64_t p = pos(i, c);
-          for (uint32_t d = 0; d < n_comp; ++d)
-            out[comp_pos(p, n_comp, d)] = data[ref.data_pos(i, c, n_comp, d)];
+      parallel_chunks(n_relevant, [&](const uint64_t i0, const uint64_t i1) {
+        for (uint32_t i = (uint32_t)i0; i < (uint32_t)i1; ++i) {
+          const uint32_t len = ref.row_length(i);
+          for (uint32_t c = 0; c < len; ++c) {
+            const uint64_t p = pos(i, c);
+            for (uint32_t d = 0; d < n_comp; ++d)
+              out[comp_pos(p, n_comp, d)] = data[ref.data_pos(i, c, n_comp, d)];
+          }
         }
-      }
+      });
       return out;
     }
 
     /* device layout -> logical CSR over owned rows (AoS per entry) */
     void gather_logical(const std::vector<double> &dev, uint32_t n_comp, double *out) const
     {
-      for (uint32_t i = 0; i < n_owned; ++i)
-        for (uint32_t c = 0; c < row_len[i]; ++c) {
-          const uint64_t p = pos(i, c);
-          for (uint32_t d = 0; d < n_comp; ++d)
-            out[(logical_ptr[i] + c) * n_comp + d] = dev[comp_pos(p, n_comp, d)];
-        }
+      parallel_chunks(n_owned, [&](const uint64_t i0, const uint64_t i1) {
+        for (uint32_t i = (uint32_t)i0; i < (uint32_t)i1; ++i)
+          for (uint32_t c = 0; c < row_len[i]; ++c) {
+            const uint64_t p = pos(i, c);
+            for (uint32_t d = 0; d < n_comp; ++d)
+              out[(logical_ptr[i] + c) * n_comp + d] = dev[comp_pos(p, n_comp, d)];
+          }
+      });
     }
   };
 } // namespace ryujin_hip

@@ -12,6 +12,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstddef>
 #include <cstdlib>
@@ -632,10 +633,12 @@ void ryujin_hip_ctx::create(const ryujin_hip_offline &o, const ryujin_hip_params
     /* bit c of lower_mask[row] <=> column c of the row lies below the diagonal (cols < row) */
     std::vector<uint32_t> lower_mask(L.rows_padded, 0u);
     if (L.max_row_len <= 32)
-      for (uint32_t i = 0; i < L.n_owned; ++i)
-        for (uint32_t c = 1; c < L.row_len[i]; ++c)
-          if (L.cols[L.pos(i, c)] < i)
-            lower_mask[i] |= 1u << c;
+      parallel_chunks(L.n_owned, [&](const uint64_t i0, const uint64_t i1) {
+        for (uint32_t i = (uint32_t)i0; i < (uint32_t)i1; ++i)
+          for (uint32_t c = 1; c < L.row_len[i]; ++c)
+            if (L.cols[L.pos(i, c)] < i)
+              lower_mask[i] |= 1u << c;
+      });
     d_lower_mask.upload(lower_mask);
   }
   {
@@ -686,12 +689,19 @@ void ryujin_hip_ctx::create(const ryujin_hip_offline &o, const ryujin_hip_params
   n_export_slices = std::min<uint32_t>(L.n_slices, (o.n_export + kWave - 1) / kWave);
   /* The overlap of the exchanges with the interior rows rests on: only export rows couple to ghost columns
    * (true for a symmetric stencil: if i sees the ghost j, the owner of j sees i). Checked, not assumed. */
-  for (uint32_t i = n_export_slices * kWave; i < L.n_owned && !interior_reads_ghosts; ++i)
-    for (uint32_t c = 0; c < L.row_len[i]; ++c)
-      if (L.cols[L.pos(i, c)] >= L.n_owned) {
-        interior_reads_ghosts = true;
-        break;
-      }
+  if (L.n_owned > n_export_slices * kWave) {
+    const uint32_t first = n_export_slices * kWave;
+    std::atomic<bool> found{false};
+    parallel_chunks(L.n_owned - first, [&](const uint64_t i0, const uint64_t i1) {
+      for (uint32_t i = first + (uint32_t)i0; i < first + (uint32_t)i1 && !found.load(std::memory_order_relaxed); ++i)
+        for (uint32_t c = 0; c < L.row_len[i]; ++c)
+          if (L.cols[L.pos(i, c)] >= L.n_owned) {
+            found.store(true, std::memory_order_relaxed);
+            break;
+          }
+    });
+    interior_reads_ghosts = found.load();
+  }
   /* test hooks (ryujin_hip_params::debug_*; tests/test_gpu_parity.py runs the partitioned cases through both
    * branches of each): force the fallback choreography / move the mesh size below which boundary conditions
    * ride on the pre-pass / small meshes run the kernels of the large ones */
