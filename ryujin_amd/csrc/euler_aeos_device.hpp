@@ -32,6 +32,7 @@ namespace ryujin_hip
     static constexpr int DIMENSION = DIM;
     static constexpr int K = DIM + 2;
     static constexpr int NB = 4;    /* rho_min, rho_max, s_min, gamma_min: limiter.h:111 */
+    static constexpr bool kFusablePrecompute = false; /* two precomputation cycles, the second over the stencil */
     static constexpr int NPREC = 4; /* p, gamma_min, s, eta */
     using Params = EulerAeosParams;
 

@@ -282,6 +282,9 @@ namespace ryujin_hip
     /* the row's own column contributes exact zeros to the indicator sums (eta_j / rho_j - eta_i / rho_i and
      * f_j - f_i vanish bit for bit for j = i): the sweep skips it */
     static constexpr bool kIndicatorDiagonalIsZero = true;
+    /* precompute() and riemann_record() are functions of the row's state alone: the last sweep of a step can
+     * leave them behind for the next prepare_state_vector() (FusedPrecompute) */
+    static constexpr bool kFusablePrecompute = true;
 
     /* Indicator (entropy-viscosity commutator): indicator.h:187-258 */
     struct Indicator {

@@ -140,7 +140,10 @@ namespace ryujin_hip
 #define RYUJIN_OCC_HO 2
 #endif
 #ifndef RYUJIN_STAGE0_PIJ
-#define RYUJIN_STAGE0_PIJ 1 /* Euler, stages == 0: P_ij formed on the fly in steps 5-7 (kernels_limiter_stage0.hpp) */
+#define RYUJIN_STAGE0_PIJ 1 /* Euler, stages == 0: P_ij formed once, in step 5 (kernels_limiter_stage0.hpp) */
+#endif
+#ifndef RYUJIN_FUSE_PRECOMPUTE
+#define RYUJIN_FUSE_PRECOMPUTE 1 /* device-resident RK driver: the last sweep of a stage leaves the precomputed values and Riemann records of the next one (FusedPrecompute) */
 #endif
 
   constexpr int kBlock = 256;
@@ -385,6 +388,37 @@ namespace ryujin_hip
     if (g >= n_groups)
       return;
     apply_bc_group<E>(P, B, g, b_i[B.grp_start[g]], U);
+  }
+
+  /* the same for a state vector whose precomputed values and Riemann records were left behind by the last sweep of
+   * the step that produced it (FusedPrecompute, kernels_limiter.hpp): those of the boundary rows are redone from
+   * the state the boundary conditions leave */
+  template <typename E>
+  __global__ void __launch_bounds__(kBlock)
+  k_apply_bc_records(const typename E::Params P, const uint32_t n_groups, const uint32_t *__restrict__ b_i,
+                     const uint8_t *__restrict__ row_len, const BcFold B, double *U, double *__restrict__ prec,
+                     double *__restrict__ rec)
+  {
+    constexpr int K = E::K, RS = E::RS;
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_groups)
+      return;
+    const uint32_t i = b_i[B.grp_start[g]];
+    apply_bc_group<E>(P, B, g, i, U);
+    if (row_len[i] == 1)
+      return;
+    double U_i[K], r[RS];
+    load_state<K>(U, i, U_i);
+    reinterpret_cast<double2 *>(prec)[i] = E::precompute(P, U_i);
+    E::riemann_record(P, U_i, r);
+    double2 *out = reinterpret_cast<double2 *>(rec + (size_t)i * RS);
+#pragma unroll
+    for (int q = 0; q < RS / 2; ++q) {
+      double2 t;
+      t.x = r[2 * q];
+      t.y = r[2 * q + 1];
+      out[q] = t;
+    }
   }
 
   /* precomputation_loop (source/euler/hyperbolic_system.h:702-737, shallow_water/hyperbolic_system.h:676-716):

@@ -317,6 +317,35 @@ namespace ryujin_hip
     const double *src;
   };
 
+  /* The precomputation pass of the NEXT prepare_state_vector() (k_precompute_records: precomputed values and the
+   * per-node Riemann record of the row, functions of the row's new state alone) fused into the last sweep of a
+   * step, which holds that state in registers: saves the pre-pass its read of U and a launch per Runge-Kutta
+   * stage. Armed by the device-resident RK driver, whose next call on the new vector IS prepare_state_vector();
+   * boundary rows are redone behind the boundary conditions (k_apply_bc_records). prec == nullptr: plain step. */
+  struct FusedPrecompute {
+    double *prec, *rec;
+  };
+
+  template <typename E>
+  RYUJIN_DEV void fused_precompute(const typename E::Params &P, const FusedPrecompute &FP, const uint32_t i,
+                                   const double (&U_i)[E::K])
+  {
+    if constexpr (E::kFusablePrecompute) {
+      constexpr int RS = E::RS;
+      double r[RS];
+      reinterpret_cast<double2 *>(FP.prec)[i] = E::precompute(P, U_i);
+      E::riemann_record(P, U_i, r);
+      double2 *out = reinterpret_cast<double2 *>(FP.rec + (size_t)i * RS);
+#pragma unroll
+      for (int g = 0; g < RS / 2; ++g) {
+        double2 t;
+        t.x = r[2 * g];
+        t.y = r[2 * g + 1];
+        out[g] = t;
+      }
+    }
+  }
+
   /* Generic variant: two passes over the row's stencil (the second one re-reads l_ij, l_ji, P_ij). */
   template <typename E, bool LAST_ROUND>
   __global__ void __launch_bounds__(kBlock, RYUJIN_OCC_HO)
@@ -427,8 +456,9 @@ namespace ryujin_hip
    * back -- only for the columns in which some row of the slice has l != 0 (see the note at the top). */
   template <typename E, int MAXW, int CHUNK>
   __global__ void __launch_bounds__(kBlock, (MAXW > 9 ? RYUJIN_OCC_LAST_3D : 1))
-  k_high_order_last_cached(const typename E::Params, const DeviceMesh M, double *__restrict__ new_U,
-                           const double *__restrict__ pij, const double *__restrict__ lij, const FusedSadd F)
+  k_high_order_last_cached(const typename E::Params P, const DeviceMesh M, double *__restrict__ new_U,
+                           const double *__restrict__ pij, const double *__restrict__ lij, const FusedSadd F,
+                           const FusedPrecompute FP)
   {
     constexpr int K = E::K;
     const RowCtx r = row_context(M);
@@ -491,6 +521,8 @@ namespace ryujin_hip
     }
     if (row_active || (F.src != nullptr && r.row < M.n_owned))
       store_state<K>(new_U, i, U_i_new);
+    if (FP.prec != nullptr && row_active) /* rows of length 1 are skipped by the pre-pass as well */
+      fused_precompute<E>(P, FP, i, U_i_new);
   }
 
   /* Register-cached variant for stencils of at most MAXW columns (2-D Q1: 9, 1-D: 3): the row's

@@ -147,7 +147,7 @@ namespace
   EulerAeosParams make_aeos_params(const ryujin_hip_params &p)
   {
     EulerAeosParams aeosparams{};
-  aeosparams.eos = p.eos;
+    aeosparams.eos = p.eos;
     aeosparams.strict = p.compute_strict_bounds != 0;
     aeosparams.gamma = p.gamma;
     aeosparams.eos_b = p.eos_covolume_b;
@@ -353,6 +353,7 @@ struct ryujin_hip_ctx {
   hipEvent_t ev_comm = nullptr;
   hipStream_t launch_stream = nullptr; /* the stream the sweep lambdas launch on (stream or comm_stream) */
   FusedSadd pending_sadd{0., 0., nullptr}; /* set by time_step for the SSPRK stages, consumed by step */
+  bool pending_precompute = false; /* set by time_step: the next call on the new vector is prepare_state_vector */
   hipEvent_t ev_prev = nullptr; /* compute stream -> comm_stream: everything enqueued so far */
   hipEvent_t ev_exp = nullptr;  /* comm_stream -> compute stream: the latest export part (not its exchange) */
   bool comm_pending = false;    /* comm_stream holds work the compute stream has not joined */
@@ -426,6 +427,9 @@ struct ryujin_hip_ctx {
     DeviceBuffer<double> U, prec;
     DeviceBuffer<double> rrec; /* Euler, EulerAEOS, shallow water: per-node Riemann records (E::riemann_record) */
     bool used = false;
+    /* prec and rrec of the owned rows belong to the U stored here, before boundary conditions (left behind by the
+     * last sweep of the step that wrote U: FusedPrecompute); cleared by whatever else writes U */
+    bool precomputed = false;
   };
   std::vector<std::unique_ptr<State>> states;
 
@@ -1102,13 +1106,25 @@ void ryujin_hip_ctx::prepare_state_vector(int h, const double *dirichlet)
   const BcFold bc{n_groups ? d_bc_mask.ptr : nullptr, d_bc_first.ptr, d_grp_start.ptr, d_b_normal.ptr,
                   d_b_id.ptr,   d_dirichlet.ptr};
   const bool fold_bc = L.n_slices <= bc_fold_max_slices;
+  /* the step that wrote this vector left its precomputed values and Riemann records behind (FusedPrecompute):
+   * no pre-pass sweep, the boundary rows are redone behind the boundary conditions */
+  bool have_records = false;
+  if constexpr (E::kFusablePrecompute)
+    have_records = s.precomputed && !fold_bc;
+  s.precomputed = false;
   if (!fold_bc && n_groups) {
     if (exchange_after_exp)
       wait_comm();
     else
       join_export();
-    hipLaunchKernelGGL(k_apply_bc<E>, dim3(grid_for(n_groups)), block, 0, stream, eparams, n_groups, d_b_i.ptr,
-                       bc, s.U.ptr);
+    if constexpr (E::kFusablePrecompute) {
+      if (have_records)
+        hipLaunchKernelGGL(k_apply_bc_records<E>, dim3(grid_for(n_groups)), block, 0, stream, eparams, n_groups,
+                           d_b_i.ptr, d_row_len.ptr, bc, s.U.ptr, s.prec.ptr, s.rrec.ptr);
+    }
+    if (!have_records)
+      hipLaunchKernelGGL(k_apply_bc<E>, dim3(grid_for(n_groups)), block, 0, stream, eparams, n_groups, d_b_i.ptr,
+                         bc, s.U.ptr);
   }
   /* U.update_ghost_values(), :148, is enqueued BEHIND the export part of the first pre-pass sweep, which
    * reads owned states only: the interior part of step 2 then waits for that export part alone, and the
@@ -1158,15 +1174,22 @@ void ryujin_hip_ctx::prepare_state_vector(int h, const double *dirichlet)
     /* The pre-pass reads owned U only. Precomputed values and records of the ghost rows are computed locally
      * from the exchanged ghost states (functions of U_j alone: nothing to exchange, :157-160 moves the same
      * numbers), behind the exchange of U on comm_stream. */
-    sweep([&](const DeviceMesh &mm, dim3 grid) {
-      if (fold_bc)
-        hipLaunchKernelGGL((k_precompute_records<E, true>), grid, block, 0, launch_stream, eparams, mm, bc, s.U.ptr,
-                         s.prec.ptr, s.rrec.ptr);
-      else
-        hipLaunchKernelGGL((k_precompute_records<E, false>), grid, block, 0, launch_stream, eparams, mm, bc, s.U.ptr,
-                         s.prec.ptr, s.rrec.ptr);
-    });
-    exchange_vector(s.U.ptr, KP, true);
+    if (have_records) {
+      /* the owned rows are complete. Their producers: the last sweep of the step (its export part sits on
+       * comm_stream, in front of this exchange in stream order) and, for boundary rows, the kernel above on the
+       * compute stream -- with boundary DoFs the exchange is ordered behind the compute stream as well */
+      exchange_vector(s.U.ptr, KP, n_groups == 0);
+    } else {
+      sweep([&](const DeviceMesh &mm, dim3 grid) {
+        if (fold_bc)
+          hipLaunchKernelGGL((k_precompute_records<E, true>), grid, block, 0, launch_stream, eparams, mm, bc,
+                             s.U.ptr, s.prec.ptr, s.rrec.ptr);
+        else
+          hipLaunchKernelGGL((k_precompute_records<E, false>), grid, block, 0, launch_stream, eparams, mm, bc,
+                             s.U.ptr, s.prec.ptr, s.rrec.ptr);
+      });
+      exchange_vector(s.U.ptr, KP, true);
+    }
     if (L.n_relevant > L.n_owned) {
       hipLaunchKernelGGL(k_ghost_precompute_records<E>, dim3(grid_for(L.n_relevant - L.n_owned)), block, 0,
                          n_nbr ? comm_stream : stream, eparams, L.n_owned, L.n_relevant, s.U.ptr, s.prec.ptr,
@@ -1194,6 +1217,7 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
   State &nw = state(h_new);
   if (h_old == h_new)
     throw HipError(RYUJIN_ERR_ARG, "old and new state vector must differ");
+  nw.precomputed = false; /* rewritten below */
 
   const dim3 block(kBlock);
 
@@ -1342,8 +1366,9 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
    * to 1.34 ms on 4.2 M gridpoints but step 5 grows from 2.16 to 2.77-2.94 ms (27 flux evaluations per row at
    * 240 registers): -0.7 % ... +1.5 % per update, inside the run-to-run spread -- so only for dim <= 2. */
   const bool recompute_p = is_euler && DIM <= 2 && stages == 0 && params.limiter_iterations != 0 && !dg;
-  /* Euler, stages == 0, Q1 stencil widths: P_ij is never materialised, steps 5-7 form it on the fly from
-   * d_ij, m_ij and the per-node vectors (kernels_limiter_stage0.hpp) -- any dimension */
+  /* Euler and EulerAEOS, stages == 0, Q1 stencil widths: step 4 does not touch P_ij; step 5 forms it once from
+   * d_ij, m_ij and the per-node vectors, limits it and stores it for steps 6 and 7 (kernels_limiter_stage0.hpp)
+   * -- any dimension */
   constexpr int kStage0Width = DIM == 1 ? 3 : (DIM == 2 ? 9 : 27);
   const bool stage0_pij = RYUJIN_STAGE0_PIJ && (is_euler || is_aeos) && stages == 0 && params.limiter_iterations != 0 && !dg &&
                           L.max_row_len <= (uint32_t)kStage0Width;
@@ -1527,6 +1552,16 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
   /* a pending sadd of the device-resident RK driver is applied by the last sweep */
   const FusedSadd fused_sadd = pending_sadd;
   pending_sadd = FusedSadd{0., 0., nullptr};
+  /* ... and so are the precomputed values and Riemann records of the new vector, where the next pre-pass would be a
+   * sweep of its own (large meshes: below bc_fold_max_slices the boundary conditions ride on that sweep) */
+  bool fuse_precompute = false;
+  if constexpr (E::kFusablePrecompute)
+    fuse_precompute = RYUJIN_FUSE_PRECOMPUTE && pending_precompute && n_iterations != 0 &&
+                      L.n_slices > bc_fold_max_slices &&
+                      L.max_row_len <= (uint32_t)(DIM == 1 ? 3 : (DIM == 2 ? 9 : 27));
+  pending_precompute = false;
+  nw.precomputed = false;
+  const FusedPrecompute fused_prec{fuse_precompute ? nw.prec.ptr : nullptr, fuse_precompute ? nw.rrec.ptr : nullptr};
   if (fused_sadd.src && n_iterations == 0)
     throw HipError(RYUJIN_ERR_ARG, "internal: fused sadd without a limiter pass");
   for (int pass = 0; pass < n_iterations; ++pass) {
@@ -1538,7 +1573,8 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
       sweep([&](const DeviceMesh &mm, dim3 grid) {
         if (L.max_row_len <= (uint32_t)kCachedWidth)
           hipLaunchKernelGGL((k_high_order_last_cached<E, kCachedWidth, (DIM == 3 ? RYUJIN_LAST_CHUNK_3D : (DIM == 2 ? RYUJIN_LAST_CHUNK_2D : kCachedWidth))>), grid,
-                             block, 0, launch_stream, eparams, mm, nw.U.ptr, d_pij.ptr, d_lij.ptr, fused_sadd);
+                             block, 0, launch_stream, eparams, mm, nw.U.ptr, d_pij.ptr, d_lij.ptr, fused_sadd,
+                             fused_prec);
         else
           hipLaunchKernelGGL((k_high_order<E, true>), grid, block, 0, launch_stream, eparams, mm, nw.U.ptr,
                              d_bounds.ptr, d_pij.ptr, d_lij.ptr, d_lij_next.ptr, fused_sadd);
@@ -1571,6 +1607,7 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
   }
   for (int k = 5 + n_iterations; k <= 7; ++k)
     mark(k);
+  nw.precomputed = fuse_precompute;
 
   join_export(); /* (the exchange of U_new stays in flight: whoever reads its ghost range joins it) */
   if (!deferred)
@@ -1690,9 +1727,9 @@ int ryujin_hip_ctx::time_step(int scheme, int h_state, int n_tmp, const int *h_t
     double dummy = 0.;
     deferred = true;
     struct Guard {
-      bool &flag;
-      ~Guard() { flag = false; }
-    } guard{deferred};
+      bool &flag, &armed;
+      ~Guard() { flag = armed = false; }
+    } guard{deferred, pending_precompute};
     int result = -1; /* handle that holds the new solution */
     const double no_limit = std::numeric_limits<double>::max();
     const int none[1] = {0};
@@ -1729,6 +1766,7 @@ int ryujin_hip_ctx::time_step(int scheme, int h_state, int n_tmp, const int *h_t
 
     rk_stage = 0;
     prepare_state_vector<E>(U, dirichlet_at(0));
+    pending_precompute = true; /* every stage's result goes straight into the next prepare_state_vector() */
     step<E>(U, 0, none, no_w, T[0], 0., first_tau_max, &dummy);
     result = T[0];
     if (want_tau_early) {
@@ -1741,6 +1779,7 @@ int ryujin_hip_ctx::time_step(int scheme, int h_state, int n_tmp, const int *h_t
       for (int st = 1; st < n_stages; ++st) {
         rk_stage = st;
         prepare_state_vector<E>(T[st - 1], dirichlet_at(st));
+        pending_precompute = true;
         step<E>(T[st - 1], erk_stage[st].n, erk_stage[st].h, erk_stage[st].w, T[st], 1. /*device tau*/,
                 no_limit, &dummy);
         result = T[st];
@@ -1756,6 +1795,7 @@ int ryujin_hip_ctx::time_step(int scheme, int h_state, int n_tmp, const int *h_t
         } disarm{pending_sadd};
         if (fuse)
           pending_sadd = FusedSadd{sa, sb, state(U).U.ptr};
+        pending_precompute = fuse; /* (an sadd of its own rewrites the vector) */
         step<E>(h_old, 0, none, no_w, h_new, 1., no_limit, &dummy);
         if (!fuse)
           ryujin_hip_sadd(this, h_new, sa, sb, U);
@@ -2149,6 +2189,7 @@ int ryujin_hip_state_alloc(ryujin_hip_ctx *ctx, int *handle)
         ctx->states[h]->rrec.alloc((size_t)ctx->L.n_relevant * ((2 + ctx->dim + 1) / 2 * 2));
     }
     ctx->states[h]->used = true;
+    ctx->states[h]->precomputed = false;
     *handle = h;
     return RYUJIN_OK;
   });
@@ -2169,6 +2210,7 @@ int ryujin_hip_state_upload(ryujin_hip_ctx *ctx, int handle, const double *U_aos
     const size_t n = ctx->L.n_relevant;
     const int K = ctx->K, KP = ctx->KP;
     ctx->finish();
+    s.precomputed = false;
     if (K == KP) {
       HIP_CHECK(hipMemcpy(s.U.ptr, U_aos, n * K * sizeof(double), hipMemcpyHostToDevice));
     } else {
@@ -2335,6 +2377,7 @@ int ryujin_hip_sadd(ryujin_hip_ctx *ctx, int h_dst, double s, double b, int h_sr
     auto &dst = ctx->state(h_dst);
     auto &src = ctx->state(h_src);
     const size_t n = (size_t)ctx->L.n_relevant * ctx->KP;
+    dst.precomputed = false;
     ctx->wait_comm();
     const int grid = (int)std::min<size_t>(2048, (n / 2 + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(k_sadd, dim3(std::max(1, grid)), dim3(kBlock), 0, ctx->stream, n, s, b,

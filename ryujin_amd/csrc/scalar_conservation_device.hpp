@@ -28,6 +28,7 @@ namespace ryujin_hip
     static constexpr int DIMENSION = DIM;
     static constexpr int K = 1;
     static constexpr int NB = 2;
+    static constexpr bool kFusablePrecompute = false; /* (FusedPrecompute: Euler and shallow water only) */
     static constexpr int NPREC = 2 * DIM;
     using Params = ScalarParams;
 

@@ -245,6 +245,9 @@ namespace ryujin_hip
     /* `left` accumulates (eta_j + p_j) v_j . c_ij, not a difference: the row's own column counts (c_ii != 0 on the
      * boundary) */
     static constexpr bool kIndicatorDiagonalIsZero = false;
+    /* precompute() and riemann_record() are functions of the row's state alone: the last sweep of a step can
+     * leave them behind for the next prepare_state_vector() (FusedPrecompute) */
+    static constexpr bool kFusablePrecompute = true;
 
     /* ------------------------------------------------------------------ Indicator */
     struct Indicator {
