@@ -580,6 +580,7 @@ def main():
                                              "(profiles/r03h_counter_calibration.md)") if traffic_file else None,
                      "algorithmic_bytes_per_gridpoint": alg[dom],
                      "mean_launch_ms": per_sweep[dom]},
+        "limiter": m.limiter_statistics(),  # fraction of limited slices and whether P_ij was stored
         "roofline_update": {"bound": "hbm", "achieved": upd_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": upd_gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_gridpoint": b_alg,
                             "device_ms_per_update": ev_ms.value / args.steps,

@@ -155,11 +155,15 @@ typedef struct ryujin_hip_params {
    *   debug_join_exchanges != 0: every sweep joins the ghost exchanges (the choreography of a non-symmetric
    *   stencil); debug_bc_fold_max_slices: boundary conditions ride on the pre-pass kernel up to n slices of
    *   64 rows (0 = default 4096, < 0 = always a launch of their own); debug_no_small_mesh_split != 0: meshes
-   *   that do not fill the device run the same step-5/6 kernels as large ones. */
+   *   that do not fill the device run the same step-5/6 kernels as large ones; debug_pij_storage: the matrix
+   *   P_ij of an update without stage vectors is stored by step 5 or formed again where steps 6/7 need it,
+   *   chosen per step from the measured fraction of limited slices (0); > 0: never stored where the kernels
+   *   allow it, < 0: always stored. */
   int system_scope_events;
   int debug_join_exchanges;
   int debug_bc_fold_max_slices;
   int debug_no_small_mesh_split;
+  int debug_pij_storage;
 } ryujin_hip_params;
 
 /* ---- offline data (input contract) ------------------------------------- */
@@ -378,6 +382,11 @@ int ryujin_hip_get_cfl(ryujin_hip_ctx *ctx, double *cfl);
 int ryujin_hip_set_id_violation_strategy(ryujin_hip_ctx *ctx, int strategy);
 int ryujin_hip_get_alpha(ryujin_hip_ctx *ctx, double *alpha /* [n_relevant] */);
 int ryujin_hip_get_counters(ryujin_hip_ctx *ctx, unsigned *n_restarts, unsigned *n_warnings);
+/* What the data-dependent choice of the limiter sweeps saw at the latest host synchronisation: the fraction of
+ * (sampled) 64-row slices in which the first high-order sweep found a limited pair, and whether the latest step
+ * stored the matrix P_ij (hyperbolic_module.template.h:795-846) or formed it where needed -- the results are the
+ * same bit for bit, the fraction only decides which is cheaper. Diagnostics. */
+int ryujin_hip_limiter_statistics(ryujin_hip_ctx *ctx, double *limited_slice_fraction, int *pij_stored);
 
 /* ---- introspection for parity tests and profiling ------------------------ */
 /* Module-owned intermediates of the LAST step() in the reference's logical

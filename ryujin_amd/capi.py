@@ -65,6 +65,7 @@ class Params(C.Structure):
         # run-time switches of the library (no ParameterAcceptor counterpart; 0 = default)
         ("system_scope_events", C.c_int), ("debug_join_exchanges", C.c_int),
         ("debug_bc_fold_max_slices", C.c_int), ("debug_no_small_mesh_split", C.c_int),
+        ("debug_pij_storage", C.c_int),
     ]
 
 
@@ -170,7 +171,7 @@ HIP_SYMBOLS = [
     "ryujin_hip_prepare_state_vector", "ryujin_hip_step", "ryujin_hip_sadd", "ryujin_hip_time_step", "ryujin_hip_time_step_n",
     "ryujin_hip_get_timers_accum",
     "ryujin_hip_set_cfl", "ryujin_hip_get_cfl", "ryujin_hip_set_id_violation_strategy",
-    "ryujin_hip_get_alpha", "ryujin_hip_get_counters", "ryujin_hip_debug_fetch",
+    "ryujin_hip_get_alpha", "ryujin_hip_get_counters", "ryujin_hip_limiter_statistics", "ryujin_hip_debug_fetch",
     "ryujin_hip_set_timers", "ryujin_hip_get_timers", "ryujin_hip_synchronize",
     "ryujin_hip_event_record", "ryujin_hip_event_elapsed_ms", "ryujin_hip_last_error",
     "ryujin_hip_version", "ryujin_hip_debug_layout", "ryujin_hip_debug_pow", "ryujin_hip_debug_function", "ryujin_hip_debug_rk_outcome",

@@ -310,6 +310,83 @@ namespace ryujin_hip
 
   /* ------------------------------------------------------------------ steps 6, 7 */
 
+  /* ---- P_ij without stage vectors, formed from d_ij, m_ij and per-node vectors (see kernels_limiter_stage0.hpp
+   * for the derivation): used by step 5 and -- where P_ij is not stored at all -- by the limited slices of steps
+   * 6 and 7 */
+
+  /* what a row needs of a neighbour to form P_ij */
+  template <int K>
+  struct PairData {
+    double U_j[K], F_j[K];
+    double d_ij, m_ij, alpha_j, m_j_inv;
+  };
+
+  /* per-row constants */
+  template <int K>
+  struct RowData {
+    double U_i[K], F_i[K];
+    double alpha_i, m_i_inv, factor; /* factor = tau / m_i * (row_length - 1) */
+  };
+
+  template <int K>
+  RYUJIN_DEV void load_pair(const DeviceMesh &M, const double *__restrict__ old_U,
+                            const double *__restrict__ r_in, const double *__restrict__ alpha,
+                            const double *__restrict__ dij, const uint64_t pos, const uint32_t j, PairData<K> &p)
+  {
+    p.d_ij = dij[pos];
+    p.m_ij = ld_stream(M.mij + pos);
+    load_state<K>(old_U, j, p.U_j);
+    load_state<K>(r_in, j, p.F_j);
+    p.alpha_j = alpha[j];
+    p.m_j_inv = M.mi_inv[j];
+  }
+
+  /* P_ij for stages == 0 */
+  template <int K>
+  RYUJIN_DEV void pij_stage0(const RowData<K> &row, const PairData<K> &p, double (&P_ij)[K])
+  {
+    const double d_ijH = p.d_ij * ((row.alpha_i + p.alpha_j) * .5);
+    const double dd = d_ijH - p.d_ij;
+    /* Neumann series: b_ij = delta_ij - m_ij/m_j, b_ji = delta_ij - m_ij/m_i (:987-996) */
+    const double b_ij = 0. - p.m_ij * p.m_j_inv;
+    const double b_ji = 0. - p.m_ij * row.m_i_inv;
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+      double v = dd * (p.U_j[q] - row.U_i[q]);
+      v += b_ij * p.F_j[q] - b_ji * row.F_i[q];
+      P_ij[q] = v * row.factor;
+    }
+  }
+
+  /* where steps 6 and 7 take P_ij from when step 5 did not store it (ONFLY kernels): the operands of pij_stage0 */
+  struct Stage0Src {
+    DeviceScalars *scalars; /* tau; and the limited-slice counters of step 6 */
+    const double *old_U, *alpha, *dij, *r_in;
+  };
+
+  template <int K>
+  RYUJIN_DEV void load_row_data(const DeviceMesh &M, const Stage0Src &S0, const uint32_t i, const uint32_t len,
+                                RowData<K> &row)
+  {
+    load_state<K>(S0.old_U, i, row.U_i);
+    load_state<K>(S0.r_in, i, row.F_i);
+    row.alpha_i = S0.alpha[i];
+    row.m_i_inv = M.mi_inv[i];
+    row.factor = S0.scalars->tau * row.m_i_inv * (double)(len - 1);
+  }
+
+  /* P_ij of column `colbase` of the row, exactly the value step 5 formed (same function, same operands) */
+  template <int K>
+  RYUJIN_DEV void pij_on_the_fly(const DeviceMesh &M, const Stage0Src &S0, const RowData<K> &row,
+                                 const uint64_t colbase, const uint32_t lane, double (&P_ij)[K])
+  {
+    const uint64_t pos = colbase * 64 + lane;
+    const uint32_t j = M.cols[pos];
+    PairData<K> pd;
+    load_pair<K>(M, S0.old_U, S0.r_in, S0.alpha, S0.dij, pos, j, pd);
+    pij_stage0<K>(row, pd, P_ij);
+  }
+
   /* TimeIntegrator::sadd (time_integrator.template.h:18-25) fused into the last sweep of a step:
    * new_U = s * new_U + b * src for the rows the sweep writes (src == nullptr: plain step). */
   struct FusedSadd {
@@ -454,16 +531,20 @@ namespace ryujin_hip
   /* Last round for stencils of at most MAXW columns: all l_ij = min(l_ij, l_ji) of the row are fetched up
    * front (independent loads), then P_ij is read -- in chunks of CHUNK columns whose loads are issued back to
    * back -- only for the columns in which some row of the slice has l != 0 (see the note at the top). */
-  template <typename E, int MAXW, int CHUNK>
-  __global__ void __launch_bounds__(kBlock, (MAXW > 9 ? RYUJIN_OCC_LAST_3D : 1))
-  k_high_order_last_cached(const typename E::Params P, const DeviceMesh M, double *__restrict__ new_U,
-                           const double *__restrict__ pij, const double *__restrict__ lij, const FusedSadd F,
-                           const FusedPrecompute FP)
+  /* Step 5 may have stored no P_ij (kernels_limiter_stage0.hpp). The sweep then runs as two launches:
+   *   DEFER  the slices in which no column needs a P_ij (all of those in which step 6 found nothing limited) are
+   *          finished here -- the light kernel, high occupancy; the others are left untouched;
+   *   ONFLY  a small grid walks the work list step 6 left (the slices in which something was limited) and
+   *          forms P_ij again for the columns that need it (pij_on_the_fly); slices the DEFER launch finished
+   *          are recognised by the same test and skipped. */
+  template <typename E, int MAXW, int CHUNK, bool ONFLY, bool DEFER>
+  RYUJIN_DEV void last_cached_slice(const typename E::Params &P, const DeviceMesh &M, const RowCtx &r,
+                                    double *__restrict__ new_U, const double *__restrict__ pij,
+                                    const double *__restrict__ lij, const FusedSadd &F, const FusedPrecompute &FP,
+                                    const Stage0Src &S0)
   {
+    static_assert(!(ONFLY && DEFER), "one or the other");
     constexpr int K = E::K;
-    const RowCtx r = row_context(M);
-    if (!r.valid)
-      return;
     const bool row_active = r.len > 1;
     const uint32_t i = row_active ? r.row : (r.row < M.n_owned ? r.row : M.n_owned - 1);
     const uint32_t *__restrict__ idx_t = M.idx_t;
@@ -492,14 +573,28 @@ namespace ryujin_hip
       if (__any(l[c] != 0.))
         needed |= 1u << c;
 
+    if constexpr (DEFER) {
+      if (needed != 0u)
+        return; /* the work-list launch behind this one */
+    }
+    RowData<K> row;
+    if constexpr (ONFLY) {
+      if (needed == 0u)
+        return; /* finished by the DEFER launch */
+      load_row_data<K>(M, S0, i, r.len, row);
+    }
 #pragma unroll
     for (int c0 = 1; c0 < MAXW; c0 += CHUNK) {
       double p[CHUNK][K];
 #pragma unroll
       for (int cc = 0; cc < CHUNK; ++cc) {
         const int c = c0 + cc;
-        if (c < MAXW && ((needed >> c) & 1u))
-          load_entry<K>(pij, (uint64_t)r.base + c, r.lane, p[cc]);
+        if (c < MAXW && ((needed >> c) & 1u)) {
+          if constexpr (ONFLY)
+            pij_on_the_fly<K>(M, S0, row, (uint64_t)r.base + c, r.lane, p[cc]);
+          else
+            load_entry<K>(pij, (uint64_t)r.base + c, r.lane, p[cc]);
+        }
       }
 #pragma unroll
       for (int cc = 0; cc < CHUNK; ++cc) {
@@ -525,6 +620,46 @@ namespace ryujin_hip
       fused_precompute<E>(P, FP, i, U_i_new);
   }
 
+  RYUJIN_DEV RowCtx row_context_of_slice(const DeviceMesh &M, const uint32_t slice)
+  {
+    RowCtx r;
+    r.lane = threadIdx.x & 63;
+    r.slice = slice;
+    r.valid = true;
+    r.row = slice * 64 + r.lane;
+    r.len = M.row_len[r.row];
+    r.base = M.slice_off[slice];
+    r.width = M.slice_off[slice + 1] - r.base;
+    return r;
+  }
+
+  template <typename E, int MAXW, int CHUNK, bool DEFER = false>
+  __global__ void __launch_bounds__(kBlock, (MAXW > 9 ? RYUJIN_OCC_LAST_3D : 1))
+  k_high_order_last_cached(const typename E::Params P, const DeviceMesh M, double *__restrict__ new_U,
+                           const double *__restrict__ pij, const double *__restrict__ lij, const FusedSadd F,
+                           const FusedPrecompute FP)
+  {
+    const RowCtx r = row_context(M);
+    if (!r.valid)
+      return;
+    last_cached_slice<E, MAXW, CHUNK, false, DEFER>(P, M, r, new_U, pij, lij, F, FP, Stage0Src{});
+  }
+
+  /* the ONFLY half: any grid; wave w takes the entries w, w + n_waves, ... of the work list */
+  template <typename E, int MAXW, int CHUNK>
+  __global__ void __launch_bounds__(kBlock, (MAXW > 9 ? RYUJIN_OCC_LAST_3D_ONFLY : 1))
+  k_high_order_last_worklist(const typename E::Params P, const DeviceMesh M, double *__restrict__ new_U,
+                             const double *__restrict__ lij, const FusedSadd F, const FusedPrecompute FP,
+                             const Stage0Src S0, const uint32_t *__restrict__ worklist,
+                             const unsigned int *__restrict__ count)
+  {
+    const uint32_t n = *count;
+    const uint32_t n_waves = gridDim.x * kWavesPerBlock;
+    for (uint32_t w = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6); w < n; w += n_waves)
+      last_cached_slice<E, MAXW, CHUNK, true, false>(P, M, row_context_of_slice(M, worklist[w]), new_U, nullptr, lij,
+                                                     F, FP, S0);
+  }
+
   /* Register-cached variant for stencils of at most MAXW columns (2-D Q1: 9, 1-D: 3): the row's
    * l_ij = min(l_ij, l_ji) and P_ij stay in registers between the update and the next limiter pass,
    * so step 6 reads every array exactly once (the generic variant fetches ~2x the algorithmic bytes)
@@ -534,33 +669,31 @@ namespace ryujin_hip
   /* SPLIT (small meshes, the sweep is one wave's latency chain): the four waves of a block share ONE slice; all
    * of them form the new U_i (bitwise the same sum), the first one stores it -- behind a block barrier, the update
    * is in place -- and wave w runs the second limiter pass for the columns 1 + w, 5 + w, ... only. */
-  template <typename E, int MAXW, int CP = MAXW, bool SPLIT = false>
-  __global__ void __launch_bounds__(kBlock, (MAXW > 9 ? (CP < MAXW ? RYUJIN_OCC_HO_3D : 1) : RYUJIN_OCC_HO))
-  k_high_order_next_cached(const typename E::Params P, const DeviceMesh M, double *__restrict__ new_U,
-                           const double *__restrict__ bounds, const double *__restrict__ pij,
-                           const double *__restrict__ lij, double *__restrict__ lij_next,
-                           const double *__restrict__ V_unlimited = nullptr)
+  /* Step 5 may have stored no P_ij (kernels_limiter_stage0.hpp); V_unlimited is required then, and the sweep runs
+   * as two launches:
+   *   DEFER  slices in which nothing was limited take V_i -- the light kernel; the others are appended to a work
+   *          list (which the last sweep walks as well) and left untouched;
+   *   ONFLY  a small grid walks the work list and forms P_ij again from the operands step 5 used
+   *          (pij_on_the_fly: six gathers per column instead of a coalesced stream -- slower per slice, but step
+   *          5 saves the 8 k S bytes per row of EVERY slice; the host takes this path while few slices are
+   *          limited, ryujin_hip_ctx::limited_fraction). */
+  struct WorkList {
+    uint32_t *slices;
+    unsigned int *count;
+  };
+
+  template <typename E, int MAXW, int CP, bool SPLIT, bool ONFLY, bool DEFER>
+  RYUJIN_DEV void next_cached_slice(const typename E::Params &P, const DeviceMesh &M, const RowCtx &r,
+                                    const uint32_t group, double *__restrict__ new_U,
+                                    const double *__restrict__ bounds, const double *__restrict__ pij,
+                                    const double *__restrict__ lij, double *__restrict__ lij_next,
+                                    const double *__restrict__ V_unlimited, const Stage0Src &S0, const WorkList &W)
   {
     constexpr int K = E::K;
     constexpr int NB = E::NB;
     static_assert(!SPLIT || CP == MAXW, "the split variant caches the whole row");
-    RowCtx r;
-    const uint32_t group = SPLIT ? (threadIdx.x >> 6) : 0u;
-    if constexpr (SPLIT) { /* one slice per block (uniform over the block: the barrier below is safe) */
-      r.lane = threadIdx.x & 63;
-      r.slice = M.slice_begin + blockIdx.x;
-      r.valid = r.slice < M.slice_end;
-      if (!r.valid)
-        return;
-      r.row = r.slice * 64 + r.lane;
-      r.len = M.row_len[r.row];
-      r.base = M.slice_off[r.slice];
-      r.width = M.slice_off[r.slice + 1] - r.base;
-    } else {
-      r = row_context(M);
-      if (!r.valid)
-        return;
-    }
+    static_assert(!(SPLIT && (ONFLY || DEFER)), "small meshes keep the stored P_ij");
+    static_assert(!(ONFLY && DEFER), "one or the other");
     const bool row_active = r.len > 1;
     const uint32_t i = row_active ? r.row : (r.row < M.n_owned ? r.row : M.n_owned - 1);
     const uint32_t *__restrict__ idx_t = M.idx_t;
@@ -576,7 +709,14 @@ namespace ryujin_hip
 
     double l[MAXW];
     double p[CP][K];
-    if (V_unlimited != nullptr) {
+    RowData<K> row;
+    auto load_P = [&](const uint64_t colbase, double (&out)[K]) {
+      if constexpr (ONFLY)
+        pij_on_the_fly<K>(M, S0, row, colbase, r.lane, out);
+      else
+        load_entry<K>(pij, colbase, r.lane, out);
+    };
+    if (DEFER || V_unlimited != nullptr) {
       /* Step 5 left V_i = U_i^low + sum_j lambda P_ij, accumulated exactly as the update below accumulates it
        * when every l_ij is 1 (k_lij_stage0). If no pair of the slice was limited -- wave-uniform; most of a
        * developed flow -- that IS the new U_i bit for bit, the second pass stores (1 - l) l' = 0, and P_ij is
@@ -593,7 +733,15 @@ namespace ryujin_hip
           limited = limited || (row_active && (uint32_t)c < r.len && l[c] != 1.);
         }
       }
-      if (!__any(limited)) {
+      const bool slice_limited = __any(limited);
+      if constexpr (!ONFLY) { /* (the work-list launch sees limited slices only, and sees them a second time) */
+        if (S0.scalars != nullptr && (r.slice & 15u) == 0 && r.lane == 0 && (!SPLIT || group == 0)) {
+          atomicAdd(&S0.scalars->n_sampled_slices, 1u);
+          if (slice_limited)
+            atomicAdd(&S0.scalars->n_sampled_limited, 1u);
+        }
+      }
+      if (!slice_limited) {
         if (row_active) {
           double V_i[K];
           load_state<K>(V_unlimited, i, V_i);
@@ -606,15 +754,24 @@ namespace ryujin_hip
         }
         return;
       }
+      if constexpr (DEFER) {
+        if (r.lane == 0)
+          W.slices[atomicAdd(W.count, 1u)] = r.slice;
+        return;
+      }
+      if constexpr (ONFLY)
+        load_row_data<K>(M, S0, i, r.len, row);
 #pragma unroll
       for (int c = 1; c < CP; ++c) {
 #pragma unroll
         for (int q = 0; q < K; ++q)
           p[c][q] = 0.;
         if ((uint32_t)c < r.width)
-          load_entry<K>(pij, (uint64_t)r.base + c, r.lane, p[c]);
+          load_P((uint64_t)r.base + c, p[c]);
       }
     } else {
+      if constexpr (ONFLY)
+        load_row_data<K>(M, S0, i, r.len, row);
 #pragma unroll
       for (int c = 1; c < MAXW; ++c) {
         l[c] = 0.;
@@ -630,7 +787,7 @@ namespace ryujin_hip
           const double l_b = lij[idx_t[pos]];
           l[c] = fmin(l_a, l_b);
           if (c < CP)
-            load_entry<K>(pij, colbase, r.lane, p[c < CP ? c : 0]);
+            load_P(colbase, p[c < CP ? c : 0]);
         }
       }
     }
@@ -644,7 +801,7 @@ namespace ryujin_hip
         }
       } else if ((uint32_t)c < r.width) {
         double pt[K];
-        load_entry<K>(pij, (uint64_t)r.base + c, r.lane, pt);
+        load_P((uint64_t)r.base + c, pt);
         if (row_active && (uint32_t)c < r.len) {
 #pragma unroll
           for (int q = 0; q < K; ++q)
@@ -682,7 +839,7 @@ namespace ryujin_hip
         for (int q = 0; q < K; ++q)
           pc[q] = p[c < CP ? c : 0][q];
       } else {
-        load_entry<K>(pij, (uint64_t)r.base + c, r.lane, pc);
+        load_P((uint64_t)r.base + c, pc);
       }
       if (row_active && (uint32_t)c < r.len) {
         double new_p_ij[K];
@@ -705,7 +862,7 @@ namespace ryujin_hip
       const uint64_t pos = colbase * 64 + r.lane;
       const double old_l_ij = fmin(lij[pos], lij[idx_t[pos]]);
       double p_ij[K], new_p_ij[K];
-      load_entry<K>(pij, colbase, r.lane, p_ij);
+      load_P(colbase, p_ij);
 #pragma unroll
       for (int q = 0; q < K; ++q)
         new_p_ij[q] = (1. - old_l_ij) * p_ij[q];
@@ -713,5 +870,43 @@ namespace ryujin_hip
       const double new_l_ij = E::limit(P, bnd, U_i_new, new_p_ij, success);
       st_stream(lij_next + (pos), (1. - old_l_ij) * new_l_ij);
     }
+  }
+
+  template <typename E, int MAXW, int CP = MAXW, bool SPLIT = false, bool DEFER = false>
+  __global__ void __launch_bounds__(kBlock, (MAXW > 9 ? (CP < MAXW ? RYUJIN_OCC_HO_3D : 1) : RYUJIN_OCC_HO))
+  k_high_order_next_cached(const typename E::Params P, const DeviceMesh M, double *__restrict__ new_U,
+                           const double *__restrict__ bounds, const double *__restrict__ pij,
+                           const double *__restrict__ lij, double *__restrict__ lij_next,
+                           const double *__restrict__ V_unlimited = nullptr, const Stage0Src S0 = Stage0Src{},
+                           const WorkList W = WorkList{})
+  {
+    RowCtx r;
+    const uint32_t group = SPLIT ? (threadIdx.x >> 6) : 0u;
+    if constexpr (SPLIT) { /* one slice per block (uniform over the block: the barrier in the body is safe) */
+      if (M.slice_begin + blockIdx.x >= M.slice_end)
+        return;
+      r = row_context_of_slice(M, M.slice_begin + blockIdx.x);
+    } else {
+      r = row_context(M);
+      if (!r.valid)
+        return;
+    }
+    next_cached_slice<E, MAXW, CP, SPLIT, false, DEFER>(P, M, r, group, new_U, bounds, pij, lij, lij_next,
+                                                        V_unlimited, S0, W);
+  }
+
+  /* the ONFLY half: any grid; wave w takes the entries w, w + n_waves, ... of the work list */
+  template <typename E, int MAXW, int CP = MAXW>
+  __global__ void __launch_bounds__(kBlock, (MAXW > 9 ? RYUJIN_OCC_HO_3D_ONFLY : RYUJIN_OCC_HO))
+  k_high_order_next_worklist(const typename E::Params P, const DeviceMesh M, double *__restrict__ new_U,
+                             const double *__restrict__ bounds, const double *__restrict__ lij,
+                             double *__restrict__ lij_next, const double *__restrict__ V_unlimited,
+                             const Stage0Src S0, const WorkList W)
+  {
+    const uint32_t n = *W.count;
+    const uint32_t n_waves = gridDim.x * kWavesPerBlock;
+    for (uint32_t w = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6); w < n; w += n_waves)
+      next_cached_slice<E, MAXW, CP, false, true, false>(P, M, row_context_of_slice(M, W.slices[w]), 0u, new_U,
+                                                         bounds, nullptr, lij, lij_next, V_unlimited, S0, W);
   }
 } // namespace ryujin_hip

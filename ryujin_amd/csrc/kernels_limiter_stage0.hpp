@@ -22,10 +22,17 @@
 // U_i^low + sum_j l_ij lambda P_ij when every l_ij is 1: in slices where nothing was limited step 6 takes V_i
 // and never reads P_ij (kernels_limiter.hpp) -- bit-identical, and most of a developed flow.
 //
-// (Measured and dropped, profiles/r03f_ab_variants_*: forming P_ij on the fly in steps 6 and 7 as well, so that it
-// is never stored. Step 5 gained what is kept here, but the two high-order sweeps lost more than the P_ij stream
-// costs them -- six dependent gathers per column through the texture addresser against two coalesced 16-byte
-// streams: 2-D step 6 0.227 -> 0.332 ms, 3-D 1.61 -> 2.06 ms.)
+// STORE_P = false: P_ij is not stored at all. A developed flow limits something in 2 - 3 % of its 64-row slices
+// (measured: step2d, sedov3d, step2d_aeos); everywhere else steps 6 and 7 never look at P_ij (V_i; l' = 0), and
+// the 8 k S bytes per row step 5 writes are wasted. Without the store step 6 runs as a light launch (V_i or "this
+// slice is limited": appended to a work list) plus a small work-list launch that forms P_ij again through
+// pij_stage0() for the limited slices, and step 7 likewise (kernels_limiter.hpp). Forming P_ij again costs six
+// dependent gathers per column against two coalesced streams (a first version that did so in EVERY slice lost
+// more in steps 6/7 than step 5 gained: profiles/r03f_*; with a limited pair in 86 % of the slices -- the 3-D
+// cylinder channel -- the work-list form costs +68 %: profiles/r03u_ab_3d.log), so the host chooses per step from the
+// fraction of limited slices step 6 counted in the previous one (ryujin_hip_ctx::limited_fraction; thresholds
+// RYUJIN_NEVER_STORE_MAX_LIMITED_*). Same bits either way: -5.4 % per update on C2, -10.4 % on the 3-D radial
+// contrast, -3.1 % on EulerAEOS (profiles/r03u_ab_*).
 
 #pragma once
 
@@ -52,53 +59,13 @@ namespace ryujin_hip
     return E::DIMENSION == 3 ? RYUJIN_OCC_LIJ0_3D : RYUJIN_OCC_LIJ0;
   }
 
-  /* what a row needs of a neighbour to form P_ij */
-  template <int K>
-  struct PairData {
-    double U_j[K], F_j[K];
-    double d_ij, m_ij, alpha_j, m_j_inv;
-  };
-
-  /* per-row constants */
-  template <int K>
-  struct RowData {
-    double U_i[K], F_i[K];
-    double alpha_i, m_i_inv, factor; /* factor = tau / m_i * (row_length - 1) */
-  };
-
-  template <int K>
-  RYUJIN_DEV void load_pair(const DeviceMesh &M, const double *__restrict__ old_U,
-                            const double *__restrict__ r_in, const double *__restrict__ alpha,
-                            const double *__restrict__ dij, const uint64_t pos, const uint32_t j, PairData<K> &p)
-  {
-    p.d_ij = dij[pos];
-    p.m_ij = ld_stream(M.mij + pos);
-    load_state<K>(old_U, j, p.U_j);
-    load_state<K>(r_in, j, p.F_j);
-    p.alpha_j = alpha[j];
-    p.m_j_inv = M.mi_inv[j];
-  }
-
-  /* P_ij for stages == 0 (see the header comment) */
-  template <int K>
-  RYUJIN_DEV void pij_stage0(const RowData<K> &row, const PairData<K> &p, double (&P_ij)[K])
-  {
-    const double d_ijH = p.d_ij * ((row.alpha_i + p.alpha_j) * .5);
-    const double dd = d_ijH - p.d_ij;
-    /* Neumann series: b_ij = delta_ij - m_ij/m_j, b_ji = delta_ij - m_ij/m_i (:987-996) */
-    const double b_ij = 0. - p.m_ij * p.m_j_inv;
-    const double b_ji = 0. - p.m_ij * row.m_i_inv;
-#pragma unroll
-    for (int q = 0; q < K; ++q) {
-      double v = dd * (p.U_j[q] - row.U_i[q]);
-      v += b_ij * p.F_j[q] - b_ji * row.F_i[q];
-      P_ij[q] = v * row.factor;
-    }
-  }
+  /* (PairData, RowData, load_pair, pij_stage0: kernels_limiter.hpp -- steps 6 and 7 use them as well) */
 
   /* NY > 1 (small meshes): NY waves (blockIdx.y) share a slice, wave y taking the columns 1 + y, 1 + y + NY, ...;
-   * no V_i then (the row's sum is spread over several waves): the caller passes V_out = nullptr */
-  template <typename E, int NY = 1>
+   * no V_i then (the row's sum is spread over several waves): the caller passes V_out = nullptr.
+   * STORE_P = false: P_ij is not stored at all; steps 6 and 7 take V_i where nothing was limited and form P_ij
+   * again elsewhere (their ONFLY variants). */
+  template <typename E, int NY = 1, bool STORE_P = true>
   __global__ void __launch_bounds__(kBlock, lij0_waves_per_simd<E>())
   k_lij_stage0(const typename E::Params P, const DeviceMesh M, DeviceScalars *__restrict__ scalars,
                const double *__restrict__ old_U, const double *__restrict__ alpha,
@@ -156,7 +123,8 @@ namespace ryujin_hip
       }
       if (!active)
         continue;
-      store_entry<K>(pij, colbase, r.lane, P_ij);
+      if constexpr (STORE_P)
+        store_entry<K>(pij, colbase, r.lane, P_ij);
       if (NY == 1) {
         /* what the first high-order pass adds when nothing is limited: U += l lambda P with l = 1 (:1107-1131) */
 #pragma unroll
@@ -181,12 +149,37 @@ namespace ryujin_hip
       undecided_mask &= undecided_mask - 1;
       const uint64_t colbase = (uint64_t)r.base + c;
       double P_ij[K];
-      load_entry<K>(pij, colbase, r.lane, P_ij);
+      if constexpr (STORE_P) {
+        load_entry<K>(pij, colbase, r.lane, P_ij);
+      } else {
+        PairData<K> pd;
+        load_pair<K>(M, old_U, r_in, alpha, dij, colbase * 64 + r.lane, cols[colbase * 64 + r.lane], pd);
+        pij_stage0<K>(row, pd, P_ij);
+      }
       bool success;
       const double l_ij = E::limit(P, bnd, U_i_new, P_ij, success);
       lij[colbase * 64 + r.lane] = l_ij;
       all_ok = all_ok && success;
     }
     flag_restart(scalars, all_ok, r.lane);
+  }
+
+  /* ryujin_hip_debug_fetch(P_ij) behind a step that stored none: the same pij_stage0() on the same operands
+   * (all of them outlive the step), written to the matrix the parity tests read */
+  template <typename E>
+  __global__ void __launch_bounds__(kBlock)
+  k_pij_stage0_store(const DeviceMesh M, const Stage0Src S0, double *__restrict__ pij)
+  {
+    constexpr int K = E::K;
+    const RowCtx r = row_context(M);
+    if (!r.valid || r.len <= 1)
+      return;
+    RowData<K> row;
+    load_row_data<K>(M, S0, r.row, r.len, row);
+    for (uint32_t c = 1; c < r.len; ++c) {
+      double P_ij[K];
+      pij_on_the_fly<K>(M, S0, row, (uint64_t)r.base + c, r.lane, P_ij);
+      store_entry<K>(pij, (uint64_t)r.base + c, r.lane, P_ij);
+    }
   }
 } // namespace ryujin_hip

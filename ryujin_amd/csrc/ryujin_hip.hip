@@ -444,11 +444,30 @@ struct ryujin_hip_ctx {
   /* step 5 of the running step left V_i = U_i^low + sum_j lambda P_ij (k_lij_stage0, k_pij_lij): step 6 may take it */
   DeviceBuffer<double> d_V;
   bool stage0_V = false;
+  /* the last step stored no P_ij (never_store below): ryujin_hip_debug_fetch forms it again from these operands */
+  bool last_never_stored = false;
+  Stage0Src last_s0{};
+  DeviceBuffer<uint32_t> d_worklist; /* [2][n_slices]: limited slices of the export / interior part of step 6 */
+  /* fraction of the slices in which the first high-order sweep found a limited pair, from the device counters
+   * at the latest host synchronisation (DeviceScalars::n_sampled_*); 1 until the first measurement */
+  double limited_fraction = 1.;
+  unsigned int seen_sampled_slices = 0, seen_sampled_limited = 0;
+  void update_limited_fraction()
+  {
+    const unsigned int d_slices = h_scalars->n_sampled_slices - seen_sampled_slices;
+    const unsigned int d_limited = h_scalars->n_sampled_limited - seen_sampled_limited;
+    seen_sampled_slices = h_scalars->n_sampled_slices;
+    seen_sampled_limited = h_scalars->n_sampled_limited;
+    if (d_slices != 0)
+      limited_fraction = (double)d_limited / (double)d_slices;
+  }
   void ensure_pij()
   {
     if (d_pij.n == 0)
       d_pij.alloc(L.nnz_total * (size_t)K);
   }
+  template <typename E>
+  void store_pij_for_debug();
 
   unsigned n_restarts = 0, n_warnings = 0;
   unsigned long long n_exchanges = 0, n_allreduces = 0; /* ryujin_hip_exchange_info */
@@ -1065,6 +1084,20 @@ void ryujin_hip_ctx::exchange_matrix(double *m, bool after_split_sweep)
 }
 
 template <typename E>
+void ryujin_hip_ctx::store_pij_for_debug()
+{
+  finish();
+  DeviceMesh mm = mesh;
+  mm.begin = StepBegin{};
+  mm.slice_begin = 0;
+  mm.slice_end = L.n_slices;
+  const dim3 grid((L.n_slices + kWavesPerBlock - 1) / kWavesPerBlock), block(kBlock);
+  hipLaunchKernelGGL(k_pij_stage0_store<E>, grid, block, 0, stream, mm, last_s0, d_pij.ptr);
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipStreamSynchronize(stream));
+}
+
+template <typename E>
 void ryujin_hip_ctx::prepare_state_vector(int h, const double *dirichlet)
 {
   const auto &eparams = eq_params<E>(); /* shadows the member: the equation's parameter block */
@@ -1373,9 +1406,33 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
   const bool stage0_pij = RYUJIN_STAGE0_PIJ && (is_euler || is_aeos) && stages == 0 && params.limiter_iterations != 0 && !dg &&
                           L.max_row_len <= (uint32_t)kStage0Width;
   stage0_V = false;
-  ensure_pij();
   if (params.limiter_iterations == 2 && d_V.n == 0)
     d_V.alloc((size_t)L.n_relevant * KP);
+  /* step 5 on small meshes: up to four waves per slice, each taking a share of the columns (decided for the whole
+   * mesh, not per launch: the export and the interior part of a split sweep must agree on whether V_i exists) */
+  const uint32_t step5_groups = std::min<uint32_t>(
+      4u, resident_waves_step5 /
+              std::max<uint32_t>(1u, (L.n_slices + kWavesPerBlock - 1) / kWavesPerBlock * kWavesPerBlock));
+  /* ... and P_ij is not even stored where the update has two limiter passes and one wave per slice: step 6 takes
+   * V_i in slices where nothing was limited and forms P_ij again elsewhere, step 7 likewise (ONFLY kernels) */
+  const bool never_store = (DIM == 3 ? RYUJIN_NEVER_STORE_PIJ_3D : RYUJIN_NEVER_STORE_PIJ_2D) && stage0_pij &&
+                           params.limiter_iterations == 2 && step5_groups < 2 && params.debug_pij_storage >= 0 &&
+                           (params.debug_pij_storage > 0 ||
+                            limited_fraction <= (DIM == 3 ? RYUJIN_NEVER_STORE_MAX_LIMITED_3D
+                                                          : RYUJIN_NEVER_STORE_MAX_LIMITED_2D));
+  if (!never_store)
+    ensure_pij();
+  else if (d_worklist.n == 0)
+    d_worklist.alloc((size_t)2 * L.n_slices);
+  /* the two launches of a sweep that runs without the stored P_ij (kernels_limiter.hpp): which work list the part
+   * of the sweep that is being launched owns, and the grid of the work-list launch (any size: its waves stride) */
+  auto work_list = [&]() {
+    const int part = (n_nbr != 0 && launch_stream == comm_stream) ? 0 : 1;
+    return WorkList{d_worklist.ptr + (size_t)part * L.n_slices, &d_scalars.ptr->worklist_count[part]};
+  };
+  auto work_list_grid = [&](const dim3 grid) { return dim3(std::min<uint32_t>(grid.x, 1024u)); };
+  last_never_stored = never_store;
+  last_s0 = Stage0Src{d_scalars.ptr, old.U.ptr, d_alpha.ptr, d_dij.ptr, d_r.ptr};
   sweep([&](const DeviceMesh &mm, dim3 grid) {
     if constexpr (is_euler) {
       if (dg && stages == 0)
@@ -1490,8 +1547,7 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
         if (stage0_pij) {
           /* small meshes: up to four waves per slice, each taking a share of the columns (decided for the whole
            * mesh, not per launch: the export and the interior part of a split sweep must agree on whether V_i exists) */
-          const uint32_t n_blocks = (L.n_slices + kWavesPerBlock - 1) / kWavesPerBlock;
-          const uint32_t groups = std::min<uint32_t>(4u, resident_waves_step5 / std::max<uint32_t>(1u, n_blocks * kWavesPerBlock));
+          const uint32_t groups = step5_groups;
           auto launch5 = [&](auto ny) {
             constexpr int NY = decltype(ny)::value;
             hipLaunchKernelGGL((k_lij_stage0<E, NY>), dim3(grid.x, NY), block, 0, launch_stream, eparams, mm,
@@ -1499,7 +1555,12 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
                                d_pij.ptr, d_lij.ptr, NY == 1 ? d_V.ptr : nullptr);
             stage0_V = NY == 1 && d_V.ptr != nullptr;
           };
-          if (groups >= 4)
+          if (never_store) {
+            hipLaunchKernelGGL((k_lij_stage0<E, 1, false>), grid, block, 0, launch_stream, eparams, mm,
+                               d_scalars.ptr, old.U.ptr, d_alpha.ptr, d_dij.ptr, nw.U.ptr, d_r.ptr, d_bounds.ptr,
+                               nullptr, d_lij.ptr, d_V.ptr);
+            stage0_V = true;
+          } else if (groups >= 4)
             launch5(std::integral_constant<int, 4>{});
           else if (groups == 3)
             launch5(std::integral_constant<int, 3>{});
@@ -1571,8 +1632,20 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
     constexpr int kCachedWidth = DIM == 1 ? 3 : (DIM == 2 ? 9 : 27);
     if (last_round) {
       sweep([&](const DeviceMesh &mm, dim3 grid) {
+        constexpr int kLastChunk = DIM == 3 ? RYUJIN_LAST_CHUNK_3D : (DIM == 2 ? RYUJIN_LAST_CHUNK_2D : kCachedWidth);
+        if constexpr (is_euler || is_aeos) {
+          if (never_store) {
+            const WorkList W = work_list();
+            hipLaunchKernelGGL((k_high_order_last_cached<E, kCachedWidth, kLastChunk, true>), grid, block, 0,
+                               launch_stream, eparams, mm, nw.U.ptr, nullptr, d_lij.ptr, fused_sadd, fused_prec);
+            hipLaunchKernelGGL((k_high_order_last_worklist<E, kCachedWidth, kLastChunk>), work_list_grid(grid), block,
+                               0, launch_stream, eparams, mm, nw.U.ptr, d_lij.ptr, fused_sadd, fused_prec, last_s0,
+                               W.slices, W.count);
+            return;
+          }
+        }
         if (L.max_row_len <= (uint32_t)kCachedWidth)
-          hipLaunchKernelGGL((k_high_order_last_cached<E, kCachedWidth, (DIM == 3 ? RYUJIN_LAST_CHUNK_3D : (DIM == 2 ? RYUJIN_LAST_CHUNK_2D : kCachedWidth))>), grid,
+          hipLaunchKernelGGL((k_high_order_last_cached<E, kCachedWidth, kLastChunk>), grid,
                              block, 0, launch_stream, eparams, mm, nw.U.ptr, d_pij.ptr, d_lij.ptr, fused_sadd,
                              fused_prec);
         else
@@ -1583,20 +1656,32 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
       /* 3-D: cache all l_ij and the P_ij of the first RYUJIN_HO_CP_3D columns (0: two-pass kernel) */
       constexpr int kCachedP = DIM == 3 ? (RYUJIN_HO_CP_3D > 0 ? RYUJIN_HO_CP_3D : 27) : kCachedWidth;
       sweep([&](const DeviceMesh &mm, dim3 grid) {
+        if constexpr (is_euler || is_aeos) {
+          if (never_store) {
+            const WorkList W = work_list();
+            hipLaunchKernelGGL((k_high_order_next_cached<E, kCachedWidth, kCachedP, false, true>), grid, block, 0,
+                               launch_stream, eparams, mm, nw.U.ptr, d_bounds.ptr, nullptr, d_lij.ptr,
+                               d_lij_next.ptr, d_V.ptr, last_s0, W);
+            hipLaunchKernelGGL((k_high_order_next_worklist<E, kCachedWidth, kCachedP>), work_list_grid(grid), block, 0,
+                               launch_stream, eparams, mm, nw.U.ptr, d_bounds.ptr, d_lij.ptr, d_lij_next.ptr,
+                               d_V.ptr, last_s0, W);
+            return;
+          }
+        }
         if constexpr (DIM <= 2) {
           /* small meshes: the four waves of a block share one slice (see the kernel) while all of them fit */
           const uint32_t n_launch = mm.slice_end - mm.slice_begin;
           if (L.max_row_len <= (uint32_t)kCachedWidth && n_launch * kWavesPerBlock <= resident_waves_step6) {
             hipLaunchKernelGGL((k_high_order_next_cached<E, kCachedWidth, kCachedWidth, true>), dim3(n_launch),
                                block, 0, launch_stream, eparams, mm, nw.U.ptr, d_bounds.ptr, d_pij.ptr,
-                               d_lij.ptr, d_lij_next.ptr, stage0_V ? d_V.ptr : nullptr);
+                               d_lij.ptr, d_lij_next.ptr, stage0_V ? d_V.ptr : nullptr, last_s0);
             return;
           }
         }
         if ((DIM <= 2 || RYUJIN_HO_CP_3D > 0) && L.max_row_len <= (uint32_t)kCachedWidth)
           hipLaunchKernelGGL((k_high_order_next_cached<E, kCachedWidth, kCachedP>), grid, block, 0,
                              launch_stream, eparams, mm, nw.U.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr,
-                             d_lij_next.ptr, stage0_V ? d_V.ptr : nullptr);
+                             d_lij_next.ptr, stage0_V ? d_V.ptr : nullptr, last_s0);
         else
           hipLaunchKernelGGL((k_high_order<E, false>), grid, block, 0, launch_stream, eparams, mm, nw.U.ptr,
                              d_bounds.ptr, d_pij.ptr, d_lij.ptr, d_lij_next.ptr, FusedSadd{0., 0., nullptr});
@@ -1623,6 +1708,7 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
   HIP_CHECK(hipMemcpyAsync(h_scalars, d_scalars.ptr, sizeof(DeviceScalars), hipMemcpyDeviceToHost,
                            stream));
   HIP_CHECK(hipStreamSynchronize(stream));
+  update_limited_fraction();
 
   if (timers_enabled) {
     for (int k = 0; k < 7; ++k) {
@@ -1826,6 +1912,7 @@ int ryujin_hip_ctx::time_step(int scheme, int h_state, int n_tmp, const int *h_t
     HIP_CHECK(hipMemcpyAsync(h_scalars, d_scalars.ptr, sizeof(DeviceScalars), hipMemcpyDeviceToHost,
                              stream));
     HIP_CHECK(hipStreamSynchronize(stream));
+    update_limited_fraction();
     if (timers_enabled) {
       for (int st = 0; st < n_stages; ++st) {
         for (int k = 0; k < 7; ++k) {
@@ -2020,6 +2107,7 @@ void ryujin_hip_default_params(ryujin_hip_params *p, int equation, int dim)
   p->debug_join_exchanges = 0;
   p->debug_bc_fold_max_slices = 0;
   p->debug_no_small_mesh_split = 0;
+  p->debug_pij_storage = 0;
 }
 
 int ryujin_hip_comm_unique_id(char id[RYUJIN_HIP_UNIQUE_ID_BYTES])
@@ -2474,6 +2562,19 @@ int ryujin_hip_get_counters(ryujin_hip_ctx *ctx, unsigned *n_restarts, unsigned 
   return RYUJIN_OK;
 }
 
+int ryujin_hip_limiter_statistics(ryujin_hip_ctx *ctx, double *limited_slice_fraction, int *pij_stored)
+{
+  return guarded([&]() {
+    if (!ctx)
+      throw HipError(RYUJIN_ERR_ARG, "null context");
+    if (limited_slice_fraction)
+      *limited_slice_fraction = ctx->limited_fraction;
+    if (pij_stored)
+      *pij_stored = ctx->last_never_stored ? 0 : 1;
+    return RYUJIN_OK;
+  });
+}
+
 int ryujin_hip_debug_fetch(ryujin_hip_ctx *ctx, int what, double *out, size_t n_doubles)
 {
   return guarded_ctx(ctx, [&]() {
@@ -2491,6 +2592,14 @@ int ryujin_hip_debug_fetch(ryujin_hip_ctx *ctx, int what, double *out, size_t n_
     case 1: fetch_matrix(ctx->d_lij.ptr, 1); break;
     case 2:
       ctx->ensure_pij();
+      if (ctx->last_never_stored)
+        dispatch_equation(ctx->params.equation, ctx->dim, [&](auto tag) {
+          using E = typename decltype(tag)::type;
+          if constexpr (std::is_same<typename E::Params, EulerParams>::value ||
+                        std::is_same<typename E::Params, EulerAeosParams>::value)
+            ctx->template store_pij_for_debug<E>();
+          return 0;
+        });
       fetch_matrix(ctx->d_pij.ptr, (uint32_t)ctx->K);
       break;
     case 5: fetch_matrix(ctx->d_lij_next.ptr, 1); break;

@@ -262,6 +262,16 @@ class HyperbolicModule:
         return dict(neighbours=[nbr[q] for q in range(min(n_nbr.value, 64))], n_exchanges=nx.value,
                     n_allreduces=nr.value)
 
+    def limiter_statistics(self) -> dict:
+        """Fraction of the 64-row slices in which the first high-order sweep found a limited pair (as of the
+        latest host synchronisation) and whether the latest step stored P_ij (ryujin_hip_limiter_statistics;
+        device backend only)."""
+        f, stored = C.c_double(1.0), C.c_int(1)
+        fn = self._f("limiter_statistics")
+        fn.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        self._check(fn(self._ctx, C.byref(f), C.byref(stored)))
+        return dict(limited_slice_fraction=f.value, pij_stored=bool(stored.value))
+
     def debug_fetch(self, what: str) -> np.ndarray:
         """`*_all`: over all locally relevant rows, i.e. including the ghost rows / ghost range received from
         the neighbour ranks."""

@@ -97,3 +97,6 @@ print("%-8s " % "variant" + " ".join("%9s" % n for n in names) + "     total(2-7
 for name, (lib, m, drv, acc, cnt) in mods.items():
     ms = acc[1:7] / cnt[0]
     print("%-8s " % name + " ".join("%9.4f" % x for x in ms) + "  %9.4f  %9.4f" % (ms.sum(), cnt[1] / cnt[0]), flush=True)
+for name, (lib, m, drv, acc, cnt) in mods.items():
+    if hasattr(lib, "ryujin_hip_limiter_statistics"):
+        print("%-8s " % name + "limiter statistics: %s" % m.limiter_statistics(), flush=True)
