@@ -49,6 +49,10 @@ def test_committed_bench_lines_follow_the_contract(path):
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    if "reference_structure" in r:   # from r03x on: the numerator is what THIS implementation's kernel touches once
+        assert 0.0 < r["frac"] <= 1.0 and r["reference_structure"]["frac"] >= r["frac"]
+        assert r["traffic_frac"] is None or r["frac"] <= r["traffic_frac"] * 1.02 <= 1.02
+        assert isinstance(d["limiter"]["pij_stored"], bool) and 0.0 <= d["limiter"]["limited_slice_fraction"] <= 1.0
     # value is consistent with the time per step and the size of the job
     dofs = d["config"]["dofs_total"]
     assert abs(d["value"] - dofs / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * d["value"]
