@@ -541,7 +541,7 @@ namespace ryujin_hip
   RYUJIN_DEV void last_cached_slice(const typename E::Params &P, const DeviceMesh &M, const RowCtx &r,
                                     double *__restrict__ new_U, const double *__restrict__ pij,
                                     const double *__restrict__ lij, const FusedSadd &F, const FusedPrecompute &FP,
-                                    const Stage0Src &S0)
+                                    const Stage0Src &S0, const uint8_t *__restrict__ slice_unlimited = nullptr)
   {
     static_assert(!(ONFLY && DEFER), "one or the other");
     constexpr int K = E::K;
@@ -558,20 +558,29 @@ namespace ryujin_hip
 
     double l[MAXW];
     uint32_t needed = 0; /* wave-uniform: bit c <=> some row of the slice has l(c) != 0 */
-#pragma unroll
-    for (int c = 1; c < MAXW; ++c) {
-      l[c] = 0.;
-      if ((uint32_t)c < r.width) {
-        const uint32_t pos = (uint32_t)(((uint64_t)r.base + c) * 64 + r.lane);
-        const double l_a = lij[pos];
-        const double l_b = lij[idx_t[pos]];
-        l[c] = (row_active && (uint32_t)c < r.len) ? fmin(l_a, l_b) : 0.;
-      }
-    }
+    /* (DEFER) step 6 found nothing limited in this slice: every l of its rows is an exact zero (WorkList::unlimited),
+     * nothing to fetch */
+    bool known_unlimited = false;
+    if constexpr (DEFER)
+      known_unlimited = slice_unlimited != nullptr && slice_unlimited[r.slice] != 0;
 #pragma unroll
     for (int c = 1; c < MAXW; ++c)
-      if (__any(l[c] != 0.))
-        needed |= 1u << c;
+      l[c] = 0.;
+    if (!known_unlimited) {
+#pragma unroll
+      for (int c = 1; c < MAXW; ++c) {
+        if ((uint32_t)c < r.width) {
+          const uint32_t pos = (uint32_t)(((uint64_t)r.base + c) * 64 + r.lane);
+          const double l_a = lij[pos];
+          const double l_b = lij[idx_t[pos]];
+          l[c] = (row_active && (uint32_t)c < r.len) ? fmin(l_a, l_b) : 0.;
+        }
+      }
+#pragma unroll
+      for (int c = 1; c < MAXW; ++c)
+        if (__any(l[c] != 0.))
+          needed |= 1u << c;
+    }
 
     if constexpr (DEFER) {
       if (needed != 0u)
@@ -637,12 +646,12 @@ namespace ryujin_hip
   __global__ void __launch_bounds__(kBlock, (MAXW > 9 ? RYUJIN_OCC_LAST_3D : 1))
   k_high_order_last_cached(const typename E::Params P, const DeviceMesh M, double *__restrict__ new_U,
                            const double *__restrict__ pij, const double *__restrict__ lij, const FusedSadd F,
-                           const FusedPrecompute FP)
+                           const FusedPrecompute FP, const uint8_t *__restrict__ slice_unlimited = nullptr)
   {
     const RowCtx r = row_context(M);
     if (!r.valid)
       return;
-    last_cached_slice<E, MAXW, CHUNK, false, DEFER>(P, M, r, new_U, pij, lij, F, FP, Stage0Src{});
+    last_cached_slice<E, MAXW, CHUNK, false, DEFER>(P, M, r, new_U, pij, lij, F, FP, Stage0Src{}, slice_unlimited);
   }
 
   /* the ONFLY half: any grid; wave w takes the entries w, w + n_waves, ... of the work list */
@@ -680,6 +689,9 @@ namespace ryujin_hip
   struct WorkList {
     uint32_t *slices;
     unsigned int *count;
+    /* [n_slices] 1: step 6 found no limited pair in the slice. Then every l'_ij of its rows is an exact zero, and so
+     * is every transposed l'_ji (min(l_ij, l_ji) = 1 is symmetric, (1 - 1) l' = 0): the last sweep needs neither. */
+    uint8_t *unlimited;
   };
 
   template <typename E, int MAXW, int CP, bool SPLIT, bool ONFLY, bool DEFER>
@@ -740,6 +752,10 @@ namespace ryujin_hip
           if (slice_limited)
             atomicAdd(&S0.scalars->n_sampled_limited, 1u);
         }
+      }
+      if constexpr (DEFER) {
+        if (r.lane == 0)
+          W.unlimited[r.slice] = slice_limited ? 0 : 1;
       }
       if (!slice_limited) {
         if (row_active) {

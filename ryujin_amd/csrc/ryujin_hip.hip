@@ -448,6 +448,7 @@ struct ryujin_hip_ctx {
   bool last_never_stored = false;
   Stage0Src last_s0{};
   DeviceBuffer<uint32_t> d_worklist; /* [2][n_slices]: limited slices of the export / interior part of step 6 */
+  DeviceBuffer<uint8_t> d_slice_unlimited; /* [n_slices]: WorkList::unlimited */
   /* fraction of the slices in which the first high-order sweep found a limited pair, from the device counters
    * at the latest host synchronisation (DeviceScalars::n_sampled_*); 1 until the first measurement */
   double limited_fraction = 1.;
@@ -1422,13 +1423,16 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
                                                           : RYUJIN_NEVER_STORE_MAX_LIMITED_2D));
   if (!never_store)
     ensure_pij();
-  else if (d_worklist.n == 0)
+  else if (d_worklist.n == 0) {
     d_worklist.alloc((size_t)2 * L.n_slices);
+    d_slice_unlimited.alloc(L.n_slices);
+  }
   /* the two launches of a sweep that runs without the stored P_ij (kernels_limiter.hpp): which work list the part
    * of the sweep that is being launched owns, and the grid of the work-list launch (any size: its waves stride) */
   auto work_list = [&]() {
     const int part = (n_nbr != 0 && launch_stream == comm_stream) ? 0 : 1;
-    return WorkList{d_worklist.ptr + (size_t)part * L.n_slices, &d_scalars.ptr->worklist_count[part]};
+    return WorkList{d_worklist.ptr + (size_t)part * L.n_slices, &d_scalars.ptr->worklist_count[part],
+                    d_slice_unlimited.ptr};
   };
   auto work_list_grid = [&](const dim3 grid) { return dim3(std::min<uint32_t>(grid.x, 1024u)); };
   last_never_stored = never_store;
@@ -1637,7 +1641,8 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
           if (never_store) {
             const WorkList W = work_list();
             hipLaunchKernelGGL((k_high_order_last_cached<E, kCachedWidth, kLastChunk, true>), grid, block, 0,
-                               launch_stream, eparams, mm, nw.U.ptr, nullptr, d_lij.ptr, fused_sadd, fused_prec);
+                               launch_stream, eparams, mm, nw.U.ptr, nullptr, d_lij.ptr, fused_sadd, fused_prec,
+                               W.unlimited);
             hipLaunchKernelGGL((k_high_order_last_worklist<E, kCachedWidth, kLastChunk>), work_list_grid(grid), block,
                                0, launch_stream, eparams, mm, nw.U.ptr, d_lij.ptr, fused_sadd, fused_prec, last_s0,
                                W.slices, W.count);
