@@ -14,9 +14,13 @@
 //     k_dij_alpha for rows wider than 32)
 //   k_dij_boundary + k_dij_diag[_unrolled]         step 3  :432-564
 //   k_low_order (finalize_tau)                     step 4  :597-884
-//   k_pij_lij[_recompute]                          step 5  :892-1041
-//   k_high_order_next_cached / k_high_order<false> step 6  :1053-1182
-//   k_high_order_last_cached / k_high_order<true>  step 7  :1053-1182
+//   k_lij_stage0 (no stage vectors: P_ij formed    step 5  :892-1041
+//     here, kernels_limiter_stage0.hpp) /
+//     k_pij_lij[_recompute]
+//   k_high_order_next_cached (+ _next_worklist     step 6  :1053-1182
+//     where P_ij was not stored) / k_high_order<false>
+//   k_high_order_last_cached (+ _last_worklist)    step 7  :1053-1182
+//     / k_high_order<true>
 
 #pragma once
 
