@@ -558,10 +558,10 @@ namespace ryujin_hip
 
     double l[MAXW];
     uint32_t needed = 0; /* wave-uniform: bit c <=> some row of the slice has l(c) != 0 */
-    /* (DEFER) step 6 found nothing limited in this slice: every l of its rows is an exact zero (WorkList::unlimited),
+    /* step 6 found nothing limited in this slice: every l of its rows is an exact zero (WorkList::unlimited),
      * nothing to fetch */
     bool known_unlimited = false;
-    if constexpr (DEFER)
+    if constexpr (!ONFLY)
       known_unlimited = slice_unlimited != nullptr && slice_unlimited[r.slice] != 0;
 #pragma unroll
     for (int c = 1; c < MAXW; ++c)
@@ -753,10 +753,8 @@ namespace ryujin_hip
             atomicAdd(&S0.scalars->n_sampled_limited, 1u);
         }
       }
-      if constexpr (DEFER) {
-        if (r.lane == 0)
-          W.unlimited[r.slice] = slice_limited ? 0 : 1;
-      }
+      if (W.unlimited != nullptr && r.lane == 0 && (!SPLIT || group == 0))
+        W.unlimited[r.slice] = slice_limited ? 0 : 1;
       if (!slice_limited) {
         if (row_active) {
           double V_i[K];

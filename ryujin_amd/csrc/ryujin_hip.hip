@@ -1407,8 +1407,10 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
   const bool stage0_pij = RYUJIN_STAGE0_PIJ && (is_euler || is_aeos) && stages == 0 && params.limiter_iterations != 0 && !dg &&
                           L.max_row_len <= (uint32_t)kStage0Width;
   stage0_V = false;
-  if (params.limiter_iterations == 2 && d_V.n == 0)
+  if (params.limiter_iterations == 2 && d_V.n == 0) {
     d_V.alloc((size_t)L.n_relevant * KP);
+    d_slice_unlimited.alloc(L.n_slices);
+  }
   /* step 5 on small meshes: up to four waves per slice, each taking a share of the columns (decided for the whole
    * mesh, not per launch: the export and the interior part of a split sweep must agree on whether V_i exists) */
   const uint32_t step5_groups = std::min<uint32_t>(
@@ -1423,10 +1425,8 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
                                                           : RYUJIN_NEVER_STORE_MAX_LIMITED_2D));
   if (!never_store)
     ensure_pij();
-  else if (d_worklist.n == 0) {
+  else if (d_worklist.n == 0)
     d_worklist.alloc((size_t)2 * L.n_slices);
-    d_slice_unlimited.alloc(L.n_slices);
-  }
   /* the two launches of a sweep that runs without the stored P_ij (kernels_limiter.hpp): which work list the part
    * of the sweep that is being launched owns, and the grid of the work-list launch (any size: its waves stride) */
   auto work_list = [&]() {
@@ -1629,6 +1629,7 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
   const FusedPrecompute fused_prec{fuse_precompute ? nw.prec.ptr : nullptr, fuse_precompute ? nw.rrec.ptr : nullptr};
   if (fused_sadd.src && n_iterations == 0)
     throw HipError(RYUJIN_ERR_ARG, "internal: fused sadd without a limiter pass");
+  bool step6_flags = false; /* step 6 left WorkList::unlimited for every slice: the last sweep may use it */
   for (int pass = 0; pass < n_iterations; ++pass) {
     const bool last_round = (pass + 1 == n_iterations);
     if (n_iterations == 2 && last_round)
@@ -1652,7 +1653,7 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
         if (L.max_row_len <= (uint32_t)kCachedWidth)
           hipLaunchKernelGGL((k_high_order_last_cached<E, kCachedWidth, kLastChunk>), grid,
                              block, 0, launch_stream, eparams, mm, nw.U.ptr, d_pij.ptr, d_lij.ptr, fused_sadd,
-                             fused_prec);
+                             fused_prec, step6_flags ? d_slice_unlimited.ptr : nullptr);
         else
           hipLaunchKernelGGL((k_high_order<E, true>), grid, block, 0, launch_stream, eparams, mm, nw.U.ptr,
                              d_bounds.ptr, d_pij.ptr, d_lij.ptr, d_lij_next.ptr, fused_sadd);
@@ -1679,15 +1680,19 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
           if (L.max_row_len <= (uint32_t)kCachedWidth && n_launch * kWavesPerBlock <= resident_waves_step6) {
             hipLaunchKernelGGL((k_high_order_next_cached<E, kCachedWidth, kCachedWidth, true>), dim3(n_launch),
                                block, 0, launch_stream, eparams, mm, nw.U.ptr, d_bounds.ptr, d_pij.ptr,
-                               d_lij.ptr, d_lij_next.ptr, stage0_V ? d_V.ptr : nullptr, last_s0);
+                               d_lij.ptr, d_lij_next.ptr, stage0_V ? d_V.ptr : nullptr, last_s0,
+                               WorkList{nullptr, nullptr, stage0_V ? d_slice_unlimited.ptr : nullptr});
+            step6_flags = stage0_V;
             return;
           }
         }
-        if ((DIM <= 2 || RYUJIN_HO_CP_3D > 0) && L.max_row_len <= (uint32_t)kCachedWidth)
+        if ((DIM <= 2 || RYUJIN_HO_CP_3D > 0) && L.max_row_len <= (uint32_t)kCachedWidth) {
           hipLaunchKernelGGL((k_high_order_next_cached<E, kCachedWidth, kCachedP>), grid, block, 0,
                              launch_stream, eparams, mm, nw.U.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr,
-                             d_lij_next.ptr, stage0_V ? d_V.ptr : nullptr, last_s0);
-        else
+                             d_lij_next.ptr, stage0_V ? d_V.ptr : nullptr, last_s0,
+                             WorkList{nullptr, nullptr, stage0_V ? d_slice_unlimited.ptr : nullptr});
+          step6_flags = stage0_V;
+        } else
           hipLaunchKernelGGL((k_high_order<E, false>), grid, block, 0, launch_stream, eparams, mm, nw.U.ptr,
                              d_bounds.ptr, d_pij.ptr, d_lij.ptr, d_lij_next.ptr, FusedSadd{0., 0., nullptr});
       });
