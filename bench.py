@@ -47,37 +47,61 @@ KERNEL_OF_SWEEP = {  # sweep name -> kernel-name prefixes in the rocprof summari
 }
 
 
+def source_fingerprint() -> str:
+    """Hash of the kernel sources (ryujin_amd/csrc/*.{hip,hpp,h}, comments and whitespace stripped): what a committed
+    profile has to have been taken with for its counters to be attached to a bench line of this tree."""
+    import glob
+    import hashlib
+    import re
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "ryujin_amd", "csrc", "*"))):
+        if f.endswith((".hip", ".hpp", ".h")):
+            text = open(f, encoding="utf-8", errors="replace").read()
+            text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+            text = re.sub(r"//[^\n]*", " ", text)
+            h.update(os.path.basename(f).encode())
+            h.update(" ".join(text.split()).encode())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic_bytes(sweep: str, workload: str):
-    """(HBM bytes per launch of the sweep's kernel, profile file) from the newest committed rocprofv3 --pmc
+    """(HBM bytes per launch of the sweep's kernel, profile file, note) from the newest committed rocprofv3 --pmc
     passes of this same command (profiles/r*_pmc.md for the bench line, profiles/r*_pmc_<workload>.md for the
     other workloads: (2*FETCH_SIZE + WRITE_SIZE)*1024, the gfx950 correction of MI355X_MICROARCH.md). PMC
-    cannot be collected inside this process; (None, None) if no profile matches. The file name travels
-    with the number so that a stale profile is visible in the bench line."""
+    cannot be collected inside this process. A profile taken with OTHER kernel sources than this tree's (its
+    `kernel sources:` line against source_fingerprint()) is refused: bytes None, the note says why."""
     import glob
     suffix = "" if workload == "step2d" else "_" + workload
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc{suffix}.md")))
     if not files:
-        return None, None
+        return None, None, "no committed PMC pass of this workload"
+    rel = os.path.relpath(files[-1], ROOT)
     rows = {}
+    taken_with = None
     for line in open(files[-1]):
+        if line.startswith("kernel sources:"):
+            taken_with = line.split(":", 1)[1].strip()
         if line.startswith("| k_"):
             cells = [c.strip() for c in line.strip().strip("|").split("|")]
             try:
                 rows[cells[0]] = (float(cells[-1]) * 1e6, int(cells[1]))
             except ValueError:
                 pass
+    now = source_fingerprint()
+    if taken_with != now:
+        return None, rel, (f"REFUSED as stale: {rel} was taken with kernel sources {taken_with}, this tree is {now}")
     last = sweep.startswith("7")
-    best = None  # several variants of a sweep's kernel may have run (the first update stores P_ij): the usual one
+    best = None  # several variants of a sweep's kernel may have run: the one with the most bytes in total
     for name, (val, n_dispatches) in rows.items():
         for prefix in KERNEL_OF_SWEEP.get(sweep, ()):
             if name.startswith(prefix):
                 if prefix == "k_high_order<" and (("true" in name) != last):
                     continue
-                if best is None or n_dispatches > best[1]:
+                if best is None or val * n_dispatches > best[0] * best[1]:
                     best = (val, n_dispatches)
     if best is not None:
-        return best[0], os.path.relpath(files[-1], ROOT)
-    return None, None
+        return best[0], rel, None
+    return None, rel, "the profile holds no kernel of this sweep"
 
 
 class Ssprk33Stages:
@@ -145,6 +169,79 @@ def usable_cores() -> int:
     return max(1, n)
 
 
+def interpolate_from_lattice(spec_c, pos_c, U_c, pos_f, n_fill: int = 3):
+    """Multilinear interpolation of nodal values given on the Cartesian lattice of a coarse synthetic mesh
+    (nodes pos_c [n, dim] of spec_c, values U_c [n, k]) to the points pos_f. Lattice nodes the mesh does not have
+    (cut-outs: the step, the staircase cylinder) are filled from their nearest existing axis neighbours, n_fill
+    layers deep -- a fine fluid point next to a coarser staircase may sit in a cell with such a corner. A convex
+    combination of admissible states is admissible (the invariant set is convex)."""
+    import numpy as np
+    dim = spec_c.dim
+    lower = np.array(spec_c.lower[:dim], dtype=np.float64)
+    upper = np.array(spec_c.upper[:dim], dtype=np.float64)
+    n_cells = np.array(spec_c.n_cells[:dim], dtype=np.int64)
+    h = (upper - lower) / n_cells
+    k = U_c.shape[1]
+    grid = np.full(tuple(n_cells + 1) + (k,), np.nan)
+    idx = np.rint((pos_c - lower) / h).astype(np.int64)
+    grid[tuple(idx.T)] = U_c
+    for _ in range(n_fill):
+        hole = np.isnan(grid[..., 0])
+        if not hole.any():
+            break
+        acc = np.zeros_like(grid)
+        cnt = np.zeros(grid.shape[:-1])
+        for ax in range(dim):
+            for shift in (1, -1):
+                nb = np.roll(grid, shift, axis=ax)
+                edge = [slice(None)] * dim
+                edge[ax] = 0 if shift == 1 else -1
+                nb[tuple(edge)] = np.nan  # no wrap-around
+                ok = ~np.isnan(nb[..., 0])
+                acc[ok] += nb[ok]
+                cnt[ok] += 1.0
+        fill = hole & (cnt > 0)
+        grid[fill] = acc[fill] / cnt[fill][:, None]
+    x = np.clip((pos_f - lower) / h, 0.0, n_cells.astype(np.float64))
+    i0 = np.minimum(np.floor(x).astype(np.int64), n_cells - 1)
+    t = x - i0
+    out = np.zeros((pos_f.shape[0], k))
+    for corner in range(1 << dim):
+        w = np.ones(pos_f.shape[0])
+        ii = []
+        for ax in range(dim):
+            bit = (corner >> ax) & 1
+            w = w * (t[:, ax] if bit else 1.0 - t[:, ax])
+            ii.append(i0[:, ax] + bit)
+        v = grid[tuple(ii)]
+        # a corner that does not exist (deep inside a cut-out) must carry no weight for a fluid point
+        bad = np.isnan(v[:, 0])
+        assert not (bad & (w > 1e-9)).any(), "fine point inside a coarse cut-out: raise n_fill"
+        v = np.where(bad[:, None], 0.0, v)
+        out += w[:, None] * v
+    return out
+
+
+def develop_on_coarse_mesh(spec_c, U0_fn, dirichlet_fn, equation, t_final: float, device: int = 0):
+    """Run the flow to t_final with SSPRK33 at cfl 0.9 on a coarse mesh of the same domain (one rank, no
+    communicator, device-resident driver): (coarse offline data, state at t_final, number of RK steps)."""
+    import numpy as np
+    from ryujin_amd import HyperbolicModule, capi, offline
+    off_c = offline.SyntheticOffline(spec_c)
+    m = HyperbolicModule(off_c, equation=equation, backend="hip", device=device)
+    m.cfl = 0.9
+    U = m.new_state_vector(U0_fn(off_c.positions))
+    temps = [m.new_state_vector() for _ in range(3)]
+    dirichlet = dirichlet_fn(off_c.b_positions) if (dirichlet_fn is not None and off_c.n_bdry) else None
+    t, n = 0.0, 0
+    while t < t_final * (1.0 - 1e-12):
+        t += m.time_step("ssprk 33", U, temps, dirichlet if n == 0 else None, tau_max=t_final - t)
+        n += 1
+    U_c = U.download()
+    m.close()
+    return off_c, U_c, n
+
+
 def cpu_baseline(spec, U0, dirichlet, budget_s: float = 15.0, equation: int = 0) -> dict:
     """The CPU restatement of the reference path (oracle/, OpenMP over all host cores) timed on a
     bounded sample of the SAME workload: n forward-Euler updates of the same mesh."""
@@ -208,11 +305,28 @@ def main():
                          "contrast box, --size cells per direction, default 200 -> 8.1M gridpoints); "
                          "sw2d = configs[4] (shallow-water circular dam break, default 1825^2 gridpoints)")
     ap.add_argument("--size", type=int, default=0)
-    ap.add_argument("--develop", type=int, default=900,
-                    help="untimed forward-Euler updates run before the warm-up so that the bow shock and its "
-                         "reflections exist (a uniform state would never enter the limiter's Newton branch)")
+    ap.add_argument("--develop-time", type=float, default=None,
+                    help="simulated time the flow is developed to before anything is timed (default per workload: "
+                         "2.0 for the Mach-3 step, mid-way through the reference's run to t = 4.0, "
+                         "prm/benchmarks/euler-mach3-forward-facing-step.prm:30). The flow runs to that time on a "
+                         "mesh --coarse-factor times coarser, is interpolated to the benchmark mesh and re-sharpened "
+                         "by --develop updates there. 0: no coarse run, --develop updates from the initial state")
+    ap.add_argument("--coarse-factor", type=int, default=4)
+    ap.add_argument("--save-state", default=None,
+                    help="N = 1: write the developed state (the one the warm-up starts from) to this .npz file")
+    ap.add_argument("--load-state", default=None,
+                    help="N = 1: start from a state written by --save-state of the same command instead of developing "
+                         "it (profiling passes: the coarse run would dispatch the same kernels on another mesh)")
+    ap.add_argument("--develop", type=int, default=None,
+                    help="untimed forward-Euler updates on the benchmark mesh before the warm-up (default 600 behind "
+                         "a coarse run: shocks interpolated from the coarse mesh steepen to the fine mesh's width "
+                         "within ~100 updates; 900 with --develop-time 0, the start-up phase of the flow)")
     ap.add_argument("--perturbation", type=float, default=0.0,
-                    help="multiplicative random perturbation of the initial state (initial_values.template.h:198-218)")
+                    help="multiplicative random perturbation of the state the timed updates start from "
+                         "(initial_values.template.h:198-218): the limiter becomes active wherever it is applied")
+    ap.add_argument("--perturbed-fraction", type=float, default=1.0,
+                    help="apply --perturbation to this fraction of the rows only (those with the lowest indices: a "
+                         "contiguous part of the mesh), to sweep the fraction of limited slices")
     ap.add_argument("--stagewise", action="store_true",
                     help="drive every forward-Euler update through prepare_state_vector/step/sadd calls "
                          "(one host synchronisation per update) instead of ryujin_hip_time_step")
@@ -314,16 +428,22 @@ def main():
         dist.barrier()
 
     # ---- workload: BASELINE.json configs[1] per GPU, lengthened channel for N GPUs (weak scaling)
+    # every workload: make_spec(resolution, n_ranks, rank) -> MeshSpec, initial state and Dirichlet data as functions
+    # of positions (the coarse run that develops the flow uses the same recipes on a coarser mesh)
     equation = capi.EQ_EULER
     rng = np.random.default_rng(42 + rank)
+    dirichlet_fn = None
     if args.workload in ("step2d", "step2d_aeos"):
         # weak scaling: the channel is lengthened so that every GPU keeps the gridpoint count of the
         # single-GPU mesh (area 0.8 L + 0.12 with the step cut out: 2.52 per GPU)
         length = 3.0 if n_gpus == 1 else (2.52 * n_gpus - 0.12) / 0.8
-        spec = offline.mach3_step_2d(args.cells_per_unit, length_units=length, n_ranks=n_gpus, rank=rank)
-        off = offline.SyntheticOffline(spec)
-        U0 = euler_uniform(off.positions)  # prm/benchmarks/euler-mach3-forward-facing-step.prm:55-66
-        dirichlet = euler_uniform(off.b_positions) if off.n_bdry else None
+        resolution = args.cells_per_unit
+        coarse_resolution = max(20, int(round(resolution / args.coarse_factor / 5.0)) * 5)
+
+        def make_spec(n, n_ranks, r):
+            return offline.mach3_step_2d(n, length_units=length, n_ranks=n_ranks, rank=r)
+        U0_fn = dirichlet_fn = euler_uniform  # prm/benchmarks/euler-mach3-forward-facing-step.prm:55-66
+        default_develop_time = 2.0            # of the prm's final time 4.0 (:30)
         workload_name = ("2D Euler Mach-3 forward-facing step, Q1, SSPRK33 stage sequence "
                          "(BASELINE.json configs[1])")
         if args.workload == "step2d_aeos":  # same problem through the EulerAEOS Description (f-3)
@@ -334,33 +454,45 @@ def main():
         # BASELINE.json configs[3]: h = 1/126 on [0,4]x[-1,1]^2 over 8 GPUs is 4M gridpoints per GPU; fewer
         # GPUs keep that per-GPU count with a shorter channel (half a unit of length per GPU, at least 1.25)
         # (the cylinder needs 1.25 units of channel: one or two GPUs run h = 1/96 and 1/120 instead)
-        n = args.size or {1: 96, 2: 120}.get(n_gpus, 126)
+        resolution = args.size or {1: 96, 2: 120}.get(n_gpus, 126)
+        coarse_resolution = max(8, resolution // args.coarse_factor)
         length = max(1.25, 0.5 * n_gpus)
-        spec = offline.cylinder_channel_3d(n, length_units=length, n_ranks=n_gpus, rank=rank)
-        off = offline.SyntheticOffline(spec)
-        U0 = euler_uniform(off.positions)  # prm/benchmarks/euler-mach3-cylinder-3d.prm:49-91
-        dirichlet = euler_uniform(off.b_positions) if off.n_bdry else None
+
+        def make_spec(n, n_ranks, r):
+            return offline.cylinder_channel_3d(n, length_units=length, n_ranks=n_ranks, rank=r)
+        U0_fn = dirichlet_fn = euler_uniform  # prm/benchmarks/euler-mach3-cylinder-3d.prm:49-91
+        default_develop_time = 1.0            # the bow shock stands and has reflected off the channel walls (final time 5.0, :41)
         workload_name = "3D Euler Mach-3 cylinder in a channel, Q1 (BASELINE.json configs[3])"
     elif args.workload == "sedov3d":
         from ryujin_amd.initial_states import euler_radial_contrast
-        n = args.size or 200
-        spec = offline.box_3d(n, nx=n * n_gpus, upper=(2.0 * n_gpus - 1.0, 1.0, 1.0), n_ranks=n_gpus, rank=rank)
-        off = offline.SyntheticOffline(spec)
-        U0 = euler_radial_contrast(off.positions, inner=(1.0, 0.0, 100.0), outer=(1.0, 0.0, 0.1), radius=0.1)
-        dirichlet = None
+        resolution = args.size or 200
+        coarse_resolution = max(8, resolution // args.coarse_factor)
+
+        def make_spec(n, n_ranks, r):
+            return offline.box_3d(n, nx=n * n_gpus, upper=(2.0 * n_gpus - 1.0, 1.0, 1.0), n_ranks=n_ranks, rank=r)
+
+        def U0_fn(positions):
+            return euler_radial_contrast(positions, inner=(1.0, 0.0, 100.0), outer=(1.0, 0.0, 0.1), radius=0.1)
+        default_develop_time = 0.25           # the blast wave is half-way to the walls
         workload_name = "3D Euler Sedov-like radial contrast, rectangular domain, Q1 (BASELINE.json configs[2])"
     else:
         from ryujin_amd.initial_states import sw_circular_dam_break
         equation = capi.EQ_SHALLOW_WATER
-        n = args.size or 1824
-        spec = offline.rectangle_2d(n * n_gpus, (-5.0, -5.0), (10.0 * n_gpus - 5.0, 5.0), ny=n, n_ranks=n_gpus,
-                                    rank=rank)
-        off = offline.SyntheticOffline(spec)
-        U0 = sw_circular_dam_break(off.positions)
-        dirichlet = None
+        resolution = args.size or 1824
+        coarse_resolution = max(8, resolution // args.coarse_factor)
+
+        def make_spec(n, n_ranks, r):
+            return offline.rectangle_2d(n * n_gpus, (-5.0, -5.0), (10.0 * n_gpus - 5.0, 5.0), ny=n, n_ranks=n_ranks,
+                                        rank=r)
+        U0_fn = sw_circular_dam_break
+        default_develop_time = 0.5            # the bore has travelled half-way to the walls
         workload_name = "2D shallow-water circular dam break, Q1 (BASELINE.json configs[4])"
-    if args.perturbation != 0.0:
-        U0 *= 1.0 + args.perturbation * rng.uniform(-1.0, 1.0, size=U0.shape)
+    n = resolution
+    spec = make_spec(resolution, n_gpus, rank)
+    off = offline.SyntheticOffline(spec)
+    dirichlet = dirichlet_fn(off.b_positions) if (dirichlet_fn is not None and off.n_bdry) else None
+    develop_time = default_develop_time if args.develop_time is None else args.develop_time
+    n_develop = args.develop if args.develop is not None else (600 if develop_time > 0.0 else 900)
 
     lib = capi.load_hip()
     comm = None
@@ -390,8 +522,35 @@ def main():
         mod.cfl = 0.9
         return mod
 
+    # ---- the state the timed updates start from. The reference's benchmark runs to t = 4.0; its cost does not
+    # depend on the state, ours does (the limiter sweeps skip what an unlimited slice does not need), so the state
+    # has to look like the benchmark: the flow is run to develop_time on a coarse mesh of the same domain (every
+    # rank on its own, the whole domain, no communicator), interpolated to the benchmark mesh, and re-sharpened
+    # by n_develop updates there.
+    t_start = 0.0
+    coarse = None
+    if args.load_state:
+        assert n_gpus == 1, "--load-state: one GPU"
+        z = np.load(args.load_state)
+        U0, t_start = z["U"], float(z["t"])
+        assert U0.shape[0] == off.n_relevant, "the state file belongs to another mesh"
+        coarse = {"loaded_from": os.path.basename(args.load_state)}
+        n_develop = 0
+    elif develop_time > 0.0:
+        t0 = time.perf_counter()
+        spec_c = make_spec(coarse_resolution, 1, 0)
+        off_c, U_c, n_rk = develop_on_coarse_mesh(spec_c, U0_fn, dirichlet_fn, equation, develop_time, device)
+        U0 = interpolate_from_lattice(spec_c, off_c.positions[: off_c.n_owned], U_c[: off_c.n_owned], off.positions)
+        coarse = {"resolution": coarse_resolution, "gridpoints": off_c.n_owned, "ssprk33_steps": n_rk,
+                  "seconds": round(time.perf_counter() - t0, 2)}
+        off_c.close()
+        t_start = develop_time
+    else:
+        U0 = U0_fn(off.positions)
+
     m = make_module(args.system_events)
     drv = Ssprk33Stages(m, U0, dirichlet)
+    drv.t = t_start
     ctx = m._ctx
 
     def barrier():
@@ -399,9 +558,27 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    for _ in range(args.develop):  # untimed: let the flow develop
+    for _ in range(n_develop):  # untimed: let the flow develop / re-sharpen
         drv.update()
-    U_developed = drv.U.download() if (n_gpus == 1 and not args.no_cpu_baseline) else None
+    if args.perturbation != 0.0:
+        # the pessimistic variant: a random perturbation of the developed state makes the limiter work in every
+        # perturbed row (--perturbed-fraction: a contiguous part of the mesh, to sweep the limited fraction)
+        while drv.stage != 0:
+            drv.update()
+        U_p = drv.U.download()
+        n_p = int(round(args.perturbed_fraction * U_p.shape[0]))
+        U_p[:n_p] *= 1.0 + args.perturbation * rng.uniform(-1.0, 1.0, size=U_p[:n_p].shape)
+        t_p = drv.t
+        drv = Ssprk33Stages(m, U_p, dirichlet)
+        drv.t = t_p
+        for _ in range(6):
+            drv.update()
+    U_developed = drv.U.download() if (n_gpus == 1 and (not args.no_cpu_baseline or args.save_state)) else None
+    if args.save_state and n_gpus == 1:
+        while drv.stage != 0:
+            drv.update()
+        U_developed = drv.U.download()
+        np.savez(args.save_state, U=U_developed, t=np.float64(drv.t))
 
     # ---- N > 1: device-scope against system-scope events, before anything is timed. The events that tie the
     # compute and the exchange stream carry no system-scope fence by default; whether that
@@ -430,7 +607,9 @@ def main():
             events = {"kind": "system", "check": "device-scope events gave DIFFERENT results on some rank "
                                                  "(stale ghost data): timed on system-scope events"}
             m, ctx = m_sys, m_sys._ctx
+            t_keep = drv.t
             drv = Ssprk33Stages(m, U_start, dirichlet)
+            drv.t = t_keep
     for _ in range(args.warmup):
         drv.update()
 
@@ -560,15 +739,17 @@ def main():
     if equation in (capi.EQ_EULER, capi.EQ_EULER_AEOS):
         own["4 low_order"] -= 8 * k * S
         own["5 pij_lij"] += -8 * k * S + 8 * S + 8 * k + 8 * k  # - first part; + m_ij, F_i read, V_i written
-        if not limiter["pij_stored"]:
-            own["5 pij_lij"] -= 8 * k * S
+        # P_ij is written in the slices steps 6/7 read it in (counted by the library over the instrumented pass)
+        own["5 pij_lij"] -= (1.0 - limiter["pij_stored_slice_fraction"]) * 8 * k * S
     dom_gbs = own[dom] * n_q_local / (per_sweep[dom] * 1e-3) / 1e9
     ref_gbs = alg[dom] * n_q_local / (per_sweep[dom] * 1e-3) / 1e9
 
     # the committed PMC passes were taken on the default problem of each workload: do not attach them to a run
     # of another size or with a perturbed state
-    default_problem = (args.cells_per_unit == 995 and args.size == 0 and args.perturbation == 0.0 and n_gpus == 1)
-    traffic, traffic_file = pmc_traffic_bytes(dom, args.workload) if default_problem else (None, None)
+    default_problem = (args.cells_per_unit == 995 and args.size == 0 and args.perturbation == 0.0 and n_gpus == 1 and
+                       args.develop_time is None and args.develop is None and args.coarse_factor == 4)
+    traffic, traffic_file, traffic_note = (pmc_traffic_bytes(dom, args.workload) if default_problem
+                                           else (None, None, "not the default problem of the workload"))
     out = {
         "metric": "MDoF-updates/s per Euler forward step; achieved HBM GB/s vs roofline",
         "value": k * n_q_total * args.steps / wall / 1e6,
@@ -583,18 +764,22 @@ def main():
                    "gridpoints_per_gpu": n_q_local, "gridpoints_total": n_q_total,
                    "dofs_total": k * n_q_total, "nnz_per_row": round(S, 3),
                    "cells_per_unit": (args.cells_per_unit if args.workload.startswith("step2d") else n), "partition": f"x-slabs x{n_gpus}, equal gridpoint counts",
-                   "cfl": 0.9, "limiter_iterations": 2, "develop_updates": args.develop,
-                   "simulated_time_at_start": drv.t, "perturbation": args.perturbation},
+                   "cfl": 0.9, "limiter_iterations": 2,
+                   # how the state the timed updates start from was made: run to develop_time on the coarse mesh,
+                   # interpolated, develop_updates updates on this mesh (develop_time 0: from the initial state)
+                   "develop_time": develop_time, "coarse_run": coarse, "develop_updates": n_develop,
+                   "simulated_time_at_start": drv.t, "perturbation": args.perturbation,
+                   "perturbed_fraction": args.perturbed_fraction if args.perturbation != 0.0 else None},
         "mq_per_s": n_q_total * args.steps / wall / 1e6,
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": dom_gbs, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": dom_gbs / HBM_PEAK_GBS,
                      "traffic": traffic,
-                     "traffic_source": (f"{traffic_file} (separate rocprofv3 --pmc passes of this command, "
-                                        "bytes per launch)") if traffic_file else None,
+                     "traffic_source": (f"{traffic_file} (separate rocprofv3 --pmc passes of this command, bytes per "
+                                        f"launch; kernel sources {source_fingerprint()})") if traffic else traffic_note,
                      "traffic_calibration": ("(2 FETCH_SIZE + WRITE_SIZE) x 1024; factor 2.000 measured for streaming "
                                              "reads of 4/8/16 B per lane, 1.98-1.99 for stencil-order gathers of "
                                              "32/64-byte records, WRITE_SIZE 1.000 "
-                                             "(profiles/r03h_counter_calibration.md)") if traffic_file else None,
+                                             "(profiles/r03h_counter_calibration.md)") if traffic else None,
                      "traffic_frac": (traffic / (per_sweep[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                      "algorithmic_bytes_per_gridpoint": own[dom],
                      "mean_launch_ms": per_sweep[dom],

@@ -17,10 +17,10 @@
 //   k_lij_stage0 (no stage vectors: P_ij formed    step 5  :892-1041
 //     here, kernels_limiter_stage0.hpp) /
 //     k_pij_lij[_recompute]
-//   k_high_order_next_cached (+ _next_worklist     step 6  :1053-1182
-//     where P_ij was not stored) / k_high_order<false>
-//   k_high_order_last_cached (+ _last_worklist)    step 7  :1053-1182
-//     / k_high_order<true>
+//   k_high_order_next_cached (a light and a heavy  step 6  :1053-1182
+//     launch where P_ij is stored per slice)
+//     / k_high_order<false>
+//   k_high_order_last_cached / k_high_order<true>  step 7  :1053-1182
 
 #pragma once
 
@@ -85,12 +85,9 @@ namespace ryujin_hip
     int use_device_tau;
     int stage;
     /* running counters (never reset on the device; the host takes differences): every 16th slice that passes the
-     * first high-order sweep, and those of them in which some pair was limited -- the fraction decides whether
-     * the next step stores P_ij (ryujin_hip_ctx::limited_fraction) */
-    unsigned int n_sampled_slices, n_sampled_limited;
-    /* length of the work lists of the running step (slices in which step 6 found a limited pair and P_ij was not
-     * stored), one for the export part and one for the interior part of the sweep; reset by step_begin() */
-    unsigned int worklist_count[2];
+     * first high-order sweep, those of them in which some pair was limited, and every 16th slice whose P_ij step 5
+     * stored (diagnostics: ryujin_hip_limiter_statistics) */
+    unsigned int n_sampled_slices, n_sampled_limited, n_sampled_stored;
   };
   constexpr int kStageCode = 100;
 
@@ -109,8 +106,6 @@ namespace ryujin_hip
     scalars->tau_max_bits = (unsigned long long)__double_as_longlong(M.begin.tau_max_in);
     scalars->restart_needed = 0;
     scalars->tau_invalid = 0;
-    scalars->worklist_count[0] = 0;
-    scalars->worklist_count[1] = 0;
     scalars->tau_in = M.begin.tau_in;
     scalars->use_device_tau = M.begin.use_device_tau;
     scalars->stage = M.begin.stage;
@@ -155,28 +150,8 @@ namespace ryujin_hip
 #ifndef RYUJIN_STAGE0_PIJ
 #define RYUJIN_STAGE0_PIJ 1 /* Euler, stages == 0: P_ij formed once, in step 5 (kernels_limiter_stage0.hpp) */
 #endif
-#ifndef RYUJIN_OCC_HO_3D_ONFLY
-#define RYUJIN_OCC_HO_3D_ONFLY 1 /* the work-list (ONFLY) kernels hold the row's pij_stage0 operands as well: 76 / 308 B/lane of scratch at 2 / 3 waves; small grids */
-#endif
-#ifndef RYUJIN_OCC_LAST_3D_ONFLY
-#define RYUJIN_OCC_LAST_3D_ONFLY 2
-#endif
-#ifndef RYUJIN_NEVER_STORE_PIJ_2D
-#define RYUJIN_NEVER_STORE_PIJ_2D 1 /* stages == 0, two limiter passes: step 5 stores no P_ij; steps 6/7 take V_i or form it again */
-#endif
-#ifndef RYUJIN_NEVER_STORE_PIJ_3D
-#define RYUJIN_NEVER_STORE_PIJ_3D 1
-#endif
-/* ... while at most this fraction of the slices saw a limited pair in the first high-order sweep of the latest
- * measured step. A/B on MI355X, profiles/r03u_ab_*: 2 - 3 % limited slices (developed 2-D step, 3-D radial contrast,
- * EulerAEOS step): -5.4 %, -10.4 %, -3.1 % per update without the store; 86 % limited (3-D cylinder channel): the
- * work-list launches would cost +68 % -- the choice falls back to the stored matrix there. In between the work
- * list is a few rounds of a 1024-block grid; the thresholds keep that below what step 5 saves. */
-#ifndef RYUJIN_NEVER_STORE_MAX_LIMITED_2D
-#define RYUJIN_NEVER_STORE_MAX_LIMITED_2D 0.25
-#endif
-#ifndef RYUJIN_NEVER_STORE_MAX_LIMITED_3D
-#define RYUJIN_NEVER_STORE_MAX_LIMITED_3D 0.2
+#ifndef RYUJIN_PER_SLICE_PIJ
+#define RYUJIN_PER_SLICE_PIJ 1 /* stages == 0, two limiter passes: step 5 stores P_ij only in the slices steps 6/7 will read it in (kernels_limiter_stage0.hpp); 0: everywhere */
 #endif
 #ifndef RYUJIN_FUSE_PRECOMPUTE
 #define RYUJIN_FUSE_PRECOMPUTE 1 /* device-resident RK driver: the last sweep of a stage leaves the precomputed values and Riemann records of the next one (FusedPrecompute) */

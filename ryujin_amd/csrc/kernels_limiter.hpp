@@ -30,6 +30,13 @@ namespace ryujin_hip
    * set) the reference stores (1 - l) l' = 0 * NaN = NaN and adds 0 * inf = NaN, the shortcuts store / add 0: the
    * device result looks clean in that one entry where the reference propagates the NaN. Such a state raises the
    * restart flag in step 5 of the same update (the limiter reports failure on it), which is what the caller acts on. */
+  /* l = min(l_ij, l_ji) (:1100-1106) that propagates a NaN of either operand (fmin would drop it: a NaN l_ij next to
+   * l_ji = 1 must not pass for "not limited") */
+  RYUJIN_DEV double lmin(const double a, const double b)
+  {
+    return (a == a && b == b) ? fmin(a, b) : a + b;
+  }
+
   RYUJIN_DEV void flag_restart(DeviceScalars *scalars, const bool all_ok, const uint32_t lane)
   {
     if (__any(!all_ok)) {
@@ -449,8 +456,8 @@ namespace ryujin_hip
       const bool active = row_active && c < r.len;
       const double l_a = lij[pos];
       const double l_b = lij[idx_t[pos]];
-      const double l_ij = fmin(l_a, l_b);
-      if (LAST_ROUND && !__any(active && l_ij != 0.))
+      const double l_ij = lmin(l_a, l_b);
+      if (LAST_ROUND && !__any(active && !(l_ij == 0.)))
         continue;
       double p_ij[K];
       load_entry<K>(pij, colbase, r.lane, p_ij);
@@ -488,8 +495,8 @@ namespace ryujin_hip
         const bool active = row_active && c < r.len;
         const double l_a = lij[pos];
         const double l_b = lij[idx_t[pos]];
-        const double old_l_ij = fmin(l_a, l_b);
-        if (!__any(active && old_l_ij != 1.)) {
+        const double old_l_ij = lmin(l_a, l_b);
+        if (!__any(active && !(old_l_ij == 1.))) {
           if (active)
             st_stream(lij_next + (pos), 0.);
           continue;
@@ -515,7 +522,7 @@ namespace ryujin_hip
         undecided_mask &= undecided_mask - 1;
         const uint64_t colbase = (uint64_t)r.base + c;
         const uint64_t pos = colbase * 64 + r.lane;
-        const double old_l_ij = fmin(lij[pos], lij[idx_t[pos]]);
+        const double old_l_ij = lmin(lij[pos], lij[idx_t[pos]]);
         double p_ij[K], new_p_ij[K];
         load_entry<K>(pij, colbase, r.lane, p_ij);
 #pragma unroll
@@ -528,22 +535,50 @@ namespace ryujin_hip
     }
   }
 
+  /* Per-slice bookkeeping of the limiter sweeps of an update without stage vectors (kernels_limiter_stage0.hpp):
+   * one byte per 64-row slice each, written by exactly one wave per launch.
+   *   unlimited  written by step 6: 1 = no pair of the slice was limited in the first high-order pass. EXACT for
+   *              the last sweep of the same update (every l'_ij of such a slice is an exact zero, and so is every
+   *              transposed l'_ji: min(l_ij, l_ji) = 1 is symmetric, (1 - 1) l' = 0 -- it reads neither), and the
+   *              PREDICTION step 5 of the next update stores P_ij by (a limited region moves by less than a cell
+   *              per update);
+   *   p_stored   written by step 5: the slice's P_ij is in the matrix (predicted limited, or one of its own l_ij
+   *              came out limited); set by the repair prologue of step 6 for the slices that turn out limited
+   *              through a neighbour's l_ji alone. Exact;
+   *   todo       written by the light launch of step 6 for the heavy one: 0 finished (V_i), 1 stored P_ij,
+   *              2 form and store P_ij first. */
+  struct SliceFlags {
+    uint8_t *unlimited, *p_stored, *todo;
+  };
+
+  /* form and store all P_ij of the row (the repair prologue of step 6, ryujin_hip_debug_fetch): exactly the value
+   * step 5 formed (same function, same operands) */
+  template <int K>
+  RYUJIN_DEV void form_and_store_pij(const DeviceMesh &M, const Stage0Src &S0, const RowCtx &r,
+                                     double *__restrict__ pij)
+  {
+    if (r.len <= 1)
+      return;
+    RowData<K> row;
+    load_row_data<K>(M, S0, r.row, r.len, row);
+    for (uint32_t c = 1; c < r.len; ++c) {
+      double P_ij[K];
+      pij_on_the_fly<K>(M, S0, row, (uint64_t)r.base + c, r.lane, P_ij);
+      store_entry<K>(pij, (uint64_t)r.base + c, r.lane, P_ij);
+    }
+  }
+
   /* Last round for stencils of at most MAXW columns: all l_ij = min(l_ij, l_ji) of the row are fetched up
    * front (independent loads), then P_ij is read -- in chunks of CHUNK columns whose loads are issued back to
-   * back -- only for the columns in which some row of the slice has l != 0 (see the note at the top). */
-  /* Step 5 may have stored no P_ij (kernels_limiter_stage0.hpp). The sweep then runs as two launches:
-   *   DEFER  the slices in which no column needs a P_ij (all of those in which step 6 found nothing limited) are
-   *          finished here -- the light kernel, high occupancy; the others are left untouched;
-   *   ONFLY  a small grid walks the work list step 6 left (the slices in which something was limited) and
-   *          forms P_ij again for the columns that need it (pij_on_the_fly); slices the DEFER launch finished
-   *          are recognised by the same test and skipped. */
-  template <typename E, int MAXW, int CHUNK, bool ONFLY, bool DEFER>
+   * back -- only for the columns in which some row of the slice has l != 0 (see the note at the top).
+   * slice_unlimited (SliceFlags::unlimited of this update's step 6, or NULL): slices in which nothing was limited
+   * fetch nothing at all. */
+  template <typename E, int MAXW, int CHUNK>
   RYUJIN_DEV void last_cached_slice(const typename E::Params &P, const DeviceMesh &M, const RowCtx &r,
                                     double *__restrict__ new_U, const double *__restrict__ pij,
                                     const double *__restrict__ lij, const FusedSadd &F, const FusedPrecompute &FP,
-                                    const Stage0Src &S0, const uint8_t *__restrict__ slice_unlimited = nullptr)
+                                    const uint8_t *__restrict__ slice_unlimited = nullptr)
   {
-    static_assert(!(ONFLY && DEFER), "one or the other");
     constexpr int K = E::K;
     const bool row_active = r.len > 1;
     const uint32_t i = row_active ? r.row : (r.row < M.n_owned ? r.row : M.n_owned - 1);
@@ -558,11 +593,7 @@ namespace ryujin_hip
 
     double l[MAXW];
     uint32_t needed = 0; /* wave-uniform: bit c <=> some row of the slice has l(c) != 0 */
-    /* step 6 found nothing limited in this slice: every l of its rows is an exact zero (WorkList::unlimited),
-     * nothing to fetch */
-    bool known_unlimited = false;
-    if constexpr (!ONFLY)
-      known_unlimited = slice_unlimited != nullptr && slice_unlimited[r.slice] != 0;
+    const bool known_unlimited = slice_unlimited != nullptr && slice_unlimited[r.slice] != 0;
 #pragma unroll
     for (int c = 1; c < MAXW; ++c)
       l[c] = 0.;
@@ -573,7 +604,7 @@ namespace ryujin_hip
           const uint32_t pos = (uint32_t)(((uint64_t)r.base + c) * 64 + r.lane);
           const double l_a = lij[pos];
           const double l_b = lij[idx_t[pos]];
-          l[c] = (row_active && (uint32_t)c < r.len) ? fmin(l_a, l_b) : 0.;
+          l[c] = (row_active && (uint32_t)c < r.len) ? lmin(l_a, l_b) : 0.;
         }
       }
 #pragma unroll
@@ -582,28 +613,14 @@ namespace ryujin_hip
           needed |= 1u << c;
     }
 
-    if constexpr (DEFER) {
-      if (needed != 0u)
-        return; /* the work-list launch behind this one */
-    }
-    RowData<K> row;
-    if constexpr (ONFLY) {
-      if (needed == 0u)
-        return; /* finished by the DEFER launch */
-      load_row_data<K>(M, S0, i, r.len, row);
-    }
 #pragma unroll
     for (int c0 = 1; c0 < MAXW; c0 += CHUNK) {
       double p[CHUNK][K];
 #pragma unroll
       for (int cc = 0; cc < CHUNK; ++cc) {
         const int c = c0 + cc;
-        if (c < MAXW && ((needed >> c) & 1u)) {
-          if constexpr (ONFLY)
-            pij_on_the_fly<K>(M, S0, row, (uint64_t)r.base + c, r.lane, p[cc]);
-          else
-            load_entry<K>(pij, (uint64_t)r.base + c, r.lane, p[cc]);
-        }
+        if (c < MAXW && ((needed >> c) & 1u))
+          load_entry<K>(pij, (uint64_t)r.base + c, r.lane, p[cc]);
       }
 #pragma unroll
       for (int cc = 0; cc < CHUNK; ++cc) {
@@ -642,7 +659,7 @@ namespace ryujin_hip
     return r;
   }
 
-  template <typename E, int MAXW, int CHUNK, bool DEFER = false>
+  template <typename E, int MAXW, int CHUNK>
   __global__ void __launch_bounds__(kBlock, (MAXW > 9 ? RYUJIN_OCC_LAST_3D : 1))
   k_high_order_last_cached(const typename E::Params P, const DeviceMesh M, double *__restrict__ new_U,
                            const double *__restrict__ pij, const double *__restrict__ lij, const FusedSadd F,
@@ -651,22 +668,7 @@ namespace ryujin_hip
     const RowCtx r = row_context(M);
     if (!r.valid)
       return;
-    last_cached_slice<E, MAXW, CHUNK, false, DEFER>(P, M, r, new_U, pij, lij, F, FP, Stage0Src{}, slice_unlimited);
-  }
-
-  /* the ONFLY half: any grid; wave w takes the entries w, w + n_waves, ... of the work list */
-  template <typename E, int MAXW, int CHUNK>
-  __global__ void __launch_bounds__(kBlock, (MAXW > 9 ? RYUJIN_OCC_LAST_3D_ONFLY : 1))
-  k_high_order_last_worklist(const typename E::Params P, const DeviceMesh M, double *__restrict__ new_U,
-                             const double *__restrict__ lij, const FusedSadd F, const FusedPrecompute FP,
-                             const Stage0Src S0, const uint32_t *__restrict__ worklist,
-                             const unsigned int *__restrict__ count)
-  {
-    const uint32_t n = *count;
-    const uint32_t n_waves = gridDim.x * kWavesPerBlock;
-    for (uint32_t w = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6); w < n; w += n_waves)
-      last_cached_slice<E, MAXW, CHUNK, true, false>(P, M, row_context_of_slice(M, worklist[w]), new_U, nullptr, lij,
-                                                     F, FP, S0);
+    last_cached_slice<E, MAXW, CHUNK>(P, M, r, new_U, pij, lij, F, FP, slice_unlimited);
   }
 
   /* Register-cached variant for stencils of at most MAXW columns (2-D Q1: 9, 1-D: 3): the row's
@@ -678,37 +680,76 @@ namespace ryujin_hip
   /* SPLIT (small meshes, the sweep is one wave's latency chain): the four waves of a block share ONE slice; all
    * of them form the new U_i (bitwise the same sum), the first one stores it -- behind a block barrier, the update
    * is in place -- and wave w runs the second limiter pass for the columns 1 + w, 5 + w, ... only. */
-  /* Step 5 may have stored no P_ij (kernels_limiter_stage0.hpp); V_unlimited is required then, and the sweep runs
-   * as two launches:
-   *   DEFER  slices in which nothing was limited take V_i -- the light kernel; the others are appended to a work
-   *          list (which the last sweep walks as well) and left untouched;
-   *   ONFLY  a small grid walks the work list and forms P_ij again from the operands step 5 used
-   *          (pij_on_the_fly: six gathers per column instead of a coalesced stream -- slower per slice, but step
-   *          5 saves the 8 k S bytes per row of EVERY slice; the host takes this path while few slices are
-   *          limited, ryujin_hip_ctx::limited_fraction). */
-  struct WorkList {
-    uint32_t *slices;
-    unsigned int *count;
-    /* [n_slices] 1: step 6 found no limited pair in the slice. Then every l'_ij of its rows is an exact zero, and so
-     * is every transposed l'_ji (min(l_ij, l_ji) = 1 is symmetric, (1 - 1) l' = 0): the last sweep needs neither. */
-    uint8_t *unlimited;
-  };
+  /* MODE (updates whose step 5 stored P_ij per slice, kernels_limiter_stage0.hpp; V_unlimited and the flags are
+   * required then): the sweep runs as two launches over all slices,
+   *   kHoLight  slices whose P_ij step 5 did not store: fetch l_ij / l_ji; if nothing is limited take V_i and
+   *             finish -- a kernel of 20 registers at full occupancy, most of a developed flow --, otherwise leave
+   *             the slice to the second launch (todo = 2: limited through a neighbour's l_ji alone). Slices with a
+   *             stored P_ij are left to the second launch unseen (todo = 1);
+   *   kHoHeavy  waves of finished slices retire at once; the others run the sweep on the stored P_ij (todo = 2:
+   *             behind a prologue that forms and stores it, for the last sweep as well).
+   * kHoPlain: the whole sweep in one launch (P_ij stored everywhere). */
+  constexpr int kHoPlain = 0, kHoLight = 1, kHoHeavy = 2;
 
-  template <typename E, int MAXW, int CP, bool SPLIT, bool ONFLY, bool DEFER>
+  template <typename E, int MAXW, int CP, bool SPLIT, int MODE>
   RYUJIN_DEV void next_cached_slice(const typename E::Params &P, const DeviceMesh &M, const RowCtx &r,
                                     const uint32_t group, double *__restrict__ new_U,
-                                    const double *__restrict__ bounds, const double *__restrict__ pij,
+                                    const double *__restrict__ bounds, double *__restrict__ pij,
                                     const double *__restrict__ lij, double *__restrict__ lij_next,
-                                    const double *__restrict__ V_unlimited, const Stage0Src &S0, const WorkList &W)
+                                    const double *__restrict__ V_unlimited, const Stage0Src &S0, const SliceFlags &W,
+                                    const uint32_t todo = 1)
   {
     constexpr int K = E::K;
     constexpr int NB = E::NB;
     static_assert(!SPLIT || CP == MAXW, "the split variant caches the whole row");
-    static_assert(!(SPLIT && (ONFLY || DEFER)), "small meshes keep the stored P_ij");
-    static_assert(!(ONFLY && DEFER), "one or the other");
+    static_assert(!(SPLIT && MODE != kHoPlain), "small meshes keep the stored P_ij");
     const bool row_active = r.len > 1;
     const uint32_t i = row_active ? r.row : (r.row < M.n_owned ? r.row : M.n_owned - 1);
     const uint32_t *__restrict__ idx_t = M.idx_t;
+
+    if constexpr (MODE == kHoHeavy) {
+      if (todo == 2) {
+        form_and_store_pij<K>(M, S0, r, pij);
+        if (r.lane == 0)
+          W.p_stored[r.slice] = 1;
+      }
+    }
+
+    double l[MAXW];
+    if constexpr (MODE == kHoLight) {
+      bool limited = false;
+#pragma unroll
+      for (int c = 1; c < MAXW; ++c) {
+        if ((uint32_t)c < r.width) {
+          const uint32_t pos = (uint32_t)(((uint64_t)r.base + c) * 64 + r.lane);
+          const double l_a = lij[pos];
+          const double l_b = lij[idx_t[pos]];
+          /* (NaN counts as limited: !(l == 1), not l != 1 through fmin, which drops a NaN operand) */
+          limited = limited || (row_active && (uint32_t)c < r.len && !(l_a == 1. && l_b == 1.));
+        }
+      }
+      const bool slice_limited = __any(limited);
+      if ((r.slice & 15u) == 0 && r.lane == 0) {
+        atomicAdd(&S0.scalars->n_sampled_slices, 1u);
+        if (slice_limited)
+          atomicAdd(&S0.scalars->n_sampled_limited, 1u);
+      }
+      if (r.lane == 0) {
+        W.todo[r.slice] = slice_limited ? 2 : 0;
+        if (!slice_limited)
+          W.unlimited[r.slice] = 1;
+      }
+      if (!slice_limited && row_active) {
+        double V_i[K];
+        load_state<K>(V_unlimited, i, V_i);
+        store_state<K>(new_U, i, V_i);
+#pragma unroll
+        for (int c = 1; c < MAXW; ++c)
+          if ((uint32_t)c < r.len)
+            st_stream(lij_next + ((r.base + c) * 64 + r.lane), 0.);
+      }
+      return;
+    }
 
     double U_i_new[K];
     load_state<K>(new_U, i, U_i_new);
@@ -719,16 +760,8 @@ namespace ryujin_hip
     for (int b = 0; b < NB; ++b)
       bnd[b] = bounds[(size_t)b * stride + i];
 
-    double l[MAXW];
     double p[CP][K];
-    RowData<K> row;
-    auto load_P = [&](const uint64_t colbase, double (&out)[K]) {
-      if constexpr (ONFLY)
-        pij_on_the_fly<K>(M, S0, row, colbase, r.lane, out);
-      else
-        load_entry<K>(pij, colbase, r.lane, out);
-    };
-    if (DEFER || V_unlimited != nullptr) {
+    if (V_unlimited != nullptr) {
       /* Step 5 left V_i = U_i^low + sum_j lambda P_ij, accumulated exactly as the update below accumulates it
        * when every l_ij is 1 (k_lij_stage0). If no pair of the slice was limited -- wave-uniform; most of a
        * developed flow -- that IS the new U_i bit for bit, the second pass stores (1 - l) l' = 0, and P_ij is
@@ -741,17 +774,17 @@ namespace ryujin_hip
           const uint32_t pos = (uint32_t)(((uint64_t)r.base + c) * 64 + r.lane);
           const double l_a = lij[pos];
           const double l_b = lij[idx_t[pos]];
-          l[c] = fmin(l_a, l_b);
-          limited = limited || (row_active && (uint32_t)c < r.len && l[c] != 1.);
+          l[c] = lmin(l_a, l_b);
+          limited = limited || (row_active && (uint32_t)c < r.len && !(l_a == 1. && l_b == 1.));
         }
       }
       const bool slice_limited = __any(limited);
-      if constexpr (!ONFLY) { /* (the work-list launch sees limited slices only, and sees them a second time) */
-        if (S0.scalars != nullptr && (r.slice & 15u) == 0 && r.lane == 0 && (!SPLIT || group == 0)) {
-          atomicAdd(&S0.scalars->n_sampled_slices, 1u);
-          if (slice_limited)
-            atomicAdd(&S0.scalars->n_sampled_limited, 1u);
-        }
+      /* (slices the light launch left with todo = 2 were counted there) */
+      if (S0.scalars != nullptr && (r.slice & 15u) == 0 && r.lane == 0 && (!SPLIT || group == 0) &&
+          !(MODE == kHoHeavy && todo == 2)) {
+        atomicAdd(&S0.scalars->n_sampled_slices, 1u);
+        if (slice_limited)
+          atomicAdd(&S0.scalars->n_sampled_limited, 1u);
       }
       if (W.unlimited != nullptr && r.lane == 0 && (!SPLIT || group == 0))
         W.unlimited[r.slice] = slice_limited ? 0 : 1;
@@ -768,24 +801,15 @@ namespace ryujin_hip
         }
         return;
       }
-      if constexpr (DEFER) {
-        if (r.lane == 0)
-          W.slices[atomicAdd(W.count, 1u)] = r.slice;
-        return;
-      }
-      if constexpr (ONFLY)
-        load_row_data<K>(M, S0, i, r.len, row);
 #pragma unroll
       for (int c = 1; c < CP; ++c) {
 #pragma unroll
         for (int q = 0; q < K; ++q)
           p[c][q] = 0.;
         if ((uint32_t)c < r.width)
-          load_P((uint64_t)r.base + c, p[c]);
+          load_entry<K>(pij, (uint64_t)r.base + c, r.lane, p[c]);
       }
     } else {
-      if constexpr (ONFLY)
-        load_row_data<K>(M, S0, i, r.len, row);
 #pragma unroll
       for (int c = 1; c < MAXW; ++c) {
         l[c] = 0.;
@@ -799,9 +823,9 @@ namespace ryujin_hip
           const uint32_t pos = (uint32_t)(colbase * 64 + r.lane);
           const double l_a = lij[pos];
           const double l_b = lij[idx_t[pos]];
-          l[c] = fmin(l_a, l_b);
+          l[c] = lmin(l_a, l_b);
           if (c < CP)
-            load_P(colbase, p[c < CP ? c : 0]);
+            load_entry<K>(pij, colbase, r.lane, p[c < CP ? c : 0]);
         }
       }
     }
@@ -815,7 +839,7 @@ namespace ryujin_hip
         }
       } else if ((uint32_t)c < r.width) {
         double pt[K];
-        load_P((uint64_t)r.base + c, pt);
+        load_entry<K>(pij, (uint64_t)r.base + c, r.lane, pt);
         if (row_active && (uint32_t)c < r.len) {
 #pragma unroll
           for (int q = 0; q < K; ++q)
@@ -841,7 +865,7 @@ namespace ryujin_hip
         continue;
       {
         const bool lane_on = row_active && (uint32_t)c < r.len;
-        if (!__any(lane_on && l[c] != 1.)) {
+        if (!__any(lane_on && !(l[c] == 1.))) {
           if (lane_on)
             st_stream(lij_next + ((r.base + c) * 64 + r.lane), 0.);
           continue;
@@ -853,7 +877,7 @@ namespace ryujin_hip
         for (int q = 0; q < K; ++q)
           pc[q] = p[c < CP ? c : 0][q];
       } else {
-        load_P((uint64_t)r.base + c, pc);
+        load_entry<K>(pij, (uint64_t)r.base + c, r.lane, pc);
       }
       if (row_active && (uint32_t)c < r.len) {
         double new_p_ij[K];
@@ -874,9 +898,9 @@ namespace ryujin_hip
       undecided_mask &= undecided_mask - 1;
       const uint64_t colbase = (uint64_t)r.base + c;
       const uint64_t pos = colbase * 64 + r.lane;
-      const double old_l_ij = fmin(lij[pos], lij[idx_t[pos]]);
+      const double old_l_ij = lmin(lij[pos], lij[idx_t[pos]]);
       double p_ij[K], new_p_ij[K];
-      load_P(colbase, p_ij);
+      load_entry<K>(pij, colbase, r.lane, p_ij);
 #pragma unroll
       for (int q = 0; q < K; ++q)
         new_p_ij[q] = (1. - old_l_ij) * p_ij[q];
@@ -886,41 +910,44 @@ namespace ryujin_hip
     }
   }
 
-  template <typename E, int MAXW, int CP = MAXW, bool SPLIT = false, bool DEFER = false>
+  template <typename E, int MAXW, int CP = MAXW, bool SPLIT = false, int MODE = kHoPlain>
   __global__ void __launch_bounds__(kBlock, (MAXW > 9 ? (CP < MAXW ? RYUJIN_OCC_HO_3D : 1) : RYUJIN_OCC_HO))
   k_high_order_next_cached(const typename E::Params P, const DeviceMesh M, double *__restrict__ new_U,
-                           const double *__restrict__ bounds, const double *__restrict__ pij,
+                           const double *__restrict__ bounds, double *__restrict__ pij,
                            const double *__restrict__ lij, double *__restrict__ lij_next,
                            const double *__restrict__ V_unlimited = nullptr, const Stage0Src S0 = Stage0Src{},
-                           const WorkList W = WorkList{})
+                           const SliceFlags W = SliceFlags{})
   {
     RowCtx r;
     const uint32_t group = SPLIT ? (threadIdx.x >> 6) : 0u;
+    uint32_t todo = 1;
     if constexpr (SPLIT) { /* one slice per block (uniform over the block: the barrier in the body is safe) */
       if (M.slice_begin + blockIdx.x >= M.slice_end)
         return;
       r = row_context_of_slice(M, M.slice_begin + blockIdx.x);
+    } else if constexpr (MODE != kHoPlain) {
+      /* the flag first: most waves of a developed flow retire on it */
+      const uint32_t slice = M.slice_begin + blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+      if (slice >= M.slice_end)
+        return;
+      if constexpr (MODE == kHoLight) {
+        if (W.p_stored[slice] != 0) {
+          if ((threadIdx.x & 63) == 0)
+            W.todo[slice] = 1;
+          return;
+        }
+      } else {
+        todo = W.todo[slice];
+        if (todo == 0)
+          return;
+      }
+      r = row_context_of_slice(M, slice);
     } else {
       r = row_context(M);
       if (!r.valid)
         return;
     }
-    next_cached_slice<E, MAXW, CP, SPLIT, false, DEFER>(P, M, r, group, new_U, bounds, pij, lij, lij_next,
-                                                        V_unlimited, S0, W);
-  }
-
-  /* the ONFLY half: any grid; wave w takes the entries w, w + n_waves, ... of the work list */
-  template <typename E, int MAXW, int CP = MAXW>
-  __global__ void __launch_bounds__(kBlock, (MAXW > 9 ? RYUJIN_OCC_HO_3D_ONFLY : RYUJIN_OCC_HO))
-  k_high_order_next_worklist(const typename E::Params P, const DeviceMesh M, double *__restrict__ new_U,
-                             const double *__restrict__ bounds, const double *__restrict__ lij,
-                             double *__restrict__ lij_next, const double *__restrict__ V_unlimited,
-                             const Stage0Src S0, const WorkList W)
-  {
-    const uint32_t n = *W.count;
-    const uint32_t n_waves = gridDim.x * kWavesPerBlock;
-    for (uint32_t w = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6); w < n; w += n_waves)
-      next_cached_slice<E, MAXW, CP, false, true, false>(P, M, row_context_of_slice(M, W.slices[w]), 0u, new_U,
-                                                         bounds, nullptr, lij, lij_next, V_unlimited, S0, W);
+    next_cached_slice<E, MAXW, CP, SPLIT, MODE>(P, M, r, group, new_U, bounds, pij, lij, lij_next, V_unlimited, S0,
+                                                W, todo);
   }
 } // namespace ryujin_hip

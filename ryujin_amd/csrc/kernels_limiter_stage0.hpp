@@ -22,17 +22,22 @@
 // U_i^low + sum_j l_ij lambda P_ij when every l_ij is 1: in slices where nothing was limited step 6 takes V_i
 // and never reads P_ij (kernels_limiter.hpp) -- bit-identical, and most of a developed flow.
 //
-// STORE_P = false: P_ij is not stored at all. A developed flow limits something in 2 - 3 % of its 64-row slices
-// (measured: step2d, sedov3d, step2d_aeos); everywhere else steps 6 and 7 never look at P_ij (V_i; l' = 0), and
-// the 8 k S bytes per row step 5 writes are wasted. Without the store step 6 runs as a light launch (V_i or "this
-// slice is limited": appended to a work list) plus a small work-list launch that forms P_ij again through
-// pij_stage0() for the limited slices, and step 7 likewise (kernels_limiter.hpp). Forming P_ij again costs six
-// dependent gathers per column against two coalesced streams (a first version that did so in EVERY slice lost
-// more in steps 6/7 than step 5 gained: profiles/r03f_*; with a limited pair in 86 % of the slices -- the 3-D
-// cylinder channel -- the work-list form costs +68 %: profiles/r03u_ab_3d.log), so the host chooses per step from the
-// fraction of limited slices step 6 counted in the previous one (ryujin_hip_ctx::limited_fraction; thresholds
-// RYUJIN_NEVER_STORE_MAX_LIMITED_*). Same bits either way: -5.4 % per update on C2, -10.4 % on the 3-D radial
-// contrast, -3.1 % on EulerAEOS (profiles/r03u_ab_*).
+// PER_SLICE: P_ij IS STORED ONLY WHERE STEPS 6 AND 7 WILL READ IT. A developed flow limits something in a few
+// per cent (Mach-3 step early on, 3-D radial contrast) up to nearly all (cylinder channel) of its 64-row slices;
+// everywhere else steps 6 and 7 never look at P_ij (V_i; l' = 0) and the 8 k S bytes per row step 5 would write --
+// a third of its traffic -- are wasted. Round 3 chose between "store everywhere" and "store nowhere, form it again
+// in steps 6/7" for the whole mesh from the measured fraction of limited slices: a cliff at 20 - 25 %, and a chain
+// of six dependent gathers per column in every limited slice below it. Now the wave of a slice decides for itself:
+//   * the slice held a limited pair in the previous update (SliceFlags::unlimited of that update's step 6 -- a
+//     limited region moves by less than a cell per update): store as P_ij is formed;
+//   * otherwise do not -- unless one of the slice's own l_ij comes out limited (or undecided) at column c: store
+//     from c on and form the columns before c a second time (their operands are in L1/L2);
+//   * SliceFlags::p_stored says which. A slice that turns out limited only through a neighbour's l_ji (step 6 sees
+//     that, step 5 cannot) gets its P_ij from the repair prologue of step 6 (kernels_limiter.hpp).
+// The cost of steps 5 - 7 therefore follows the limited fraction smoothly between the two extremes of round 3
+// (profiles/r04*_ab_limited_fraction*). Same bits whatever is stored: whoever reads P_ij reads pij_stage0() of the
+// same operands. ryujin_hip_params::debug_pij_storage overrides the prediction: < 0 every slice is predicted
+// limited (always stored), > 0 none is (everything through the trigger / the repair prologue).
 
 #pragma once
 
@@ -63,16 +68,17 @@ namespace ryujin_hip
 
   /* NY > 1 (small meshes): NY waves (blockIdx.y) share a slice, wave y taking the columns 1 + y, 1 + y + NY, ...;
    * no V_i then (the row's sum is spread over several waves): the caller passes V_out = nullptr.
-   * STORE_P = false: P_ij is not stored at all; steps 6 and 7 take V_i where nothing was limited and form P_ij
-   * again elsewhere (their ONFLY variants). */
-  template <typename E, int NY = 1, bool STORE_P = true>
+   * PER_SLICE: see the head of the file (NY == 1 only); otherwise P_ij is stored everywhere. */
+  template <typename E, int NY = 1, bool PER_SLICE = false>
   __global__ void __launch_bounds__(kBlock, lij0_waves_per_simd<E>())
   k_lij_stage0(const typename E::Params P, const DeviceMesh M, DeviceScalars *__restrict__ scalars,
                const double *__restrict__ old_U, const double *__restrict__ alpha,
                const double *__restrict__ dij, const double *__restrict__ new_U,
                const double *__restrict__ r_in, const double *__restrict__ bounds, double *__restrict__ pij,
-               double *__restrict__ lij, double *__restrict__ V_out)
+               double *__restrict__ lij, double *__restrict__ V_out, const SliceFlags W = SliceFlags{},
+               const int predict_override = 0)
   {
+    static_assert(!PER_SLICE || NY == 1, "one wave per slice decides");
     constexpr int K = E::K;
     constexpr int NB = E::NB;
     const RowCtx r = row_context(M);
@@ -103,6 +109,12 @@ namespace ryujin_hip
     unsigned long long undecided_mask = 0;
 
     const uint32_t c0 = 1 + (NY > 1 ? blockIdx.y : 0);
+    /* wave-uniform: P_ij of this slice goes to the matrix; from column first_stored on */
+    bool storing = true;
+    uint32_t first_stored = c0;
+    if constexpr (PER_SLICE)
+      storing = predict_override < 0 || (predict_override == 0 && W.unlimited[r.slice] == 0);
+
     /* software pipeline: the loads of the next column are in flight while column c is limited */
     uint32_t j_n = r.width > c0 ? ld_stream(cols + (((uint64_t)r.base + c0) * 64 + r.lane)) : i;
     uint32_t j_nn = r.width > c0 + NY ? ld_stream(cols + (((uint64_t)r.base + c0 + NY) * 64 + r.lane)) : i;
@@ -121,18 +133,27 @@ namespace ryujin_hip
         load_pair<K>(M, old_U, r_in, alpha, dij, (colbase + NY) * 64 + r.lane, j_n, next);
         j_nn = (c + 2 * NY < r.width) ? ld_stream(cols + ((colbase + 2 * NY) * 64 + r.lane)) : i;
       }
+      bool success = true, undecided = false;
+      double l_ij = 1.;
+      if (active) {
+        if (NY == 1) {
+          /* what the first high-order pass adds when nothing is limited: U += l lambda P with l = 1 (:1107-1131) */
+#pragma unroll
+          for (int q = 0; q < K; ++q)
+            V_i[q] += lambda * P_ij[q];
+        }
+        l_ij = E::limit_fast(P, bnd, U_i_new, P_ij, success, undecided);
+      }
+      if constexpr (PER_SLICE) {
+        if (!storing && __any(active && (undecided || !(l_ij == 1.)))) {
+          storing = true;
+          first_stored = c;
+        }
+      }
       if (!active)
         continue;
-      if constexpr (STORE_P)
+      if (storing)
         store_entry<K>(pij, colbase, r.lane, P_ij);
-      if (NY == 1) {
-        /* what the first high-order pass adds when nothing is limited: U += l lambda P with l = 1 (:1107-1131) */
-#pragma unroll
-        for (int q = 0; q < K; ++q)
-          V_i[q] += lambda * P_ij[q];
-      }
-      bool success, undecided;
-      const double l_ij = E::limit_fast(P, bnd, U_i_new, P_ij, success, undecided);
       if (undecided) {
         undecided_mask |= 1ull << c;
       } else {
@@ -143,19 +164,32 @@ namespace ryujin_hip
     if (NY == 1 && V_out != nullptr && row_active)
       store_state<K>(V_out, i, V_i);
 
-    /* the few pairs that need the Newton iteration */
+    if constexpr (PER_SLICE) {
+      /* the columns in front of the one that made the slice store: once more (operands in L1/L2) */
+      if (storing && row_active) {
+        for (uint32_t c = c0; c < first_stored && c < r.len; ++c) {
+          const uint64_t colbase = (uint64_t)r.base + c;
+          PairData<K> pd;
+          load_pair<K>(M, old_U, r_in, alpha, dij, colbase * 64 + r.lane, cols[colbase * 64 + r.lane], pd);
+          double P_ij[K];
+          pij_stage0<K>(row, pd, P_ij);
+          store_entry<K>(pij, colbase, r.lane, P_ij);
+        }
+      }
+      if (r.lane == 0) {
+        W.p_stored[r.slice] = storing ? 1 : 0;
+        if ((r.slice & 15u) == 0 && storing)
+          atomicAdd(&scalars->n_sampled_stored, 1u);
+      }
+    }
+
+    /* the few pairs that need the Newton iteration (an undecided pair makes its slice store: P_ij is there) */
     while (undecided_mask) {
       const uint32_t c = (uint32_t)__builtin_ctzll(undecided_mask);
       undecided_mask &= undecided_mask - 1;
       const uint64_t colbase = (uint64_t)r.base + c;
       double P_ij[K];
-      if constexpr (STORE_P) {
-        load_entry<K>(pij, colbase, r.lane, P_ij);
-      } else {
-        PairData<K> pd;
-        load_pair<K>(M, old_U, r_in, alpha, dij, colbase * 64 + r.lane, cols[colbase * 64 + r.lane], pd);
-        pij_stage0<K>(row, pd, P_ij);
-      }
+      load_entry<K>(pij, colbase, r.lane, P_ij);
       bool success;
       const double l_ij = E::limit(P, bnd, U_i_new, P_ij, success);
       lij[colbase * 64 + r.lane] = l_ij;
@@ -164,22 +198,20 @@ namespace ryujin_hip
     flag_restart(scalars, all_ok, r.lane);
   }
 
-  /* ryujin_hip_debug_fetch(P_ij) behind a step that stored none: the same pij_stage0() on the same operands
-   * (all of them outlive the step), written to the matrix the parity tests read */
+  /* ryujin_hip_debug_fetch(P_ij) behind a step that did not store all of it: the same pij_stage0() on the same
+   * operands (all of them outlive the step), written to the matrix the parity tests read for the slices the
+   * sweeps left out (p_stored == NULL: for all) */
   template <typename E>
   __global__ void __launch_bounds__(kBlock)
-  k_pij_stage0_store(const DeviceMesh M, const Stage0Src S0, double *__restrict__ pij)
+  k_pij_stage0_store(const DeviceMesh M, const Stage0Src S0, double *__restrict__ pij,
+                     const uint8_t *__restrict__ p_stored)
   {
     constexpr int K = E::K;
     const RowCtx r = row_context(M);
     if (!r.valid || r.len <= 1)
       return;
-    RowData<K> row;
-    load_row_data<K>(M, S0, r.row, r.len, row);
-    for (uint32_t c = 1; c < r.len; ++c) {
-      double P_ij[K];
-      pij_on_the_fly<K>(M, S0, row, (uint64_t)r.base + c, r.lane, P_ij);
-      store_entry<K>(pij, (uint64_t)r.base + c, r.lane, P_ij);
-    }
+    if (p_stored != nullptr && p_stored[r.slice] != 0)
+      return;
+    form_and_store_pij<K>(M, S0, r, pij);
   }
 } // namespace ryujin_hip

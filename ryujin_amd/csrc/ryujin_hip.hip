@@ -444,23 +444,30 @@ struct ryujin_hip_ctx {
   /* step 5 of the running step left V_i = U_i^low + sum_j lambda P_ij (k_lij_stage0, k_pij_lij): step 6 may take it */
   DeviceBuffer<double> d_V;
   bool stage0_V = false;
-  /* the last step stored no P_ij (never_store below): ryujin_hip_debug_fetch forms it again from these operands */
-  bool last_never_stored = false;
+  /* the last step stored P_ij per slice (per_slice below): ryujin_hip_debug_fetch forms it from these operands for
+   * the slices the sweeps left out */
+  bool last_per_slice = false;
   Stage0Src last_s0{};
-  DeviceBuffer<uint32_t> d_worklist; /* [2][n_slices]: limited slices of the export / interior part of step 6 */
-  DeviceBuffer<uint8_t> d_slice_unlimited; /* [n_slices]: WorkList::unlimited */
-  /* fraction of the slices in which the first high-order sweep found a limited pair, from the device counters
-   * at the latest host synchronisation (DeviceScalars::n_sampled_*); 1 until the first measurement */
-  double limited_fraction = 1.;
-  unsigned int seen_sampled_slices = 0, seen_sampled_limited = 0;
+  /* SliceFlags (kernels_limiter.hpp), [n_slices] each; `unlimited` starts at 0 = "limited": the first update of a
+   * context stores P_ij everywhere */
+  DeviceBuffer<uint8_t> d_slice_unlimited, d_slice_pstored, d_slice_todo;
+  /* fractions of the (sampled) slices in which the first high-order sweep found a limited pair / whose P_ij step 5
+   * stored, from the device counters at the latest host synchronisation (DeviceScalars::n_sampled_*); 1 until the
+   * first measurement. Diagnostics only: nothing is decided from them. */
+  double limited_fraction = 1., stored_fraction = 1.;
+  unsigned int seen_sampled_slices = 0, seen_sampled_limited = 0, seen_sampled_stored = 0;
   void update_limited_fraction()
   {
     const unsigned int d_slices = h_scalars->n_sampled_slices - seen_sampled_slices;
     const unsigned int d_limited = h_scalars->n_sampled_limited - seen_sampled_limited;
+    const unsigned int d_stored = h_scalars->n_sampled_stored - seen_sampled_stored;
     seen_sampled_slices = h_scalars->n_sampled_slices;
     seen_sampled_limited = h_scalars->n_sampled_limited;
-    if (d_slices != 0)
+    seen_sampled_stored = h_scalars->n_sampled_stored;
+    if (d_slices != 0) {
       limited_fraction = (double)d_limited / (double)d_slices;
+      stored_fraction = last_per_slice ? (double)d_stored / (double)d_slices : 1.;
+    }
   }
   void ensure_pij()
   {
@@ -1093,7 +1100,8 @@ void ryujin_hip_ctx::store_pij_for_debug()
   mm.slice_begin = 0;
   mm.slice_end = L.n_slices;
   const dim3 grid((L.n_slices + kWavesPerBlock - 1) / kWavesPerBlock), block(kBlock);
-  hipLaunchKernelGGL(k_pij_stage0_store<E>, grid, block, 0, stream, mm, last_s0, d_pij.ptr);
+  hipLaunchKernelGGL(k_pij_stage0_store<E>, grid, block, 0, stream, mm, last_s0, d_pij.ptr,
+                     (const uint8_t *)d_slice_pstored.ptr);
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipStreamSynchronize(stream));
 }
@@ -1416,26 +1424,16 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
   const uint32_t step5_groups = std::min<uint32_t>(
       4u, resident_waves_step5 /
               std::max<uint32_t>(1u, (L.n_slices + kWavesPerBlock - 1) / kWavesPerBlock * kWavesPerBlock));
-  /* ... and P_ij is not even stored where the update has two limiter passes and one wave per slice: step 6 takes
-   * V_i in slices where nothing was limited and forms P_ij again elsewhere, step 7 likewise (ONFLY kernels) */
-  const bool never_store = (DIM == 3 ? RYUJIN_NEVER_STORE_PIJ_3D : RYUJIN_NEVER_STORE_PIJ_2D) && stage0_pij &&
-                           params.limiter_iterations == 2 && step5_groups < 2 && params.debug_pij_storage >= 0 &&
-                           (params.debug_pij_storage > 0 ||
-                            limited_fraction <= (DIM == 3 ? RYUJIN_NEVER_STORE_MAX_LIMITED_3D
-                                                          : RYUJIN_NEVER_STORE_MAX_LIMITED_2D));
-  if (!never_store)
-    ensure_pij();
-  else if (d_worklist.n == 0)
-    d_worklist.alloc((size_t)2 * L.n_slices);
-  /* the two launches of a sweep that runs without the stored P_ij (kernels_limiter.hpp): which work list the part
-   * of the sweep that is being launched owns, and the grid of the work-list launch (any size: its waves stride) */
-  auto work_list = [&]() {
-    const int part = (n_nbr != 0 && launch_stream == comm_stream) ? 0 : 1;
-    return WorkList{d_worklist.ptr + (size_t)part * L.n_slices, &d_scalars.ptr->worklist_count[part],
-                    d_slice_unlimited.ptr};
-  };
-  auto work_list_grid = [&](const dim3 grid) { return dim3(std::min<uint32_t>(grid.x, 1024u)); };
-  last_never_stored = never_store;
+  /* ... and P_ij is stored per slice where the update has two limiter passes and one wave per slice: only where
+   * steps 6 and 7 will read it (kernels_limiter_stage0.hpp); step 6 takes V_i in slices where nothing was limited */
+  const bool per_slice = RYUJIN_PER_SLICE_PIJ && stage0_pij && params.limiter_iterations == 2 && step5_groups < 2;
+  ensure_pij();
+  if (per_slice && d_slice_pstored.n == 0) {
+    d_slice_pstored.alloc(L.n_slices);
+    d_slice_todo.alloc(L.n_slices);
+  }
+  const SliceFlags slice_flags{d_slice_unlimited.ptr, d_slice_pstored.ptr, d_slice_todo.ptr};
+  last_per_slice = per_slice;
   last_s0 = Stage0Src{d_scalars.ptr, old.U.ptr, d_alpha.ptr, d_dij.ptr, d_r.ptr};
   sweep([&](const DeviceMesh &mm, dim3 grid) {
     if constexpr (is_euler) {
@@ -1559,10 +1557,10 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
                                d_pij.ptr, d_lij.ptr, NY == 1 ? d_V.ptr : nullptr);
             stage0_V = NY == 1 && d_V.ptr != nullptr;
           };
-          if (never_store) {
-            hipLaunchKernelGGL((k_lij_stage0<E, 1, false>), grid, block, 0, launch_stream, eparams, mm,
+          if (per_slice) {
+            hipLaunchKernelGGL((k_lij_stage0<E, 1, true>), grid, block, 0, launch_stream, eparams, mm,
                                d_scalars.ptr, old.U.ptr, d_alpha.ptr, d_dij.ptr, nw.U.ptr, d_r.ptr, d_bounds.ptr,
-                               nullptr, d_lij.ptr, d_V.ptr);
+                               d_pij.ptr, d_lij.ptr, d_V.ptr, slice_flags, params.debug_pij_storage);
             stage0_V = true;
           } else if (groups >= 4)
             launch5(std::integral_constant<int, 4>{});
@@ -1629,7 +1627,7 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
   const FusedPrecompute fused_prec{fuse_precompute ? nw.prec.ptr : nullptr, fuse_precompute ? nw.rrec.ptr : nullptr};
   if (fused_sadd.src && n_iterations == 0)
     throw HipError(RYUJIN_ERR_ARG, "internal: fused sadd without a limiter pass");
-  bool step6_flags = false; /* step 6 left WorkList::unlimited for every slice: the last sweep may use it */
+  bool step6_flags = false; /* step 6 left SliceFlags::unlimited for every slice: the last sweep may use it */
   for (int pass = 0; pass < n_iterations; ++pass) {
     const bool last_round = (pass + 1 == n_iterations);
     if (n_iterations == 2 && last_round)
@@ -1638,18 +1636,6 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
     if (last_round) {
       sweep([&](const DeviceMesh &mm, dim3 grid) {
         constexpr int kLastChunk = DIM == 3 ? RYUJIN_LAST_CHUNK_3D : (DIM == 2 ? RYUJIN_LAST_CHUNK_2D : kCachedWidth);
-        if constexpr (is_euler || is_aeos) {
-          if (never_store) {
-            const WorkList W = work_list();
-            hipLaunchKernelGGL((k_high_order_last_cached<E, kCachedWidth, kLastChunk, true>), grid, block, 0,
-                               launch_stream, eparams, mm, nw.U.ptr, nullptr, d_lij.ptr, fused_sadd, fused_prec,
-                               W.unlimited);
-            hipLaunchKernelGGL((k_high_order_last_worklist<E, kCachedWidth, kLastChunk>), work_list_grid(grid), block,
-                               0, launch_stream, eparams, mm, nw.U.ptr, d_lij.ptr, fused_sadd, fused_prec, last_s0,
-                               W.slices, W.count);
-            return;
-          }
-        }
         if (L.max_row_len <= (uint32_t)kCachedWidth)
           hipLaunchKernelGGL((k_high_order_last_cached<E, kCachedWidth, kLastChunk>), grid,
                              block, 0, launch_stream, eparams, mm, nw.U.ptr, d_pij.ptr, d_lij.ptr, fused_sadd,
@@ -1663,14 +1649,16 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
       constexpr int kCachedP = DIM == 3 ? (RYUJIN_HO_CP_3D > 0 ? RYUJIN_HO_CP_3D : 27) : kCachedWidth;
       sweep([&](const DeviceMesh &mm, dim3 grid) {
         if constexpr (is_euler || is_aeos) {
-          if (never_store) {
-            const WorkList W = work_list();
-            hipLaunchKernelGGL((k_high_order_next_cached<E, kCachedWidth, kCachedP, false, true>), grid, block, 0,
-                               launch_stream, eparams, mm, nw.U.ptr, d_bounds.ptr, nullptr, d_lij.ptr,
-                               d_lij_next.ptr, d_V.ptr, last_s0, W);
-            hipLaunchKernelGGL((k_high_order_next_worklist<E, kCachedWidth, kCachedP>), work_list_grid(grid), block, 0,
-                               launch_stream, eparams, mm, nw.U.ptr, d_bounds.ptr, d_lij.ptr, d_lij_next.ptr,
-                               d_V.ptr, last_s0, W);
+          if (per_slice) {
+            /* two launches over all slices: the light one finishes the slices without a stored P_ij in which nothing
+             * was limited (V_i), the heavy one runs the others (kernels_limiter.hpp) */
+            hipLaunchKernelGGL((k_high_order_next_cached<E, kCachedWidth, kCachedP, false, kHoLight>), grid, block, 0,
+                               launch_stream, eparams, mm, nw.U.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr,
+                               d_lij_next.ptr, d_V.ptr, last_s0, slice_flags);
+            hipLaunchKernelGGL((k_high_order_next_cached<E, kCachedWidth, kCachedP, false, kHoHeavy>), grid, block, 0,
+                               launch_stream, eparams, mm, nw.U.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr,
+                               d_lij_next.ptr, d_V.ptr, last_s0, slice_flags);
+            step6_flags = true;
             return;
           }
         }
@@ -1681,7 +1669,7 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
             hipLaunchKernelGGL((k_high_order_next_cached<E, kCachedWidth, kCachedWidth, true>), dim3(n_launch),
                                block, 0, launch_stream, eparams, mm, nw.U.ptr, d_bounds.ptr, d_pij.ptr,
                                d_lij.ptr, d_lij_next.ptr, stage0_V ? d_V.ptr : nullptr, last_s0,
-                               WorkList{nullptr, nullptr, stage0_V ? d_slice_unlimited.ptr : nullptr});
+                               SliceFlags{stage0_V ? d_slice_unlimited.ptr : nullptr, nullptr, nullptr});
             step6_flags = stage0_V;
             return;
           }
@@ -1690,7 +1678,7 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
           hipLaunchKernelGGL((k_high_order_next_cached<E, kCachedWidth, kCachedP>), grid, block, 0,
                              launch_stream, eparams, mm, nw.U.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr,
                              d_lij_next.ptr, stage0_V ? d_V.ptr : nullptr, last_s0,
-                             WorkList{nullptr, nullptr, stage0_V ? d_slice_unlimited.ptr : nullptr});
+                             SliceFlags{stage0_V ? d_slice_unlimited.ptr : nullptr, nullptr, nullptr});
           step6_flags = stage0_V;
         } else
           hipLaunchKernelGGL((k_high_order<E, false>), grid, block, 0, launch_stream, eparams, mm, nw.U.ptr,
@@ -2572,7 +2560,8 @@ int ryujin_hip_get_counters(ryujin_hip_ctx *ctx, unsigned *n_restarts, unsigned 
   return RYUJIN_OK;
 }
 
-int ryujin_hip_limiter_statistics(ryujin_hip_ctx *ctx, double *limited_slice_fraction, int *pij_stored)
+int ryujin_hip_limiter_statistics(ryujin_hip_ctx *ctx, double *limited_slice_fraction, int *pij_stored,
+                                  double *stored_slice_fraction)
 {
   return guarded([&]() {
     if (!ctx)
@@ -2580,7 +2569,9 @@ int ryujin_hip_limiter_statistics(ryujin_hip_ctx *ctx, double *limited_slice_fra
     if (limited_slice_fraction)
       *limited_slice_fraction = ctx->limited_fraction;
     if (pij_stored)
-      *pij_stored = ctx->last_never_stored ? 0 : 1;
+      *pij_stored = ctx->last_per_slice ? 2 : 1;
+    if (stored_slice_fraction)
+      *stored_slice_fraction = ctx->stored_fraction;
     return RYUJIN_OK;
   });
 }
@@ -2602,7 +2593,7 @@ int ryujin_hip_debug_fetch(ryujin_hip_ctx *ctx, int what, double *out, size_t n_
     case 1: fetch_matrix(ctx->d_lij.ptr, 1); break;
     case 2:
       ctx->ensure_pij();
-      if (ctx->last_never_stored)
+      if (ctx->last_per_slice)
         dispatch_equation(ctx->params.equation, ctx->dim, [&](auto tag) {
           using E = typename decltype(tag)::type;
           if constexpr (std::is_same<typename E::Params, EulerParams>::value ||

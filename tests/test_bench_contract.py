@@ -52,7 +52,8 @@ def test_committed_bench_lines_follow_the_contract(path):
     if "reference_structure" in r:   # from r03x on: the numerator is what THIS implementation's kernel touches once
         assert 0.0 < r["frac"] <= 1.0 and r["reference_structure"]["frac"] >= r["frac"]
         assert r["traffic_frac"] is None or r["frac"] <= r["traffic_frac"] * 1.02 <= 1.02
-        assert isinstance(d["limiter"]["pij_stored"], bool) and 0.0 <= d["limiter"]["limited_slice_fraction"] <= 1.0
+        assert d["limiter"]["pij_stored"] in (True, False, "everywhere", "per slice")  # (bool: lines of round 3)
+        assert 0.0 <= d["limiter"]["limited_slice_fraction"] <= 1.0
     # value is consistent with the time per step and the size of the job
     dofs = d["config"]["dofs_total"]
     assert abs(d["value"] - dofs / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * d["value"]
@@ -83,3 +84,38 @@ def test_bench_launches_its_own_ranks():
     lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, res.stdout
     assert json.loads(lines[0]) == {"probe": True, "world": 2, "n_gpus": 2, "rank_sum": 1}
+
+
+@pytest.mark.parametrize("mesh", ["step2d", "cylinder3d", "box3d"])
+def test_bench_interpolates_the_coarse_state_to_the_benchmark_mesh(mesh):
+    """bench.py develops the flow on a coarse mesh of the same domain and interpolates it to the benchmark mesh
+    (interpolate_from_lattice): a function that is linear in the coordinates must arrive exactly, also next to the
+    cut-outs (the step; the staircase cylinder, whose coarse staircase differs from the fine one), and no fine
+    point may pick up a lattice node the coarse mesh does not have."""
+    import numpy as np
+
+    import bench
+    from ryujin_amd import offline
+    if mesh == "step2d":
+        spec_c, spec_f = offline.mach3_step_2d(10), offline.mach3_step_2d(35)
+    elif mesh == "cylinder3d":
+        spec_c, spec_f = offline.cylinder_channel_3d(6, length_units=1.25), offline.cylinder_channel_3d(20, length_units=1.25)
+    else:
+        spec_c, spec_f = offline.box_3d(4), offline.box_3d(10)
+    off_c, off_f = offline.SyntheticOffline(spec_c), offline.SyntheticOffline(spec_f)
+    coeff = np.array([[1.0, -2.0, 0.5], [0.25, 3.0, -1.0]])[:, : off_c.dim]
+
+    def f(x):
+        return 2.0 + x @ coeff.T
+    U_f = bench.interpolate_from_lattice(spec_c, off_c.positions[: off_c.n_owned], f(off_c.positions[: off_c.n_owned]),
+                                         off_f.positions)
+    assert U_f.shape == (off_f.n_relevant, 2) and np.isfinite(U_f).all()
+    if mesh == "cylinder3d":
+        # filled lattice nodes (inside the coarse staircase) carry averages of their neighbours: exact only away
+        # from the cylinder; next to it the interpolant stays within the range of the surrounding values
+        d = np.hypot(off_f.positions[:, 0] - 0.6, off_f.positions[:, 1])
+        far = d > 0.25 + 2.0 / 6.0
+        assert np.abs(U_f[far] - f(off_f.positions[far])).max() < 1e-12
+        assert np.abs(U_f - f(off_f.positions)).max() < 1.5  # |grad f| h_c-sized
+    else:
+        assert np.abs(U_f - f(off_f.positions)).max() < 1e-12

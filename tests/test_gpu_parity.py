@@ -251,7 +251,7 @@ def test_device_pow_accuracy():
 
 
 @pytest.mark.parametrize("n_ranks,mode", [(2, ""), (3, ""), (3, "join_exchanges"), (3, "bc_launch"),
-                                          (3, "system_events"), (3, "never_store_pij")])
+                                          (3, "system_events"), (3, "per_slice_pij")])
 def test_partitioned_hip_matches_single_rank(n_ranks, mode, monkeypatch):
     """Multi-rank code path of the library on ONE GPU: n contexts (one host thread each) own x-slabs of
     the mesh and exchange ghosts through the in-process transport (ryujin_hip_comm_init_local), which
@@ -260,7 +260,8 @@ def test_partitioned_hip_matches_single_rank(n_ranks, mode, monkeypatch):
     mode: the branches small meshes do not take by themselves -- "join_exchanges": the fallback
     choreography of an asymmetric stencil (every sweep joins the exchanges); "bc_launch": boundary
     conditions as a launch of their own in front of the pre-pass (large meshes); "system_events": the events
-    between the two streams created with the system-scope fence (ryujin_hip_params::system_scope_events)."""
+    between the two streams created with the system-scope fence (ryujin_hip_params::system_scope_events);
+    "per_slice_pij": the kernels of large meshes with P_ij stored per 64-row slice and no slice predicted limited."""
     import ctypes as C
     import threading
 
@@ -270,7 +271,7 @@ def test_partitioned_hip_matches_single_rank(n_ranks, mode, monkeypatch):
         monkeypatch.setattr(HyperbolicModule, "library_switches", {"debug_bc_fold_max_slices": -1})
     elif mode == "system_events":
         monkeypatch.setattr(HyperbolicModule, "library_switches", {"system_scope_events": 1})
-    elif mode == "never_store_pij":  # the two-launch sweeps with one work list per part of a split sweep
+    elif mode == "per_slice_pij":  # nothing predicted: trigger, repair prologue, two-launch step 6 in both parts
         monkeypatch.setattr(HyperbolicModule, "library_switches",
                             {"debug_pij_storage": 1, "debug_no_small_mesh_split": 1, "debug_bc_fold_max_slices": -1})
 
@@ -1584,22 +1585,24 @@ def test_unstructured_p1_mesh_scalar_conservation(oracle):
 
 
 @pytest.mark.parametrize("which", ["euler_2d", "euler_1d", "euler_erk33", "sw_2d", "sw_1d", "aeos_2d", "scalar_2d",
-                                   "euler_2d:never_store", "euler_1d:never_store", "euler_erk33:never_store",
-                                   "aeos_2d:never_store"])
+                                   "euler_2d:no_prediction", "euler_1d:no_prediction", "euler_erk33:no_prediction",
+                                   "aeos_2d:no_prediction", "euler_2d:always_store", "aeos_2d:always_store"])
 def test_step_parity_with_the_kernels_of_large_meshes(oracle, monkeypatch, which):
     """The meshes of this file do not fill an MI355X, so they take the small-mesh branches of the library
     (boundary conditions folded into the pre-pass, steps 5 and 6 with the columns of a slice spread over several
     waves). Re-run one case per Description with those branches switched off: the kernels BASELINE-sized meshes
     run (also covered at full size for Euler and shallow water in test_gpu_parity_fullsize.py).
-    `:never_store`: the variant of an update without stage vectors that large meshes take while few slices are
-    limited -- step 5 stores no P_ij, step 6 takes V_i or leaves the slice to its work-list launch, which forms P_ij
-    again, and so does step 7 (kernels_limiter.hpp) -- forced here (a library run chooses from the measured
-    fraction of limited slices; the first update of a context always stores). The P_ij the comparison fetches is
-    the one those sweeps form (ryujin_hip_debug_fetch recomputes it through the same device function)."""
+    An update without stage vectors stores P_ij per 64-row slice there (kernels_limiter_stage0.hpp): where the slice
+    held a limited pair in the previous update -- the first update of a context stores everywhere --, or where one
+    of its own l_ij comes out limited (stored from that column on, the columns before it formed a second time);
+    a slice limited through a neighbour's l_ji alone gets its P_ij from the repair prologue of step 6, which runs as a
+    light and a heavy launch. `:no_prediction` predicts no slice limited (every stored slice goes through the
+    trigger or the repair prologue), `:always_store` all of them. The P_ij the comparison fetches is what the sweeps
+    stored, completed through the same device function for the slices they left out (ryujin_hip_debug_fetch)."""
     switches = {"debug_no_small_mesh_split": 1, "debug_bc_fold_max_slices": -1}
     which, _, variant = which.partition(":")
-    if variant == "never_store":
-        switches["debug_pij_storage"] = 1
+    if variant:
+        switches["debug_pij_storage"] = {"no_prediction": 1, "always_store": -1}[variant]
     monkeypatch.setattr(HyperbolicModule, "library_switches", switches)
     {
         "euler_2d": lambda: test_step_parity_2d_step_geometry(oracle),

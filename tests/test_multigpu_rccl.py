@@ -136,7 +136,7 @@ def test_bench_self_launches_its_ranks(n):
     if _n_gpus() < n:
         pytest.skip(f"needs {n} GPUs")
     res = _run_group([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "6",
-                      "--warmup", "3", "--develop", "30", "--cells-per-unit", "200", "--watchdog", "360"])
+                      "--warmup", "3", "--develop-time", "0.3", "--develop", "30", "--cells-per-unit", "200", "--watchdog", "360"])
     assert res.returncode == 0, res.stderr[-4000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, res.stdout
