@@ -37,9 +37,12 @@
 // downloads (synchronize_to_host() fetches on demand), and time_step() runs a whole explicit Runge-Kutta step of
 // TimeIntegrator::step (time_integrator.template.h:207-403) inside the library with one host synchronisation.
 //
-// Written against the reference snapshot; it needs deal.II and the ryujin headers and was NOT compiled in the
-// build image of ryujin_amd (no deal.II there). Everything in it that does not need a deal.II type lives in
-// ryujin_hip_binding.h and IS compiled and tested there (tests/test_binding_cpp.py).
+// Written against the reference snapshot; it needs deal.II and the ryujin headers. deal.II is not installed in the
+// build image of ryujin_amd: there the header is TYPE CHECKED -- the reference's unmodified TimeIntegrator (all
+// schemes) and VTUOutput are explicitly instantiated on top of it for all four Descriptions, against a patched
+// copy of the reference tree and stand-in deal.II headers (tests/test_binding_compile.py, tests/cpp/dealii_mock/);
+// it has not been linked or run against deal.II. Everything in it that does not need a deal.II type lives in
+// ryujin_hip_binding.h and is compiled AND run there (tests/test_binding_cpp.py).
 //
 #pragma once
 
@@ -446,8 +449,7 @@ namespace ryujin
       } else if constexpr (std::is_same<Description, ShallowWater::Description>::value) {
         ryujin_hip_binding::fill_params_shallow_water(params_, view, indicator_parameters_, limiter_parameters_);
       } else if constexpr (std::is_same<Description, EulerAEOS::Description>::value) {
-        ryujin_hip_binding::fill_params_common(params_, indicator_parameters_, limiter_parameters_,
-                                               riemann_solver_parameters_);
+        ryujin_hip_binding::fill_params_indicator_limiter(params_, indicator_parameters_, limiter_parameters_);
         params_.reference_density = view.reference_density();
         params_.vacuum_state_relaxation_small = view.vacuum_state_relaxation_small();
         params_.vacuum_state_relaxation_large = view.vacuum_state_relaxation_large();

@@ -264,15 +264,24 @@ namespace ryujin_hip_binding
 
   /* "/HyperbolicModule/{indicator,limiter,riemann solver}" of the Euler Description
    * (euler/indicator.h:34, euler/limiter.h:51-54, euler/riemann_solver.h:41-42) */
-  template <typename IndicatorParameters, typename LimiterParameters, typename RiemannSolverParameters>
-  void fill_params_common(ryujin_hip_params &p, const IndicatorParameters &indicator,
-                          const LimiterParameters &limiter, const RiemannSolverParameters &riemann_solver)
+  template <typename IndicatorParameters, typename LimiterParameters>
+  void fill_params_indicator_limiter(ryujin_hip_params &p, const IndicatorParameters &indicator,
+                                     const LimiterParameters &limiter)
   {
     p.indicator_evc_factor = indicator.evc_factor();
     p.limiter_iterations = static_cast<int>(limiter.iterations());
     p.limiter_newton_tolerance = limiter.newton_tolerance();
     p.limiter_newton_max_iterations = static_cast<int>(limiter.newton_max_iterations());
     p.limiter_relaxation_factor = limiter.relaxation_factor();
+  }
+
+  /* (the Riemann solver of the EulerAEOS Description has no run-time parameters, euler_aeos/riemann_solver.h:19-27:
+   * it takes fill_params_indicator_limiter() alone) */
+  template <typename IndicatorParameters, typename LimiterParameters, typename RiemannSolverParameters>
+  void fill_params_common(ryujin_hip_params &p, const IndicatorParameters &indicator,
+                          const LimiterParameters &limiter, const RiemannSolverParameters &riemann_solver)
+  {
+    fill_params_indicator_limiter(p, indicator, limiter);
     p.riemann_newton_tolerance = riemann_solver.newton_tolerance();
     p.riemann_newton_max_iterations = static_cast<int>(riemann_solver.newton_max_iterations());
   }

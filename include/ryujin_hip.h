@@ -156,10 +156,11 @@ typedef struct ryujin_hip_params {
    *   stencil); debug_bc_fold_max_slices: boundary conditions ride on the pre-pass kernel up to n slices of
    *   64 rows (0 = default 4096, < 0 = always a launch of their own); debug_no_small_mesh_split != 0: meshes
    *   that do not fill the device run the same step-5/6 kernels as large ones; debug_pij_storage: the matrix
-   *   P_ij of an update without stage vectors is stored per 64-row slice, where the slice held a limited pair in
-   *   the previous update or one of its own l_ij comes out limited (0); > 0: no slice is predicted limited
-   *   (every stored slice goes through the trigger in step 5 or the repair prologue of step 6), < 0: every
-   *   slice is (always stored). */
+   *   P_ij of an update without stage vectors is stored everywhere, or -- while few 64-row slices hold a limited
+   *   pair -- per slice: where the slice held a limited pair in the previous update or one of its own l_ij comes
+   *   out limited, the rest completed where step 6 needs it (0: chosen from the measured fraction); > 0: always
+   *   per slice and no slice predicted limited (every stored slice goes through the trigger in step 5 or the
+   *   repair launch of step 6), < 0: always stored everywhere. */
   int system_scope_events;
   int debug_join_exchanges;
   int debug_bc_fold_max_slices;

@@ -64,7 +64,8 @@ def hipcc_path() -> str | None:
 
 def build_hip(force: bool = False, defines: tuple = (), out: str | None = None) -> str:
     """defines/out: build an A/B variant (e.g. defines=("RYUJIN_OCC_DIJ=3",)) into another file;
-    select it at run time with RYUJIN_HIP_LIB=<path>."""
+    select it at run time with RYUJIN_HIP_LIB=<path>. The production library is always built with
+    -ffp-contract=off (the parity contract); RYUJIN_FP_CONTRACT is honoured for variant builds only."""
     src = [os.path.join(CSRC, "ryujin_hip.hip")]
     deps = src + _sources(CSRC, (".hpp", ".h", ".hip")) + _headers()
     if out is not None:
@@ -82,7 +83,7 @@ def build_hip(force: bool = False, defines: tuple = (), out: str | None = None) 
             raise RuntimeError("hipcc not found and no prebuilt libryujin_hip.so")
         os.makedirs(LIBDIR, exist_ok=True)
         _run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-              "-ffp-contract=" + os.environ.get("RYUJIN_FP_CONTRACT", "off"), "-I" + INCLUDE, "-I" + CSRC, *src,
+              "-ffp-contract=off", "-I" + INCLUDE, "-I" + CSRC, *src,
               "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib", "-o", HIP_SO])
     return HIP_SO
 

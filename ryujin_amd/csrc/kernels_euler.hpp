@@ -153,6 +153,9 @@ namespace ryujin_hip
 #ifndef RYUJIN_PER_SLICE_PIJ
 #define RYUJIN_PER_SLICE_PIJ 1 /* stages == 0, two limiter passes: step 5 stores P_ij only in the slices steps 6/7 will read it in (kernels_limiter_stage0.hpp); 0: everywhere */
 #endif
+#ifndef RYUJIN_PER_SLICE_MAX_LIMITED
+#define RYUJIN_PER_SLICE_MAX_LIMITED 0.5 /* ... while at most this fraction of the slices held a limited pair in the latest measured update */
+#endif
 #ifndef RYUJIN_FUSE_PRECOMPUTE
 #define RYUJIN_FUSE_PRECOMPUTE 1 /* device-resident RK driver: the last sweep of a stage leaves the precomputed values and Riemann records of the next one (FusedPrecompute) */
 #endif

@@ -537,31 +537,32 @@ namespace ryujin_hip
 
   /* Per-slice bookkeeping of the limiter sweeps of an update without stage vectors (kernels_limiter_stage0.hpp):
    * one byte per 64-row slice each, written by exactly one wave per launch.
-   *   unlimited  written by step 6: 1 = no pair of the slice was limited in the first high-order pass. EXACT for
-   *              the last sweep of the same update (every l'_ij of such a slice is an exact zero, and so is every
-   *              transposed l'_ji: min(l_ij, l_ji) = 1 is symmetric, (1 - 1) l' = 0 -- it reads neither), and the
-   *              PREDICTION step 5 of the next update stores P_ij by (a limited region moves by less than a cell
-   *              per update);
-   *   p_stored   written by step 5: the slice's P_ij is in the matrix (predicted limited, or one of its own l_ij
-   *              came out limited); set by the repair prologue of step 6 for the slices that turn out limited
-   *              through a neighbour's l_ji alone. Exact;
-   *   todo       written by the light launch of step 6 for the heavy one: 0 finished (V_i), 1 stored P_ij,
-   *              2 form and store P_ij first. */
+   *   unlimited     written by step 6: 1 = no pair of the slice was limited in the first high-order pass. EXACT for
+   *                 the last sweep of the same update (every l'_ij of such a slice is an exact zero, and so is every
+   *                 transposed l'_ji: min(l_ij, l_ji) = 1 is symmetric, (1 - 1) l' = 0 -- it reads neither), and
+   *                 the PREDICTION step 5 of the next update stores P_ij by (a limited region moves by less than a
+   *                 cell per update);
+   *   first_stored  written by step 5 where it stores P_ij per slice: 0 = nothing of the slice is in the matrix, k =
+   *                 the columns k, k + 1, ... are (1: all of them -- the slice was predicted limited; k > 1: its
+   *                 own l_ij of column k came out limited). The repair launch of step 6 completes the slices that
+   *                 need it and sets 1. Exact;
+   *   todo          written by the light launch of step 6 for the two behind it: 0 finished (V_i), 1 P_ij complete,
+   *                 2 the repair launch has to complete it first. */
   struct SliceFlags {
-    uint8_t *unlimited, *p_stored, *todo;
+    uint8_t *unlimited, *first_stored, *todo;
   };
 
-  /* form and store all P_ij of the row (the repair prologue of step 6, ryujin_hip_debug_fetch): exactly the value
-   * step 5 formed (same function, same operands) */
+  /* form and store the P_ij of the columns [1, c_end) of the row (the repair launch of step 6,
+   * ryujin_hip_debug_fetch): exactly the value step 5 formed (same function, same operands) */
   template <int K>
-  RYUJIN_DEV void form_and_store_pij(const DeviceMesh &M, const Stage0Src &S0, const RowCtx &r,
-                                     double *__restrict__ pij)
+  RYUJIN_DEV void backfill_pij(const DeviceMesh &M, const Stage0Src &S0, const RowCtx &r,
+                               double *__restrict__ pij, const uint32_t c_end)
   {
     if (r.len <= 1)
       return;
     RowData<K> row;
     load_row_data<K>(M, S0, r.row, r.len, row);
-    for (uint32_t c = 1; c < r.len; ++c) {
+    for (uint32_t c = 1; c < c_end && c < r.len; ++c) {
       double P_ij[K];
       pij_on_the_fly<K>(M, S0, row, (uint64_t)r.base + c, r.lane, P_ij);
       store_entry<K>(pij, (uint64_t)r.base + c, r.lane, P_ij);
@@ -681,14 +682,19 @@ namespace ryujin_hip
    * of them form the new U_i (bitwise the same sum), the first one stores it -- behind a block barrier, the update
    * is in place -- and wave w runs the second limiter pass for the columns 1 + w, 5 + w, ... only. */
   /* MODE (updates whose step 5 stored P_ij per slice, kernels_limiter_stage0.hpp; V_unlimited and the flags are
-   * required then): the sweep runs as two launches over all slices,
-   *   kHoLight  slices whose P_ij step 5 did not store: fetch l_ij / l_ji; if nothing is limited take V_i and
-   *             finish -- a kernel of 20 registers at full occupancy, most of a developed flow --, otherwise leave
-   *             the slice to the second launch (todo = 2: limited through a neighbour's l_ji alone). Slices with a
-   *             stored P_ij are left to the second launch unseen (todo = 1);
-   *   kHoHeavy  waves of finished slices retire at once; the others run the sweep on the stored P_ij (todo = 2:
-   *             behind a prologue that forms and stores it, for the last sweep as well).
-   * kHoPlain: the whole sweep in one launch (P_ij stored everywhere). */
+   * required then): the sweep runs as three launches over all slices,
+   *   kHoLight   slices of which step 5 stored nothing: fetch l_ij / l_ji; if nothing is limited take V_i and finish
+   *              -- a kernel of 20 registers at full occupancy --, otherwise leave the slice to the launches behind
+   *              (todo = 2: limited through a neighbour's l_ji alone). Slices with a complete P_ij are passed on
+   *              unseen (todo = 1), slices stored from some column on are limited for sure (todo = 2);
+   *   k_pij_repair  forms and stores what is missing of the P_ij of the slices with todo = 2;
+   *   kHoHeavy   waves of finished slices retire at once; the others run the sweep on the stored P_ij.
+   * kHoPlain: the whole sweep in one launch (P_ij stored everywhere).
+   * With V_i the new state is formed as V_i - sum_j (1 - l_ij) lambda P_ij over the (slice, column) tiles in which
+   * some pair is limited -- the terms of all other tiles are exact zeros, and P_ij is read for those tiles only,
+   * once, for the sum and for the second limiter pass. Against U_i^low + sum_j l_ij lambda P_ij in column order
+   * (the reference, :1107-1131, and the variant without V_i below) this is another rounding of the same sum:
+   * differences of a few ulp of lambda |P_ij|, orders inside the 1e-11 contract on the new state. */
   constexpr int kHoPlain = 0, kHoLight = 1, kHoHeavy = 2;
 
   template <typename E, int MAXW, int CP, bool SPLIT, int MODE>
@@ -706,14 +712,6 @@ namespace ryujin_hip
     const bool row_active = r.len > 1;
     const uint32_t i = row_active ? r.row : (r.row < M.n_owned ? r.row : M.n_owned - 1);
     const uint32_t *__restrict__ idx_t = M.idx_t;
-
-    if constexpr (MODE == kHoHeavy) {
-      if (todo == 2) {
-        form_and_store_pij<K>(M, S0, r, pij);
-        if (r.lane == 0)
-          W.p_stored[r.slice] = 1;
-      }
-    }
 
     double l[MAXW];
     if constexpr (MODE == kHoLight) {
@@ -735,7 +733,7 @@ namespace ryujin_hip
           atomicAdd(&S0.scalars->n_sampled_limited, 1u);
       }
       if (r.lane == 0) {
-        W.todo[r.slice] = slice_limited ? 2 : 0;
+        W.todo[r.slice] = slice_limited ? 3 : 0; /* 3: limited, nothing stored, and counted above */
         if (!slice_limited)
           W.unlimited[r.slice] = 1;
       }
@@ -752,7 +750,6 @@ namespace ryujin_hip
     }
 
     double U_i_new[K];
-    load_state<K>(new_U, i, U_i_new);
     const double lambda = 1. / (double)(r.len - 1);
     const size_t stride = M.bounds_stride;
     double bnd[NB];
@@ -761,39 +758,43 @@ namespace ryujin_hip
       bnd[b] = bounds[(size_t)b * stride + i];
 
     double p[CP][K];
+    uint32_t needed = 0; /* wave-uniform: bit c <=> some pair of the (slice, column) tile is limited */
     if (V_unlimited != nullptr) {
-      /* Step 5 left V_i = U_i^low + sum_j lambda P_ij, accumulated exactly as the update below accumulates it
-       * when every l_ij is 1 (k_lij_stage0). If no pair of the slice was limited -- wave-uniform; most of a
-       * developed flow -- that IS the new U_i bit for bit, the second pass stores (1 - l) l' = 0, and P_ij is
-       * not read at all. */
+      /* Step 5 left V_i = U_i^low + sum_j lambda P_ij, accumulated exactly as the reference accumulates the update
+       * when every l_ij is 1 (k_lij_stage0). If no pair of the slice was limited -- wave-uniform -- that IS the
+       * new U_i bit for bit, the second pass stores (1 - l) l' = 0, and P_ij is not read at all. */
       bool limited = false;
 #pragma unroll
       for (int c = 1; c < MAXW; ++c) {
-        l[c] = 0.;
+        l[c] = 1.;
         if ((uint32_t)c < r.width) {
           const uint32_t pos = (uint32_t)(((uint64_t)r.base + c) * 64 + r.lane);
           const double l_a = lij[pos];
           const double l_b = lij[idx_t[pos]];
-          l[c] = lmin(l_a, l_b);
-          limited = limited || (row_active && (uint32_t)c < r.len && !(l_a == 1. && l_b == 1.));
+          const bool lane_on = row_active && (uint32_t)c < r.len;
+          const bool lim = lane_on && !(l_a == 1. && l_b == 1.);
+          l[c] = lane_on ? lmin(l_a, l_b) : 1.;
+          limited = limited || lim;
+          if (__any(lim))
+            needed |= 1u << c;
         }
       }
-      const bool slice_limited = __any(limited);
-      /* (slices the light launch left with todo = 2 were counted there) */
+      const bool slice_limited = needed != 0u;
+      (void)limited;
+      /* (slices the light launch found limited, todo = 3, were counted there) */
       if (S0.scalars != nullptr && (r.slice & 15u) == 0 && r.lane == 0 && (!SPLIT || group == 0) &&
-          !(MODE == kHoHeavy && todo == 2)) {
+          !(MODE == kHoHeavy && todo == 3)) {
         atomicAdd(&S0.scalars->n_sampled_slices, 1u);
         if (slice_limited)
           atomicAdd(&S0.scalars->n_sampled_limited, 1u);
       }
       if (W.unlimited != nullptr && r.lane == 0 && (!SPLIT || group == 0))
         W.unlimited[r.slice] = slice_limited ? 0 : 1;
+      load_state<K>(V_unlimited, i, U_i_new);
       if (!slice_limited) {
         if (row_active) {
-          double V_i[K];
-          load_state<K>(V_unlimited, i, V_i);
           if (!SPLIT || group == 0)
-            store_state<K>(new_U, i, V_i);
+            store_state<K>(new_U, i, U_i_new);
 #pragma unroll
           for (int c = 1; c < MAXW; ++c)
             if ((uint32_t)c < r.len && (!SPLIT || (uint32_t)(c - 1) % kWavesPerBlock == group))
@@ -801,15 +802,33 @@ namespace ryujin_hip
         }
         return;
       }
+      /* U_i = V_i - sum over the limited tiles of (1 - l_ij) lambda P_ij: P_ij of those tiles only */
 #pragma unroll
       for (int c = 1; c < CP; ++c) {
 #pragma unroll
         for (int q = 0; q < K; ++q)
           p[c][q] = 0.;
-        if ((uint32_t)c < r.width)
+        if ((needed >> c) & 1u)
           load_entry<K>(pij, (uint64_t)r.base + c, r.lane, p[c]);
       }
+#pragma unroll
+      for (int c = 1; c < MAXW; ++c) {
+        if (!((needed >> c) & 1u))
+          continue;
+        if (c < CP) {
+#pragma unroll
+          for (int q = 0; q < K; ++q)
+            U_i_new[q] -= (1. - l[c]) * lambda * p[c < CP ? c : 0][q];
+        } else {
+          double pt[K];
+          load_entry<K>(pij, (uint64_t)r.base + c, r.lane, pt);
+#pragma unroll
+          for (int q = 0; q < K; ++q)
+            U_i_new[q] -= (1. - l[c]) * lambda * pt[q];
+        }
+      }
     } else {
+      load_state<K>(new_U, i, U_i_new);
 #pragma unroll
       for (int c = 1; c < MAXW; ++c) {
         l[c] = 0.;
@@ -826,24 +845,26 @@ namespace ryujin_hip
           l[c] = lmin(l_a, l_b);
           if (c < CP)
             load_entry<K>(pij, colbase, r.lane, p[c < CP ? c : 0]);
+          if (__any(row_active && (uint32_t)c < r.len && !(l[c] == 1.)))
+            needed |= 1u << c;
         }
       }
-    }
 #pragma unroll
-    for (int c = 1; c < MAXW; ++c) {
-      if (c < CP) {
-        if (row_active && (uint32_t)c < r.len) {
+      for (int c = 1; c < MAXW; ++c) {
+        if (c < CP) {
+          if (row_active && (uint32_t)c < r.len) {
 #pragma unroll
-          for (int q = 0; q < K; ++q)
-            U_i_new[q] += l[c] * lambda * p[c < CP ? c : 0][q];
-        }
-      } else if ((uint32_t)c < r.width) {
-        double pt[K];
-        load_entry<K>(pij, (uint64_t)r.base + c, r.lane, pt);
-        if (row_active && (uint32_t)c < r.len) {
+            for (int q = 0; q < K; ++q)
+              U_i_new[q] += l[c] * lambda * p[c < CP ? c : 0][q];
+          }
+        } else if ((uint32_t)c < r.width) {
+          double pt[K];
+          load_entry<K>(pij, (uint64_t)r.base + c, r.lane, pt);
+          if (row_active && (uint32_t)c < r.len) {
 #pragma unroll
-          for (int q = 0; q < K; ++q)
-            U_i_new[q] += l[c] * lambda * pt[q];
+            for (int q = 0; q < K; ++q)
+              U_i_new[q] += l[c] * lambda * pt[q];
+          }
         }
       }
     }
@@ -863,13 +884,11 @@ namespace ryujin_hip
         continue;
       if (SPLIT && (uint32_t)(c - 1) % kWavesPerBlock != group)
         continue;
-      {
-        const bool lane_on = row_active && (uint32_t)c < r.len;
-        if (!__any(lane_on && !(l[c] == 1.))) {
-          if (lane_on)
-            st_stream(lij_next + ((r.base + c) * 64 + r.lane), 0.);
-          continue;
-        }
+      const bool lane_on = row_active && (uint32_t)c < r.len;
+      if (!((needed >> c) & 1u)) {
+        if (lane_on)
+          st_stream(lij_next + ((r.base + c) * 64 + r.lane), 0.);
+        continue;
       }
       double pc[K];
       if (c < CP) {
@@ -879,7 +898,7 @@ namespace ryujin_hip
       } else {
         load_entry<K>(pij, (uint64_t)r.base + c, r.lane, pc);
       }
-      if (row_active && (uint32_t)c < r.len) {
+      if (lane_on) {
         double new_p_ij[K];
 #pragma unroll
         for (int q = 0; q < K; ++q)
@@ -910,6 +929,21 @@ namespace ryujin_hip
     }
   }
 
+  /* the launch between the light and the heavy one: completes the P_ij of the slices the light launch marked */
+  template <typename E>
+  __global__ void __launch_bounds__(kBlock)
+  k_pij_repair(const DeviceMesh M, const Stage0Src S0, double *__restrict__ pij, const SliceFlags W)
+  {
+    const uint32_t slice = M.slice_begin + blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (slice >= M.slice_end || W.todo[slice] < 2)
+      return;
+    const uint32_t fs = W.first_stored[slice];
+    const RowCtx r = row_context_of_slice(M, slice);
+    backfill_pij<E::K>(M, S0, r, pij, fs == 0 ? 0xffffffffu : fs);
+    if (r.lane == 0)
+      W.first_stored[slice] = 1;
+  }
+
   template <typename E, int MAXW, int CP = MAXW, bool SPLIT = false, int MODE = kHoPlain>
   __global__ void __launch_bounds__(kBlock, (MAXW > 9 ? (CP < MAXW ? RYUJIN_OCC_HO_3D : 1) : RYUJIN_OCC_HO))
   k_high_order_next_cached(const typename E::Params P, const DeviceMesh M, double *__restrict__ new_U,
@@ -931,9 +965,10 @@ namespace ryujin_hip
       if (slice >= M.slice_end)
         return;
       if constexpr (MODE == kHoLight) {
-        if (W.p_stored[slice] != 0) {
+        const uint32_t fs = W.first_stored[slice];
+        if (fs != 0) { /* complete (1), or stored from the column on whose l_ij came out limited */
           if ((threadIdx.x & 63) == 0)
-            W.todo[slice] = 1;
+            W.todo[slice] = fs == 1 ? 1 : 2;
           return;
         }
       } else {

@@ -31,13 +31,16 @@
 //   * the slice held a limited pair in the previous update (SliceFlags::unlimited of that update's step 6 -- a
 //     limited region moves by less than a cell per update): store as P_ij is formed;
 //   * otherwise do not -- unless one of the slice's own l_ij comes out limited (or undecided) at column c: store
-//     from c on and form the columns before c a second time (their operands are in L1/L2);
-//   * SliceFlags::p_stored says which. A slice that turns out limited only through a neighbour's l_ji (step 6 sees
-//     that, step 5 cannot) gets its P_ij from the repair prologue of step 6 (kernels_limiter.hpp).
-// The cost of steps 5 - 7 therefore follows the limited fraction smoothly between the two extremes of round 3
-// (profiles/r04*_ab_limited_fraction*). Same bits whatever is stored: whoever reads P_ij reads pij_stage0() of the
-// same operands. ryujin_hip_params::debug_pij_storage overrides the prediction: < 0 every slice is predicted
-// limited (always stored), > 0 none is (everything through the trigger / the repair prologue).
+//     from c on;
+//   * SliceFlags::first_stored says which. What is missing where step 6 needs P_ij -- the columns in front of c, or
+//     all of a slice that turns out limited only through a neighbour's l_ji (step 6 sees that, step 5 cannot) --
+//     is formed by the small repair launch inside step 6 (kernels_limiter.hpp).
+// The cost of steps 5 - 7 therefore follows the limited fraction smoothly (profiles/r04*_ab_limited_fraction*); once
+// most slices are limited -- a developed Mach-3 flow: 70 - 95 % -- the bookkeeping buys nothing and the host runs the
+// plain kernels (P_ij stored everywhere, step 6 in one launch; ryujin_hip_ctx::step, RYUJIN_PER_SLICE_MAX_LIMITED).
+// Same bits whatever is stored: whoever reads P_ij reads pij_stage0() of the same operands.
+// ryujin_hip_params::debug_pij_storage: < 0 always the plain kernels, > 0 always per slice with no slice predicted
+// limited (everything through the trigger / the repair launch).
 
 #pragma once
 
@@ -133,6 +136,10 @@ namespace ryujin_hip
         load_pair<K>(M, old_U, r_in, alpha, dij, (colbase + NY) * 64 + r.lane, j_n, next);
         j_nn = (c + 2 * NY < r.width) ? ld_stream(cols + ((colbase + 2 * NY) * 64 + r.lane)) : i;
       }
+      /* a slice that stores already: as soon as P_ij is formed (the store overlaps the limiter) */
+      const bool stored_early = storing;
+      if (stored_early && active)
+        store_entry<K>(pij, colbase, r.lane, P_ij);
       bool success = true, undecided = false;
       double l_ij = 1.;
       if (active) {
@@ -152,8 +159,10 @@ namespace ryujin_hip
       }
       if (!active)
         continue;
-      if (storing)
-        store_entry<K>(pij, colbase, r.lane, P_ij);
+      if constexpr (PER_SLICE) {
+        if (storing && !stored_early)
+          store_entry<K>(pij, colbase, r.lane, P_ij);
+      }
       if (undecided) {
         undecided_mask |= 1ull << c;
       } else {
@@ -165,19 +174,8 @@ namespace ryujin_hip
       store_state<K>(V_out, i, V_i);
 
     if constexpr (PER_SLICE) {
-      /* the columns in front of the one that made the slice store: once more (operands in L1/L2) */
-      if (storing && row_active) {
-        for (uint32_t c = c0; c < first_stored && c < r.len; ++c) {
-          const uint64_t colbase = (uint64_t)r.base + c;
-          PairData<K> pd;
-          load_pair<K>(M, old_U, r_in, alpha, dij, colbase * 64 + r.lane, cols[colbase * 64 + r.lane], pd);
-          double P_ij[K];
-          pij_stage0<K>(row, pd, P_ij);
-          store_entry<K>(pij, colbase, r.lane, P_ij);
-        }
-      }
       if (r.lane == 0) {
-        W.p_stored[r.slice] = storing ? 1 : 0;
+        W.first_stored[r.slice] = storing ? (uint8_t)first_stored : 0;
         if ((r.slice & 15u) == 0 && storing)
           atomicAdd(&scalars->n_sampled_stored, 1u);
       }
@@ -199,19 +197,19 @@ namespace ryujin_hip
   }
 
   /* ryujin_hip_debug_fetch(P_ij) behind a step that did not store all of it: the same pij_stage0() on the same
-   * operands (all of them outlive the step), written to the matrix the parity tests read for the slices the
-   * sweeps left out (p_stored == NULL: for all) */
+   * operands (all of them outlive the step), written to the matrix the parity tests read for the columns the
+   * sweeps left out */
   template <typename E>
   __global__ void __launch_bounds__(kBlock)
   k_pij_stage0_store(const DeviceMesh M, const Stage0Src S0, double *__restrict__ pij,
-                     const uint8_t *__restrict__ p_stored)
+                     const uint8_t *__restrict__ first_stored)
   {
-    constexpr int K = E::K;
     const RowCtx r = row_context(M);
     if (!r.valid || r.len <= 1)
       return;
-    if (p_stored != nullptr && p_stored[r.slice] != 0)
+    const uint32_t fs = first_stored[r.slice];
+    if (fs == 1)
       return;
-    form_and_store_pij<K>(M, S0, r, pij);
+    backfill_pij<E::K>(M, S0, r, pij, fs == 0 ? 0xffffffffu : fs);
   }
 } // namespace ryujin_hip

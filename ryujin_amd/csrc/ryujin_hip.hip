@@ -450,7 +450,7 @@ struct ryujin_hip_ctx {
   Stage0Src last_s0{};
   /* SliceFlags (kernels_limiter.hpp), [n_slices] each; `unlimited` starts at 0 = "limited": the first update of a
    * context stores P_ij everywhere */
-  DeviceBuffer<uint8_t> d_slice_unlimited, d_slice_pstored, d_slice_todo;
+  DeviceBuffer<uint8_t> d_slice_unlimited, d_slice_first_stored, d_slice_todo;
   /* fractions of the (sampled) slices in which the first high-order sweep found a limited pair / whose P_ij step 5
    * stored, from the device counters at the latest host synchronisation (DeviceScalars::n_sampled_*); 1 until the
    * first measurement. Diagnostics only: nothing is decided from them. */
@@ -1101,7 +1101,7 @@ void ryujin_hip_ctx::store_pij_for_debug()
   mm.slice_end = L.n_slices;
   const dim3 grid((L.n_slices + kWavesPerBlock - 1) / kWavesPerBlock), block(kBlock);
   hipLaunchKernelGGL(k_pij_stage0_store<E>, grid, block, 0, stream, mm, last_s0, d_pij.ptr,
-                     (const uint8_t *)d_slice_pstored.ptr);
+                     (const uint8_t *)d_slice_first_stored.ptr);
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipStreamSynchronize(stream));
 }
@@ -1424,15 +1424,24 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
   const uint32_t step5_groups = std::min<uint32_t>(
       4u, resident_waves_step5 /
               std::max<uint32_t>(1u, (L.n_slices + kWavesPerBlock - 1) / kWavesPerBlock * kWavesPerBlock));
-  /* ... and P_ij is stored per slice where the update has two limiter passes and one wave per slice: only where
-   * steps 6 and 7 will read it (kernels_limiter_stage0.hpp); step 6 takes V_i in slices where nothing was limited */
-  const bool per_slice = RYUJIN_PER_SLICE_PIJ && stage0_pij && params.limiter_iterations == 2 && step5_groups < 2;
+  /* ... and P_ij is stored per slice -- only where steps 6 and 7 will read it (kernels_limiter_stage0.hpp) -- where the
+   * update has two limiter passes and one wave per slice, WHILE that pays: its bookkeeping (the prediction and the
+   * trigger in step 5, step 6 as three launches) costs a few per cent of the three sweeps, the savings are
+   * proportional to the share of unlimited slices. Above RYUJIN_PER_SLICE_MAX_LIMITED (the measured break-even,
+   * profiles/r04*_ab_limited_fraction*) the plain kernels run: P_ij stored everywhere, step 6 in one launch. Same
+   * bits either way; the fraction is the one step 6 counted between the two latest host synchronisations (1 until
+   * the first: the first update of a context runs the plain kernels). */
+  const bool per_slice_possible =
+      RYUJIN_PER_SLICE_PIJ && stage0_pij && params.limiter_iterations == 2 && step5_groups < 2;
+  const bool per_slice =
+      per_slice_possible && params.debug_pij_storage >= 0 &&
+      (params.debug_pij_storage > 0 || limited_fraction <= (double)RYUJIN_PER_SLICE_MAX_LIMITED);
   ensure_pij();
-  if (per_slice && d_slice_pstored.n == 0) {
-    d_slice_pstored.alloc(L.n_slices);
+  if (per_slice && d_slice_first_stored.n == 0) {
+    d_slice_first_stored.alloc(L.n_slices);
     d_slice_todo.alloc(L.n_slices);
   }
-  const SliceFlags slice_flags{d_slice_unlimited.ptr, d_slice_pstored.ptr, d_slice_todo.ptr};
+  const SliceFlags slice_flags{d_slice_unlimited.ptr, d_slice_first_stored.ptr, d_slice_todo.ptr};
   last_per_slice = per_slice;
   last_s0 = Stage0Src{d_scalars.ptr, old.U.ptr, d_alpha.ptr, d_dij.ptr, d_r.ptr};
   sweep([&](const DeviceMesh &mm, dim3 grid) {
@@ -1650,11 +1659,13 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
       sweep([&](const DeviceMesh &mm, dim3 grid) {
         if constexpr (is_euler || is_aeos) {
           if (per_slice) {
-            /* two launches over all slices: the light one finishes the slices without a stored P_ij in which nothing
-             * was limited (V_i), the heavy one runs the others (kernels_limiter.hpp) */
+            /* three launches over all slices: the light one finishes the slices without a stored P_ij in which
+             * nothing was limited (V_i), the repair launch completes the P_ij of the slices that turned out limited
+             * without (all of) it, the heavy one runs the limited slices (kernels_limiter.hpp) */
             hipLaunchKernelGGL((k_high_order_next_cached<E, kCachedWidth, kCachedP, false, kHoLight>), grid, block, 0,
                                launch_stream, eparams, mm, nw.U.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr,
                                d_lij_next.ptr, d_V.ptr, last_s0, slice_flags);
+            hipLaunchKernelGGL(k_pij_repair<E>, grid, block, 0, launch_stream, mm, last_s0, d_pij.ptr, slice_flags);
             hipLaunchKernelGGL((k_high_order_next_cached<E, kCachedWidth, kCachedP, false, kHoHeavy>), grid, block, 0,
                                launch_stream, eparams, mm, nw.U.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr,
                                d_lij_next.ptr, d_V.ptr, last_s0, slice_flags);

@@ -9,7 +9,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 defs = [a for a in sys.argv[1:] if a.startswith("-D")]
 filters = [a for a in sys.argv[1:] if not a.startswith("-D")]
-cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=" + os.environ.get("RYUJIN_FP_CONTRACT", "off"),
+cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
        "-Rpass-analysis=kernel-resource-usage", *defs, "-I" + os.path.join(ROOT, "include"),
        "-I" + os.path.join(ROOT, "ryujin_amd", "csrc"), os.path.join(ROOT, "ryujin_amd", "csrc", "ryujin_hip.hip"),
        "-L/opt/rocm/lib", "-lrccl", "-o", "/tmp/kernel_resources.so"]
