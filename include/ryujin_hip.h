@@ -155,12 +155,8 @@ typedef struct ryujin_hip_params {
    *   debug_join_exchanges != 0: every sweep joins the ghost exchanges (the choreography of a non-symmetric
    *   stencil); debug_bc_fold_max_slices: boundary conditions ride on the pre-pass kernel up to n slices of
    *   64 rows (0 = default 4096, < 0 = always a launch of their own); debug_no_small_mesh_split != 0: meshes
-   *   that do not fill the device run the same step-5/6 kernels as large ones; debug_pij_storage: the matrix
-   *   P_ij of an update without stage vectors is stored everywhere, or -- while few 64-row slices hold a limited
-   *   pair -- per slice: where the slice held a limited pair in the previous update or one of its own l_ij comes
-   *   out limited, the rest completed where step 6 needs it (0: chosen from the measured fraction); > 0: always
-   *   per slice and no slice predicted limited (every stored slice goes through the trigger in step 5 or the
-   *   repair launch of step 6), < 0: always stored everywhere. */
+   *   that do not fill the device run the same step-5/6 kernels as large ones; debug_pij_storage: < 0: an
+   *   update without stage vectors stores all of the matrix P_ij instead of the tiles steps 6 and 7 read. */
   int system_scope_events;
   int debug_join_exchanges;
   int debug_bc_fold_max_slices;
@@ -384,13 +380,13 @@ int ryujin_hip_get_cfl(ryujin_hip_ctx *ctx, double *cfl);
 int ryujin_hip_set_id_violation_strategy(ryujin_hip_ctx *ctx, int strategy);
 int ryujin_hip_get_alpha(ryujin_hip_ctx *ctx, double *alpha /* [n_relevant] */);
 int ryujin_hip_get_counters(ryujin_hip_ctx *ctx, unsigned *n_restarts, unsigned *n_warnings);
-/* What the data-dependent limiter sweeps saw between the two latest host synchronisations: the fraction of
- * (sampled) 64-row slices in which the first high-order sweep found a limited pair; how the latest step kept the
- * matrix P_ij (hyperbolic_module.template.h:795-846): 1 stored everywhere, 2 stored per slice -- only where steps
- * 6 and 7 read it; and the fraction of slices it was stored in. The results are the same bit for bit whatever is
- * stored. Diagnostics; any pointer may be NULL. */
+/* What the data-dependent limiter sweeps saw between the two latest host synchronisations (sampled): the fraction of
+ * 64-row slices in which the first high-order sweep found a limited pair; how the latest step kept the matrix P_ij
+ * (hyperbolic_module.template.h:795-846): 1 all of it, 2 tile storage -- only the (slice, column) tiles steps 6 and
+ * 7 read; the fraction of tiles that hold a limited pair and the fraction step 5 stored.
+ * Diagnostics; any pointer may be NULL. */
 int ryujin_hip_limiter_statistics(ryujin_hip_ctx *ctx, double *limited_slice_fraction, int *pij_stored,
-                                  double *stored_slice_fraction);
+                                  double *limited_tile_fraction, double *stored_tile_fraction);
 
 /* ---- introspection for parity tests and profiling ------------------------ */
 /* Module-owned intermediates of the LAST step() in the reference's logical

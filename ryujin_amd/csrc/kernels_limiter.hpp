@@ -348,9 +348,13 @@ namespace ryujin_hip
     p.m_j_inv = M.mi_inv[j];
   }
 
-  /* P_ij for stages == 0 */
+  /* The bracket Q_ij of P_ij = tau / m_i (S - 1) Q_ij for stages == 0. It is antisymmetric BIT FOR BIT, Q_ji = -Q_ij,
+   * wherever m_ij = m_ji bit for bit (d_ij = d_ji after step 3, alpha_i + alpha_j commutes, every product and
+   * difference below changes sign exactly when i and j are exchanged): what row j stores for the pair is what row i
+   * needs, with the other sign -- the tile storage of steps 5 - 7 rests on this (ryujin_hip_create checks the mass
+   * matrix). */
   template <int K>
-  RYUJIN_DEV void pij_stage0(const RowData<K> &row, const PairData<K> &p, double (&P_ij)[K])
+  RYUJIN_DEV void qij_stage0(const RowData<K> &row, const PairData<K> &p, double (&Q_ij)[K])
   {
     const double d_ijH = p.d_ij * ((row.alpha_i + p.alpha_j) * .5);
     const double dd = d_ijH - p.d_ij;
@@ -361,11 +365,21 @@ namespace ryujin_hip
     for (int q = 0; q < K; ++q) {
       double v = dd * (p.U_j[q] - row.U_i[q]);
       v += b_ij * p.F_j[q] - b_ji * row.F_i[q];
-      P_ij[q] = v * row.factor;
+      Q_ij[q] = v;
     }
   }
 
-  /* where steps 6 and 7 take P_ij from when step 5 did not store it (ONFLY kernels): the operands of pij_stage0 */
+  /* P_ij for stages == 0 */
+  template <int K>
+  RYUJIN_DEV void pij_stage0(const RowData<K> &row, const PairData<K> &p, double (&P_ij)[K])
+  {
+    qij_stage0<K>(row, p, P_ij);
+#pragma unroll
+    for (int q = 0; q < K; ++q)
+      P_ij[q] *= row.factor;
+  }
+
+  /* the operands of pij_stage0 (ryujin_hip_debug_fetch forms the entries no sweep stored from them) */
   struct Stage0Src {
     DeviceScalars *scalars; /* tau; and the limited-slice counters of step 6 */
     const double *old_U, *alpha, *dij, *r_in;
@@ -535,50 +549,75 @@ namespace ryujin_hip
     }
   }
 
-  /* Per-slice bookkeeping of the limiter sweeps of an update without stage vectors (kernels_limiter_stage0.hpp):
-   * one byte per 64-row slice each, written by exactly one wave per launch.
-   *   unlimited     written by step 6: 1 = no pair of the slice was limited in the first high-order pass. EXACT for
-   *                 the last sweep of the same update (every l'_ij of such a slice is an exact zero, and so is every
-   *                 transposed l'_ji: min(l_ij, l_ji) = 1 is symmetric, (1 - 1) l' = 0 -- it reads neither), and
-   *                 the PREDICTION step 5 of the next update stores P_ij by (a limited region moves by less than a
-   *                 cell per update);
-   *   first_stored  written by step 5 where it stores P_ij per slice: 0 = nothing of the slice is in the matrix, k =
-   *                 the columns k, k + 1, ... are (1: all of them -- the slice was predicted limited; k > 1: its
-   *                 own l_ij of column k came out limited). The repair launch of step 6 completes the slices that
-   *                 need it and sets 1. Exact;
-   *   todo          written by the light launch of step 6 for the two behind it: 0 finished (V_i), 1 P_ij complete,
-   *                 2 the repair launch has to complete it first. */
-  struct SliceFlags {
-    uint8_t *unlimited, *first_stored, *todo;
+
+  /* ---- Tile storage of P_ij (updates without stage vectors, kernels_limiter_stage0.hpp). A tile is one column of one
+   * 64-row slice. With V_i = U_i^low + sum_j lambda P_ij from step 5 the high-order update is
+   *   U_i = V_i - sum_j (1 - l_ij) lambda P_ij,   l_ij = min(l_ij, l_ji),
+   * so steps 6 and 7 read P_ij only for pairs with l_ij < 1, and a pair is limited because row i's own l_ij < 1
+   * or because row j's l_ji < 1. Step 5 therefore stores the tile (as the bracket Q_ij, qij_stage0) exactly when
+   * one of its own l_ij came out below 1 -- it knows that much --, and a reader takes
+   *   the own tile           if some row of the slice has an own l_ij < 1 in that column (the same test on the
+   *                          stored l_ij: the tile is there);
+   *   -Q_ji of the transpose otherwise: the pair is limited through l_ji < 1, so row j stored ITS tile.
+   * No flags, no prediction, nothing to repair: the rule is exact and local. Export slices (rows other ranks hold
+   * as ghosts; several ranks only) store every tile: the transpose of a ghost column lives on another rank.
+   * tile_own[slice] (bit c: the own tile of column c is stored), written by step 6, spares step 7 the reads of
+   * the first-pass l_ij it would need to redo the test. */
+  struct TileSrc {
+    const double *q;        /* the tile matrix Q_ij; NULL: the full matrix P_ij of the other updates (pij argument) */
+    uint32_t *tile_own;     /* [n_slices] */
+    uint32_t n_export_slices;
+    const DeviceScalars *scalars; /* tau */
   };
 
-  /* form and store the P_ij of the columns [1, c_end) of the row (the repair launch of step 6,
-   * ryujin_hip_debug_fetch): exactly the value step 5 formed (same function, same operands) */
+  /* Q entry of (row, column) at flat scalar position pos = colbase * 64 + lane */
   template <int K>
-  RYUJIN_DEV void backfill_pij(const DeviceMesh &M, const Stage0Src &S0, const RowCtx &r,
-                               double *__restrict__ pij, const uint32_t c_end)
+  RYUJIN_DEV void load_entry_at(const double *__restrict__ m, const uint32_t pos, double (&v)[K])
   {
-    if (r.len <= 1)
-      return;
-    RowData<K> row;
-    load_row_data<K>(M, S0, r.row, r.len, row);
-    for (uint32_t c = 1; c < c_end && c < r.len; ++c) {
-      double P_ij[K];
-      pij_on_the_fly<K>(M, S0, row, (uint64_t)r.base + c, r.lane, P_ij);
-      store_entry<K>(pij, (uint64_t)r.base + c, r.lane, P_ij);
+    const uint32_t colbase = pos >> 6, lane = pos & 63u;
+    const double *b = m + (size_t)colbase * 64 * K;
+#pragma unroll
+    for (int g = 0; g < K / 2; ++g) {
+      const double2 t = *reinterpret_cast<const double2 *>(b + g * 128 + lane * 2);
+      v[2 * g] = t.x;
+      v[2 * g + 1] = t.y;
+    }
+    if (K & 1)
+      v[K - 1] = b[(K / 2) * 128 + lane];
+  }
+
+  /* P_ij of the tile (colbase, lane) for a reader of the tile storage: own tile or the transpose's, times the
+   * row's factor tau / m_i (S - 1) */
+  template <int K>
+  RYUJIN_DEV void load_tile(const DeviceMesh &M, const double *__restrict__ q, const uint64_t colbase,
+                            const uint32_t lane, const bool own, const double factor, double (&P_ij)[K])
+  {
+    if (own) {
+      load_entry<K>(q, colbase, lane, P_ij);
+#pragma unroll
+      for (int c = 0; c < K; ++c)
+        P_ij[c] *= factor;
+    } else {
+      load_entry_at<K>(q, M.idx_t[colbase * 64 + lane], P_ij);
+#pragma unroll
+      for (int c = 0; c < K; ++c)
+        P_ij[c] = -P_ij[c] * factor;
     }
   }
+
+  /* [n_slices] 1: step 6 found no limited pair in the slice. Then every l'_ij of its rows is an exact zero, and so is
+   * every transposed l'_ji (min(l_ij, l_ji) = 1 is symmetric, (1 - 1) l' = 0): the last sweep reads neither. */
 
   /* Last round for stencils of at most MAXW columns: all l_ij = min(l_ij, l_ji) of the row are fetched up
    * front (independent loads), then P_ij is read -- in chunks of CHUNK columns whose loads are issued back to
    * back -- only for the columns in which some row of the slice has l != 0 (see the note at the top).
-   * slice_unlimited (SliceFlags::unlimited of this update's step 6, or NULL): slices in which nothing was limited
-   * fetch nothing at all. */
+   * slice_unlimited (written by this update's step 6, or NULL): slices in which nothing was limited fetch
+   * nothing at all. */
   template <typename E, int MAXW, int CHUNK>
   RYUJIN_DEV void last_cached_slice(const typename E::Params &P, const DeviceMesh &M, const RowCtx &r,
                                     double *__restrict__ new_U, const double *__restrict__ pij,
                                     const double *__restrict__ lij, const FusedSadd &F, const FusedPrecompute &FP,
-                                    const uint8_t *__restrict__ slice_unlimited = nullptr)
+                                    const uint8_t *__restrict__ slice_unlimited, const TileSrc &T)
   {
     constexpr int K = E::K;
     const bool row_active = r.len > 1;
@@ -613,6 +652,13 @@ namespace ryujin_hip
         if (__any(l[c] != 0.))
           needed |= 1u << c;
     }
+    uint32_t own = 0xffffffffu;
+    double factor = 1.;
+    if (T.q != nullptr && needed != 0u) {
+      own = T.tile_own[r.slice];
+      factor = T.scalars->tau * M.mi_inv[i] * (double)(r.len - 1);
+    }
+    const double *__restrict__ src = T.q != nullptr ? T.q : pij;
 
 #pragma unroll
     for (int c0 = 1; c0 < MAXW; c0 += CHUNK) {
@@ -620,14 +666,19 @@ namespace ryujin_hip
 #pragma unroll
       for (int cc = 0; cc < CHUNK; ++cc) {
         const int c = c0 + cc;
-        if (c < MAXW && ((needed >> c) & 1u))
-          load_entry<K>(pij, (uint64_t)r.base + c, r.lane, p[cc]);
+        if (c < MAXW && ((needed >> c) & 1u)) {
+          if (T.q != nullptr)
+            load_tile<K>(M, src, (uint64_t)r.base + c, r.lane, (own >> c) & 1u, factor, p[cc]);
+          else
+            load_entry<K>(src, (uint64_t)r.base + c, r.lane, p[cc]);
+        }
       }
 #pragma unroll
       for (int cc = 0; cc < CHUNK; ++cc) {
         const int c = c0 + cc;
         if (c < MAXW && ((needed >> c) & 1u)) {
-          if (row_active && (uint32_t)c < r.len) { /* padding entries of P_ij are never read into U */
+          /* padding entries, and pairs with l = 0 (their tile may hold nothing), are never read into U */
+          if (row_active && (uint32_t)c < r.len && l[c] != 0.) {
 #pragma unroll
             for (int q = 0; q < K; ++q)
               U_i_new[q] += l[c] * lambda * p[cc][q];
@@ -664,12 +715,13 @@ namespace ryujin_hip
   __global__ void __launch_bounds__(kBlock, (MAXW > 9 ? RYUJIN_OCC_LAST_3D : 1))
   k_high_order_last_cached(const typename E::Params P, const DeviceMesh M, double *__restrict__ new_U,
                            const double *__restrict__ pij, const double *__restrict__ lij, const FusedSadd F,
-                           const FusedPrecompute FP, const uint8_t *__restrict__ slice_unlimited = nullptr)
+                           const FusedPrecompute FP, const uint8_t *__restrict__ slice_unlimited = nullptr,
+                           const TileSrc T = TileSrc{})
   {
     const RowCtx r = row_context(M);
     if (!r.valid)
       return;
-    last_cached_slice<E, MAXW, CHUNK>(P, M, r, new_U, pij, lij, F, FP, slice_unlimited);
+    last_cached_slice<E, MAXW, CHUNK>(P, M, r, new_U, pij, lij, F, FP, slice_unlimited, T);
   }
 
   /* Register-cached variant for stencils of at most MAXW columns (2-D Q1: 9, 1-D: 3): the row's
@@ -681,74 +733,34 @@ namespace ryujin_hip
   /* SPLIT (small meshes, the sweep is one wave's latency chain): the four waves of a block share ONE slice; all
    * of them form the new U_i (bitwise the same sum), the first one stores it -- behind a block barrier, the update
    * is in place -- and wave w runs the second limiter pass for the columns 1 + w, 5 + w, ... only. */
-  /* MODE (updates whose step 5 stored P_ij per slice, kernels_limiter_stage0.hpp; V_unlimited and the flags are
-   * required then): the sweep runs as three launches over all slices,
-   *   kHoLight   slices of which step 5 stored nothing: fetch l_ij / l_ji; if nothing is limited take V_i and finish
-   *              -- a kernel of 20 registers at full occupancy --, otherwise leave the slice to the launches behind
-   *              (todo = 2: limited through a neighbour's l_ji alone). Slices with a complete P_ij are passed on
-   *              unseen (todo = 1), slices stored from some column on are limited for sure (todo = 2);
-   *   k_pij_repair  forms and stores what is missing of the P_ij of the slices with todo = 2;
-   *   kHoHeavy   waves of finished slices retire at once; the others run the sweep on the stored P_ij.
-   * kHoPlain: the whole sweep in one launch (P_ij stored everywhere).
-   * With V_i the new state is formed as V_i - sum_j (1 - l_ij) lambda P_ij over the (slice, column) tiles in which
-   * some pair is limited -- the terms of all other tiles are exact zeros, and P_ij is read for those tiles only,
-   * once, for the sum and for the second limiter pass. Against U_i^low + sum_j l_ij lambda P_ij in column order
-   * (the reference, :1107-1131, and the variant without V_i below) this is another rounding of the same sum:
-   * differences of a few ulp of lambda |P_ij|, orders inside the 1e-11 contract on the new state. */
-  constexpr int kHoPlain = 0, kHoLight = 1, kHoHeavy = 2;
-
-  template <typename E, int MAXW, int CP, bool SPLIT, int MODE>
+  /* With V_i (V_unlimited != NULL: step 5 left V_i = U_i^low + sum_j lambda P_ij, accumulated as the reference
+   * accumulates the update when every l_ij is 1) a slice without a limited pair takes V_i as it is -- bit for bit
+   * the reference's result -- and never reads P_ij.
+   * T.q != NULL (tile storage: Euler and EulerAEOS without stage vectors): a limited slice forms the new state as
+   * V_i - sum_j (1 - l_ij) lambda P_ij over the tiles in which some pair is limited -- the terms of all other tiles
+   * are exact zeros --, reading P_ij for those tiles only, once, for the sum and for the second limiter pass. Against
+   * U_i^low + sum_j l_ij lambda P_ij in column order (the reference, :1107-1131, and every other path of this
+   * function) this is another rounding of the same sum: a few ulp of lambda |P_ij| where the state is O(1) -- orders
+   * inside the 1e-11 contract on the new state and inside the limiter's own relaxation of its bounds (1e4 eps,
+   * limiter.template.h:24-27). Not for shallow water: there l = 0 has to return U_i^low = 0 exactly on a dry node. */
+  template <typename E, int MAXW, int CP, bool SPLIT>
   RYUJIN_DEV void next_cached_slice(const typename E::Params &P, const DeviceMesh &M, const RowCtx &r,
                                     const uint32_t group, double *__restrict__ new_U,
-                                    const double *__restrict__ bounds, double *__restrict__ pij,
+                                    const double *__restrict__ bounds, const double *__restrict__ pij,
                                     const double *__restrict__ lij, double *__restrict__ lij_next,
-                                    const double *__restrict__ V_unlimited, const Stage0Src &S0, const SliceFlags &W,
-                                    const uint32_t todo = 1)
+                                    const double *__restrict__ V_unlimited, DeviceScalars *__restrict__ scalars,
+                                    uint8_t *__restrict__ slice_unlimited, const TileSrc &T)
   {
     constexpr int K = E::K;
     constexpr int NB = E::NB;
     static_assert(!SPLIT || CP == MAXW, "the split variant caches the whole row");
-    static_assert(!(SPLIT && MODE != kHoPlain), "small meshes keep the stored P_ij");
     const bool row_active = r.len > 1;
     const uint32_t i = row_active ? r.row : (r.row < M.n_owned ? r.row : M.n_owned - 1);
     const uint32_t *__restrict__ idx_t = M.idx_t;
+    const bool tiles = T.q != nullptr;
+    const double *__restrict__ src = tiles ? T.q : pij;
 
     double l[MAXW];
-    if constexpr (MODE == kHoLight) {
-      bool limited = false;
-#pragma unroll
-      for (int c = 1; c < MAXW; ++c) {
-        if ((uint32_t)c < r.width) {
-          const uint32_t pos = (uint32_t)(((uint64_t)r.base + c) * 64 + r.lane);
-          const double l_a = lij[pos];
-          const double l_b = lij[idx_t[pos]];
-          /* (NaN counts as limited: !(l == 1), not l != 1 through fmin, which drops a NaN operand) */
-          limited = limited || (row_active && (uint32_t)c < r.len && !(l_a == 1. && l_b == 1.));
-        }
-      }
-      const bool slice_limited = __any(limited);
-      if ((r.slice & 15u) == 0 && r.lane == 0) {
-        atomicAdd(&S0.scalars->n_sampled_slices, 1u);
-        if (slice_limited)
-          atomicAdd(&S0.scalars->n_sampled_limited, 1u);
-      }
-      if (r.lane == 0) {
-        W.todo[r.slice] = slice_limited ? 3 : 0; /* 3: limited, nothing stored, and counted above */
-        if (!slice_limited)
-          W.unlimited[r.slice] = 1;
-      }
-      if (!slice_limited && row_active) {
-        double V_i[K];
-        load_state<K>(V_unlimited, i, V_i);
-        store_state<K>(new_U, i, V_i);
-#pragma unroll
-        for (int c = 1; c < MAXW; ++c)
-          if ((uint32_t)c < r.len)
-            st_stream(lij_next + ((r.base + c) * 64 + r.lane), 0.);
-      }
-      return;
-    }
-
     double U_i_new[K];
     const double lambda = 1. / (double)(r.len - 1);
     const size_t stride = M.bounds_stride;
@@ -759,11 +771,16 @@ namespace ryujin_hip
 
     double p[CP][K];
     uint32_t needed = 0; /* wave-uniform: bit c <=> some pair of the (slice, column) tile is limited */
+    uint32_t own = 0xffffffffu; /* wave-uniform: bit c <=> the slice's own tile of column c is stored */
+    double factor = 1.;
+    auto load_P = [&](const int c, double (&out)[K]) {
+      if (tiles)
+        load_tile<K>(M, src, (uint64_t)r.base + c, r.lane, (own >> c) & 1u, factor, out);
+      else
+        load_entry<K>(src, (uint64_t)r.base + c, r.lane, out);
+    };
     if (V_unlimited != nullptr) {
-      /* Step 5 left V_i = U_i^low + sum_j lambda P_ij, accumulated exactly as the reference accumulates the update
-       * when every l_ij is 1 (k_lij_stage0). If no pair of the slice was limited -- wave-uniform -- that IS the
-       * new U_i bit for bit, the second pass stores (1 - l) l' = 0, and P_ij is not read at all. */
-      bool limited = false;
+      uint32_t own_seen = 0;
 #pragma unroll
       for (int c = 1; c < MAXW; ++c) {
         l[c] = 1.;
@@ -772,24 +789,33 @@ namespace ryujin_hip
           const double l_a = lij[pos];
           const double l_b = lij[idx_t[pos]];
           const bool lane_on = row_active && (uint32_t)c < r.len;
-          const bool lim = lane_on && !(l_a == 1. && l_b == 1.);
+          /* (NaN counts as limited: !(l == 1), and lmin propagates it) */
           l[c] = lane_on ? lmin(l_a, l_b) : 1.;
-          limited = limited || lim;
-          if (__any(lim))
+          if (__any(lane_on && !(l_a == 1. && l_b == 1.)))
             needed |= 1u << c;
+          if (__any(lane_on && !(l_a == 1.)))
+            own_seen |= 1u << c;
         }
       }
       const bool slice_limited = needed != 0u;
-      (void)limited;
-      /* (slices the light launch found limited, todo = 3, were counted there) */
-      if (S0.scalars != nullptr && (r.slice & 15u) == 0 && r.lane == 0 && (!SPLIT || group == 0) &&
-          !(MODE == kHoHeavy && todo == 3)) {
-        atomicAdd(&S0.scalars->n_sampled_slices, 1u);
+      if (scalars != nullptr && (r.slice & 15u) == 0 && r.lane == 0 && (!SPLIT || group == 0)) {
+        atomicAdd(&scalars->n_sampled_slices, 1u);
         if (slice_limited)
-          atomicAdd(&S0.scalars->n_sampled_limited, 1u);
+          atomicAdd(&scalars->n_sampled_limited, 1u);
+        if ((r.slice & 63u) == 0) { /* tile statistics (diagnostics): every 64th slice */
+          atomicAdd(&scalars->n_sampled_tiles, (unsigned int)(r.width - 1));
+          atomicAdd(&scalars->n_sampled_tiles_limited, (unsigned int)__popc(needed));
+          atomicAdd(&scalars->n_sampled_tiles_stored, (unsigned int)__popc(own_seen));
+        }
       }
-      if (W.unlimited != nullptr && r.lane == 0 && (!SPLIT || group == 0))
-        W.unlimited[r.slice] = slice_limited ? 0 : 1;
+      if (slice_unlimited != nullptr && r.lane == 0 && (!SPLIT || group == 0))
+        slice_unlimited[r.slice] = slice_limited ? 0 : 1;
+      if (tiles) {
+        own = r.slice < T.n_export_slices ? 0xffffffffu : own_seen;
+        if (r.lane == 0 && slice_limited)
+          T.tile_own[r.slice] = own;
+        factor = T.scalars->tau * M.mi_inv[i] * (double)(r.len - 1);
+      }
       load_state<K>(V_unlimited, i, U_i_new);
       if (!slice_limited) {
         if (row_active) {
@@ -802,29 +828,65 @@ namespace ryujin_hip
         }
         return;
       }
-      /* U_i = V_i - sum over the limited tiles of (1 - l_ij) lambda P_ij: P_ij of those tiles only */
+      if (tiles) {
 #pragma unroll
-      for (int c = 1; c < CP; ++c) {
-#pragma unroll
-        for (int q = 0; q < K; ++q)
-          p[c][q] = 0.;
-        if ((needed >> c) & 1u)
-          load_entry<K>(pij, (uint64_t)r.base + c, r.lane, p[c]);
-      }
-#pragma unroll
-      for (int c = 1; c < MAXW; ++c) {
-        if (!((needed >> c) & 1u))
-          continue;
-        if (c < CP) {
+        for (int c = 1; c < CP; ++c) {
 #pragma unroll
           for (int q = 0; q < K; ++q)
-            U_i_new[q] -= (1. - l[c]) * lambda * p[c < CP ? c : 0][q];
-        } else {
-          double pt[K];
-          load_entry<K>(pij, (uint64_t)r.base + c, r.lane, pt);
+            p[c][q] = 0.;
+          if ((needed >> c) & 1u)
+            load_P(c, p[c]);
+        }
+#pragma unroll
+        for (int c = 1; c < MAXW; ++c) {
+          if (!((needed >> c) & 1u))
+            continue;
+          /* (a pair with l = 1 adds an exact zero; its tile entry may hold nothing: not touched) */
+          if (c < CP) {
+            if (!(l[c] == 1.)) {
+#pragma unroll
+              for (int q = 0; q < K; ++q)
+                U_i_new[q] -= (1. - l[c]) * lambda * p[c < CP ? c : 0][q];
+            }
+          } else {
+            double pt[K];
+            load_P(c, pt);
+            if (!(l[c] == 1.)) {
+#pragma unroll
+              for (int q = 0; q < K; ++q)
+                U_i_new[q] -= (1. - l[c]) * lambda * pt[q];
+            }
+          }
+        }
+      } else {
+        /* the full matrix of the other updates (stage vectors, shallow water, ...): the reference's sum in the
+         * reference's order -- with l = 0 it returns U_i^low exactly, which a dry state relies on */
+        load_state<K>(new_U, i, U_i_new);
+#pragma unroll
+        for (int c = 1; c < CP; ++c) {
 #pragma unroll
           for (int q = 0; q < K; ++q)
-            U_i_new[q] -= (1. - l[c]) * lambda * pt[q];
+            p[c][q] = 0.;
+          if ((uint32_t)c < r.width)
+            load_entry<K>(src, (uint64_t)r.base + c, r.lane, p[c]);
+        }
+#pragma unroll
+        for (int c = 1; c < MAXW; ++c) {
+          if (c < CP) {
+            if (row_active && (uint32_t)c < r.len) {
+#pragma unroll
+              for (int q = 0; q < K; ++q)
+                U_i_new[q] += l[c] * lambda * p[c < CP ? c : 0][q];
+            }
+          } else if ((uint32_t)c < r.width) {
+            double pt[K];
+            load_entry<K>(src, (uint64_t)r.base + c, r.lane, pt);
+            if (row_active && (uint32_t)c < r.len) {
+#pragma unroll
+              for (int q = 0; q < K; ++q)
+                U_i_new[q] += l[c] * lambda * pt[q];
+            }
+          }
         }
       }
     } else {
@@ -844,7 +906,7 @@ namespace ryujin_hip
           const double l_b = lij[idx_t[pos]];
           l[c] = lmin(l_a, l_b);
           if (c < CP)
-            load_entry<K>(pij, colbase, r.lane, p[c < CP ? c : 0]);
+            load_entry<K>(src, colbase, r.lane, p[c < CP ? c : 0]);
           if (__any(row_active && (uint32_t)c < r.len && !(l[c] == 1.)))
             needed |= 1u << c;
         }
@@ -859,7 +921,7 @@ namespace ryujin_hip
           }
         } else if ((uint32_t)c < r.width) {
           double pt[K];
-          load_entry<K>(pij, (uint64_t)r.base + c, r.lane, pt);
+          load_entry<K>(src, (uint64_t)r.base + c, r.lane, pt);
           if (row_active && (uint32_t)c < r.len) {
 #pragma unroll
             for (int q = 0; q < K; ++q)
@@ -896,9 +958,13 @@ namespace ryujin_hip
         for (int q = 0; q < K; ++q)
           pc[q] = p[c < CP ? c : 0][q];
       } else {
-        load_entry<K>(pij, (uint64_t)r.base + c, r.lane, pc);
+        load_P(c, pc);
       }
       if (lane_on) {
+        if (l[c] == 1.) { /* (1 - l) l' = 0 whatever l' is; the tile entry may hold nothing */
+          st_stream(lij_next + ((r.base + c) * 64 + r.lane), 0.);
+          continue;
+        }
         double new_p_ij[K];
 #pragma unroll
         for (int q = 0; q < K; ++q)
@@ -919,7 +985,7 @@ namespace ryujin_hip
       const uint64_t pos = colbase * 64 + r.lane;
       const double old_l_ij = lmin(lij[pos], lij[idx_t[pos]]);
       double p_ij[K], new_p_ij[K];
-      load_entry<K>(pij, colbase, r.lane, p_ij);
+      load_P((int)c, p_ij);
 #pragma unroll
       for (int q = 0; q < K; ++q)
         new_p_ij[q] = (1. - old_l_ij) * p_ij[q];
@@ -929,60 +995,27 @@ namespace ryujin_hip
     }
   }
 
-  /* the launch between the light and the heavy one: completes the P_ij of the slices the light launch marked */
-  template <typename E>
-  __global__ void __launch_bounds__(kBlock)
-  k_pij_repair(const DeviceMesh M, const Stage0Src S0, double *__restrict__ pij, const SliceFlags W)
-  {
-    const uint32_t slice = M.slice_begin + blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-    if (slice >= M.slice_end || W.todo[slice] < 2)
-      return;
-    const uint32_t fs = W.first_stored[slice];
-    const RowCtx r = row_context_of_slice(M, slice);
-    backfill_pij<E::K>(M, S0, r, pij, fs == 0 ? 0xffffffffu : fs);
-    if (r.lane == 0)
-      W.first_stored[slice] = 1;
-  }
-
-  template <typename E, int MAXW, int CP = MAXW, bool SPLIT = false, int MODE = kHoPlain>
+  template <typename E, int MAXW, int CP = MAXW, bool SPLIT = false>
   __global__ void __launch_bounds__(kBlock, (MAXW > 9 ? (CP < MAXW ? RYUJIN_OCC_HO_3D : 1) : RYUJIN_OCC_HO))
   k_high_order_next_cached(const typename E::Params P, const DeviceMesh M, double *__restrict__ new_U,
-                           const double *__restrict__ bounds, double *__restrict__ pij,
+                           const double *__restrict__ bounds, const double *__restrict__ pij,
                            const double *__restrict__ lij, double *__restrict__ lij_next,
-                           const double *__restrict__ V_unlimited = nullptr, const Stage0Src S0 = Stage0Src{},
-                           const SliceFlags W = SliceFlags{})
+                           const double *__restrict__ V_unlimited = nullptr,
+                           DeviceScalars *__restrict__ scalars = nullptr,
+                           uint8_t *__restrict__ slice_unlimited = nullptr, const TileSrc T = TileSrc{})
   {
     RowCtx r;
     const uint32_t group = SPLIT ? (threadIdx.x >> 6) : 0u;
-    uint32_t todo = 1;
     if constexpr (SPLIT) { /* one slice per block (uniform over the block: the barrier in the body is safe) */
       if (M.slice_begin + blockIdx.x >= M.slice_end)
         return;
       r = row_context_of_slice(M, M.slice_begin + blockIdx.x);
-    } else if constexpr (MODE != kHoPlain) {
-      /* the flag first: most waves of a developed flow retire on it */
-      const uint32_t slice = M.slice_begin + blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-      if (slice >= M.slice_end)
-        return;
-      if constexpr (MODE == kHoLight) {
-        const uint32_t fs = W.first_stored[slice];
-        if (fs != 0) { /* complete (1), or stored from the column on whose l_ij came out limited */
-          if ((threadIdx.x & 63) == 0)
-            W.todo[slice] = fs == 1 ? 1 : 2;
-          return;
-        }
-      } else {
-        todo = W.todo[slice];
-        if (todo == 0)
-          return;
-      }
-      r = row_context_of_slice(M, slice);
     } else {
       r = row_context(M);
       if (!r.valid)
         return;
     }
-    next_cached_slice<E, MAXW, CP, SPLIT, MODE>(P, M, r, group, new_U, bounds, pij, lij, lij_next, V_unlimited, S0,
-                                                W, todo);
+    next_cached_slice<E, MAXW, CP, SPLIT>(P, M, r, group, new_U, bounds, pij, lij, lij_next, V_unlimited, scalars,
+                                          slice_unlimited, T);
   }
 } // namespace ryujin_hip

@@ -264,14 +264,16 @@ class HyperbolicModule:
 
     def limiter_statistics(self) -> dict:
         """Fraction of the 64-row slices in which the first high-order sweep found a limited pair (between the two
-        latest host synchronisations), how the latest step kept P_ij ("everywhere" / "per slice") and the fraction
-        of slices it was stored in (ryujin_hip_limiter_statistics; device backend only)."""
-        f, stored, fs = C.c_double(1.0), C.c_int(1), C.c_double(1.0)
+        latest host synchronisations), how the latest step kept P_ij ("all" / "tiles"), the fraction of (slice,
+        column) tiles with a limited pair and the fraction step 5 stored (ryujin_hip_limiter_statistics; device
+        backend only)."""
+        f, stored, ft, fs = C.c_double(1.0), C.c_int(1), C.c_double(1.0), C.c_double(1.0)
         fn = self._f("limiter_statistics")
-        fn.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double)]
-        self._check(fn(self._ctx, C.byref(f), C.byref(stored), C.byref(fs)))
-        return dict(limited_slice_fraction=f.value, pij_stored={1: "everywhere", 2: "per slice"}.get(stored.value),
-                    pij_stored_slice_fraction=fs.value)
+        fn.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double),
+                       C.POINTER(C.c_double)]
+        self._check(fn(self._ctx, C.byref(f), C.byref(stored), C.byref(ft), C.byref(fs)))
+        return dict(limited_slice_fraction=f.value, pij_stored={1: "all", 2: "tiles"}.get(stored.value),
+                    limited_tile_fraction=ft.value, stored_tile_fraction=fs.value)
 
     def debug_fetch(self, what: str) -> np.ndarray:
         """`*_all`: over all locally relevant rows, i.e. including the ghost rows / ghost range received from

@@ -251,7 +251,7 @@ def test_device_pow_accuracy():
 
 
 @pytest.mark.parametrize("n_ranks,mode", [(2, ""), (3, ""), (3, "join_exchanges"), (3, "bc_launch"),
-                                          (3, "system_events"), (3, "per_slice_pij")])
+                                          (3, "system_events"), (3, "tile_pij")])
 def test_partitioned_hip_matches_single_rank(n_ranks, mode, monkeypatch):
     """Multi-rank code path of the library on ONE GPU: n contexts (one host thread each) own x-slabs of
     the mesh and exchange ghosts through the in-process transport (ryujin_hip_comm_init_local), which
@@ -261,7 +261,8 @@ def test_partitioned_hip_matches_single_rank(n_ranks, mode, monkeypatch):
     choreography of an asymmetric stencil (every sweep joins the exchanges); "bc_launch": boundary
     conditions as a launch of their own in front of the pre-pass (large meshes); "system_events": the events
     between the two streams created with the system-scope fence (ryujin_hip_params::system_scope_events);
-    "per_slice_pij": the kernels of large meshes with P_ij stored per 64-row slice and no slice predicted limited."""
+    "tile_pij": the kernels of large meshes -- step 5 stores only the (slice, column) tiles of P_ij steps 6 and 7 read,
+    every tile in the export slices (the transpose of a ghost column lives on another rank)."""
     import ctypes as C
     import threading
 
@@ -271,9 +272,9 @@ def test_partitioned_hip_matches_single_rank(n_ranks, mode, monkeypatch):
         monkeypatch.setattr(HyperbolicModule, "library_switches", {"debug_bc_fold_max_slices": -1})
     elif mode == "system_events":
         monkeypatch.setattr(HyperbolicModule, "library_switches", {"system_scope_events": 1})
-    elif mode == "per_slice_pij":  # nothing predicted: trigger, repair prologue, two-launch step 6 in both parts
+    elif mode == "tile_pij":  # the kernels of large meshes: tile storage of P_ij, export slices store every tile
         monkeypatch.setattr(HyperbolicModule, "library_switches",
-                            {"debug_pij_storage": 1, "debug_no_small_mesh_split": 1, "debug_bc_fold_max_slices": -1})
+                            {"debug_no_small_mesh_split": 1, "debug_bc_fold_max_slices": -1})
 
     lib = capi.load_hip()
     cpu, n_updates = 40, 6
@@ -1585,24 +1586,24 @@ def test_unstructured_p1_mesh_scalar_conservation(oracle):
 
 
 @pytest.mark.parametrize("which", ["euler_2d", "euler_1d", "euler_erk33", "sw_2d", "sw_1d", "aeos_2d", "scalar_2d",
-                                   "euler_2d:no_prediction", "euler_1d:no_prediction", "euler_erk33:no_prediction",
-                                   "aeos_2d:no_prediction", "euler_2d:always_store", "aeos_2d:always_store"])
+                                   "euler_2d:full_matrix", "euler_1d:full_matrix", "euler_erk33:full_matrix",
+                                   "aeos_2d:full_matrix"])
 def test_step_parity_with_the_kernels_of_large_meshes(oracle, monkeypatch, which):
     """The meshes of this file do not fill an MI355X, so they take the small-mesh branches of the library
     (boundary conditions folded into the pre-pass, steps 5 and 6 with the columns of a slice spread over several
     waves). Re-run one case per Description with those branches switched off: the kernels BASELINE-sized meshes
     run (also covered at full size for Euler and shallow water in test_gpu_parity_fullsize.py).
-    An update without stage vectors stores P_ij per 64-row slice there (kernels_limiter_stage0.hpp): where the slice
-    held a limited pair in the previous update -- the first update of a context stores everywhere --, or where one
-    of its own l_ij comes out limited (stored from that column on, the columns before it formed a second time);
-    a slice limited through a neighbour's l_ji alone gets its P_ij from the repair prologue of step 6, which runs as a
-    light and a heavy launch. `:no_prediction` predicts no slice limited (every stored slice goes through the
-    trigger or the repair prologue), `:always_store` all of them. The P_ij the comparison fetches is what the sweeps
-    stored, completed through the same device function for the slices they left out (ryujin_hip_debug_fetch)."""
+    An update of Euler / EulerAEOS without stage vectors keeps P_ij in the tile storage there
+    (kernels_limiter.hpp, TileSrc): step 5 stores the bracket Q_ij of a (slice, column) tile only where one of its own
+    l_ij comes out below 1, steps 6 and 7 form U_i = V_i - sum (1 - l_ij) lambda P_ij over the limited pairs and take a
+    pair that is limited through the neighbour's l_ji alone from the neighbour's tile with the opposite sign. The
+    P_ij the comparison fetches is assembled the way those sweeps read it (own tile, transposed tile; pij_stage0() of
+    the operands for the pairs nobody reads). `:full_matrix` switches the tile storage off (all of P_ij stored, as
+    every other kind of update does)."""
     switches = {"debug_no_small_mesh_split": 1, "debug_bc_fold_max_slices": -1}
     which, _, variant = which.partition(":")
-    if variant:
-        switches["debug_pij_storage"] = {"no_prediction": 1, "always_store": -1}[variant]
+    if variant == "full_matrix":
+        switches["debug_pij_storage"] = -1
     monkeypatch.setattr(HyperbolicModule, "library_switches", switches)
     {
         "euler_2d": lambda: test_step_parity_2d_step_geometry(oracle),
