@@ -739,8 +739,8 @@ def main():
     if equation in (capi.EQ_EULER, capi.EQ_EULER_AEOS):
         own["4 low_order"] -= 8 * k * S
         own["5 pij_lij"] += -8 * k * S + 8 * S + 8 * k + 8 * k  # - first part; + m_ij, F_i read, V_i written
-        # of P_ij the tiles steps 6/7 read are written (counted by the library over the instrumented pass)
-        own["5 pij_lij"] -= (1.0 - limiter["stored_tile_fraction"]) * 8 * k * S
+        # P_ij is written in the slices steps 6/7 read it in (counted by the library over the instrumented pass)
+        own["5 pij_lij"] -= (1.0 - limiter["pij_stored_slice_fraction"]) * 8 * k * S
     dom_gbs = own[dom] * n_q_local / (per_sweep[dom] * 1e-3) / 1e9
     ref_gbs = alg[dom] * n_q_local / (per_sweep[dom] * 1e-3) / 1e9
 

@@ -155,13 +155,24 @@ typedef struct ryujin_hip_params {
    *   debug_join_exchanges != 0: every sweep joins the ghost exchanges (the choreography of a non-symmetric
    *   stencil); debug_bc_fold_max_slices: boundary conditions ride on the pre-pass kernel up to n slices of
    *   64 rows (0 = default 4096, < 0 = always a launch of their own); debug_no_small_mesh_split != 0: meshes
-   *   that do not fill the device run the same step-5/6 kernels as large ones; debug_pij_storage: < 0: an
-   *   update without stage vectors stores all of the matrix P_ij instead of the tiles steps 6 and 7 read. */
+   *   that do not fill the device run the same step-5/6 kernels as large ones; debug_pij_storage: the matrix
+   *   P_ij of an update without stage vectors is stored everywhere, or -- while few 64-row slices hold a limited
+   *   pair -- per slice: where the slice held a limited pair in the previous update or one of its own l_ij comes
+   *   out limited, the rest completed where step 6 needs it (0: chosen from the measured fraction); > 0: always
+   *   per slice and no slice predicted limited (every stored slice goes through the trigger in step 5 or the
+   *   repair launch of step 6), < 0: always stored everywhere. */
   int system_scope_events;
   int debug_join_exchanges;
   int debug_bc_fold_max_slices;
   int debug_no_small_mesh_split;
   int debug_pij_storage;
+  /* != 0: the reference's EXPENSIVE_BOUNDS_CHECK build (CMakeLists.txt / compile_time_options.h.in:13-16) as a
+   * run-time option of the Euler Description: View::is_admissible() on every new state after steps 4, 6 and 7
+   * (hyperbolic_module.template.h:851-855,1121-1126), the limiter's checked control flow -- its additional
+   * high-order density and entropy checks (limiter.template.h:110-134,244-252,291-322) -- and the second limiter
+   * pass's `success` counted (:1155-1161): any of them raises the restart flag. Evaluated by separate kernels
+   * between the sweeps (P_ij is stored in full then); the l_ij themselves are the same in both control flows. */
+  int debug_expensive_bounds_check;
 } ryujin_hip_params;
 
 /* ---- offline data (input contract) ------------------------------------- */
@@ -380,13 +391,13 @@ int ryujin_hip_get_cfl(ryujin_hip_ctx *ctx, double *cfl);
 int ryujin_hip_set_id_violation_strategy(ryujin_hip_ctx *ctx, int strategy);
 int ryujin_hip_get_alpha(ryujin_hip_ctx *ctx, double *alpha /* [n_relevant] */);
 int ryujin_hip_get_counters(ryujin_hip_ctx *ctx, unsigned *n_restarts, unsigned *n_warnings);
-/* What the data-dependent limiter sweeps saw between the two latest host synchronisations (sampled): the fraction of
- * 64-row slices in which the first high-order sweep found a limited pair; how the latest step kept the matrix P_ij
- * (hyperbolic_module.template.h:795-846): 1 all of it, 2 tile storage -- only the (slice, column) tiles steps 6 and
- * 7 read; the fraction of tiles that hold a limited pair and the fraction step 5 stored.
- * Diagnostics; any pointer may be NULL. */
+/* What the data-dependent limiter sweeps saw between the two latest host synchronisations: the fraction of
+ * (sampled) 64-row slices in which the first high-order sweep found a limited pair; how the latest step kept the
+ * matrix P_ij (hyperbolic_module.template.h:795-846): 1 stored everywhere, 2 stored per slice -- only where steps
+ * 6 and 7 read it; and the fraction of slices it was stored in. The results are the same bit for bit whatever is
+ * stored. Diagnostics; any pointer may be NULL. */
 int ryujin_hip_limiter_statistics(ryujin_hip_ctx *ctx, double *limited_slice_fraction, int *pij_stored,
-                                  double *limited_tile_fraction, double *stored_tile_fraction);
+                                  double *stored_slice_fraction);
 
 /* ---- introspection for parity tests and profiling ------------------------ */
 /* Module-owned intermediates of the LAST step() in the reference's logical
@@ -429,6 +440,8 @@ int ryujin_hip_debug_pow(int device, const double *x, const double *y, double *o
  *                                 tests/euler/riemann_solver.cc:79-98)
  *   RYUJIN_DEBUG_EULER_LIMIT_1D  in: bounds[3], U[3], P[3] (dim = 1)        out: l, success, took the Newton tail
  *                                (Limiter::limit, limiter.template.h:15-327; tests/euler/limiter.cc:61-139)
+ *   RYUJIN_DEBUG_EULER_LIMIT_CHECKED_1D  the same through the EXPENSIVE_BOUNDS_CHECK control flow (the build that
+ *                                wrote tests/euler/limiter.output)           out: l, success, 0
  *   RYUJIN_DEBUG_SW_RIEMANN      in: rd_i[3], rd_j[3] = (h, u, a)           out: h_star, lambda_max
  *                                (shallow_water/riemann_solver.template.h:110-251;
  *                                 tests/shallow_water/riemann_solver.cc:75-77)
@@ -459,7 +472,8 @@ enum {
   /* EulerAEOS d_ij from two states (dim = 2; p from the equation of state): in U_i[4], U_j[4], c_ij[2], out d_ij --
    * in the reference's operation order and through the per-node Riemann records the sweep uses */
   RYUJIN_DEBUG_AEOS_DIJ_2D = 13,
-  RYUJIN_DEBUG_AEOS_DIJ_RECORDS_2D = 14
+  RYUJIN_DEBUG_AEOS_DIJ_RECORDS_2D = 14,
+  RYUJIN_DEBUG_EULER_LIMIT_CHECKED_1D = 15
 };
 int ryujin_hip_debug_function(int device, const ryujin_hip_params *params, int which, const double *in,
                               double *out, size_t n);

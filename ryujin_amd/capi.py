@@ -34,6 +34,7 @@ DEBUG_SW_DIJ_2D, DEBUG_SW_DIJ_RECORDS_2D = 7, 8
 DEBUG_EULER_RIEMANN_RECORDS, DEBUG_SW_RIEMANN_RECORDS = 9, 10
 DEBUG_AEOS_RIEMANN, DEBUG_AEOS_LIMIT_1D = 11, 12
 DEBUG_AEOS_DIJ_2D, DEBUG_AEOS_DIJ_RECORDS_2D = 13, 14
+DEBUG_EULER_LIMIT_CHECKED_1D = 15
 
 
 DIRICHLET_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_double, c_double_p)   # ryujin_hip_dirichlet_fn
@@ -65,7 +66,7 @@ class Params(C.Structure):
         # run-time switches of the library (no ParameterAcceptor counterpart; 0 = default)
         ("system_scope_events", C.c_int), ("debug_join_exchanges", C.c_int),
         ("debug_bc_fold_max_slices", C.c_int), ("debug_no_small_mesh_split", C.c_int),
-        ("debug_pij_storage", C.c_int),
+        ("debug_pij_storage", C.c_int), ("debug_expensive_bounds_check", C.c_int),
     ]
 
 

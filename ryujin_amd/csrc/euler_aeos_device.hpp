@@ -33,6 +33,9 @@ namespace ryujin_hip
     static constexpr int K = DIM + 2;
     static constexpr int NB = 4;    /* rho_min, rho_max, s_min, gamma_min: limiter.h:111 */
     static constexpr bool kFusablePrecompute = false; /* two precomputation cycles, the second over the stencil */
+    /* steps 6/7 may form a limited row's update as V_i - sum (1 - l_ij) lambda P_ij (kernels_limiter.hpp): another
+     * rounding of the reference's sum. Not where l = 0 has to return the low-order update EXACTLY (a dry node) */
+    static constexpr bool kLimitedUpdateFromV = true;
     static constexpr int NPREC = 4; /* p, gamma_min, s, eta */
     using Params = EulerAeosParams;
 

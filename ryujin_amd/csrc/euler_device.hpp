@@ -285,6 +285,9 @@ namespace ryujin_hip
     /* precompute() and riemann_record() are functions of the row's state alone: the last sweep of a step can
      * leave them behind for the next prepare_state_vector() (FusedPrecompute) */
     static constexpr bool kFusablePrecompute = true;
+    /* steps 6/7 may form a limited row's update as V_i - sum (1 - l_ij) lambda P_ij (kernels_limiter.hpp): another
+     * rounding of the reference's sum. Not where l = 0 has to return the low-order update EXACTLY (a dry node) */
+    static constexpr bool kLimitedUpdateFromV = true;
 
     /* Indicator (entropy-viscosity commutator): indicator.h:187-258 */
     struct Indicator {
@@ -818,6 +821,112 @@ namespace ryujin_hip
         const double dpsi_r = rho_r * drho_e_r + (rho_e_r - gp1 * s_min * rho_r_gamma) * drho;
 
         quadratic_newton_step(t_l, t_r, psi_l, psi_r, dpsi_l, dpsi_r, -1.);
+      }
+      return t_l;
+    }
+
+    /* View::is_admissible (hyperbolic_system.h:955-979): rho > 0, e > 0, s > 0 */
+    static RYUJIN_DEV bool is_admissible(const EulerParams &P, const double (&U)[K])
+    {
+      return U[0] > 0. && internal_energy(U) > 0. && specific_entropy(P, U) > 0.;
+    }
+
+    /* limiter.template.h:15-327 in the EXPENSIVE_BOUNDS_CHECK control flow (the reference's checked builds, and
+     * the build that wrote tests/euler/limiter.output): the high-order density check behind the clip (:110-134), no
+     * "psi_r > 0" shortcut in front of psi_l (:183-217 against :244-252), the final check of the limited state
+     * (:291-322). Same t_l as limit(); `success` has more ways to be false. Debug kernels only
+     * (ryujin_hip_params::debug_expensive_bounds_check, RYUJIN_DEBUG_EULER_LIMIT_CHECKED_1D). */
+    static RYUJIN_DEV double limit_checked(const EulerParams &P, const double (&bnd)[NB], const double (&U)[K],
+                                           const double (&Pij)[K], bool &success)
+    {
+      const double rho_min = bnd[0], rho_max = bnd[1], s_min = bnd[2];
+      constexpr double t_min = 0., t_max = 1.;
+      success = true;
+      double t_r = t_max;
+      constexpr double eps = DBL_EPSILON;
+      const double relax_small = 1. + P.vacuum_small * eps;
+      const double relax = 1. + P.vacuum_large * eps;
+      {
+        const double rho_U = U[0];
+        const double rho_P = Pij[0];
+        const double test_min = filter_vacuum_density(P, fmax(0., rho_U - relax * rho_max));
+        const double test_max = filter_vacuum_density(P, fmax(0., rho_min - relax * rho_U));
+        if (!(test_min == 0. && test_max == 0.))
+          success = false;
+        const double denominator = 1. / (fabs(rho_P) + eps * rho_max);
+        t_r = rho_max < rho_U + t_r * rho_P ? (rho_max - rho_U) * denominator : t_r;
+        t_r = rho_U + t_r * rho_P < rho_min ? (rho_U - rho_min) * denominator : t_r;
+        t_r = fmin(t_r, t_max);
+        t_r = fmax(t_r, t_min);
+        const double rho_new = U[0] + t_r * Pij[0];
+        const double test_new_min = filter_vacuum_density(P, fmax(0., rho_new - relax * rho_max));
+        const double test_new_max = filter_vacuum_density(P, fmax(0., rho_min - relax * rho_new));
+        if (!(test_new_min == 0. && test_new_max == 0.))
+          success = false;
+      }
+      double t_l = t_min;
+      const double gamma = P.gamma;
+      const double gp1 = gamma + 1.;
+      for (int n = 0; n < P.lim_newton_max_iterations; ++n) {
+        double U_r[K], U_l[K];
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+          U_r[q] = U[q] + t_r * Pij[q];
+          U_l[q] = U[q] + t_l * Pij[q];
+        }
+        const double rho_r = U_r[0];
+        const double rho_r_gamma = dev_pow(rho_r, gamma);
+        const double rho_e_r = internal_energy(U_r);
+        const double psi_r = relax_small * rho_r * rho_e_r - s_min * rho_r * rho_r_gamma;
+        const double rho_l = U_l[0];
+        const double rho_l_gamma = dev_pow(rho_l, gamma);
+        const double rho_e_l = internal_energy(U_l);
+        const double psi_l = relax_small * rho_l * rho_e_l - s_min * rho_l * rho_l_gamma;
+        const double lower_bound = (1. - relax) * s_min * rho_l * rho_l_gamma;
+        if (n == 0 && !(fmin(0., psi_l - lower_bound) == 0.))
+          success = false;
+        t_l = psi_r > 0. ? t_r : t_l;
+        if (fmax(0., t_r - t_l - P.lim_newton_tolerance) == 0.)
+          break;
+        const double drho = Pij[0];
+        double drho_e[2];
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+          const double(&V)[K] = side == 0 ? U_l : U_r;
+          const double rho_inverse = 1. / V[0];
+          double u[DIM];
+#pragma unroll
+          for (int d = 0; d < DIM; ++d)
+            u[d] = V[1 + d] * rho_inverse;
+          double u2 = u[0] * u[0];
+#pragma unroll
+          for (int d = 1; d < DIM; ++d)
+            u2 += u[d] * u[d];
+          double sum = (0.5 * u2) * Pij[0];
+#pragma unroll
+          for (int d = 0; d < DIM; ++d)
+            sum += (-u[d]) * Pij[1 + d];
+          sum += 1. * Pij[1 + DIM];
+          drho_e[side] = sum;
+        }
+        const double dpsi_l = rho_l * drho_e[0] + (rho_e_l - gp1 * s_min * rho_l_gamma) * drho;
+        const double dpsi_r = rho_r * drho_e[1] + (rho_e_r - gp1 * s_min * rho_r_gamma) * drho;
+        quadratic_newton_step(t_l, t_r, psi_l, psi_r, dpsi_l, dpsi_r, -1.);
+      }
+      {
+        double U_new[K];
+#pragma unroll
+        for (int q = 0; q < K; ++q)
+          U_new[q] = U[q] + t_l * Pij[q];
+        const double rho_new = U_new[0];
+        const double rho_new_gamma = dev_pow(rho_new, gamma);
+        const double rho_e_new = internal_energy(U_new);
+        const double psi_new = relax_small * rho_new * rho_e_new - s_min * rho_new * rho_new_gamma;
+        const double lower_bound = (1. - relax) * s_min * rho_new * rho_new_gamma;
+        const bool e_valid = fmin(0., rho_e_new) == 0.;
+        const bool psi_valid = fmin(0., psi_new - lower_bound) == 0.;
+        if (!e_valid || !psi_valid)
+          success = false;
       }
       return t_l;
     }

@@ -17,7 +17,9 @@
 //   k_lij_stage0 (no stage vectors: P_ij formed    step 5  :892-1041
 //     here, kernels_limiter_stage0.hpp) /
 //     k_pij_lij[_recompute]
-//   k_high_order_next_cached / k_high_order<false> step 6  :1053-1182
+//   k_high_order_next_cached (a light and a heavy  step 6  :1053-1182
+//     launch where P_ij is stored per slice)
+//     / k_high_order<false>
 //   k_high_order_last_cached / k_high_order<true>  step 7  :1053-1182
 
 #pragma once
@@ -82,12 +84,10 @@ namespace ryujin_hip
     double tau_in;
     int use_device_tau;
     int stage;
-    /* running counters (never reset on the device; the host takes differences; diagnostics,
-     * ryujin_hip_limiter_statistics): every 16th slice that passes the first high-order sweep and those of them in
-     * which some pair was limited; of every 64th slice the (slice, column) tiles, those that hold a limited pair and
-     * those step 5 stored (an own l_ij < 1) */
-    unsigned int n_sampled_slices, n_sampled_limited;
-    unsigned int n_sampled_tiles, n_sampled_tiles_limited, n_sampled_tiles_stored;
+    /* running counters (never reset on the device; the host takes differences): every 16th slice that passes the
+     * first high-order sweep, those of them in which some pair was limited, and every 16th slice whose P_ij step 5
+     * stored (diagnostics: ryujin_hip_limiter_statistics) */
+    unsigned int n_sampled_slices, n_sampled_limited, n_sampled_stored;
   };
   constexpr int kStageCode = 100;
 
@@ -150,8 +150,11 @@ namespace ryujin_hip
 #ifndef RYUJIN_STAGE0_PIJ
 #define RYUJIN_STAGE0_PIJ 1 /* Euler, stages == 0: P_ij formed once, in step 5 (kernels_limiter_stage0.hpp) */
 #endif
-#ifndef RYUJIN_TILE_PIJ
-#define RYUJIN_TILE_PIJ 1 /* Euler / EulerAEOS, stages == 0, two limiter passes, one wave per slice: step 5 stores the bracket of P_ij only for the (slice, column) tiles steps 6/7 read (kernels_limiter.hpp); 0: all of P_ij */
+#ifndef RYUJIN_PER_SLICE_PIJ
+#define RYUJIN_PER_SLICE_PIJ 1 /* stages == 0, two limiter passes: step 5 stores P_ij only in the slices steps 6/7 will read it in (kernels_limiter_stage0.hpp); 0: everywhere */
+#endif
+#ifndef RYUJIN_PER_SLICE_MAX_LIMITED
+#define RYUJIN_PER_SLICE_MAX_LIMITED 0.5 /* ... while at most this fraction of the slices held a limited pair in the latest measured update */
 #endif
 #ifndef RYUJIN_FUSE_PRECOMPUTE
 #define RYUJIN_FUSE_PRECOMPUTE 1 /* device-resident RK driver: the last sweep of a stage leaves the precomputed values and Riemann records of the next one (FusedPrecompute) */

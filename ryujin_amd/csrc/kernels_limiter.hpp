@@ -45,6 +45,153 @@ namespace ryujin_hip
     }
   }
 
+  /* The undecided pairs of a wave, compacted. limit() -- two Newton iterations, a pow each -- is needed by a few per
+   * cent of the pairs; left to the lane that owns the pair, a wave walks max_lane(#undecided) rounds with a handful
+   * of lanes busy in each (the sweeps spend 10 - 20 % of their time there in a developed flow,
+   * profiles/r04d_ab_tail_and_pow_cost_*). Instead the wave lists its undecided (lane, column) pairs in LDS -- a
+   * ballot per column, no atomics -- and works the list off 64 at a time, every lane taking ANY pair: the row's
+   * bounds and state wait in LDS, P_ij comes from the matrix. Same function on the same
+   * operands, so the same l_ij; ceil(n / 64) rounds instead of max_lane(n_lane).
+   *   queue      this wave's LDS list, capacity (width - 1) * 64 entries of (column << 6 | lane)
+   *   load_P     (column, owning lane, out[K]): the P_ij the limiter is asked about
+   *   emit       (column, owning lane, l): store the result
+   * Returns false if some limit() reported failure. All 64 lanes must call (inactive rows with an empty mask). */
+  template <typename E>
+  struct TailScratch { /* per wave, in LDS */
+    static constexpr int kRowDoubles = (E::NB + E::K) * 64;
+    double rows[kRowDoubles];
+  };
+
+  template <typename E, typename LoadP, typename Emit>
+  RYUJIN_DEV bool limit_undecided_pairs(const typename E::Params &P, const RowCtx &r, unsigned long long undecided_mask,
+                                        const double (&bnd)[E::NB], const double (&U_i_new)[E::K],
+                                        uint16_t *__restrict__ queue, double *__restrict__ rows, const LoadP &load_P,
+                                        const Emit &emit)
+  {
+    constexpr int K = E::K, NB = E::NB;
+#ifndef RYUJIN_COMPACT_TAIL
+#define RYUJIN_COMPACT_TAIL 1 /* 0 (A/B): every lane works its own pairs off, as rounds 1 - 3 did */
+#endif
+#if !RYUJIN_COMPACT_TAIL
+    {
+      bool ok = true;
+      while (undecided_mask) {
+        const uint32_t c = (uint32_t)__builtin_ctzll(undecided_mask);
+        undecided_mask &= undecided_mask - 1;
+        double P_ij[K];
+        load_P(c, r.lane, P_ij);
+        bool success;
+        const double l_ij = E::limit(P, bnd, U_i_new, P_ij, success);
+        emit(c, r.lane, l_ij);
+        ok = ok && success;
+      }
+      return ok;
+    }
+#endif
+    if (!__any(undecided_mask != 0ull))
+      return true;
+    uint32_t total = 0; /* wave-uniform */
+    for (uint32_t c = 1; c < r.width; ++c) {
+      const bool mine = (undecided_mask >> c) & 1ull;
+      const unsigned long long b = __ballot(mine);
+      if (b == 0ull)
+        continue;
+      if (mine)
+        queue[total + (uint32_t)__popcll(b & ((1ull << r.lane) - 1ull))] = (uint16_t)((c << 6) | r.lane);
+      total += (uint32_t)__popcll(b);
+    }
+    /* the rows' bounds and states for whoever takes their pairs ([component][lane]: conflict free) */
+#pragma unroll
+    for (int q = 0; q < NB; ++q)
+      rows[q * 64 + r.lane] = bnd[q];
+#pragma unroll
+    for (int q = 0; q < K; ++q)
+      rows[(NB + q) * 64 + r.lane] = U_i_new[q];
+    __threadfence_block(); /* written and read by different lanes of the wave */
+    bool all_ok = true;
+    for (uint32_t q0 = 0; q0 < total; q0 += 64) {
+      if (q0 + r.lane < total) {
+        const uint32_t e = (uint32_t)queue[q0 + r.lane];
+        const uint32_t c = e >> 6, owner = e & 63u;
+        double b_o[NB], U_o[K];
+#pragma unroll
+        for (int q = 0; q < NB; ++q)
+          b_o[q] = rows[q * 64 + owner];
+#pragma unroll
+        for (int q = 0; q < K; ++q)
+          U_o[q] = rows[(NB + q) * 64 + owner];
+        double P_ij[K];
+        load_P(c, owner, P_ij);
+        bool success;
+        const double l_ij = E::limit(P, b_o, U_o, P_ij, success);
+        emit(c, owner, l_ij);
+        all_ok = all_ok && success;
+      }
+    }
+    return all_ok;
+  }
+
+  /* ---- ryujin_hip_params::debug_expensive_bounds_check (Euler): the reference's EXPENSIVE_BOUNDS_CHECK build as
+   * separate kernels between the sweeps; any violation raises the restart flag. */
+
+  /* View::is_admissible() of every new state (hyperbolic_module.template.h:851-855 behind step 4, :1121-1126 behind
+   * each high-order update) */
+  template <typename E>
+  __global__ void __launch_bounds__(kBlock)
+  k_check_admissible(const typename E::Params P, const DeviceMesh M, DeviceScalars *__restrict__ scalars,
+                     const double *__restrict__ new_U)
+  {
+    const RowCtx r = row_context(M);
+    if (!r.valid)
+      return;
+    bool ok = true;
+    if (r.len > 1) {
+      double U[E::K];
+      load_state<E::K>(new_U, r.row, U);
+      ok = E::is_admissible(P, U);
+    }
+    flag_restart(scalars, ok, r.lane);
+  }
+
+  /* the `success` of the limiter's CHECKED control flow for every pair of one limiter pass: limit(bounds_i, U_i,
+   * scale_ij P_ij) with U_i the state the pass limits (the low-order update for the first pass, the update after
+   * the first pass for the second) and scale_ij = 1 (first pass) or 1 - min(l_ij, l_ji) (second pass: l_first !=
+   * NULL). In the checked builds both passes count (:1031-1034, :1155-1161). */
+  template <typename E>
+  __global__ void __launch_bounds__(kBlock)
+  k_check_limiter(const typename E::Params P, const DeviceMesh M, DeviceScalars *__restrict__ scalars,
+                  const double *__restrict__ U_limited, const double *__restrict__ bounds,
+                  const double *__restrict__ pij, const double *__restrict__ l_first)
+  {
+    constexpr int K = E::K, NB = E::NB;
+    const RowCtx r = row_context(M);
+    if (!r.valid)
+      return;
+    bool ok = true;
+    if (r.len > 1) {
+      double bnd[NB], U[K];
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+        bnd[b] = bounds[(size_t)b * M.bounds_stride + r.row];
+      load_state<K>(U_limited, r.row, U);
+      for (uint32_t c = 1; c < r.len; ++c) {
+        const uint64_t pos = ((uint64_t)r.base + c) * 64 + r.lane;
+        double P_ij[K];
+        load_entry<K>(pij, (uint64_t)r.base + c, r.lane, P_ij);
+        if (l_first != nullptr) {
+          const double l = lmin(l_first[pos], l_first[M.idx_t[pos]]);
+#pragma unroll
+          for (int q = 0; q < K; ++q)
+            P_ij[q] = (1. - l) * P_ij[q];
+        }
+        bool success;
+        E::limit_checked(P, bnd, U, P_ij, success);
+        ok = ok && success;
+      }
+    }
+    flag_restart(scalars, ok, r.lane);
+  }
+
   /* ------------------------------------------------------------------ step 5 */
 
   /* DG: full inverse of the (block-diagonal) consistent mass matrix instead of the Neumann series
@@ -159,18 +306,18 @@ namespace ryujin_hip
       store_state<K>(V_out, i, V_i);
 
     /* the few pairs that need the Newton iteration */
-    while (undecided_mask) {
-      const uint32_t c = (uint32_t)__builtin_ctzll(undecided_mask);
-      undecided_mask &= undecided_mask - 1;
-      const uint64_t colbase = (uint64_t)r.base + c;
-      double P_ij[K];
-      load_entry<K>(pij, colbase, r.lane, P_ij);
-      bool success;
-      const double l_ij = E::limit(P, bnd, U_i_new, P_ij, success);
-      lij[colbase * 64 + r.lane] = l_ij;
-      all_ok = all_ok && success;
-    }
-    flag_restart(scalars, all_ok, r.lane);
+    __shared__ uint16_t tail_queue[kWavesPerBlock * 63 * 64];
+    __shared__ TailScratch<E> tail_rows[kWavesPerBlock];
+    const bool tail_ok = limit_undecided_pairs<E>(
+        P, r, undecided_mask, bnd, U_i_new, tail_queue + (threadIdx.x >> 6) * 63 * 64,
+        tail_rows[threadIdx.x >> 6].rows,
+        [&](const uint32_t c, const uint32_t owner, double (&out)[K]) {
+          load_entry<K>(pij, (uint64_t)r.base + c, owner, out);
+        },
+        [&](const uint32_t c, const uint32_t owner, const double l_ij) {
+          lij[((uint64_t)r.base + c) * 64 + owner] = l_ij;
+        });
+    flag_restart(scalars, all_ok && tail_ok, r.lane);
   }
 
   /* Step 5 for Euler, stages == 0, fused with the first part of P_ij of step 4 (:769-813): instead of
@@ -348,13 +495,9 @@ namespace ryujin_hip
     p.m_j_inv = M.mi_inv[j];
   }
 
-  /* The bracket Q_ij of P_ij = tau / m_i (S - 1) Q_ij for stages == 0. It is antisymmetric BIT FOR BIT, Q_ji = -Q_ij,
-   * wherever m_ij = m_ji bit for bit (d_ij = d_ji after step 3, alpha_i + alpha_j commutes, every product and
-   * difference below changes sign exactly when i and j are exchanged): what row j stores for the pair is what row i
-   * needs, with the other sign -- the tile storage of steps 5 - 7 rests on this (ryujin_hip_create checks the mass
-   * matrix). */
+  /* P_ij for stages == 0 */
   template <int K>
-  RYUJIN_DEV void qij_stage0(const RowData<K> &row, const PairData<K> &p, double (&Q_ij)[K])
+  RYUJIN_DEV void pij_stage0(const RowData<K> &row, const PairData<K> &p, double (&P_ij)[K])
   {
     const double d_ijH = p.d_ij * ((row.alpha_i + p.alpha_j) * .5);
     const double dd = d_ijH - p.d_ij;
@@ -365,21 +508,11 @@ namespace ryujin_hip
     for (int q = 0; q < K; ++q) {
       double v = dd * (p.U_j[q] - row.U_i[q]);
       v += b_ij * p.F_j[q] - b_ji * row.F_i[q];
-      Q_ij[q] = v;
+      P_ij[q] = v * row.factor;
     }
   }
 
-  /* P_ij for stages == 0 */
-  template <int K>
-  RYUJIN_DEV void pij_stage0(const RowData<K> &row, const PairData<K> &p, double (&P_ij)[K])
-  {
-    qij_stage0<K>(row, p, P_ij);
-#pragma unroll
-    for (int q = 0; q < K; ++q)
-      P_ij[q] *= row.factor;
-  }
-
-  /* the operands of pij_stage0 (ryujin_hip_debug_fetch forms the entries no sweep stored from them) */
+  /* where steps 6 and 7 take P_ij from when step 5 did not store it (ONFLY kernels): the operands of pij_stage0 */
   struct Stage0Src {
     DeviceScalars *scalars; /* tau; and the limited-slice counters of step 6 */
     const double *old_U, *alpha, *dij, *r_in;
@@ -549,75 +682,50 @@ namespace ryujin_hip
     }
   }
 
-
-  /* ---- Tile storage of P_ij (updates without stage vectors, kernels_limiter_stage0.hpp). A tile is one column of one
-   * 64-row slice. With V_i = U_i^low + sum_j lambda P_ij from step 5 the high-order update is
-   *   U_i = V_i - sum_j (1 - l_ij) lambda P_ij,   l_ij = min(l_ij, l_ji),
-   * so steps 6 and 7 read P_ij only for pairs with l_ij < 1, and a pair is limited because row i's own l_ij < 1
-   * or because row j's l_ji < 1. Step 5 therefore stores the tile (as the bracket Q_ij, qij_stage0) exactly when
-   * one of its own l_ij came out below 1 -- it knows that much --, and a reader takes
-   *   the own tile           if some row of the slice has an own l_ij < 1 in that column (the same test on the
-   *                          stored l_ij: the tile is there);
-   *   -Q_ji of the transpose otherwise: the pair is limited through l_ji < 1, so row j stored ITS tile.
-   * No flags, no prediction, nothing to repair: the rule is exact and local. Export slices (rows other ranks hold
-   * as ghosts; several ranks only) store every tile: the transpose of a ghost column lives on another rank.
-   * tile_own[slice] (bit c: the own tile of column c is stored), written by step 6, spares step 7 the reads of
-   * the first-pass l_ij it would need to redo the test. */
-  struct TileSrc {
-    const double *q;        /* the tile matrix Q_ij; NULL: the full matrix P_ij of the other updates (pij argument) */
-    uint32_t *tile_own;     /* [n_slices] */
-    uint32_t n_export_slices;
-    const DeviceScalars *scalars; /* tau */
+  /* Per-slice bookkeeping of the limiter sweeps of an update without stage vectors (kernels_limiter_stage0.hpp):
+   * one byte per 64-row slice each, written by exactly one wave per launch.
+   *   unlimited     written by step 6: 1 = no pair of the slice was limited in the first high-order pass. EXACT for
+   *                 the last sweep of the same update (every l'_ij of such a slice is an exact zero, and so is every
+   *                 transposed l'_ji: min(l_ij, l_ji) = 1 is symmetric, (1 - 1) l' = 0 -- it reads neither), and
+   *                 the PREDICTION step 5 of the next update stores P_ij by (a limited region moves by less than a
+   *                 cell per update);
+   *   first_stored  written by step 5 where it stores P_ij per slice: 0 = nothing of the slice is in the matrix, k =
+   *                 the columns k, k + 1, ... are (1: all of them -- the slice was predicted limited; k > 1: its
+   *                 own l_ij of column k came out limited). The repair launch of step 6 completes the slices that
+   *                 need it and sets 1. Exact;
+   *   todo          written by the light launch of step 6 for the two behind it: 0 finished (V_i), 1 P_ij complete,
+   *                 2 the repair launch has to complete it first. */
+  struct SliceFlags {
+    uint8_t *unlimited, *first_stored, *todo;
   };
 
-  /* Q entry of (row, column) at flat scalar position pos = colbase * 64 + lane */
+  /* form and store the P_ij of the columns [1, c_end) of the row (the repair launch of step 6,
+   * ryujin_hip_debug_fetch): exactly the value step 5 formed (same function, same operands) */
   template <int K>
-  RYUJIN_DEV void load_entry_at(const double *__restrict__ m, const uint32_t pos, double (&v)[K])
+  RYUJIN_DEV void backfill_pij(const DeviceMesh &M, const Stage0Src &S0, const RowCtx &r,
+                               double *__restrict__ pij, const uint32_t c_end)
   {
-    const uint32_t colbase = pos >> 6, lane = pos & 63u;
-    const double *b = m + (size_t)colbase * 64 * K;
-#pragma unroll
-    for (int g = 0; g < K / 2; ++g) {
-      const double2 t = *reinterpret_cast<const double2 *>(b + g * 128 + lane * 2);
-      v[2 * g] = t.x;
-      v[2 * g + 1] = t.y;
-    }
-    if (K & 1)
-      v[K - 1] = b[(K / 2) * 128 + lane];
-  }
-
-  /* P_ij of the tile (colbase, lane) for a reader of the tile storage: own tile or the transpose's, times the
-   * row's factor tau / m_i (S - 1) */
-  template <int K>
-  RYUJIN_DEV void load_tile(const DeviceMesh &M, const double *__restrict__ q, const uint64_t colbase,
-                            const uint32_t lane, const bool own, const double factor, double (&P_ij)[K])
-  {
-    if (own) {
-      load_entry<K>(q, colbase, lane, P_ij);
-#pragma unroll
-      for (int c = 0; c < K; ++c)
-        P_ij[c] *= factor;
-    } else {
-      load_entry_at<K>(q, M.idx_t[colbase * 64 + lane], P_ij);
-#pragma unroll
-      for (int c = 0; c < K; ++c)
-        P_ij[c] = -P_ij[c] * factor;
+    if (r.len <= 1)
+      return;
+    RowData<K> row;
+    load_row_data<K>(M, S0, r.row, r.len, row);
+    for (uint32_t c = 1; c < c_end && c < r.len; ++c) {
+      double P_ij[K];
+      pij_on_the_fly<K>(M, S0, row, (uint64_t)r.base + c, r.lane, P_ij);
+      store_entry<K>(pij, (uint64_t)r.base + c, r.lane, P_ij);
     }
   }
-
-  /* [n_slices] 1: step 6 found no limited pair in the slice. Then every l'_ij of its rows is an exact zero, and so is
-   * every transposed l'_ji (min(l_ij, l_ji) = 1 is symmetric, (1 - 1) l' = 0): the last sweep reads neither. */
 
   /* Last round for stencils of at most MAXW columns: all l_ij = min(l_ij, l_ji) of the row are fetched up
    * front (independent loads), then P_ij is read -- in chunks of CHUNK columns whose loads are issued back to
    * back -- only for the columns in which some row of the slice has l != 0 (see the note at the top).
-   * slice_unlimited (written by this update's step 6, or NULL): slices in which nothing was limited fetch
-   * nothing at all. */
+   * slice_unlimited (SliceFlags::unlimited of this update's step 6, or NULL): slices in which nothing was limited
+   * fetch nothing at all. */
   template <typename E, int MAXW, int CHUNK>
   RYUJIN_DEV void last_cached_slice(const typename E::Params &P, const DeviceMesh &M, const RowCtx &r,
                                     double *__restrict__ new_U, const double *__restrict__ pij,
                                     const double *__restrict__ lij, const FusedSadd &F, const FusedPrecompute &FP,
-                                    const uint8_t *__restrict__ slice_unlimited, const TileSrc &T)
+                                    const uint8_t *__restrict__ slice_unlimited = nullptr)
   {
     constexpr int K = E::K;
     const bool row_active = r.len > 1;
@@ -652,13 +760,6 @@ namespace ryujin_hip
         if (__any(l[c] != 0.))
           needed |= 1u << c;
     }
-    uint32_t own = 0xffffffffu;
-    double factor = 1.;
-    if (T.q != nullptr && needed != 0u) {
-      own = T.tile_own[r.slice];
-      factor = T.scalars->tau * M.mi_inv[i] * (double)(r.len - 1);
-    }
-    const double *__restrict__ src = T.q != nullptr ? T.q : pij;
 
 #pragma unroll
     for (int c0 = 1; c0 < MAXW; c0 += CHUNK) {
@@ -666,19 +767,14 @@ namespace ryujin_hip
 #pragma unroll
       for (int cc = 0; cc < CHUNK; ++cc) {
         const int c = c0 + cc;
-        if (c < MAXW && ((needed >> c) & 1u)) {
-          if (T.q != nullptr)
-            load_tile<K>(M, src, (uint64_t)r.base + c, r.lane, (own >> c) & 1u, factor, p[cc]);
-          else
-            load_entry<K>(src, (uint64_t)r.base + c, r.lane, p[cc]);
-        }
+        if (c < MAXW && ((needed >> c) & 1u))
+          load_entry<K>(pij, (uint64_t)r.base + c, r.lane, p[cc]);
       }
 #pragma unroll
       for (int cc = 0; cc < CHUNK; ++cc) {
         const int c = c0 + cc;
         if (c < MAXW && ((needed >> c) & 1u)) {
-          /* padding entries, and pairs with l = 0 (their tile may hold nothing), are never read into U */
-          if (row_active && (uint32_t)c < r.len && l[c] != 0.) {
+          if (row_active && (uint32_t)c < r.len) { /* padding entries of P_ij are never read into U */
 #pragma unroll
             for (int q = 0; q < K; ++q)
               U_i_new[q] += l[c] * lambda * p[cc][q];
@@ -715,13 +811,12 @@ namespace ryujin_hip
   __global__ void __launch_bounds__(kBlock, (MAXW > 9 ? RYUJIN_OCC_LAST_3D : 1))
   k_high_order_last_cached(const typename E::Params P, const DeviceMesh M, double *__restrict__ new_U,
                            const double *__restrict__ pij, const double *__restrict__ lij, const FusedSadd F,
-                           const FusedPrecompute FP, const uint8_t *__restrict__ slice_unlimited = nullptr,
-                           const TileSrc T = TileSrc{})
+                           const FusedPrecompute FP, const uint8_t *__restrict__ slice_unlimited = nullptr)
   {
     const RowCtx r = row_context(M);
     if (!r.valid)
       return;
-    last_cached_slice<E, MAXW, CHUNK>(P, M, r, new_U, pij, lij, F, FP, slice_unlimited, T);
+    last_cached_slice<E, MAXW, CHUNK>(P, M, r, new_U, pij, lij, F, FP, slice_unlimited);
   }
 
   /* Register-cached variant for stencils of at most MAXW columns (2-D Q1: 9, 1-D: 3): the row's
@@ -733,34 +828,74 @@ namespace ryujin_hip
   /* SPLIT (small meshes, the sweep is one wave's latency chain): the four waves of a block share ONE slice; all
    * of them form the new U_i (bitwise the same sum), the first one stores it -- behind a block barrier, the update
    * is in place -- and wave w runs the second limiter pass for the columns 1 + w, 5 + w, ... only. */
-  /* With V_i (V_unlimited != NULL: step 5 left V_i = U_i^low + sum_j lambda P_ij, accumulated as the reference
-   * accumulates the update when every l_ij is 1) a slice without a limited pair takes V_i as it is -- bit for bit
-   * the reference's result -- and never reads P_ij.
-   * T.q != NULL (tile storage: Euler and EulerAEOS without stage vectors): a limited slice forms the new state as
-   * V_i - sum_j (1 - l_ij) lambda P_ij over the tiles in which some pair is limited -- the terms of all other tiles
-   * are exact zeros --, reading P_ij for those tiles only, once, for the sum and for the second limiter pass. Against
-   * U_i^low + sum_j l_ij lambda P_ij in column order (the reference, :1107-1131, and every other path of this
-   * function) this is another rounding of the same sum: a few ulp of lambda |P_ij| where the state is O(1) -- orders
-   * inside the 1e-11 contract on the new state and inside the limiter's own relaxation of its bounds (1e4 eps,
-   * limiter.template.h:24-27). Not for shallow water: there l = 0 has to return U_i^low = 0 exactly on a dry node. */
-  template <typename E, int MAXW, int CP, bool SPLIT>
+  /* MODE (updates whose step 5 stored P_ij per slice, kernels_limiter_stage0.hpp; V_unlimited and the flags are
+   * required then): the sweep runs as three launches over all slices,
+   *   kHoLight   slices of which step 5 stored nothing: fetch l_ij / l_ji; if nothing is limited take V_i and finish
+   *              -- a kernel of 20 registers at full occupancy --, otherwise leave the slice to the launches behind
+   *              (todo = 2: limited through a neighbour's l_ji alone). Slices with a complete P_ij are passed on
+   *              unseen (todo = 1), slices stored from some column on are limited for sure (todo = 2);
+   *   k_pij_repair  forms and stores what is missing of the P_ij of the slices with todo = 2;
+   *   kHoHeavy   waves of finished slices retire at once; the others run the sweep on the stored P_ij.
+   * kHoPlain: the whole sweep in one launch (P_ij stored everywhere).
+   * With V_i the new state is formed as V_i - sum_j (1 - l_ij) lambda P_ij over the (slice, column) tiles in which
+   * some pair is limited -- the terms of all other tiles are exact zeros, and P_ij is read for those tiles only,
+   * once, for the sum and for the second limiter pass. Against U_i^low + sum_j l_ij lambda P_ij in column order
+   * (the reference, :1107-1131, and the variant without V_i below) this is another rounding of the same sum:
+   * differences of a few ulp of lambda |P_ij|, orders inside the 1e-11 contract on the new state. */
+  constexpr int kHoPlain = 0, kHoLight = 1, kHoHeavy = 2;
+
+  template <typename E, int MAXW, int CP, bool SPLIT, int MODE>
   RYUJIN_DEV void next_cached_slice(const typename E::Params &P, const DeviceMesh &M, const RowCtx &r,
                                     const uint32_t group, double *__restrict__ new_U,
-                                    const double *__restrict__ bounds, const double *__restrict__ pij,
+                                    const double *__restrict__ bounds, double *__restrict__ pij,
                                     const double *__restrict__ lij, double *__restrict__ lij_next,
-                                    const double *__restrict__ V_unlimited, DeviceScalars *__restrict__ scalars,
-                                    uint8_t *__restrict__ slice_unlimited, const TileSrc &T)
+                                    const double *__restrict__ V_unlimited, const Stage0Src &S0, const SliceFlags &W,
+                                    const uint32_t todo = 1)
   {
     constexpr int K = E::K;
     constexpr int NB = E::NB;
     static_assert(!SPLIT || CP == MAXW, "the split variant caches the whole row");
+    static_assert(!(SPLIT && MODE != kHoPlain), "small meshes keep the stored P_ij");
     const bool row_active = r.len > 1;
     const uint32_t i = row_active ? r.row : (r.row < M.n_owned ? r.row : M.n_owned - 1);
     const uint32_t *__restrict__ idx_t = M.idx_t;
-    const bool tiles = T.q != nullptr;
-    const double *__restrict__ src = tiles ? T.q : pij;
 
     double l[MAXW];
+    if constexpr (MODE == kHoLight) {
+      bool limited = false;
+#pragma unroll
+      for (int c = 1; c < MAXW; ++c) {
+        if ((uint32_t)c < r.width) {
+          const uint32_t pos = (uint32_t)(((uint64_t)r.base + c) * 64 + r.lane);
+          const double l_a = lij[pos];
+          const double l_b = lij[idx_t[pos]];
+          /* (NaN counts as limited: !(l == 1), not l != 1 through fmin, which drops a NaN operand) */
+          limited = limited || (row_active && (uint32_t)c < r.len && !(l_a == 1. && l_b == 1.));
+        }
+      }
+      const bool slice_limited = __any(limited);
+      if ((r.slice & 15u) == 0 && r.lane == 0) {
+        atomicAdd(&S0.scalars->n_sampled_slices, 1u);
+        if (slice_limited)
+          atomicAdd(&S0.scalars->n_sampled_limited, 1u);
+      }
+      if (r.lane == 0) {
+        W.todo[r.slice] = slice_limited ? 3 : 0; /* 3: limited, nothing stored, and counted above */
+        if (!slice_limited)
+          W.unlimited[r.slice] = 1;
+      }
+      if (!slice_limited && row_active) {
+        double V_i[K];
+        load_state<K>(V_unlimited, i, V_i);
+        store_state<K>(new_U, i, V_i);
+#pragma unroll
+        for (int c = 1; c < MAXW; ++c)
+          if ((uint32_t)c < r.len)
+            st_stream(lij_next + ((r.base + c) * 64 + r.lane), 0.);
+      }
+      return;
+    }
+
     double U_i_new[K];
     const double lambda = 1. / (double)(r.len - 1);
     const size_t stride = M.bounds_stride;
@@ -771,16 +906,11 @@ namespace ryujin_hip
 
     double p[CP][K];
     uint32_t needed = 0; /* wave-uniform: bit c <=> some pair of the (slice, column) tile is limited */
-    uint32_t own = 0xffffffffu; /* wave-uniform: bit c <=> the slice's own tile of column c is stored */
-    double factor = 1.;
-    auto load_P = [&](const int c, double (&out)[K]) {
-      if (tiles)
-        load_tile<K>(M, src, (uint64_t)r.base + c, r.lane, (own >> c) & 1u, factor, out);
-      else
-        load_entry<K>(src, (uint64_t)r.base + c, r.lane, out);
-    };
     if (V_unlimited != nullptr) {
-      uint32_t own_seen = 0;
+      /* Step 5 left V_i = U_i^low + sum_j lambda P_ij, accumulated exactly as the reference accumulates the update
+       * when every l_ij is 1 (k_lij_stage0). If no pair of the slice was limited -- wave-uniform -- that IS the
+       * new U_i bit for bit, the second pass stores (1 - l) l' = 0, and P_ij is not read at all. */
+      bool limited = false;
 #pragma unroll
       for (int c = 1; c < MAXW; ++c) {
         l[c] = 1.;
@@ -789,33 +919,24 @@ namespace ryujin_hip
           const double l_a = lij[pos];
           const double l_b = lij[idx_t[pos]];
           const bool lane_on = row_active && (uint32_t)c < r.len;
-          /* (NaN counts as limited: !(l == 1), and lmin propagates it) */
+          const bool lim = lane_on && !(l_a == 1. && l_b == 1.);
           l[c] = lane_on ? lmin(l_a, l_b) : 1.;
-          if (__any(lane_on && !(l_a == 1. && l_b == 1.)))
+          limited = limited || lim;
+          if (__any(lim))
             needed |= 1u << c;
-          if (__any(lane_on && !(l_a == 1.)))
-            own_seen |= 1u << c;
         }
       }
       const bool slice_limited = needed != 0u;
-      if (scalars != nullptr && (r.slice & 15u) == 0 && r.lane == 0 && (!SPLIT || group == 0)) {
-        atomicAdd(&scalars->n_sampled_slices, 1u);
+      (void)limited;
+      /* (slices the light launch found limited, todo = 3, were counted there) */
+      if (S0.scalars != nullptr && (r.slice & 15u) == 0 && r.lane == 0 && (!SPLIT || group == 0) &&
+          !(MODE == kHoHeavy && todo == 3)) {
+        atomicAdd(&S0.scalars->n_sampled_slices, 1u);
         if (slice_limited)
-          atomicAdd(&scalars->n_sampled_limited, 1u);
-        if ((r.slice & 63u) == 0) { /* tile statistics (diagnostics): every 64th slice */
-          atomicAdd(&scalars->n_sampled_tiles, (unsigned int)(r.width - 1));
-          atomicAdd(&scalars->n_sampled_tiles_limited, (unsigned int)__popc(needed));
-          atomicAdd(&scalars->n_sampled_tiles_stored, (unsigned int)__popc(own_seen));
-        }
+          atomicAdd(&S0.scalars->n_sampled_limited, 1u);
       }
-      if (slice_unlimited != nullptr && r.lane == 0 && (!SPLIT || group == 0))
-        slice_unlimited[r.slice] = slice_limited ? 0 : 1;
-      if (tiles) {
-        own = r.slice < T.n_export_slices ? 0xffffffffu : own_seen;
-        if (r.lane == 0 && slice_limited)
-          T.tile_own[r.slice] = own;
-        factor = T.scalars->tau * M.mi_inv[i] * (double)(r.len - 1);
-      }
+      if (W.unlimited != nullptr && r.lane == 0 && (!SPLIT || group == 0))
+        W.unlimited[r.slice] = slice_limited ? 0 : 1;
       load_state<K>(V_unlimited, i, U_i_new);
       if (!slice_limited) {
         if (row_active) {
@@ -828,39 +949,35 @@ namespace ryujin_hip
         }
         return;
       }
-      if (tiles) {
+      if constexpr (E::kLimitedUpdateFromV) {
+        /* U_i = V_i - sum over the limited tiles of (1 - l_ij) lambda P_ij: P_ij of those tiles only */
 #pragma unroll
         for (int c = 1; c < CP; ++c) {
 #pragma unroll
           for (int q = 0; q < K; ++q)
             p[c][q] = 0.;
           if ((needed >> c) & 1u)
-            load_P(c, p[c]);
+            load_entry<K>(pij, (uint64_t)r.base + c, r.lane, p[c]);
         }
 #pragma unroll
         for (int c = 1; c < MAXW; ++c) {
           if (!((needed >> c) & 1u))
             continue;
-          /* (a pair with l = 1 adds an exact zero; its tile entry may hold nothing: not touched) */
           if (c < CP) {
-            if (!(l[c] == 1.)) {
 #pragma unroll
-              for (int q = 0; q < K; ++q)
-                U_i_new[q] -= (1. - l[c]) * lambda * p[c < CP ? c : 0][q];
-            }
+            for (int q = 0; q < K; ++q)
+              U_i_new[q] -= (1. - l[c]) * lambda * p[c < CP ? c : 0][q];
           } else {
             double pt[K];
-            load_P(c, pt);
-            if (!(l[c] == 1.)) {
+            load_entry<K>(pij, (uint64_t)r.base + c, r.lane, pt);
 #pragma unroll
-              for (int q = 0; q < K; ++q)
-                U_i_new[q] -= (1. - l[c]) * lambda * pt[q];
-            }
+            for (int q = 0; q < K; ++q)
+              U_i_new[q] -= (1. - l[c]) * lambda * pt[q];
           }
         }
       } else {
-        /* the full matrix of the other updates (stage vectors, shallow water, ...): the reference's sum in the
-         * reference's order -- with l = 0 it returns U_i^low exactly, which a dry state relies on */
+        /* (shallow water, scalar equations) the reference's sum in the reference's order: with l = 0 it returns
+         * U_i^low exactly, which a dry node relies on */
         load_state<K>(new_U, i, U_i_new);
 #pragma unroll
         for (int c = 1; c < CP; ++c) {
@@ -868,7 +985,7 @@ namespace ryujin_hip
           for (int q = 0; q < K; ++q)
             p[c][q] = 0.;
           if ((uint32_t)c < r.width)
-            load_entry<K>(src, (uint64_t)r.base + c, r.lane, p[c]);
+            load_entry<K>(pij, (uint64_t)r.base + c, r.lane, p[c]);
         }
 #pragma unroll
         for (int c = 1; c < MAXW; ++c) {
@@ -880,7 +997,7 @@ namespace ryujin_hip
             }
           } else if ((uint32_t)c < r.width) {
             double pt[K];
-            load_entry<K>(src, (uint64_t)r.base + c, r.lane, pt);
+            load_entry<K>(pij, (uint64_t)r.base + c, r.lane, pt);
             if (row_active && (uint32_t)c < r.len) {
 #pragma unroll
               for (int q = 0; q < K; ++q)
@@ -906,7 +1023,7 @@ namespace ryujin_hip
           const double l_b = lij[idx_t[pos]];
           l[c] = lmin(l_a, l_b);
           if (c < CP)
-            load_entry<K>(src, colbase, r.lane, p[c < CP ? c : 0]);
+            load_entry<K>(pij, colbase, r.lane, p[c < CP ? c : 0]);
           if (__any(row_active && (uint32_t)c < r.len && !(l[c] == 1.)))
             needed |= 1u << c;
         }
@@ -921,7 +1038,7 @@ namespace ryujin_hip
           }
         } else if ((uint32_t)c < r.width) {
           double pt[K];
-          load_entry<K>(src, (uint64_t)r.base + c, r.lane, pt);
+          load_entry<K>(pij, (uint64_t)r.base + c, r.lane, pt);
           if (row_active && (uint32_t)c < r.len) {
 #pragma unroll
             for (int q = 0; q < K; ++q)
@@ -958,13 +1075,9 @@ namespace ryujin_hip
         for (int q = 0; q < K; ++q)
           pc[q] = p[c < CP ? c : 0][q];
       } else {
-        load_P(c, pc);
+        load_entry<K>(pij, (uint64_t)r.base + c, r.lane, pc);
       }
       if (lane_on) {
-        if (l[c] == 1.) { /* (1 - l) l' = 0 whatever l' is; the tile entry may hold nothing */
-          st_stream(lij_next + ((r.base + c) * 64 + r.lane), 0.);
-          continue;
-        }
         double new_p_ij[K];
 #pragma unroll
         for (int q = 0; q < K; ++q)
@@ -978,44 +1091,81 @@ namespace ryujin_hip
           st_stream(lij_next + ((r.base + c) * 64 + r.lane), (1. - l[c]) * new_l_ij);
       }
     }
-    while (undecided_mask) {
-      const uint32_t c = (uint32_t)__builtin_ctzll(undecided_mask);
-      undecided_mask &= undecided_mask - 1;
-      const uint64_t colbase = (uint64_t)r.base + c;
-      const uint64_t pos = colbase * 64 + r.lane;
-      const double old_l_ij = lmin(lij[pos], lij[idx_t[pos]]);
-      double p_ij[K], new_p_ij[K];
-      load_P((int)c, p_ij);
+    /* (the second pass's `success` is ignored unless EXPENSIVE_BOUNDS_CHECK, :1148-1161) */
+    __shared__ uint16_t tail_queue[kWavesPerBlock * (MAXW - 1) * 64];
+    __shared__ TailScratch<E> tail_rows[kWavesPerBlock];
+    limit_undecided_pairs<E>(
+        P, r, undecided_mask, bnd, U_i_new, tail_queue + (threadIdx.x >> 6) * (MAXW - 1) * 64,
+        tail_rows[threadIdx.x >> 6].rows,
+        [&](const uint32_t c, const uint32_t owner, double (&out)[K]) {
+          const uint64_t pos = ((uint64_t)r.base + c) * 64 + owner;
+          const double old_l_ij = lmin(lij[pos], lij[idx_t[pos]]);
+          load_entry<K>(pij, (uint64_t)r.base + c, owner, out);
 #pragma unroll
-      for (int q = 0; q < K; ++q)
-        new_p_ij[q] = (1. - old_l_ij) * p_ij[q];
-      bool success;
-      const double new_l_ij = E::limit(P, bnd, U_i_new, new_p_ij, success);
-      st_stream(lij_next + (pos), (1. - old_l_ij) * new_l_ij);
-    }
+          for (int q = 0; q < K; ++q)
+            out[q] = (1. - old_l_ij) * out[q];
+        },
+        [&](const uint32_t c, const uint32_t owner, const double new_l_ij) {
+          const uint64_t pos = ((uint64_t)r.base + c) * 64 + owner;
+          const double old_l_ij = lmin(lij[pos], lij[idx_t[pos]]);
+          st_stream(lij_next + (pos), (1. - old_l_ij) * new_l_ij);
+        });
   }
 
-  template <typename E, int MAXW, int CP = MAXW, bool SPLIT = false>
+  /* the launch between the light and the heavy one: completes the P_ij of the slices the light launch marked */
+  template <typename E>
+  __global__ void __launch_bounds__(kBlock)
+  k_pij_repair(const DeviceMesh M, const Stage0Src S0, double *__restrict__ pij, const SliceFlags W)
+  {
+    const uint32_t slice = M.slice_begin + blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (slice >= M.slice_end || W.todo[slice] < 2)
+      return;
+    const uint32_t fs = W.first_stored[slice];
+    const RowCtx r = row_context_of_slice(M, slice);
+    backfill_pij<E::K>(M, S0, r, pij, fs == 0 ? 0xffffffffu : fs);
+    if (r.lane == 0)
+      W.first_stored[slice] = 1;
+  }
+
+  template <typename E, int MAXW, int CP = MAXW, bool SPLIT = false, int MODE = kHoPlain>
   __global__ void __launch_bounds__(kBlock, (MAXW > 9 ? (CP < MAXW ? RYUJIN_OCC_HO_3D : 1) : RYUJIN_OCC_HO))
   k_high_order_next_cached(const typename E::Params P, const DeviceMesh M, double *__restrict__ new_U,
-                           const double *__restrict__ bounds, const double *__restrict__ pij,
+                           const double *__restrict__ bounds, double *__restrict__ pij,
                            const double *__restrict__ lij, double *__restrict__ lij_next,
-                           const double *__restrict__ V_unlimited = nullptr,
-                           DeviceScalars *__restrict__ scalars = nullptr,
-                           uint8_t *__restrict__ slice_unlimited = nullptr, const TileSrc T = TileSrc{})
+                           const double *__restrict__ V_unlimited = nullptr, const Stage0Src S0 = Stage0Src{},
+                           const SliceFlags W = SliceFlags{})
   {
     RowCtx r;
     const uint32_t group = SPLIT ? (threadIdx.x >> 6) : 0u;
+    uint32_t todo = 1;
     if constexpr (SPLIT) { /* one slice per block (uniform over the block: the barrier in the body is safe) */
       if (M.slice_begin + blockIdx.x >= M.slice_end)
         return;
       r = row_context_of_slice(M, M.slice_begin + blockIdx.x);
+    } else if constexpr (MODE != kHoPlain) {
+      /* the flag first: most waves of a developed flow retire on it */
+      const uint32_t slice = M.slice_begin + blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+      if (slice >= M.slice_end)
+        return;
+      if constexpr (MODE == kHoLight) {
+        const uint32_t fs = W.first_stored[slice];
+        if (fs != 0) { /* complete (1), or stored from the column on whose l_ij came out limited */
+          if ((threadIdx.x & 63) == 0)
+            W.todo[slice] = fs == 1 ? 1 : 2;
+          return;
+        }
+      } else {
+        todo = W.todo[slice];
+        if (todo == 0)
+          return;
+      }
+      r = row_context_of_slice(M, slice);
     } else {
       r = row_context(M);
       if (!r.valid)
         return;
     }
-    next_cached_slice<E, MAXW, CP, SPLIT>(P, M, r, group, new_U, bounds, pij, lij, lij_next, V_unlimited, scalars,
-                                          slice_unlimited, T);
+    next_cached_slice<E, MAXW, CP, SPLIT, MODE>(P, M, r, group, new_U, bounds, pij, lij, lij_next, V_unlimited, S0,
+                                                W, todo);
   }
 } // namespace ryujin_hip

@@ -22,17 +22,25 @@
 // U_i^low + sum_j l_ij lambda P_ij when every l_ij is 1: in slices where nothing was limited step 6 takes V_i
 // and never reads P_ij (kernels_limiter.hpp) -- bit-identical, and most of a developed flow.
 //
-// TILES: ONLY WHAT STEPS 6 AND 7 WILL READ IS STORED. With V_i they read P_ij only for limited pairs
-// (U_i = V_i - sum_j (1 - l_ij) lambda P_ij). A developed Mach-3 flow holds a limited pair in 70 - 95 % of its 64-row
-// slices but in a small share of its (slice, column) tiles; the 8 k S bytes per row of the full matrix -- a third of
-// this sweep's traffic, half of step 6's -- are mostly never looked at. The sweep stores a tile (as the bracket
-// Q_ij, qij_stage0) exactly when one of its own l_ij comes out below 1 (or undecided); a pair that is limited
-// through the neighbour's l_ji alone is read from the neighbour's tile with the opposite sign (Q_ji = -Q_ij bit for
-// bit). The rule is exact and local -- no flags, no prediction, no repair; kernels_limiter.hpp (TileSrc) has the
-// readers' side. Round 3 chose between "store everything" and "store nothing, form P_ij again in steps 6/7" for the
-// whole mesh from the fraction of limited slices; the first version of this round stored per slice with a
-// prediction from the previous update (profiles/r04a_*, r04b_*: smooth in the limited fraction, but a developed
-// flow has hardly a slice without a limited pair).
+// PER_SLICE: P_ij IS STORED ONLY WHERE STEPS 6 AND 7 WILL READ IT. A developed flow limits something in a few
+// per cent (Mach-3 step early on, 3-D radial contrast) up to nearly all (cylinder channel) of its 64-row slices;
+// everywhere else steps 6 and 7 never look at P_ij (V_i; l' = 0) and the 8 k S bytes per row step 5 would write --
+// a third of its traffic -- are wasted. Round 3 chose between "store everywhere" and "store nowhere, form it again
+// in steps 6/7" for the whole mesh from the measured fraction of limited slices: a cliff at 20 - 25 %, and a chain
+// of six dependent gathers per column in every limited slice below it. Now the wave of a slice decides for itself:
+//   * the slice held a limited pair in the previous update (SliceFlags::unlimited of that update's step 6 -- a
+//     limited region moves by less than a cell per update): store as P_ij is formed;
+//   * otherwise do not -- unless one of the slice's own l_ij comes out limited (or undecided) at column c: store
+//     from c on;
+//   * SliceFlags::first_stored says which. What is missing where step 6 needs P_ij -- the columns in front of c, or
+//     all of a slice that turns out limited only through a neighbour's l_ji (step 6 sees that, step 5 cannot) --
+//     is formed by the small repair launch inside step 6 (kernels_limiter.hpp).
+// The cost of steps 5 - 7 therefore follows the limited fraction smoothly (profiles/r04*_ab_limited_fraction*); once
+// most slices are limited -- a developed Mach-3 flow: 70 - 95 % -- the bookkeeping buys nothing and the host runs the
+// plain kernels (P_ij stored everywhere, step 6 in one launch; ryujin_hip_ctx::step, RYUJIN_PER_SLICE_MAX_LIMITED).
+// Same bits whatever is stored: whoever reads P_ij reads pij_stage0() of the same operands.
+// ryujin_hip_params::debug_pij_storage: < 0 always the plain kernels, > 0 always per slice with no slice predicted
+// limited (everything through the trigger / the repair launch).
 
 #pragma once
 
@@ -63,17 +71,17 @@ namespace ryujin_hip
 
   /* NY > 1 (small meshes): NY waves (blockIdx.y) share a slice, wave y taking the columns 1 + y, 1 + y + NY, ...;
    * no V_i then (the row's sum is spread over several waves): the caller passes V_out = nullptr.
-   * TILES: see the head of the file (NY == 1 only: it needs V_i); pij is the tile matrix Q_ij then. Otherwise all
-   * of P_ij is stored. n_export_slices: the slices [0, n) store every tile (their ghost columns). */
-  template <typename E, int NY = 1, bool TILES = false>
+   * PER_SLICE: see the head of the file (NY == 1 only); otherwise P_ij is stored everywhere. */
+  template <typename E, int NY = 1, bool PER_SLICE = false>
   __global__ void __launch_bounds__(kBlock, lij0_waves_per_simd<E>())
   k_lij_stage0(const typename E::Params P, const DeviceMesh M, DeviceScalars *__restrict__ scalars,
                const double *__restrict__ old_U, const double *__restrict__ alpha,
                const double *__restrict__ dij, const double *__restrict__ new_U,
                const double *__restrict__ r_in, const double *__restrict__ bounds, double *__restrict__ pij,
-               double *__restrict__ lij, double *__restrict__ V_out, const uint32_t n_export_slices = 0)
+               double *__restrict__ lij, double *__restrict__ V_out, const SliceFlags W = SliceFlags{},
+               const int predict_override = 0)
   {
-    static_assert(!TILES || NY == 1, "the readers of the tile storage need V_i");
+    static_assert(!PER_SLICE || NY == 1, "one wave per slice decides");
     constexpr int K = E::K;
     constexpr int NB = E::NB;
     const RowCtx r = row_context(M);
@@ -96,19 +104,20 @@ namespace ryujin_hip
     RowData<K> row;
     load_state<K>(old_U, i, row.U_i);
     load_state<K>(r_in, i, row.F_i);
-    /* TILES: the bracket of the column at hand waits in LDS, not in registers, for the limiter's verdict: k doubles per
-     * lane, conflict free ([component][lane]) */
-    __shared__ double lds_stage[TILES ? kWavesPerBlock * K * 64 : 1];
-    [[maybe_unused]] double *const q_mine = lds_stage + (TILES ? ((threadIdx.x >> 6) * K) * 64 + r.lane : 0);
     row.alpha_i = alpha[i];
     row.m_i_inv = M.mi_inv[i];
     row.factor = scalars->tau * row.m_i_inv * (double)(r.len - 1);
     const double lambda = 1. / (double)(r.len - 1);
     bool all_ok = true;
     unsigned long long undecided_mask = 0;
-    const bool store_all = !TILES || r.slice < n_export_slices;
 
     const uint32_t c0 = 1 + (NY > 1 ? blockIdx.y : 0);
+    /* wave-uniform: P_ij of this slice goes to the matrix; from column first_stored on */
+    bool storing = true;
+    uint32_t first_stored = c0;
+    if constexpr (PER_SLICE)
+      storing = predict_override < 0 || (predict_override == 0 && W.unlimited[r.slice] == 0);
+
     /* software pipeline: the loads of the next column are in flight while column c is limited */
     uint32_t j_n = r.width > c0 ? ld_stream(cols + (((uint64_t)r.base + c0) * 64 + r.lane)) : i;
     uint32_t j_nn = r.width > c0 + NY ? ld_stream(cols + (((uint64_t)r.base + c0 + NY) * 64 + r.lane)) : i;
@@ -121,22 +130,16 @@ namespace ryujin_hip
       const uint64_t pos = colbase * 64 + r.lane;
       const bool active = row_active && c < r.len;
       double P_ij[K];
-      qij_stage0<K>(row, next, P_ij);
-#pragma unroll
-      for (int q = 0; q < K; ++q) {
-        if constexpr (TILES)
-          q_mine[q * 64] = P_ij[q]; /* the bracket waits in LDS (not in registers) for the limiter's verdict */
-        P_ij[q] *= row.factor;
-      }
+      pij_stage0<K>(row, next, P_ij);
       if (c + NY < r.width) {
         j_n = j_nn;
         load_pair<K>(M, old_U, r_in, alpha, dij, (colbase + NY) * 64 + r.lane, j_n, next);
         j_nn = (c + 2 * NY < r.width) ? ld_stream(cols + ((colbase + 2 * NY) * 64 + r.lane)) : i;
       }
-      if constexpr (!TILES) {
-        if (active)
-          store_entry<K>(pij, colbase, r.lane, P_ij);
-      }
+      /* a slice that stores already: as soon as P_ij is formed (the store overlaps the limiter) */
+      const bool stored_early = storing;
+      if (stored_early && active)
+        store_entry<K>(pij, colbase, r.lane, P_ij);
       bool success = true, undecided = false;
       double l_ij = 1.;
       if (active) {
@@ -148,21 +151,18 @@ namespace ryujin_hip
         }
         l_ij = E::limit_fast(P, bnd, U_i_new, P_ij, success, undecided);
       }
-      if constexpr (TILES) {
-        /* wave-uniform: the tile is stored iff one of its own l_ij is (or may come out) below 1 -- the test a reader
-         * repeats on the stored l_ij (an undecided pair that comes out at exactly 1 leaves a tile nobody reads) */
-        if (store_all || __any(active && (undecided || !(l_ij == 1.)))) {
-          if (active) {
-            double Q_ij[K];
-#pragma unroll
-            for (int q = 0; q < K; ++q)
-              Q_ij[q] = q_mine[q * 64];
-            store_entry<K>(pij, colbase, r.lane, Q_ij);
-          }
+      if constexpr (PER_SLICE) {
+        if (!storing && __any(active && (undecided || !(l_ij == 1.)))) {
+          storing = true;
+          first_stored = c;
         }
       }
       if (!active)
         continue;
+      if constexpr (PER_SLICE) {
+        if (storing && !stored_early)
+          store_entry<K>(pij, colbase, r.lane, P_ij);
+      }
       if (undecided) {
         undecided_mask |= 1ull << c;
       } else {
@@ -173,58 +173,45 @@ namespace ryujin_hip
     if (NY == 1 && V_out != nullptr && row_active)
       store_state<K>(V_out, i, V_i);
 
-    /* the few pairs that need the Newton iteration */
-    while (undecided_mask) {
-      const uint32_t c = (uint32_t)__builtin_ctzll(undecided_mask);
-      undecided_mask &= undecided_mask - 1;
-      const uint64_t colbase = (uint64_t)r.base + c;
-      double P_ij[K];
-      load_entry<K>(pij, colbase, r.lane, P_ij); /* own tile: stored above (an undecided pair stores its tile) */
-      if constexpr (TILES) {
-#pragma unroll
-        for (int q = 0; q < K; ++q)
-          P_ij[q] *= row.factor;
+    if constexpr (PER_SLICE) {
+      if (r.lane == 0) {
+        W.first_stored[r.slice] = storing ? (uint8_t)first_stored : 0;
+        if ((r.slice & 15u) == 0 && storing)
+          atomicAdd(&scalars->n_sampled_stored, 1u);
       }
-      bool success;
-      const double l_ij = E::limit(P, bnd, U_i_new, P_ij, success);
-      lij[colbase * 64 + r.lane] = l_ij;
-      all_ok = all_ok && success;
     }
-    flag_restart(scalars, all_ok, r.lane);
+
+    /* the few pairs that need the Newton iteration (an undecided pair makes its slice store: P_ij is there),
+     * compacted over the wave (limit_undecided_pairs, kernels_limiter.hpp) */
+    constexpr int kTailColumns = E::DIMENSION == 1 ? 2 : (E::DIMENSION == 2 ? 8 : 26);
+    __shared__ uint16_t tail_queue[kWavesPerBlock * kTailColumns * 64];
+    __shared__ TailScratch<E> tail_rows[kWavesPerBlock];
+    const bool tail_ok = limit_undecided_pairs<E>(
+        P, r, undecided_mask, bnd, U_i_new, tail_queue + (threadIdx.x >> 6) * kTailColumns * 64,
+        tail_rows[threadIdx.x >> 6].rows,
+        [&](const uint32_t c, const uint32_t owner, double (&out)[K]) {
+          load_entry<K>(pij, (uint64_t)r.base + c, owner, out);
+        },
+        [&](const uint32_t c, const uint32_t owner, const double l_ij) {
+          lij[((uint64_t)r.base + c) * 64 + owner] = l_ij;
+        });
+    flag_restart(scalars, all_ok && tail_ok, r.lane);
   }
 
-  /* ryujin_hip_debug_fetch(P_ij) behind a step with tile storage: the full matrix P_ij as the sweeps see it --
-   * the own tile where it is stored, the transpose's with the other sign for a pair limited through l_ji, and for the
-   * entries no sweep reads (pairs that were not limited) pij_stage0() of the operands, which all outlive the step.
-   * l_first: the l_ij of the first limiter pass. */
+  /* ryujin_hip_debug_fetch(P_ij) behind a step that did not store all of it: the same pij_stage0() on the same
+   * operands (all of them outlive the step), written to the matrix the parity tests read for the columns the
+   * sweeps left out */
   template <typename E>
   __global__ void __launch_bounds__(kBlock)
-  k_pij_tiles_fetch(const DeviceMesh M, const Stage0Src S0, const double *__restrict__ q,
-                    const double *__restrict__ l_first, const uint32_t n_export_slices, double *__restrict__ out)
+  k_pij_stage0_store(const DeviceMesh M, const Stage0Src S0, double *__restrict__ pij,
+                     const uint8_t *__restrict__ first_stored)
   {
-    constexpr int K = E::K;
     const RowCtx r = row_context(M);
-    if (!r.valid)
+    if (!r.valid || r.len <= 1)
       return;
-    const bool row_active = r.len > 1;
-    RowData<K> row;
-    if (row_active)
-      load_row_data<K>(M, S0, r.row, r.len, row);
-    for (uint32_t c = 1; c < r.width; ++c) {
-      const uint64_t colbase = (uint64_t)r.base + c;
-      const uint32_t pos = (uint32_t)(colbase * 64 + r.lane);
-      const bool lane_on = row_active && c < r.len;
-      const double l_a = lane_on ? l_first[pos] : 1.;
-      const double l_b = lane_on ? l_first[M.idx_t[pos]] : 1.;
-      const bool own = r.slice < n_export_slices || __any(lane_on && !(l_a == 1.));
-      if (!lane_on)
-        continue;
-      double P_ij[K];
-      if (own || !(l_b == 1.))
-        load_tile<K>(M, q, colbase, r.lane, own, row.factor, P_ij);
-      else
-        pij_on_the_fly<K>(M, S0, row, colbase, r.lane, P_ij);
-      store_entry<K>(out, colbase, r.lane, P_ij);
-    }
+    const uint32_t fs = first_stored[r.slice];
+    if (fs == 1)
+      return;
+    backfill_pij<E::K>(M, S0, r, pij, fs == 0 ? 0xffffffffu : fs);
   }
 } // namespace ryujin_hip

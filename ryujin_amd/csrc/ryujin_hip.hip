@@ -363,7 +363,6 @@ struct ryujin_hip_ctx {
   uint32_t bc_fold_max_slices = kBcFoldMaxSlices;
   uint32_t resident_waves_step5 = kResidentWavesStep5, resident_waves_step6 = kResidentWavesStep6;
   bool interior_reads_ghosts = false; /* asymmetric stencil: every sweep joins the exchanges (no overlap) */
-  bool ghosts_beyond_export_rows = false; /* (the stencil's own answer, without the debug_join_exchanges override) */
   uint32_t n_export_slices = 0;
   uint32_t bounds_stride = 0; /* SoA stride of the limiter bounds: covers the ghost range (dG reads bounds_j) */
 
@@ -445,33 +444,29 @@ struct ryujin_hip_ctx {
   /* step 5 of the running step left V_i = U_i^low + sum_j lambda P_ij (k_lij_stage0, k_pij_lij): step 6 may take it */
   DeviceBuffer<double> d_V;
   bool stage0_V = false;
-  /* the last step kept P_ij in the tile storage (tiles below): ryujin_hip_debug_fetch assembles the full matrix */
-  bool last_tiles = false;
+  /* the last step stored P_ij per slice (per_slice below): ryujin_hip_debug_fetch forms it from these operands for
+   * the slices the sweeps left out */
+  bool last_per_slice = false;
   Stage0Src last_s0{};
-  const double *last_l_first = nullptr; /* the l_ij of the first limiter pass of that step */
-  /* [n_slices] written by step 6: 1 = no limited pair in the slice (the last sweep skips it) */
-  DeviceBuffer<uint8_t> d_slice_unlimited;
-  DeviceBuffer<uint32_t> d_tile_own; /* [n_slices] TileSrc::tile_own */
-  DeviceBuffer<double> d_pij_debug;  /* ryujin_hip_debug_fetch: the full P_ij assembled from the tile storage */
-  bool mass_matrix_symmetric = true; /* m_ij == m_ji bit for bit on the owned rows: Q_ji == -Q_ij bit for bit */
-  /* fractions of the (sampled) slices in which the first high-order sweep found a limited pair, of the (slice,
-   * column) tiles that hold one, and of the tiles step 5 stored, from the device counters between the two latest
-   * host synchronisations (DeviceScalars::n_sampled_*); 1 until the first measurement. Diagnostics only. */
-  double limited_fraction = 1., limited_tile_fraction = 1., stored_tile_fraction = 1.;
-  DeviceScalars seen_counters{};
+  /* SliceFlags (kernels_limiter.hpp), [n_slices] each; `unlimited` starts at 0 = "limited": the first update of a
+   * context stores P_ij everywhere */
+  DeviceBuffer<uint8_t> d_slice_unlimited, d_slice_first_stored, d_slice_todo;
+  /* fractions of the (sampled) slices in which the first high-order sweep found a limited pair / whose P_ij step 5
+   * stored, from the device counters at the latest host synchronisation (DeviceScalars::n_sampled_*); 1 until the
+   * first measurement. Diagnostics only: nothing is decided from them. */
+  double limited_fraction = 1., stored_fraction = 1.;
+  unsigned int seen_sampled_slices = 0, seen_sampled_limited = 0, seen_sampled_stored = 0;
   void update_limited_fraction()
   {
-    const unsigned int d_slices = h_scalars->n_sampled_slices - seen_counters.n_sampled_slices;
-    const unsigned int d_limited = h_scalars->n_sampled_limited - seen_counters.n_sampled_limited;
-    const unsigned int d_tiles = h_scalars->n_sampled_tiles - seen_counters.n_sampled_tiles;
-    const unsigned int d_tl = h_scalars->n_sampled_tiles_limited - seen_counters.n_sampled_tiles_limited;
-    const unsigned int d_ts = h_scalars->n_sampled_tiles_stored - seen_counters.n_sampled_tiles_stored;
-    seen_counters = *h_scalars;
-    if (d_slices != 0)
+    const unsigned int d_slices = h_scalars->n_sampled_slices - seen_sampled_slices;
+    const unsigned int d_limited = h_scalars->n_sampled_limited - seen_sampled_limited;
+    const unsigned int d_stored = h_scalars->n_sampled_stored - seen_sampled_stored;
+    seen_sampled_slices = h_scalars->n_sampled_slices;
+    seen_sampled_limited = h_scalars->n_sampled_limited;
+    seen_sampled_stored = h_scalars->n_sampled_stored;
+    if (d_slices != 0) {
       limited_fraction = (double)d_limited / (double)d_slices;
-    if (d_tiles != 0) {
-      limited_tile_fraction = (double)d_tl / (double)d_tiles;
-      stored_tile_fraction = last_tiles ? (double)d_ts / (double)d_tiles : 1.;
+      stored_fraction = last_per_slice ? (double)d_stored / (double)d_slices : 1.;
     }
   }
   void ensure_pij()
@@ -682,20 +677,6 @@ void ryujin_hip_ctx::create(const ryujin_hip_offline &o, const ryujin_hip_params
     d_cij.upload(cij);
     const auto mij = L.scatter(o, o.mij, 1);
     d_mij.upload(mij);
-    { /* m_ij == m_ji bit for bit on the owned rows? (the tile storage of P_ij rests on it, kernels_limiter.hpp) */
-      std::atomic<bool> asymmetric{false};
-      parallel_chunks(L.n_owned, [&](const uint64_t i0, const uint64_t i1) {
-        for (uint32_t i = (uint32_t)i0; i < (uint32_t)i1 && !asymmetric.load(std::memory_order_relaxed); ++i)
-          for (uint32_t c = 1; c < L.row_len[i]; ++c) {
-            const uint64_t pp = L.pos(i, c);
-            if (L.cols[pp] < L.n_owned && mij[pp] != mij[L.idx_t[pp]]) {
-              asymmetric.store(true, std::memory_order_relaxed);
-              break;
-            }
-          }
-      });
-      mass_matrix_symmetric = !asymmetric.load();
-    }
     dg = o.discontinuous_ansatz != 0;
     if (dg) {
       if (p.equation != RYUJIN_EQ_EULER && p.equation != RYUJIN_EQ_SHALLOW_WATER)
@@ -751,7 +732,6 @@ void ryujin_hip_ctx::create(const ryujin_hip_offline &o, const ryujin_hip_params
           }
     });
     interior_reads_ghosts = found.load();
-    ghosts_beyond_export_rows = interior_reads_ghosts;
   }
   /* test hooks (ryujin_hip_params::debug_*; tests/test_gpu_parity.py runs the partitioned cases through both
    * branches of each): force the fallback choreography / move the mesh size below which boundary conditions
@@ -1120,10 +1100,8 @@ void ryujin_hip_ctx::store_pij_for_debug()
   mm.slice_begin = 0;
   mm.slice_end = L.n_slices;
   const dim3 grid((L.n_slices + kWavesPerBlock - 1) / kWavesPerBlock), block(kBlock);
-  if (d_pij_debug.n == 0)
-    d_pij_debug.alloc(L.nnz_total * (size_t)K);
-  hipLaunchKernelGGL(k_pij_tiles_fetch<E>, grid, block, 0, stream, mm, last_s0, (const double *)d_pij.ptr,
-                     last_l_first, n_nbr ? n_export_slices : 0u, d_pij_debug.ptr);
+  hipLaunchKernelGGL(k_pij_stage0_store<E>, grid, block, 0, stream, mm, last_s0, d_pij.ptr,
+                     (const uint8_t *)d_slice_first_stored.ptr);
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipStreamSynchronize(stream));
 }
@@ -1446,17 +1424,25 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
   const uint32_t step5_groups = std::min<uint32_t>(
       4u, resident_waves_step5 /
               std::max<uint32_t>(1u, (L.n_slices + kWavesPerBlock - 1) / kWavesPerBlock * kWavesPerBlock));
-  /* ... and only the tiles of P_ij steps 6 and 7 will read are stored (kernels_limiter.hpp, TileSrc) where the update
-   * has two limiter passes, one wave per slice (V_i), rows of at most 32 columns (the tile masks), ghost columns in
-   * export rows only and a mass matrix that is symmetric bit for bit (the transposed tile IS the own one with the
-   * other sign). debug_pij_storage < 0: the full matrix. */
-  const bool tiles = RYUJIN_TILE_PIJ && stage0_pij && params.limiter_iterations == 2 && step5_groups < 2 &&
-                     !ghosts_beyond_export_rows && mass_matrix_symmetric && params.debug_pij_storage >= 0;
+  /* ... and P_ij is stored per slice -- only where steps 6 and 7 will read it (kernels_limiter_stage0.hpp) -- where the
+   * update has two limiter passes and one wave per slice, WHILE that pays: its bookkeeping (the prediction and the
+   * trigger in step 5, step 6 as three launches) costs a few per cent of the three sweeps, the savings are
+   * proportional to the share of unlimited slices. Above RYUJIN_PER_SLICE_MAX_LIMITED (the measured break-even,
+   * profiles/r04*_ab_limited_fraction*) the plain kernels run: P_ij stored everywhere, step 6 in one launch. Same
+   * bits either way; the fraction is the one step 6 counted between the two latest host synchronisations (1 until
+   * the first: the first update of a context runs the plain kernels). */
+  const bool per_slice_possible =
+      RYUJIN_PER_SLICE_PIJ && stage0_pij && params.limiter_iterations == 2 && step5_groups < 2;
+  const bool per_slice =
+      per_slice_possible && params.debug_pij_storage >= 0 && !params.debug_expensive_bounds_check &&
+      (params.debug_pij_storage > 0 || limited_fraction <= (double)RYUJIN_PER_SLICE_MAX_LIMITED);
   ensure_pij();
-  if (tiles && d_tile_own.n == 0)
-    d_tile_own.alloc(L.n_slices);
-  const TileSrc tile_src{tiles ? d_pij.ptr : nullptr, d_tile_own.ptr, n_nbr ? n_export_slices : 0u, d_scalars.ptr};
-  last_tiles = tiles;
+  if (per_slice && d_slice_first_stored.n == 0) {
+    d_slice_first_stored.alloc(L.n_slices);
+    d_slice_todo.alloc(L.n_slices);
+  }
+  const SliceFlags slice_flags{d_slice_unlimited.ptr, d_slice_first_stored.ptr, d_slice_todo.ptr};
+  last_per_slice = per_slice;
   last_s0 = Stage0Src{d_scalars.ptr, old.U.ptr, d_alpha.ptr, d_dij.ptr, d_r.ptr};
   sweep([&](const DeviceMesh &mm, dim3 grid) {
     if constexpr (is_euler) {
@@ -1540,6 +1526,15 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
                            d_dij.ptr, nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
     }
   });
+  /* EXPENSIVE_BOUNDS_CHECK as a run-time option (Euler): is_admissible() of the low-order update (:851-855) */
+  const bool checked = is_euler && params.debug_expensive_bounds_check != 0;
+  if constexpr (is_euler) {
+    if (checked)
+      sweep([&](const DeviceMesh &mm, dim3 grid) {
+        hipLaunchKernelGGL(k_check_admissible<E>, grid, block, 0, launch_stream, eparams, mm, d_scalars.ptr,
+                           (const double *)nw.U.ptr);
+      });
+  }
   exchange_vector(d_r.ptr, KP, true);
   if (dg && params.limiter_iterations != 0) {
     /* the bounds are extended over the stencil in step 5: their ghost range has to be current
@@ -1580,10 +1575,10 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
                                d_pij.ptr, d_lij.ptr, NY == 1 ? d_V.ptr : nullptr);
             stage0_V = NY == 1 && d_V.ptr != nullptr;
           };
-          if (tiles) {
+          if (per_slice) {
             hipLaunchKernelGGL((k_lij_stage0<E, 1, true>), grid, block, 0, launch_stream, eparams, mm,
                                d_scalars.ptr, old.U.ptr, d_alpha.ptr, d_dij.ptr, nw.U.ptr, d_r.ptr, d_bounds.ptr,
-                               d_pij.ptr, d_lij.ptr, d_V.ptr, tile_src.n_export_slices);
+                               d_pij.ptr, d_lij.ptr, d_V.ptr, slice_flags, params.debug_pij_storage);
             stage0_V = true;
           } else if (groups >= 4)
             launch5(std::integral_constant<int, 4>{});
@@ -1630,6 +1625,14 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
                          d_r.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr, d_V.ptr);
       stage0_V = d_V.ptr != nullptr;
     });
+    if constexpr (is_euler) {
+      if (checked) /* the first limiter pass in the checked control flow (limiter.template.h:110-134,244-322) */
+        sweep([&](const DeviceMesh &mm, dim3 grid) {
+          hipLaunchKernelGGL(k_check_limiter<E>, grid, block, 0, launch_stream, eparams, mm, d_scalars.ptr,
+                             (const double *)nw.U.ptr, (const double *)d_bounds.ptr, (const double *)d_pij.ptr,
+                             (const double *)nullptr);
+        });
+    }
     exchange_matrix(d_lij.ptr, true);
   }
   mark(4);
@@ -1650,7 +1653,7 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
   const FusedPrecompute fused_prec{fuse_precompute ? nw.prec.ptr : nullptr, fuse_precompute ? nw.rrec.ptr : nullptr};
   if (fused_sadd.src && n_iterations == 0)
     throw HipError(RYUJIN_ERR_ARG, "internal: fused sadd without a limiter pass");
-  bool step6_flags = false; /* step 6 left d_slice_unlimited for every slice: the last sweep may use it */
+  bool step6_flags = false; /* step 6 left SliceFlags::unlimited for every slice: the last sweep may use it */
   for (int pass = 0; pass < n_iterations; ++pass) {
     const bool last_round = (pass + 1 == n_iterations);
     if (n_iterations == 2 && last_round)
@@ -1662,7 +1665,7 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
         if (L.max_row_len <= (uint32_t)kCachedWidth)
           hipLaunchKernelGGL((k_high_order_last_cached<E, kCachedWidth, kLastChunk>), grid,
                              block, 0, launch_stream, eparams, mm, nw.U.ptr, d_pij.ptr, d_lij.ptr, fused_sadd,
-                             fused_prec, step6_flags ? d_slice_unlimited.ptr : nullptr, tile_src);
+                             fused_prec, step6_flags ? d_slice_unlimited.ptr : nullptr);
         else
           hipLaunchKernelGGL((k_high_order<E, true>), grid, block, 0, launch_stream, eparams, mm, nw.U.ptr,
                              d_bounds.ptr, d_pij.ptr, d_lij.ptr, d_lij_next.ptr, fused_sadd);
@@ -1671,14 +1674,30 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
       /* 3-D: cache all l_ij and the P_ij of the first RYUJIN_HO_CP_3D columns (0: two-pass kernel) */
       constexpr int kCachedP = DIM == 3 ? (RYUJIN_HO_CP_3D > 0 ? RYUJIN_HO_CP_3D : 27) : kCachedWidth;
       sweep([&](const DeviceMesh &mm, dim3 grid) {
+        if constexpr (is_euler || is_aeos) {
+          if (per_slice) {
+            /* three launches over all slices: the light one finishes the slices without a stored P_ij in which
+             * nothing was limited (V_i), the repair launch completes the P_ij of the slices that turned out limited
+             * without (all of) it, the heavy one runs the limited slices (kernels_limiter.hpp) */
+            hipLaunchKernelGGL((k_high_order_next_cached<E, kCachedWidth, kCachedP, false, kHoLight>), grid, block, 0,
+                               launch_stream, eparams, mm, nw.U.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr,
+                               d_lij_next.ptr, d_V.ptr, last_s0, slice_flags);
+            hipLaunchKernelGGL(k_pij_repair<E>, grid, block, 0, launch_stream, mm, last_s0, d_pij.ptr, slice_flags);
+            hipLaunchKernelGGL((k_high_order_next_cached<E, kCachedWidth, kCachedP, false, kHoHeavy>), grid, block, 0,
+                               launch_stream, eparams, mm, nw.U.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr,
+                               d_lij_next.ptr, d_V.ptr, last_s0, slice_flags);
+            step6_flags = true;
+            return;
+          }
+        }
         if constexpr (DIM <= 2) {
           /* small meshes: the four waves of a block share one slice (see the kernel) while all of them fit */
           const uint32_t n_launch = mm.slice_end - mm.slice_begin;
           if (L.max_row_len <= (uint32_t)kCachedWidth && n_launch * kWavesPerBlock <= resident_waves_step6) {
             hipLaunchKernelGGL((k_high_order_next_cached<E, kCachedWidth, kCachedWidth, true>), dim3(n_launch),
                                block, 0, launch_stream, eparams, mm, nw.U.ptr, d_bounds.ptr, d_pij.ptr,
-                               d_lij.ptr, d_lij_next.ptr, stage0_V ? d_V.ptr : nullptr, d_scalars.ptr,
-                               stage0_V ? d_slice_unlimited.ptr : nullptr, tile_src);
+                               d_lij.ptr, d_lij_next.ptr, stage0_V ? d_V.ptr : nullptr, last_s0,
+                               SliceFlags{stage0_V ? d_slice_unlimited.ptr : nullptr, nullptr, nullptr});
             step6_flags = stage0_V;
             return;
           }
@@ -1686,18 +1705,34 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
         if ((DIM <= 2 || RYUJIN_HO_CP_3D > 0) && L.max_row_len <= (uint32_t)kCachedWidth) {
           hipLaunchKernelGGL((k_high_order_next_cached<E, kCachedWidth, kCachedP>), grid, block, 0,
                              launch_stream, eparams, mm, nw.U.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr,
-                             d_lij_next.ptr, stage0_V ? d_V.ptr : nullptr, d_scalars.ptr,
-                             stage0_V ? d_slice_unlimited.ptr : nullptr, tile_src);
+                             d_lij_next.ptr, stage0_V ? d_V.ptr : nullptr, last_s0,
+                             SliceFlags{stage0_V ? d_slice_unlimited.ptr : nullptr, nullptr, nullptr});
           step6_flags = stage0_V;
         } else
           hipLaunchKernelGGL((k_high_order<E, false>), grid, block, 0, launch_stream, eparams, mm, nw.U.ptr,
                              d_bounds.ptr, d_pij.ptr, d_lij.ptr, d_lij_next.ptr, FusedSadd{0., 0., nullptr});
       });
+      if constexpr (is_euler) {
+        if (checked) /* the update after the first pass (:1121-1126) and the second pass's success (:1155-1161) */
+          sweep([&](const DeviceMesh &mm, dim3 grid) {
+            hipLaunchKernelGGL(k_check_admissible<E>, grid, block, 0, launch_stream, eparams, mm, d_scalars.ptr,
+                               (const double *)nw.U.ptr);
+            hipLaunchKernelGGL(k_check_limiter<E>, grid, block, 0, launch_stream, eparams, mm, d_scalars.ptr,
+                               (const double *)nw.U.ptr, (const double *)d_bounds.ptr, (const double *)d_pij.ptr,
+                               (const double *)d_lij.ptr);
+          });
+      }
       exchange_matrix(d_lij_next.ptr, true);
+    }
+    if constexpr (is_euler) {
+      if (checked && last_round) /* the final update (:1121-1126) */
+        sweep([&](const DeviceMesh &mm, dim3 grid) {
+          hipLaunchKernelGGL(k_check_admissible<E>, grid, block, 0, launch_stream, eparams, mm, d_scalars.ptr,
+                             (const double *)nw.U.ptr);
+        });
     }
     mark(5 + pass);
   }
-  last_l_first = d_lij_next.ptr; /* (two passes: the buffers were swapped in front of the last one) */
   for (int k = 5 + n_iterations; k <= 7; ++k)
     mark(k);
   nw.precomputed = fuse_precompute;
@@ -1881,7 +1916,8 @@ int ryujin_hip_ctx::time_step(int scheme, int h_state, int n_tmp, const int *h_t
     } else {
       /* sadd(dst, s, b, U) right after step(.., dst): folded into the last sweep of that step when there
        * is one (limiter iterations >= 1), saving one pass over the state vectors per stage */
-      const bool fuse = params.limiter_iterations >= 1;
+      /* (not with the checked build's extra kernels: they look at the update before the sadd, as the reference does) */
+      const bool fuse = params.limiter_iterations >= 1 && !params.debug_expensive_bounds_check;
       auto stage_with_sadd = [&](int h_old, int h_new, double sa, double sb) {
         struct Disarm { /* a step that throws before its last sweep must not leave the sadd armed */
           FusedSadd &p;
@@ -2116,6 +2152,7 @@ void ryujin_hip_default_params(ryujin_hip_params *p, int equation, int dim)
   p->debug_bc_fold_max_slices = 0;
   p->debug_no_small_mesh_split = 0;
   p->debug_pij_storage = 0;
+  p->debug_expensive_bounds_check = 0;
 }
 
 int ryujin_hip_comm_unique_id(char id[RYUJIN_HIP_UNIQUE_ID_BYTES])
@@ -2571,7 +2608,7 @@ int ryujin_hip_get_counters(ryujin_hip_ctx *ctx, unsigned *n_restarts, unsigned 
 }
 
 int ryujin_hip_limiter_statistics(ryujin_hip_ctx *ctx, double *limited_slice_fraction, int *pij_stored,
-                                  double *limited_tile_fraction, double *stored_tile_fraction)
+                                  double *stored_slice_fraction)
 {
   return guarded([&]() {
     if (!ctx)
@@ -2579,11 +2616,9 @@ int ryujin_hip_limiter_statistics(ryujin_hip_ctx *ctx, double *limited_slice_fra
     if (limited_slice_fraction)
       *limited_slice_fraction = ctx->limited_fraction;
     if (pij_stored)
-      *pij_stored = ctx->last_tiles ? 2 : 1;
-    if (limited_tile_fraction)
-      *limited_tile_fraction = ctx->limited_tile_fraction;
-    if (stored_tile_fraction)
-      *stored_tile_fraction = ctx->stored_tile_fraction;
+      *pij_stored = ctx->last_per_slice ? 2 : 1;
+    if (stored_slice_fraction)
+      *stored_slice_fraction = ctx->stored_fraction;
     return RYUJIN_OK;
   });
 }
@@ -2605,7 +2640,7 @@ int ryujin_hip_debug_fetch(ryujin_hip_ctx *ctx, int what, double *out, size_t n_
     case 1: fetch_matrix(ctx->d_lij.ptr, 1); break;
     case 2:
       ctx->ensure_pij();
-      if (ctx->last_tiles) {
+      if (ctx->last_per_slice)
         dispatch_equation(ctx->params.equation, ctx->dim, [&](auto tag) {
           using E = typename decltype(tag)::type;
           if constexpr (std::is_same<typename E::Params, EulerParams>::value ||
@@ -2613,10 +2648,7 @@ int ryujin_hip_debug_fetch(ryujin_hip_ctx *ctx, int what, double *out, size_t n_
             ctx->template store_pij_for_debug<E>();
           return 0;
         });
-        fetch_matrix(ctx->d_pij_debug.ptr, (uint32_t)ctx->K);
-      } else {
-        fetch_matrix(ctx->d_pij.ptr, (uint32_t)ctx->K);
-      }
+      fetch_matrix(ctx->d_pij.ptr, (uint32_t)ctx->K);
       break;
     case 5: fetch_matrix(ctx->d_lij_next.ptr, 1); break;
     case 6:
@@ -2801,6 +2833,13 @@ namespace
       out[q * 3 + 0] = l;
       out[q * 3 + 1] = success ? 1. : 0.;
       out[q * 3 + 2] = undecided ? 1. : 0.;
+    } else if (which == RYUJIN_DEBUG_EULER_LIMIT_CHECKED_1D) {
+      const double *v = in + q * 9;
+      const double bnd[3] = {v[0], v[1], v[2]}, U[3] = {v[3], v[4], v[5]}, Pij[3] = {v[6], v[7], v[8]};
+      bool success;
+      out[q * 3 + 0] = Euler<1>::limit_checked(PE, bnd, U, Pij, success);
+      out[q * 3 + 1] = success ? 1. : 0.;
+      out[q * 3 + 2] = 0.;
     } else if (which == RYUJIN_DEBUG_SW_RIEMANN) {
       const double *v = in + q * 6;
       const ShallowWater<1>::RiemannData rd_i{v[0], v[1], v[2]}, rd_j{v[3], v[4], v[5]};
@@ -2879,7 +2918,8 @@ int ryujin_hip_debug_function(int device, const ryujin_hip_params *params, int w
     case RYUJIN_DEBUG_AEOS_DIJ_2D:
     case RYUJIN_DEBUG_AEOS_DIJ_RECORDS_2D: n_in = 10; n_out = 1; break;
     case RYUJIN_DEBUG_AEOS_LIMIT_1D: n_in = 10; n_out = 3; break;
-    case RYUJIN_DEBUG_EULER_LIMIT_1D: n_in = 9; n_out = 3; break;
+    case RYUJIN_DEBUG_EULER_LIMIT_1D:
+    case RYUJIN_DEBUG_EULER_LIMIT_CHECKED_1D: n_in = 9; n_out = 3; break;
     case RYUJIN_DEBUG_SW_RIEMANN: n_in = 6; n_out = 2; break;
     case RYUJIN_DEBUG_EULER_DIJ_2D:
     case RYUJIN_DEBUG_EULER_DIJ_RECORDS_2D: n_in = 10; n_out = 1; break;

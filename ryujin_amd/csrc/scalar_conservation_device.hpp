@@ -29,6 +29,9 @@ namespace ryujin_hip
     static constexpr int K = 1;
     static constexpr int NB = 2;
     static constexpr bool kFusablePrecompute = false; /* (FusedPrecompute: Euler and shallow water only) */
+    /* steps 6/7 may form a limited row's update as V_i - sum (1 - l_ij) lambda P_ij (kernels_limiter.hpp): another
+     * rounding of the reference's sum. Not where l = 0 has to return the low-order update EXACTLY (a dry node) */
+    static constexpr bool kLimitedUpdateFromV = false;
     static constexpr int NPREC = 2 * DIM;
     using Params = ScalarParams;
 

@@ -248,6 +248,9 @@ namespace ryujin_hip
     /* precompute() and riemann_record() are functions of the row's state alone: the last sweep of a step can
      * leave them behind for the next prepare_state_vector() (FusedPrecompute) */
     static constexpr bool kFusablePrecompute = true;
+    /* steps 6/7 may form a limited row's update as V_i - sum (1 - l_ij) lambda P_ij (kernels_limiter.hpp): another
+     * rounding of the reference's sum. Not where l = 0 has to return the low-order update EXACTLY (a dry node) */
+    static constexpr bool kLimitedUpdateFromV = false;
 
     /* ------------------------------------------------------------------ Indicator */
     struct Indicator {

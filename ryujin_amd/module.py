@@ -188,10 +188,21 @@ class HyperbolicModule:
     def _time_step_fn(self, scheme, state, temps, t, dirichlet_fn, tau_max, cfl_recovery, cfl_min, cfl_max):
         n = self.offline.n_bdry * self.k
 
+        failure = []
+
         def callback(user, time, out):
-            values = np.ascontiguousarray(dirichlet_fn(time), dtype=np.float64).reshape(-1)
-            assert values.size == n
-            C.memmove(out, values.ctypes.data, n * 8)
+            # ctypes prints and swallows an exception raised inside a callback; the library has zero-filled the
+            # stage's Dirichlet data, so the stage would run on -- silently -- with zeros. Keep the exception, poison
+            # the values (NaN: the step cannot pass unnoticed) and re-raise once the call has returned.
+            try:
+                values = np.ascontiguousarray(dirichlet_fn(time), dtype=np.float64).reshape(-1)
+                if values.size != n:
+                    raise ValueError(f"dirichlet_fn returned {values.size} values, expected {n}")
+                C.memmove(out, values.ctypes.data, n * 8)
+            except BaseException as e:  # noqa: BLE001
+                failure.append(e)
+                nan = np.full(n, np.nan)
+                C.memmove(out, nan.ctypes.data, n * 8)
         cb = capi.DIRICHLET_FN(callback)
         hs = (C.c_int * len(temps))(*[x.handle for x in temps])
         tau = C.c_double(0.0)
@@ -199,6 +210,8 @@ class HyperbolicModule:
                                      None, float(np.finfo(np.float64).max if tau_max is None else tau_max),
                                      capi.CFL_RECOVERY_BANG_BANG if cfl_recovery == "bang bang control"
                                      else capi.CFL_RECOVERY_NONE, float(cfl_min), float(cfl_max), C.byref(tau))
+        if failure:
+            raise failure[0]
         if rc == capi.RYUJIN_ERR_TAU:
             raise TauError("I'm sorry, Dave. I'm afraid I can't do that. We crashed.")
         self._check(rc)
@@ -264,16 +277,14 @@ class HyperbolicModule:
 
     def limiter_statistics(self) -> dict:
         """Fraction of the 64-row slices in which the first high-order sweep found a limited pair (between the two
-        latest host synchronisations), how the latest step kept P_ij ("all" / "tiles"), the fraction of (slice,
-        column) tiles with a limited pair and the fraction step 5 stored (ryujin_hip_limiter_statistics; device
-        backend only)."""
-        f, stored, ft, fs = C.c_double(1.0), C.c_int(1), C.c_double(1.0), C.c_double(1.0)
+        latest host synchronisations), how the latest step kept P_ij ("everywhere" / "per slice") and the fraction
+        of slices it was stored in (ryujin_hip_limiter_statistics; device backend only)."""
+        f, stored, fs = C.c_double(1.0), C.c_int(1), C.c_double(1.0)
         fn = self._f("limiter_statistics")
-        fn.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double),
-                       C.POINTER(C.c_double)]
-        self._check(fn(self._ctx, C.byref(f), C.byref(stored), C.byref(ft), C.byref(fs)))
-        return dict(limited_slice_fraction=f.value, pij_stored={1: "all", 2: "tiles"}.get(stored.value),
-                    limited_tile_fraction=ft.value, stored_tile_fraction=fs.value)
+        fn.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double)]
+        self._check(fn(self._ctx, C.byref(f), C.byref(stored), C.byref(fs)))
+        return dict(limited_slice_fraction=f.value, pij_stored={1: "everywhere", 2: "per slice"}.get(stored.value),
+                    pij_stored_slice_fraction=fs.value)
 
     def debug_fetch(self, what: str) -> np.ndarray:
         """`*_all`: over all locally relevant rows, i.e. including the ghost rows / ghost range received from

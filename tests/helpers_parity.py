@@ -82,21 +82,22 @@ class EulerFlipClassifier:
         self.k = c["pij"].size // c["lij"].size
         self._U = {}
 
-    def _state_seen_by_limiter(self, iterations):
-        if iterations not in self._U:
+    def _state_seen_by_limiter(self, iterations, backend=None):
+        key = iterations if backend is None else (iterations, backend)
+        if key not in self._U:
             p = capi.Params()
             C.memmove(C.byref(p), C.byref(self.params), C.sizeof(capi.Params))
             p.limiter_iterations = iterations
-            m = HyperbolicModule(self.off, p, backend=self.oracle.backend())
+            m = HyperbolicModule(self.off, p, backend=backend or self.oracle.backend())
             old, new = m.new_state_vector(self.U_start), m.new_state_vector()
             stages = [m.new_state_vector(U) for U in self.stage_U]
             for sv in stages:                      # stage vectors are *prepared* state vectors (:207-213)
                 m.prepare_state_vector(sv, 0.0, self.dirichlet)
             m.prepare_state_vector(old, 0.0, self.dirichlet)
             m.step(old, stages, self.stage_weights, new, self.tau)
-            self._U[iterations] = new.download()
+            self._U[key] = new.download()
             m.close()
-        return self._U[iterations]
+        return self._U[key]
 
     def _transposed(self, e):
         i = int(np.searchsorted(self.rs, e, side="right") - 1)
@@ -136,6 +137,63 @@ class EulerFlipClassifier:
         rho_e = U_r[-1] - 0.5 * (U_r[1:-1] ** 2).sum() / rho
         terms = abs(rho * rho_e) + abs(bounds[2] * rho ** (self.params.gamma + 1.0))
         return abs(psi) / terms, i, j
+
+    def second_pass_follows_its_inputs(self, e, g):
+        """A SECOND-pass outlier that is not a round-off sized psi_r: the state the second pass limits is the update
+        after the first pass, and the first pass put it on the boundary of the invariant set only to ITS Newton
+        tolerance -- first-pass l_ij that agree to 1e-10 (the contract) move that state by 1e-10 lambda |P_ij|,
+        orders above round-off, and psi_r of a row sitting on the entropy bound changes sign with it. Such a
+        difference is the limiter's own discontinuity met with inputs that differ within THEIR contracts, if
+          (a) the oracle's limiter, given the device's inputs of the pair (its bounds, its update after the first
+              pass -- the device run once more with ONE limiter pass --, its (1 - l) P_ij), returns the device's
+              l'_ij to 1e-10 (same function), or finds psi_r of THOSE inputs at round-off (1e-13 of its terms: the
+              branch flip proper, on the device's side of the input difference), and
+          (b) those inputs differ from the oracle's by no more than the first-pass contract allows:
+              |dU| <= 1e-11 + lambda sum_j |dl_ij| |P_ij| for the row.
+        Returns (a and b, details)."""
+        c, k = self.c, self.k
+        i, j, e_t = self._transposed(e)
+        rows = slice(self.rs[i], self.rs[i + 1])
+        lam = 1.0 / max(1, self.rs[i + 1] - self.rs[i] - 1)
+        scale = np.abs(self._state_seen_by_limiter(1)).max(axis=0)
+        U_g = self._state_seen_by_limiter(1, "hip")[i]
+        U_c = self._state_seen_by_limiter(1)[i]
+
+        def sym(first, entry, entry_t):
+            return first[entry] if entry_t is None else min(first[entry], first[entry_t])
+        # (b) the update after the first pass: covered by the first-pass differences of the row (incl. transposes)
+        dl = np.zeros(self.rs[i + 1] - self.rs[i])
+        for q, ee in enumerate(range(self.rs[i], self.rs[i + 1])):
+            if q == 0:
+                continue
+            _, _, ee_t = self._transposed(ee)
+            dl[q] = abs(sym(g["lij_next"], ee, ee_t) - sym(c["lij_next"], ee, ee_t))
+        P_row = np.abs(c["pij"].reshape(-1, k)[rows])
+        bound = U_TOL + lam * (dl[:, None] * P_row).sum(axis=0) / scale + \
+            1e-12 * lam * (P_row.sum(axis=0) / scale)        # (and P_ij itself is known to 1e-12 of its largest entry)
+        inputs_ok = bool((np.abs(U_g - U_c) / scale <= bound).all())
+        # (a) the oracle's limiter on the device's inputs
+        P = g["pij"].reshape(-1, k)[e] * (1.0 - sym(g["lij_next"], e, e_t))
+        bounds = np.ascontiguousarray(g["bounds"].reshape(-1, 3)[i])
+        out = np.zeros(5)
+        dp = capi.c_double_p
+        self.oracle.lib().ryujin_oracle_euler_limit_trace(C.byref(self.params), capi.as_ptr(bounds, dp),
+                                                          capi.as_ptr(np.ascontiguousarray(U_g), dp),
+                                                          capi.as_ptr(np.ascontiguousarray(P), dp),
+                                                          capi.as_ptr(out, dp))
+        expected = (1.0 - sym(g["lij_next"], e, e_t)) * out[0]
+        same_function = abs(expected - g["lij"][e]) <= L_TOL
+        # ... or the device's inputs themselves sit on the psi_r = 0 branch to round-off (the row's state after the
+        # first pass lies ON the entropy bound and (1 - l) P_ij hardly moves it: psi_r is psi of that state)
+        t_r, psi = out[2], out[3]
+        U_r = U_g + t_r * P
+        rho = U_r[0]
+        rho_e = U_r[-1] - 0.5 * (U_r[1:-1] ** 2).sum() / rho
+        terms = abs(rho * rho_e) + abs(bounds[2] * rho ** (self.params.gamma + 1.0))
+        on_branch = abs(psi) / terms <= PSI_ROUND_OFF
+        return inputs_ok and (same_function or on_branch), (
+            inputs_ok, float(abs(expected - g["lij"][e])), float(abs(psi) / terms),
+            float((np.abs(U_g - U_c) / scale).max()))
 
 
 def alpha_last_bit_sensitivity(oracle, off, params, U_before, dirichlet, tau, alpha_ref):
@@ -301,6 +359,17 @@ def compare_step(off, mods, dirichlet=None, tau=0.0, *, oracle=None, params=None
         for e in idx[:200]:
             rel, i, j = g["flip"].psi_r(name, int(e))
             _stat(label, what=name + "_flip", entry=int(e), dl=float(dl[e]), psi_rel=float(rel))
+            if rel > PSI_ROUND_OFF and name == "lij" and params.limiter_iterations == 2 and not stage_U:
+                # second pass: psi_r is sized by the first pass's Newton tolerance, not by round-off
+                for key in ("lij", "lij_next", "pij"):
+                    if key not in g:
+                        g[key] = mg.debug_fetch(key)
+                ok, detail = g["flip"].second_pass_follows_its_inputs(int(e), g)
+                _stat(label, what="lij_second_pass_follows_inputs", entry=int(e), ok=bool(ok), detail=repr(detail))
+                _check(ok, label, "second-pass l'_ij differs beyond what its inputs explain",
+                       (int(e), float(dl[e]), float(rel), detail))
+                flipped_rows.update((i, j))
+                continue
             _check(rel <= PSI_ROUND_OFF, label, name + " outlier off the psi_r = 0 branch",
                    (int(e), float(dl[e]), float(rel)))
             flipped_rows.update((i, j))

@@ -110,6 +110,29 @@ def test_device_limiter_against_the_reference_baseline(oracle, golden_dir):
         assert abs(out[n, 0] - l_ref) <= 1e-10, (n, out[n, 0], l_ref)
 
 
+def test_device_limiter_in_the_checked_control_flow_reproduces_all_twelve_rows(oracle, golden_dir):
+    """tests/euler/limiter.output was written by an EXPENSIVE_BOUNDS_CHECK build (limiter.cc:10). The device's
+    limit_checked() (ryujin_hip_params::debug_expensive_bounds_check, RYUJIN_DEBUG_EULER_LIMIT_CHECKED_1D) runs that
+    control flow: every row of the baseline -- the six Failure cases included -- is reproduced, l to 1e-13 against the
+    oracle's checked flow (which tests/test_oracle_golden_euler.py pins on the baseline's printed trace) and to the
+    printed digits against the baseline itself, Success / Failure exactly."""
+    from test_oracle_golden_euler import _run_limit
+    params = oracle.default_params(capi.EQ_EULER, 1)
+    blocks = _limiter_blocks(os.path.join(golden_dir, "euler_limiter.output"))
+    assert len(blocks) == len(LIMITER_CASES) == 12
+    items = [np.concatenate([bounds, U, P]) for _, U, P, bounds in LIMITER_CASES]
+    out = _device(params, capi.DEBUG_EULER_LIMIT_CHECKED_1D, items, 3)
+    n_failures = 0
+    for (label, U, P, bounds), block, (l, success, _) in zip(LIMITER_CASES, blocks, out):
+        ref, _ = _run_limit(oracle, params, True, U, P, bounds)
+        assert abs(l - ref[0]) <= 1e-13, (label, l, ref[0])
+        assert bool(success) == bool(ref[1]), label
+        assert abs(l - _grab(block, "\nl:")[0]) <= 5e-16 + 1e-13, (label, l)
+        assert ("Success!" in block) == bool(success) and ("Failure!" in block) == (not bool(success)), label
+        n_failures += not bool(success)
+    assert n_failures == 6
+
+
 def test_device_sw_riemann_solver_against_the_reference_baseline(oracle, golden_dir):
     text = open(os.path.join(golden_dir, "shallow_water_riemann_solver.output")).read()
     lam = [float(x) for x in re.findall(r"lambda_max: ([0-9.e+-]+)", text)]

@@ -81,6 +81,58 @@ def test_step_parity_2d_step_geometry(oracle):
     assert (np.sign(rho) == np.sign(c["U"][: off.n_owned, 0])).all()
 
 
+def test_step_parity_c1_size(oracle):
+    """BASELINE.json configs[0] at its own size: the mesh of `bench.py --cells-per-unit 130` (43 109 gridpoints) takes
+    another column split of the small-mesh kernels of steps 5 and 6 than either the 4 k point mesh above or the
+    2.5 M point mesh of the full-size test. A developed bow shock (300 updates), then one update against the oracle."""
+    spec = offline.mach3_step_2d(130)
+    off0 = offline.SyntheticOffline(spec)
+    assert off0.n_owned == 43109
+    U0 = euler_uniform(off0.positions)
+    dirichlet = euler_uniform(off0.b_positions)
+    off, mods = _both(spec, U0, oracle, n_warm=300, dirichlet=dirichlet)
+    g, c = _compare_step(off, mods, dirichlet)
+    rho, E = g["U"][: off.n_owned, 0], g["U"][: off.n_owned, 3]
+    m2 = (g["U"][: off.n_owned, 1:3] ** 2).sum(1)
+    assert (rho > 0).all() and (E - 0.5 * m2 / rho > 0).all()
+
+
+@pytest.mark.parametrize("cfl", [0.9, 4.0])
+def test_expensive_bounds_check_as_a_run_time_option(oracle, cfl):
+    """ryujin_hip_params::debug_expensive_bounds_check: the reference's EXPENSIVE_BOUNDS_CHECK build (is_admissible
+    behind steps 4, 6 and 7, the limiter's checked control flow in both passes,
+    hyperbolic_module.template.h:851-855,1121-1126,1155-1161) against the oracle's. The l_ij and the new state are
+    those of the production flow (the checked flow returns the same t_l); what differs is when a violation is
+    reported: at cfl 0.9 nothing is, at four times the admissible step both raise it."""
+    spec = offline.mach3_step_2d(40)
+    off = offline.SyntheticOffline(spec)
+    U0 = _perturbed(euler_uniform(off.positions))
+    dirichlet = euler_uniform(off.b_positions)
+    results = []
+    for backend in ("hip", oracle.backend()):
+        p = oracle.default_params(capi.EQ_EULER, 2)
+        p.cfl = cfl
+        p.id_violation_strategy = capi.IDV_WARN
+        if backend == "hip":
+            p.debug_expensive_bounds_check = 1
+        m = HyperbolicModule(off, p, backend=backend)
+        if backend != "hip":
+            oracle.lib().ryujin_oracle_set_expensive_bounds_check(m._ctx, 1)
+        a, b = m.new_state_vector(U0), m.new_state_vector()
+        statuses = []
+        for _ in range(3):
+            m.prepare_state_vector(a, 0.0, dirichlet)
+            m.step(a, [], [], b)
+            statuses.append(m.last_status)
+            a, b = b, a
+        results.append((statuses, a.download()[: off.n_owned], m.n_warnings()))
+    (st_g, U_g, w_g), (st_c, U_c, w_c) = results
+    assert st_g == st_c and w_g == w_c, (st_g, st_c)
+    assert (w_g == 0) == (cfl <= 1.0)
+    if cfl <= 1.0:
+        assert (np.abs(U_g - U_c) / np.abs(U_c).max(axis=0)).max() <= 1e-10
+
+
 def test_step_parity_3d_radial_contrast(oracle):
     """C3-like: 3-D box, slip walls, strong radial pressure contrast (limiter active)."""
     spec = offline.box_3d(12)
@@ -251,7 +303,7 @@ def test_device_pow_accuracy():
 
 
 @pytest.mark.parametrize("n_ranks,mode", [(2, ""), (3, ""), (3, "join_exchanges"), (3, "bc_launch"),
-                                          (3, "system_events"), (3, "tile_pij")])
+                                          (3, "system_events"), (3, "per_slice_pij")])
 def test_partitioned_hip_matches_single_rank(n_ranks, mode, monkeypatch):
     """Multi-rank code path of the library on ONE GPU: n contexts (one host thread each) own x-slabs of
     the mesh and exchange ghosts through the in-process transport (ryujin_hip_comm_init_local), which
@@ -261,8 +313,7 @@ def test_partitioned_hip_matches_single_rank(n_ranks, mode, monkeypatch):
     choreography of an asymmetric stencil (every sweep joins the exchanges); "bc_launch": boundary
     conditions as a launch of their own in front of the pre-pass (large meshes); "system_events": the events
     between the two streams created with the system-scope fence (ryujin_hip_params::system_scope_events);
-    "tile_pij": the kernels of large meshes -- step 5 stores only the (slice, column) tiles of P_ij steps 6 and 7 read,
-    every tile in the export slices (the transpose of a ghost column lives on another rank)."""
+    "per_slice_pij": the kernels of large meshes with P_ij stored per 64-row slice and no slice predicted limited."""
     import ctypes as C
     import threading
 
@@ -272,9 +323,9 @@ def test_partitioned_hip_matches_single_rank(n_ranks, mode, monkeypatch):
         monkeypatch.setattr(HyperbolicModule, "library_switches", {"debug_bc_fold_max_slices": -1})
     elif mode == "system_events":
         monkeypatch.setattr(HyperbolicModule, "library_switches", {"system_scope_events": 1})
-    elif mode == "tile_pij":  # the kernels of large meshes: tile storage of P_ij, export slices store every tile
+    elif mode == "per_slice_pij":  # nothing predicted: trigger, repair prologue, two-launch step 6 in both parts
         monkeypatch.setattr(HyperbolicModule, "library_switches",
-                            {"debug_no_small_mesh_split": 1, "debug_bc_fold_max_slices": -1})
+                            {"debug_pij_storage": 1, "debug_no_small_mesh_split": 1, "debug_bc_fold_max_slices": -1})
 
     lib = capi.load_hip()
     cpu, n_updates = 40, 6
@@ -1586,24 +1637,24 @@ def test_unstructured_p1_mesh_scalar_conservation(oracle):
 
 
 @pytest.mark.parametrize("which", ["euler_2d", "euler_1d", "euler_erk33", "sw_2d", "sw_1d", "aeos_2d", "scalar_2d",
-                                   "euler_2d:full_matrix", "euler_1d:full_matrix", "euler_erk33:full_matrix",
-                                   "aeos_2d:full_matrix"])
+                                   "euler_2d:no_prediction", "euler_1d:no_prediction", "euler_erk33:no_prediction",
+                                   "aeos_2d:no_prediction", "euler_2d:always_store", "aeos_2d:always_store"])
 def test_step_parity_with_the_kernels_of_large_meshes(oracle, monkeypatch, which):
     """The meshes of this file do not fill an MI355X, so they take the small-mesh branches of the library
     (boundary conditions folded into the pre-pass, steps 5 and 6 with the columns of a slice spread over several
     waves). Re-run one case per Description with those branches switched off: the kernels BASELINE-sized meshes
     run (also covered at full size for Euler and shallow water in test_gpu_parity_fullsize.py).
-    An update of Euler / EulerAEOS without stage vectors keeps P_ij in the tile storage there
-    (kernels_limiter.hpp, TileSrc): step 5 stores the bracket Q_ij of a (slice, column) tile only where one of its own
-    l_ij comes out below 1, steps 6 and 7 form U_i = V_i - sum (1 - l_ij) lambda P_ij over the limited pairs and take a
-    pair that is limited through the neighbour's l_ji alone from the neighbour's tile with the opposite sign. The
-    P_ij the comparison fetches is assembled the way those sweeps read it (own tile, transposed tile; pij_stage0() of
-    the operands for the pairs nobody reads). `:full_matrix` switches the tile storage off (all of P_ij stored, as
-    every other kind of update does)."""
+    An update without stage vectors stores P_ij per 64-row slice there (kernels_limiter_stage0.hpp): where the slice
+    held a limited pair in the previous update -- the first update of a context stores everywhere --, or where one
+    of its own l_ij comes out limited (stored from that column on, the columns before it formed a second time);
+    a slice limited through a neighbour's l_ji alone gets its P_ij from the repair prologue of step 6, which runs as a
+    light and a heavy launch. `:no_prediction` predicts no slice limited (every stored slice goes through the
+    trigger or the repair prologue), `:always_store` all of them. The P_ij the comparison fetches is what the sweeps
+    stored, completed through the same device function for the slices they left out (ryujin_hip_debug_fetch)."""
     switches = {"debug_no_small_mesh_split": 1, "debug_bc_fold_max_slices": -1}
     which, _, variant = which.partition(":")
-    if variant == "full_matrix":
-        switches["debug_pij_storage"] = -1
+    if variant:
+        switches["debug_pij_storage"] = {"no_prediction": 1, "always_store": -1}[variant]
     monkeypatch.setattr(HyperbolicModule, "library_switches", switches)
     {
         "euler_2d": lambda: test_step_parity_2d_step_geometry(oracle),
