@@ -473,7 +473,10 @@ enum {
    * in the reference's operation order and through the per-node Riemann records the sweep uses */
   RYUJIN_DEBUG_AEOS_DIJ_2D = 13,
   RYUJIN_DEBUG_AEOS_DIJ_RECORDS_2D = 14,
-  RYUJIN_DEBUG_EULER_LIMIT_CHECKED_1D = 15
+  RYUJIN_DEBUG_EULER_LIMIT_CHECKED_1D = 15,
+  /* the limiter as the sweeps compose it, dim = 2: in bounds[3], U[4], P[4]; out l, success, took the Newton tail,
+   * t_r behind the density clip, psi_r of the first Newton iteration (as the device evaluates it) */
+  RYUJIN_DEBUG_EULER_LIMIT_2D = 16
 };
 int ryujin_hip_debug_function(int device, const ryujin_hip_params *params, int which, const double *in,
                               double *out, size_t n);

@@ -34,7 +34,7 @@ DEBUG_SW_DIJ_2D, DEBUG_SW_DIJ_RECORDS_2D = 7, 8
 DEBUG_EULER_RIEMANN_RECORDS, DEBUG_SW_RIEMANN_RECORDS = 9, 10
 DEBUG_AEOS_RIEMANN, DEBUG_AEOS_LIMIT_1D = 11, 12
 DEBUG_AEOS_DIJ_2D, DEBUG_AEOS_DIJ_RECORDS_2D = 13, 14
-DEBUG_EULER_LIMIT_CHECKED_1D = 15
+DEBUG_EULER_LIMIT_CHECKED_1D, DEBUG_EULER_LIMIT_2D = 15, 16
 
 
 DIRICHLET_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_double, c_double_p)   # ryujin_hip_dirichlet_fn

@@ -668,18 +668,17 @@ namespace ryujin_hip
      * the masked-off lanes through it. The kernels therefore run this wave-uniform fast part over
      * all columns first and finish the few undecided (row, col) pairs with limit() afterwards.
      * Returns the limiter value if decided, otherwise sets undecided = true. */
-    static RYUJIN_DEV double limit_fast(const EulerParams &P, const double (&bnd)[NB],
-                                        const double (&U)[K], const double (&Pij)[K], bool &success,
-                                        bool &undecided)
+    /* density clip (limiter.template.h:40-108) and psi_r of the first Newton iteration (:173-182) */
+    static RYUJIN_DEV double first_psi_r(const EulerParams &P, const double (&bnd)[NB], const double (&U)[K],
+                                         const double (&Pij)[K], bool &success, double &t_r)
     {
       const double rho_min = bnd[0], rho_max = bnd[1], s_min = bnd[2];
       constexpr double t_min = 0., t_max = 1.;
       constexpr double eps = DBL_EPSILON;
       success = true;
-      undecided = false;
       const double relax_small = 1. + P.vacuum_small * eps;
       const double relax = 1. + P.vacuum_large * eps;
-      double t_r = t_max;
+      t_r = t_max;
       {
         const double rho_U = U[0];
         const double rho_P = Pij[0];
@@ -693,8 +692,6 @@ namespace ryujin_hip
         t_r = fmin(t_r, t_max);
         t_r = fmax(t_r, t_min);
       }
-      if (P.lim_newton_max_iterations <= 0)
-        return t_min;
       double U_r[K];
 #pragma unroll
       for (int q = 0; q < K; ++q)
@@ -702,7 +699,19 @@ namespace ryujin_hip
       const double rho_r = U_r[0];
       const double rho_r_gamma = dev_pow(rho_r, P.gamma);
       const double rho_e_r = internal_energy(U_r);
-      const double psi_r = relax_small * rho_r * rho_e_r - s_min * rho_r * rho_r_gamma;
+      return relax_small * rho_r * rho_e_r - s_min * rho_r * rho_r_gamma;
+    }
+
+    static RYUJIN_DEV double limit_fast(const EulerParams &P, const double (&bnd)[NB],
+                                        const double (&U)[K], const double (&Pij)[K], bool &success,
+                                        bool &undecided)
+    {
+      constexpr double t_min = 0.;
+      undecided = false;
+      double t_r;
+      const double psi_r = first_psi_r(P, bnd, U, Pij, success, t_r);
+      if (P.lim_newton_max_iterations <= 0)
+        return t_min;
       if (psi_r > 0.)
         return t_r; /* t_l = t_r, break */
       if (t_r == t_min)

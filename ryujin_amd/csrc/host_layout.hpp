@@ -103,7 +103,7 @@ namespace ryujin_hip
     uint32_t n_owned = 0, n_relevant = 0, n_slices = 0, rows_padded = 0;
     uint32_t max_row_len = 0;
     std::vector<uint32_t> slice_off; /* [n_slices+1], in units of 64-entry columns */
-    std::vector<uint8_t> row_len;    /* [rows_padded] logical row length (0 beyond n_owned) */
+    std::vector<uint16_t> row_len;    /* [rows_padded] logical row length (0 beyond n_owned) */
     std::vector<uint64_t> ghost_ptr; /* [n_ghost+1] */
     uint64_t nnz_sell = 0, nnz_total = 0, nnz_owned_logical = 0;
     std::vector<uint32_t> cols;      /* [nnz_total]; padding entries point at their own row */
@@ -146,9 +146,12 @@ namespace ryujin_hip
       max_row_len = 0;
       for (uint32_t i = 0; i < n_owned; ++i) {
         const uint32_t len = ref.row_length(i);
-        if (len == 0 || len > 64)
-          throw std::invalid_argument("row length must be in [1,64]");
-        row_len[i] = (uint8_t)len;
+        /* (a row is a lane of its SELL-64 slice and may be as wide as it likes: cG Q2 / Q3 and dG stencils have 125 to
+         * several hundred entries in 3-D, discretization.h:131-151; 1023: the column field of the limiter's list of
+         * undecided pairs, kernels_limiter.hpp) */
+        if (len == 0 || len > 1023)
+          throw std::invalid_argument("row length must be in [1,1023]");
+        row_len[i] = (uint16_t)len;
         max_row_len = std::max(max_row_len, len);
         logical_ptr[i + 1] = logical_ptr[i] + len;
       }

@@ -54,7 +54,7 @@ namespace ryujin_hip
     uint32_t bounds_stride; /* limiter bounds are SoA [n_bounds][bounds_stride], bounds_stride >= n_relevant */
     uint32_t slice_begin, slice_end; /* slice range of this launch (export rows first, then interior) */
     const uint32_t *slice_off; /* [n_slices+1] */
-    const uint8_t *row_len;    /* [n_slices*64] */
+    const uint16_t *row_len;    /* [n_slices*64] */
     const uint32_t *cols;      /* [nnz_total] */
     const uint32_t *idx_t;     /* [nnz_total] */
     const double *cij;         /* paired layout, DIM comps */
@@ -410,7 +410,7 @@ namespace ryujin_hip
   template <typename E>
   __global__ void __launch_bounds__(kBlock)
   k_apply_bc_records(const typename E::Params P, const uint32_t n_groups, const uint32_t *__restrict__ b_i,
-                     const uint8_t *__restrict__ row_len, const BcFold B, double *U, double *__restrict__ prec,
+                     const uint16_t *__restrict__ row_len, const BcFold B, double *U, double *__restrict__ prec,
                      double *__restrict__ rec)
   {
     constexpr int K = E::K, RS = E::RS;

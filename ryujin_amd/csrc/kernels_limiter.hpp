@@ -52,7 +52,8 @@ namespace ryujin_hip
    * ballot per column, no atomics -- and works the list off 64 at a time, every lane taking ANY pair: the row's
    * bounds and state wait in LDS, P_ij comes from the matrix. Same function on the same
    * operands, so the same l_ij; ceil(n / 64) rounds instead of max_lane(n_lane).
-   *   queue      this wave's LDS list, capacity (width - 1) * 64 entries of (column << 6 | lane)
+   *   queue      this wave's LDS list of (column << 6 | lane), capacity 63 * 64 entries: the mask covers the columns
+   *              c0 + 1 ... c0 + 63 (rows wider than 64 entries come in blocks of 63 columns; column < 1024)
    *   load_P     (column, owning lane, out[K]): the P_ij the limiter is asked about
    *   emit       (column, owning lane, l): store the result
    * Returns false if some limit() reported failure. All 64 lanes must call (inactive rows with an empty mask). */
@@ -66,7 +67,7 @@ namespace ryujin_hip
   RYUJIN_DEV bool limit_undecided_pairs(const typename E::Params &P, const RowCtx &r, unsigned long long undecided_mask,
                                         const double (&bnd)[E::NB], const double (&U_i_new)[E::K],
                                         uint16_t *__restrict__ queue, double *__restrict__ rows, const LoadP &load_P,
-                                        const Emit &emit)
+                                        const Emit &emit, const uint32_t c0 = 0)
   {
     constexpr int K = E::K, NB = E::NB;
 #ifndef RYUJIN_COMPACT_TAIL
@@ -76,7 +77,7 @@ namespace ryujin_hip
     {
       bool ok = true;
       while (undecided_mask) {
-        const uint32_t c = (uint32_t)__builtin_ctzll(undecided_mask);
+        const uint32_t c = c0 + (uint32_t)__builtin_ctzll(undecided_mask);
         undecided_mask &= undecided_mask - 1;
         double P_ij[K];
         load_P(c, r.lane, P_ij);
@@ -91,13 +92,13 @@ namespace ryujin_hip
     if (!__any(undecided_mask != 0ull))
       return true;
     uint32_t total = 0; /* wave-uniform */
-    for (uint32_t c = 1; c < r.width; ++c) {
-      const bool mine = (undecided_mask >> c) & 1ull;
+    for (uint32_t k = 1; k < 64 && c0 + k < r.width; ++k) { /* bit k of the mask: column c0 + k */
+      const bool mine = (undecided_mask >> k) & 1ull;
       const unsigned long long b = __ballot(mine);
       if (b == 0ull)
         continue;
       if (mine)
-        queue[total + (uint32_t)__popcll(b & ((1ull << r.lane) - 1ull))] = (uint16_t)((c << 6) | r.lane);
+        queue[total + (uint32_t)__popcll(b & ((1ull << r.lane) - 1ull))] = (uint16_t)(((c0 + k) << 6) | r.lane);
       total += (uint32_t)__popcll(b);
     }
     /* the rows' bounds and states for whoever takes their pairs ([component][lane]: conflict free) */
@@ -196,7 +197,8 @@ namespace ryujin_hip
 
   /* DG: full inverse of the (block-diagonal) consistent mass matrix instead of the Neumann series
    * (hyperbolic_module.template.h:976-986): b_ij = m_i (M^-1)_ij, b_ji = m_j (M^-1)_ij */
-  template <typename E, bool DG = false>
+  /* WIDE: rows of more than 64 entries (cG Q2 / Q3, dG in 3-D), the columns in blocks of 63 */
+  template <typename E, bool DG = false, bool WIDE = false>
   __global__ void __launch_bounds__(kBlock, RYUJIN_OCC_PIJ)
   k_pij_lij(const typename E::Params P, const DeviceMesh M, DeviceScalars *__restrict__ scalars,
             const double *__restrict__ new_U, const double *__restrict__ r_in,
@@ -251,7 +253,13 @@ namespace ryujin_hip
       mij_n = ld_stream(mij + (((uint64_t)r.base + 1) * 64 + r.lane));
     }
 
-    for (uint32_t c = 1; c < r.width; ++c) {
+    /* (rows wider than 64 entries -- cG Q2 / Q3, dG in 3-D -- in blocks of 63 columns: the undecided pairs of a block
+     * are finished before the next one starts, the mask has 64 bits) */
+    __shared__ uint16_t tail_queue[kWavesPerBlock * 63 * 64];
+    __shared__ TailScratch<E> tail_rows[kWavesPerBlock];
+    for (uint32_t c_blk = 1; c_blk < r.width; c_blk += 63) {
+    const uint32_t c_end = (WIDE && c_blk + 63 < r.width) ? c_blk + 63 : r.width;
+    for (uint32_t c = c_blk; c < c_end; ++c) {
       const uint64_t colbase = (uint64_t)r.base + c;
       const uint64_t pos = colbase * 64 + r.lane;
       const bool active = row_active && c < r.len;
@@ -296,18 +304,13 @@ namespace ryujin_hip
       const double l_ij =
           E::limit_fast(P, bnd, U_i_new, P_ij, success, undecided);
       if (undecided) {
-        undecided_mask |= 1ull << c;
+        undecided_mask |= 1ull << (c - c_blk + 1);
       } else {
         lij[pos] = l_ij;
         all_ok = all_ok && success;
       }
     }
-    if (V_out != nullptr && row_active)
-      store_state<K>(V_out, i, V_i);
-
-    /* the few pairs that need the Newton iteration */
-    __shared__ uint16_t tail_queue[kWavesPerBlock * 63 * 64];
-    __shared__ TailScratch<E> tail_rows[kWavesPerBlock];
+    /* the few pairs of the block that need the Newton iteration */
     const bool tail_ok = limit_undecided_pairs<E>(
         P, r, undecided_mask, bnd, U_i_new, tail_queue + (threadIdx.x >> 6) * 63 * 64,
         tail_rows[threadIdx.x >> 6].rows,
@@ -316,8 +319,16 @@ namespace ryujin_hip
         },
         [&](const uint32_t c, const uint32_t owner, const double l_ij) {
           lij[((uint64_t)r.base + c) * 64 + owner] = l_ij;
-        });
-    flag_restart(scalars, all_ok && tail_ok, r.lane);
+        },
+        c_blk - 1);
+    all_ok = all_ok && tail_ok;
+    undecided_mask = 0;
+    if constexpr (!WIDE)
+      break; /* (one block: the compiler sees a straight line, the pipeline registers die before the tail) */
+    }
+    if (V_out != nullptr && row_active)
+      store_state<K>(V_out, i, V_i);
+    flag_restart(scalars, all_ok, r.lane);
   }
 
   /* Step 5 for Euler, stages == 0, fused with the first part of P_ij of step 4 (:769-813): instead of
@@ -578,7 +589,7 @@ namespace ryujin_hip
   }
 
   /* Generic variant: two passes over the row's stencil (the second one re-reads l_ij, l_ji, P_ij). */
-  template <typename E, bool LAST_ROUND>
+  template <typename E, bool LAST_ROUND, bool WIDE = false>
   __global__ void __launch_bounds__(kBlock, RYUJIN_OCC_HO)
   k_high_order(const typename E::Params P, const DeviceMesh M, double *__restrict__ new_U,
                const double *__restrict__ bounds, const double *__restrict__ pij,
@@ -636,48 +647,60 @@ namespace ryujin_hip
       for (int b = 0; b < NB; ++b)
         bnd[b] = bounds[(size_t)b * stride + i];
       unsigned long long undecided_mask = 0;
-      for (uint32_t c = 1; c < r.width; ++c) {
-        const uint64_t colbase = (uint64_t)r.base + c;
-        const uint64_t pos = colbase * 64 + r.lane;
-        const bool active = row_active && c < r.len;
-        const double l_a = lij[pos];
-        const double l_b = lij[idx_t[pos]];
-        const double old_l_ij = lmin(l_a, l_b);
-        if (!__any(active && !(old_l_ij == 1.))) {
-          if (active)
-            st_stream(lij_next + (pos), 0.);
-          continue;
+      __shared__ uint16_t tail_queue[kWavesPerBlock * 63 * 64];
+      __shared__ TailScratch<E> tail_rows[kWavesPerBlock];
+      /* (blocks of 63 columns: rows wider than 64 entries, see k_pij_lij) */
+      for (uint32_t c_blk = 1; c_blk < r.width; c_blk += 63) {
+        const uint32_t c_end = (WIDE && c_blk + 63 < r.width) ? c_blk + 63 : r.width;
+        for (uint32_t c = c_blk; c < c_end; ++c) {
+          const uint64_t colbase = (uint64_t)r.base + c;
+          const uint64_t pos = colbase * 64 + r.lane;
+          const bool active = row_active && c < r.len;
+          const double l_a = lij[pos];
+          const double l_b = lij[idx_t[pos]];
+          const double old_l_ij = lmin(l_a, l_b);
+          if (!__any(active && !(old_l_ij == 1.))) {
+            if (active)
+              st_stream(lij_next + (pos), 0.);
+            continue;
+          }
+          double p_ij[K];
+          load_entry<K>(pij, colbase, r.lane, p_ij);
+          if (!active)
+            continue;
+          double new_p_ij[K];
+#pragma unroll
+          for (int q = 0; q < K; ++q)
+            new_p_ij[q] = (1. - old_l_ij) * p_ij[q];
+          bool success, undecided;
+          const double new_l_ij =
+              E::limit_fast(P, bnd, U_i_new, new_p_ij, success, undecided);
+          if (undecided)
+            undecided_mask |= 1ull << (c - c_blk + 1);
+          else
+            st_stream(lij_next + (pos), (1. - old_l_ij) * new_l_ij);
         }
-        double p_ij[K];
-        load_entry<K>(pij, colbase, r.lane, p_ij);
-        if (!active)
-          continue;
-        double new_p_ij[K];
+        /* (the second pass's `success` is ignored unless EXPENSIVE_BOUNDS_CHECK, :1148-1161) */
+        limit_undecided_pairs<E>(
+            P, r, undecided_mask, bnd, U_i_new, tail_queue + (threadIdx.x >> 6) * 63 * 64,
+            tail_rows[threadIdx.x >> 6].rows,
+            [&](const uint32_t c, const uint32_t owner, double (&out)[K]) {
+              const uint64_t pos = ((uint64_t)r.base + c) * 64 + owner;
+              const double old_l_ij = lmin(lij[pos], lij[idx_t[pos]]);
+              load_entry<K>(pij, (uint64_t)r.base + c, owner, out);
 #pragma unroll
-        for (int q = 0; q < K; ++q)
-          new_p_ij[q] = (1. - old_l_ij) * p_ij[q];
-        bool success, undecided;
-        const double new_l_ij =
-            E::limit_fast(P, bnd, U_i_new, new_p_ij, success, undecided);
-        if (undecided)
-          undecided_mask |= 1ull << c;
-        else
-          st_stream(lij_next + (pos), (1. - old_l_ij) * new_l_ij);
-      }
-      while (undecided_mask) {
-        const uint32_t c = (uint32_t)__builtin_ctzll(undecided_mask);
-        undecided_mask &= undecided_mask - 1;
-        const uint64_t colbase = (uint64_t)r.base + c;
-        const uint64_t pos = colbase * 64 + r.lane;
-        const double old_l_ij = lmin(lij[pos], lij[idx_t[pos]]);
-        double p_ij[K], new_p_ij[K];
-        load_entry<K>(pij, colbase, r.lane, p_ij);
-#pragma unroll
-        for (int q = 0; q < K; ++q)
-          new_p_ij[q] = (1. - old_l_ij) * p_ij[q];
-        bool success;
-        const double new_l_ij = E::limit(P, bnd, U_i_new, new_p_ij, success);
-        st_stream(lij_next + (pos), (1. - old_l_ij) * new_l_ij);
+              for (int q = 0; q < K; ++q)
+                out[q] = (1. - old_l_ij) * out[q];
+            },
+            [&](const uint32_t c, const uint32_t owner, const double new_l_ij) {
+              const uint64_t pos = ((uint64_t)r.base + c) * 64 + owner;
+              const double old_l_ij = lmin(lij[pos], lij[idx_t[pos]]);
+              st_stream(lij_next + (pos), (1. - old_l_ij) * new_l_ij);
+            },
+            c_blk - 1);
+        undecided_mask = 0;
+        if constexpr (!WIDE)
+          break;
       }
     }
   }

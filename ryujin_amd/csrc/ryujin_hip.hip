@@ -389,7 +389,7 @@ struct ryujin_hip_ctx {
 
   /* mesh arrays */
   DeviceBuffer<uint32_t> d_slice_off, d_cols, d_idx_t, d_lower_mask;
-  DeviceBuffer<uint8_t> d_row_len;
+  DeviceBuffer<uint16_t> d_row_len;
   DeviceBuffer<double> d_cij, d_mij, d_mi, d_mi_inv;
   bool dg = false; /* discontinuous ansatz */
   DeviceBuffer<double> d_incidence, d_minv, d_bounds_combined;
@@ -1615,14 +1615,22 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
       }
       if constexpr (is_euler || is_sw) {
         if (dg) {
-          hipLaunchKernelGGL((k_pij_lij<E, true>), grid, block, 0, launch_stream, eparams, mm, d_scalars.ptr,
-                             nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr, d_V.ptr);
+          if (L.max_row_len > 64)
+            hipLaunchKernelGGL((k_pij_lij<E, true, true>), grid, block, 0, launch_stream, eparams, mm,
+                               d_scalars.ptr, nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr, d_V.ptr);
+          else
+            hipLaunchKernelGGL((k_pij_lij<E, true>), grid, block, 0, launch_stream, eparams, mm, d_scalars.ptr,
+                               nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr, d_V.ptr);
           stage0_V = d_V.ptr != nullptr;
           return;
         }
       }
-      hipLaunchKernelGGL(k_pij_lij<E>, grid, block, 0, launch_stream, eparams, mm, d_scalars.ptr, nw.U.ptr,
-                         d_r.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr, d_V.ptr);
+      if (L.max_row_len > 64)
+        hipLaunchKernelGGL((k_pij_lij<E, false, true>), grid, block, 0, launch_stream, eparams, mm, d_scalars.ptr,
+                           nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr, d_V.ptr);
+      else
+        hipLaunchKernelGGL(k_pij_lij<E>, grid, block, 0, launch_stream, eparams, mm, d_scalars.ptr, nw.U.ptr,
+                           d_r.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr, d_V.ptr);
       stage0_V = d_V.ptr != nullptr;
     });
     if constexpr (is_euler) {
@@ -1708,7 +1716,10 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
                              d_lij_next.ptr, stage0_V ? d_V.ptr : nullptr, last_s0,
                              SliceFlags{stage0_V ? d_slice_unlimited.ptr : nullptr, nullptr, nullptr});
           step6_flags = stage0_V;
-        } else
+        } else if (L.max_row_len > 64)
+          hipLaunchKernelGGL((k_high_order<E, false, true>), grid, block, 0, launch_stream, eparams, mm, nw.U.ptr,
+                             d_bounds.ptr, d_pij.ptr, d_lij.ptr, d_lij_next.ptr, FusedSadd{0., 0., nullptr});
+        else
           hipLaunchKernelGGL((k_high_order<E, false>), grid, block, 0, launch_stream, eparams, mm, nw.U.ptr,
                              d_bounds.ptr, d_pij.ptr, d_lij.ptr, d_lij_next.ptr, FusedSadd{0., 0., nullptr});
       });
@@ -2833,6 +2844,21 @@ namespace
       out[q * 3 + 0] = l;
       out[q * 3 + 1] = success ? 1. : 0.;
       out[q * 3 + 2] = undecided ? 1. : 0.;
+    } else if (which == RYUJIN_DEBUG_EULER_LIMIT_2D) {
+      EulerParams P2 = PE; /* (the parameter block carries no dimension) */
+      const double *v = in + q * 11;
+      const double bnd[3] = {v[0], v[1], v[2]}, U[4] = {v[3], v[4], v[5], v[6]}, Pij[4] = {v[7], v[8], v[9], v[10]};
+      bool success, undecided, s2;
+      double l = Euler<2>::limit_fast(P2, bnd, U, Pij, success, undecided);
+      if (undecided)
+        l = Euler<2>::limit(P2, bnd, U, Pij, success);
+      double t_r;
+      const double psi_r = Euler<2>::first_psi_r(P2, bnd, U, Pij, s2, t_r);
+      out[q * 5 + 0] = l;
+      out[q * 5 + 1] = success ? 1. : 0.;
+      out[q * 5 + 2] = undecided ? 1. : 0.;
+      out[q * 5 + 3] = t_r;
+      out[q * 5 + 4] = psi_r;
     } else if (which == RYUJIN_DEBUG_EULER_LIMIT_CHECKED_1D) {
       const double *v = in + q * 9;
       const double bnd[3] = {v[0], v[1], v[2]}, U[3] = {v[3], v[4], v[5]}, Pij[3] = {v[6], v[7], v[8]};
@@ -2920,6 +2946,7 @@ int ryujin_hip_debug_function(int device, const ryujin_hip_params *params, int w
     case RYUJIN_DEBUG_AEOS_LIMIT_1D: n_in = 10; n_out = 3; break;
     case RYUJIN_DEBUG_EULER_LIMIT_1D:
     case RYUJIN_DEBUG_EULER_LIMIT_CHECKED_1D: n_in = 9; n_out = 3; break;
+    case RYUJIN_DEBUG_EULER_LIMIT_2D: n_in = 11; n_out = 5; break;
     case RYUJIN_DEBUG_SW_RIEMANN: n_in = 6; n_out = 2; break;
     case RYUJIN_DEBUG_EULER_DIJ_2D:
     case RYUJIN_DEBUG_EULER_DIJ_RECORDS_2D: n_in = 10; n_out = 1; break;

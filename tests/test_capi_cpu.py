@@ -149,42 +149,45 @@ def test_oracle_is_not_reachable_from_the_product():
                     "oracle/" not in text.replace("the CPU oracle", ""), f
 
 
-def test_rows_longer_than_a_slice_are_rejected():
-    """A SELL-64 slice holds at most 64 entries per row (row_len is a byte, column bitmasks are 64 bit):
-    a stencil with 65 entries must be refused with a message, not truncated."""
+def test_rows_wider_than_a_slice_has_lanes_are_laid_out():
+    """A row is a LANE of its SELL-64 slice, its entries are the slice's columns: rows may be wider than 64 entries --
+    cG Q2 in 3-D has 125 (source/discretization.h:131-151) -- up to 1023 (the column field of the limiter's list of
+    undecided pairs); 1024 is refused with a message, not truncated. Round trip through the device layout on a
+    ragged pattern with rows of 1, 2, 125 and 1023 entries."""
     from helpers_layout import OfflineView
-    n = 70
-    rows = [[i] for i in range(n)]
-    rows[0] = [0] + list(range(1, 65))          # 65 entries
-    for j in range(1, 65):
-        rows[j] = [j, 0]
-    row_starts = np.cumsum([0] + [len(r) for r in rows]).astype(np.uint64)
-    columns = np.concatenate([np.array(r, dtype=np.uint32) for r in rows])
-    nnz = len(columns)
-    v = OfflineView(1, 0, 0, n, n, 1, row_starts, columns, np.zeros((nnz, 1)), np.ones(nnz), np.ones(n),
-                    np.ones(n), 1.0, [], np.zeros((0, 1)), [], [], [], [])
     lib = capi.load_hip()
-    ptr = np.zeros(n + 1, dtype=np.uint64)
-    col = np.zeros(nnz, dtype=np.uint32)
-    out = np.zeros(nnz)
-    rc = lib.ryujin_hip_debug_layout(v.c, capi.as_ptr(ptr, capi.c_u64_p), capi.as_ptr(col, capi.c_u32_p), None,
-                                     capi.as_ptr(v._keep["mij"], capi.c_double_p), 1,
-                                     capi.as_ptr(out, capi.c_double_p))
+
+    def view(width, n):
+        rows = [[i] for i in range(n)]
+        rows[0] = [0] + list(range(1, width))
+        for j in range(1, width):
+            rows[j] = [j, 0]
+        rows[1100] = [1100] + [j for j in range(1150, 1274)]      # 125 entries, columns > row
+        for j in range(1150, 1274):
+            rows[j] = [j, 1100]
+        row_starts = np.cumsum([0] + [len(r) for r in rows]).astype(np.uint64)
+        columns = np.concatenate([np.array(r, dtype=np.uint32) for r in rows])
+        nnz = len(columns)
+        return OfflineView(1, 0, 0, n, n, 1, row_starts, columns, np.zeros((nnz, 1)), np.arange(nnz) + 1.0,
+                           np.ones(n), np.ones(n), 1.0, [], np.zeros((0, 1)), [], [], [], []), columns
+
+    def layout(v, nnz, n):
+        ptr = np.zeros(n + 1, dtype=np.uint64)
+        col = np.zeros(nnz, dtype=np.uint32)
+        out = np.zeros(nnz)
+        rc = lib.ryujin_hip_debug_layout(v.c, capi.as_ptr(ptr, capi.c_u64_p), capi.as_ptr(col, capi.c_u32_p), None,
+                                         capi.as_ptr(v._keep["mij"], capi.c_double_p), 1,
+                                         capi.as_ptr(out, capi.c_double_p))
+        return rc, col, out
+    n = 1300
+    v, columns = view(1024, n)
+    rc, _, _ = layout(v, len(columns), n)
     assert rc == capi.RYUJIN_ERR_ARG or rc < 0
-    assert b"64" in lib.ryujin_hip_last_error()
-    rows[0] = [0] + list(range(1, 64))          # 64 entries: accepted
-    rows[64] = [64]
-    row_starts = np.cumsum([0] + [len(r) for r in rows]).astype(np.uint64)
-    columns = np.concatenate([np.array(r, dtype=np.uint32) for r in rows])
-    nnz = len(columns)
-    v = OfflineView(1, 0, 0, n, n, 1, row_starts, columns, np.zeros((nnz, 1)), np.ones(nnz), np.ones(n),
-                    np.ones(n), 1.0, [], np.zeros((0, 1)), [], [], [], [])
-    col = np.zeros(nnz, dtype=np.uint32)
-    out = np.zeros(nnz)
-    rc = lib.ryujin_hip_debug_layout(v.c, capi.as_ptr(ptr, capi.c_u64_p), capi.as_ptr(col, capi.c_u32_p), None,
-                                     capi.as_ptr(v._keep["mij"], capi.c_double_p), 1,
-                                     capi.as_ptr(out, capi.c_double_p))
+    assert b"1023" in lib.ryujin_hip_last_error()
+    v, columns = view(1023, n)
+    rc, col, out = layout(v, len(columns), n)
     assert rc == 0 and np.array_equal(col, columns)
+    assert np.array_equal(out, np.arange(len(columns)) + 1.0)      # a matrix survives the scatter / gather
 
 
 def test_headers_are_plain_c_and_match_the_ctypes_mirror(tmp_path):

@@ -1382,7 +1382,7 @@ def test_isentropic_vortex_fine_golden_on_gpu(golden_dir, description, scheme, l
 def _unstructured_both(oracle, off, U0, equation, n_warm, dirichlet=None, params_edit=None):
     mods, U_start = [], U0
     for backend in ("hip", oracle.backend()):
-        p = oracle.default_params(equation, 2)
+        p = oracle.default_params(equation, off.dim)
         p.cfl = 0.5
         if params_edit:
             params_edit(p)
@@ -1455,6 +1455,52 @@ def test_unstructured_p1_mesh_shallow_water_and_aeos(oracle):
     U0 = aeos_from_primitive(p, np.where(inside, 1.0, 0.2), np.zeros((off.n_owned, 2)), np.where(inside, 8.0, 0.2))
     mods = _unstructured_both(oracle, off, U0, capi.EQ_EULER_AEOS, n_warm=100, params_edit=vdw)
     _compare_step(off, mods)
+
+
+@pytest.mark.parametrize("case", ["euler_3d", "euler_3d_erk33", "shallow_water_3d_stencil_2d", "euler_2d"])
+def test_rows_wider_than_64_entries(oracle, case):
+    """The reference's step() is ansatz agnostic: continuous Q2 elements give rows of 27 ... 125 entries in 3-D
+    (9 ... 25 in 2-D; source/discretization.h:131-151, sparse_matrix_simd.h:340-350) -- wider than a SELL-64 slice
+    has lanes. A periodic Q2 mesh assembled by tests/helpers_q2.py (tensor products of the 1-D element matrices;
+    c_ij antisymmetric, some m_ij negative, lumped masses of two sizes), a smooth density and pressure wave on a
+    uniform flow: every sweep against the oracle, single update and an ERK33 stage with stage vectors (the generic
+    kernels: k_dij_alpha, k_low_order, k_pij_lij / k_high_order in blocks of 63 columns)."""
+    from helpers_q2 import q2_periodic_offline
+    dim = 2 if case.endswith("2d") else 3
+    off, x = q2_periodic_offline(dim, 3 if dim == 3 else 5)
+    assert off.max_row_len == (125 if dim == 3 else 25)
+    w = np.sin(2.0 * np.pi * x[:, 0]) * np.cos(2.0 * np.pi * x[:, 1])
+    if case.startswith("shallow_water"):
+        eq = capi.EQ_SHALLOW_WATER
+        U0 = np.zeros((off.n_owned, dim + 1))
+        U0[:, 0] = 1.0 + 0.3 * w
+        U0[:, 1] = 0.2 * U0[:, 0]
+        off.set_initial_precomputed(0.05 * np.cos(2.0 * np.pi * x[:, 0]))
+    else:
+        eq = capi.EQ_EULER
+        rho, p = 1.0 + 0.4 * w, 1.0 + 0.3 * w
+        v = np.zeros((off.n_owned, dim))
+        v[:, 0], v[:, 1] = 0.5, -0.25
+        U0 = np.concatenate([rho[:, None], rho[:, None] * v, (p / 0.4 + 0.5 * rho * (v ** 2).sum(1))[:, None]], axis=1)
+    if case.endswith("erk33"):
+        # whole ERK33 steps: step<1>, step<2> with stage vectors (time_integrator.template.h:373-403)
+        finals = []
+        for backend in ("hip", oracle.backend()):
+            m = HyperbolicModule(off, equation=eq, backend=backend)
+            sv = m.new_state_vector(U0)
+            ti = TimeIntegrator(m, "erk 33", cfl_min=0.5, cfl_max=0.5, cfl_recovery_strategy="none")
+            t = 0.0
+            for _ in range(3):
+                sv, tau = ti.step(sv, t)
+                t += tau
+            finals.append((t, sv.download()[: off.n_owned]))
+        assert abs(finals[0][0] - finals[1][0]) < 1e-12 * finals[1][0]
+        scale = np.maximum(np.abs(finals[1][1]).max(axis=0), 1e-3 * np.abs(finals[1][1]).max())   # (m_z is 0 to round-off)
+        assert (np.abs(finals[0][1] - finals[1][1]) / scale).max() < 5e-11
+        return
+    for n_warm in (0, 6):     # the first update from the initial data, and one a few updates later
+        mods = _unstructured_both(oracle, off, U0, eq, n_warm=n_warm)
+        _compare_step(off, mods)
 
 
 @pytest.mark.parametrize("equation", ["euler", "shallow_water"])

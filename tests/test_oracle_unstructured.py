@@ -151,3 +151,29 @@ def test_p1_ball_mesh_and_oracle_conservation_3d(oracle):
     assert abs(after[0] - before[0]) < 1e-13 * before[0] and abs(after[4] - before[4]) < 1e-13 * before[4]
     assert U[:, 0].min() > 0 and (U[:, 4] - 0.5 * (U[:, 1:4] ** 2).sum(1) / U[:, 0]).min() > 0
     assert np.abs(U[:, 1:4]).max() > 0.1                            # the flow has started
+
+
+def test_oracle_conserves_on_a_q2_stencil(oracle):
+    """Rows of 27 ... 125 entries (continuous Q2, periodic; tests/helpers_q2.py): the oracle's update conserves mass,
+    momentum and energy to round-off over 20 SSPRK33 steps of a smooth wave -- c_ij = -c_ji, d_ij = d_ji and a
+    symmetric l_ij are all it needs, whatever the stencil."""
+    from helpers_q2 import q2_periodic_offline
+    off, x = q2_periodic_offline(3, 3)
+    assert off.max_row_len == 125 and off.n_owned == 216
+    w = np.sin(2.0 * np.pi * x[:, 0]) * np.cos(2.0 * np.pi * x[:, 1])
+    rho, p = 1.0 + 0.4 * w, 1.0 + 0.3 * w
+    v = np.zeros((off.n_owned, 3))
+    v[:, 0], v[:, 1] = 0.5, -0.25
+    U0 = np.concatenate([rho[:, None], rho[:, None] * v, (p / 0.4 + 0.5 * rho * (v ** 2).sum(1))[:, None]], axis=1)
+    m = HyperbolicModule(off, equation=capi.EQ_EULER, backend=oracle.backend())
+    sv = m.new_state_vector(U0)
+    ti = TimeIntegrator(m, "ssprk 33", cfl_min=0.5, cfl_max=0.5, cfl_recovery_strategy="none")
+    before = (off.mi[:, None] * U0).sum(0)
+    t = 0.0
+    for _ in range(20):
+        sv, tau = ti.step(sv, t)
+        t += tau
+    U = sv.download()
+    after = (off.mi[:, None] * U).sum(0)
+    assert np.abs(after - before).max() <= 1e-13 * np.abs(before).max()
+    assert (U[:, 0] > 0).all() and m.n_warnings() == 0
