@@ -330,6 +330,48 @@ namespace ryujin_hip
         }
       }
 
+      /* the same two from the per-node records (below): the record holds (rho, m, E), eta, 1 / rho and p of its
+       * node, computed by the expressions flux() and accumulate() use -- the same bits without a division or an
+       * internal-energy evaluation per neighbour, and one gather per neighbour instead of three */
+      template <int RS_>
+      RYUJIN_DEV void reset_record(const EulerParams &P, const double (&rec)[RS_])
+      {
+        double U_i[K];
+        Euler::state_of_record(rec, U_i);
+        rho_i_inverse = rec[kRecRinv];
+        eta_i = rec[kRecEta];
+        harten_entropy_derivative(P, U_i, d_eta_i);
+        d_eta_i[0] -= eta_i * rho_i_inverse;
+        Euler::flux_of_record(rec, f_i);
+        left = 0.;
+#pragma unroll
+        for (int q = 0; q < K; ++q)
+          right[q] = 0.;
+      }
+
+      template <int RS_>
+      RYUJIN_DEV void accumulate_record(const double (&rec_j)[RS_], const double (&c_ij)[DIM])
+      {
+        const double eta_j = rec_j[kRecEta];
+        const double rho_j_inverse = rec_j[kRecRinv];
+        double f_j[K][DIM];
+        Euler::flux_of_record(rec_j, f_j);
+        double m_j_c = rec_j[kRecM] * c_ij[0];
+#pragma unroll
+        for (int d = 1; d < DIM; ++d)
+          m_j_c += rec_j[kRecM + d] * c_ij[d];
+        const double entropy_flux = (eta_j * rho_j_inverse - eta_i * rho_i_inverse) * m_j_c;
+        left += entropy_flux;
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+          double component = (f_j[q][0] - f_i[q][0]) * c_ij[0];
+#pragma unroll
+          for (int d = 1; d < DIM; ++d)
+            component += (f_j[q][d] - f_i[q][d]) * c_ij[d];
+          right[q] += component;
+        }
+      }
+
       RYUJIN_DEV double alpha(const EulerParams &P, const double hd_i) const
       {
         double numerator = left;
@@ -549,40 +591,119 @@ namespace ryujin_hip
      * (tests/test_gpu_device_functions.py) and in every sweep comparison. With Newton iterations of the
      * Riemann solver switched on (non-default) the reference path (riemann_compute) is used on the same data.
      *
-     * record = (rho, p, a, pw, a / pw, 1 / p, v[DIM]), padded to an even number of doubles */
-    static constexpr int RS = (6 + DIM + 1) / 2 * 2;
+     * record = (rho, p, a, pw, a / pw, 1 / p, v[DIM]) padded to an even number of doubles in 1-D and 2-D (64 B).
+     * In 3-D the record is (rho, p, a, pw, a / pw, 1 / p, m[DIM], E, eta, 1 / rho), 96 B: the Riemann data of the
+     * node AND what the indicator needs of it (the state, the Harten entropy, 1 / rho), so that step 2 gathers ONE
+     * record per neighbour instead of the state (48 B), the precomputed values (16 B) and a Riemann record (80 B)
+     * from three arrays; the velocity is formed as m (1 / rho), the product the short record stores. Measured on
+     * the C4 share (profiles/r04g_*): step 2 1.434 -> 1.354 ms at 3 waves per SIMD. In 2-D the same layout trades
+     * 112 B of gathers for 96 and loses (0.240 -> 0.259 ms on C2: the sweep is not bound by its gather bytes and
+     * the longer record costs registers, 128 -> 166), so the short record stays there. */
+    static constexpr bool kRecordHoldsState = DIM == 3;
+    static constexpr int kRecRho = 0, kRecP = 1, kRecA = 2, kRecPw = 3, kRecApw = 4, kRecPinv = 5, kRecM = 6,
+                         kRecE = 6 + DIM, kRecEta = 7 + DIM, kRecRinv = 8 + DIM;
+    static constexpr int RS = ((kRecordHoldsState ? 9 : 6) + DIM + 1) / 2 * 2;
 
-    /* the record of a node with density rho, pressure p, speed of sound a, velocity v */
-    static RYUJIN_DEV void riemann_record_from_primitive(const EulerParams &P, const double rho, const double p,
-                                                         const double a, const double (&v)[DIM],
-                                                         double (&rec)[RS])
+    static RYUJIN_DEV double record_velocity(const double (&rec)[RS], const int d)
     {
-      const double pw = dev_pow(p, (P.gamma - 1.) * 0.5 * P.gamma_inverse);
-      rec[0] = rho;
-      rec[1] = p;
-      rec[2] = a;
-      rec[3] = pw;
-      rec[4] = a / pw;
-      rec[5] = 1. / p;
-#pragma unroll
-      for (int d = 0; d < DIM; ++d)
-        rec[6 + d] = v[d];
-#pragma unroll
-      for (int d = 6 + DIM; d < RS; ++d)
-        rec[d] = 0.;
+      if constexpr (kRecordHoldsState)
+        return rec[kRecM + d] * rec[kRecRinv];
+      else
+        return rec[kRecM + d];
     }
 
-    static RYUJIN_DEV void riemann_record(const EulerParams &P, const double (&U)[K], double (&rec)[RS])
+    static RYUJIN_DEV void state_of_record(const double (&rec)[RS], double (&U)[K])
+    {
+      U[0] = rec[kRecRho];
+#pragma unroll
+      for (int d = 0; d < DIM; ++d)
+        U[1 + d] = rec[kRecM + d];
+      U[1 + DIM] = rec[kRecE];
+    }
+
+    /* flux() of the record's state: 1 / rho and p are the values flux() computes (:1164-1181) */
+    static RYUJIN_DEV void flux_of_record(const double (&rec)[RS], double (&f)[K][DIM])
+    {
+      const double rho_inverse = rec[kRecRinv];
+      const double p = rec[kRecP];
+      const double E = rec[kRecE];
+#pragma unroll
+      for (int d = 0; d < DIM; ++d)
+        f[0][d] = rec[kRecM + d];
+#pragma unroll
+      for (int i = 0; i < DIM; ++i) {
+        const double s = rec[kRecM + i] * rho_inverse;
+#pragma unroll
+        for (int d = 0; d < DIM; ++d)
+          f[1 + i][d] = rec[kRecM + d] * s;
+        f[1 + i][i] += p;
+      }
+      const double s = rho_inverse * (E + p);
+#pragma unroll
+      for (int d = 0; d < DIM; ++d)
+        f[DIM + 1][d] = rec[kRecM + d] * s;
+    }
+
+    /* the record of a node with state U and Harten entropy eta */
+    static RYUJIN_DEV void node_record(const EulerParams &P, const double (&U)[K], const double2 prec,
+                                       double (&rec)[RS])
     {
       const double rho = U[0];
       const double rho_inverse = 1. / rho;
       const double p = (P.gamma - 1.) * internal_energy(U);
       const double a = sqrt(P.gamma * p * rho_inverse);
-      double v[DIM];
+      const double pw = dev_pow(p, (P.gamma - 1.) * 0.5 * P.gamma_inverse);
+      rec[kRecRho] = rho;
+      rec[kRecP] = p;
+      rec[kRecA] = a;
+      rec[kRecPw] = pw;
+      rec[kRecApw] = a / pw;
+      rec[kRecPinv] = 1. / p;
+      if constexpr (kRecordHoldsState) {
+#pragma unroll
+        for (int d = 0; d < DIM; ++d)
+          rec[kRecM + d] = U[1 + d];
+        rec[kRecE] = U[1 + DIM];
+        rec[kRecEta] = prec.y;
+        rec[kRecRinv] = rho_inverse;
+#pragma unroll
+        for (int d = 9 + DIM; d < RS; ++d)
+          rec[d] = 0.;
+      } else {
+#pragma unroll
+        for (int d = 0; d < DIM; ++d)
+          rec[kRecM + d] = U[1 + d] * rho_inverse;
+#pragma unroll
+        for (int d = 6 + DIM; d < RS; ++d)
+          rec[d] = 0.;
+      }
+    }
+
+    static RYUJIN_DEV void riemann_record(const EulerParams &P, const double (&U)[K], double (&rec)[RS])
+    {
+      node_record(P, U, precompute(P, U), rec);
+    }
+
+    /* (tests: the record of a node given by its Riemann data -- density, pressure, speed of sound, velocity) */
+    static RYUJIN_DEV void riemann_record_from_primitive(const EulerParams &P, const double rho, const double p,
+                                                         const double a, const double (&v)[DIM],
+                                                         double (&rec)[RS])
+    {
+      const double pw = dev_pow(p, (P.gamma - 1.) * 0.5 * P.gamma_inverse);
+#pragma unroll
+      for (int d = 0; d < RS; ++d)
+        rec[d] = 0.;
+      rec[kRecRho] = rho;
+      rec[kRecP] = p;
+      rec[kRecA] = a;
+      rec[kRecPw] = pw;
+      rec[kRecApw] = a / pw;
+      rec[kRecPinv] = 1. / p;
+      if constexpr (kRecordHoldsState)
+        rec[kRecRinv] = 1.; /* (m := v, 1 / rho := 1: the velocity the Riemann solver forms is v itself) */
 #pragma unroll
       for (int d = 0; d < DIM; ++d)
-        v[d] = U[1 + d] * rho_inverse;
-      riemann_record_from_primitive(P, rho, p, a, v, rec);
+        rec[kRecM + d] = v[d];
     }
 
     /* GENERAL = false: Newton iterations off and integral rarefaction exponent (the defaults with
@@ -592,12 +713,12 @@ namespace ryujin_hip
                                               const double (&rj)[RS], const double (&c)[DIM])
     {
       double norm2 = c[0] * c[0];
-      double vc_i = ri[6] * c[0], vc_j = rj[6] * c[0];
+      double vc_i = record_velocity(ri, 0) * c[0], vc_j = record_velocity(rj, 0) * c[0];
 #pragma unroll
       for (int d = 1; d < DIM; ++d) {
         norm2 += c[d] * c[d];
-        vc_i += ri[6 + d] * c[d];
-        vc_j += rj[6 + d] * c[d];
+        vc_i += record_velocity(ri, d) * c[d];
+        vc_j += record_velocity(rj, d) * c[d];
       }
       const double norm = sqrt(norm2);
       const double inverse_norm = 1. / norm;

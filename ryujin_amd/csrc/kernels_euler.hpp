@@ -115,7 +115,16 @@ namespace ryujin_hip
   /* minimum waves per SIMD requested from the register allocator for the heavy sweeps (second
    * __launch_bounds__ argument): 512 registers / waves. Tuned on MI355X, see DESIGN.md. */
 #ifndef RYUJIN_HO_CP_3D
-#define RYUJIN_HO_CP_3D 6 /* step 6 in 3-D: 0 = two-pass kernel, n = l_ij and the first n P_ij columns in registers (the others are read a second time, unless the whole tile is unlimited). Round 1, all at 2 waves/SIMD: 3.07 ms (0), 2.43 (8), 2.24 (14), 2.36 (18); round 2 see RYUJIN_OCC_HO_3D */
+#define RYUJIN_HO_CP_3D 2 /* step 6 in 3-D: 0 = two-pass kernel, n = l_ij and the first n P_ij columns in registers (the others are read a second time, unless the whole tile is unlimited). Round 1, all at 2 waves/SIMD: 3.07 ms (0), 2.43 (8), 2.24 (14), 2.36 (18); round 2 see RYUJIN_OCC_HO_3D; round 4 (developed C4 state, all slices limited, limited update from V_i with tile-predicated P loads, 3 waves): whole update 8.30 ms (6), 8.06 (3), 8.02 (2), 8.13 (1) -- the second read of an unlimited tile is skipped anyway, fewer held columns leave the registers to the loads in flight */
+#endif
+#ifndef RYUJIN_OCC_DIJ_NODE_RECORD
+#define RYUJIN_OCC_DIJ_NODE_RECORD 3 /* step 2 on the combined node record (3-D Euler): 168 registers without scratch; C4 share 1.47 ms at 2 waves (184 registers), 1.35 at 3 */
+#endif
+#ifndef RYUJIN_DIJ_PREFETCH_RECORD
+#define RYUJIN_DIJ_PREFETCH_RECORD 1 /* step 2 on node records: the next neighbour's record is loaded one column ahead */
+#endif
+#ifndef RYUJIN_HO_CP_2D
+#define RYUJIN_HO_CP_2D 9 /* step 6 in 2-D: P_ij columns kept in registers between the update and the second limiter pass (9: all) */
 #endif
 #ifndef RYUJIN_OCC_HO_3D
 #define RYUJIN_OCC_HO_3D 3 /* step 6 in 3-D: waves per SIMD asked of the register allocator. A/B on MI355X (4.2 M gridpoints): CP 14 at 2 waves 1.96 ms, CP 6 at 3 waves 1.72 ms */
@@ -154,7 +163,7 @@ namespace ryujin_hip
 #define RYUJIN_PER_SLICE_PIJ 1 /* stages == 0, two limiter passes: step 5 stores P_ij only in the slices steps 6/7 will read it in (kernels_limiter_stage0.hpp); 0: everywhere */
 #endif
 #ifndef RYUJIN_PER_SLICE_MAX_LIMITED
-#define RYUJIN_PER_SLICE_MAX_LIMITED 0.5 /* ... while at most this fraction of the slices held a limited pair in the latest measured update */
+#define RYUJIN_PER_SLICE_MAX_LIMITED 0.8 /* ... while at most this fraction of the slices held a limited pair in the latest measured update. Break-even on the developed Mach-3 step (profiles/r04f_ab_per_slice_vs_plain_real_flow_2d.log): per slice -1.9 % per update at 53 % limited slices, -0.5 % at 71 %, +1.2 % at 93 % */
 #endif
 #ifndef RYUJIN_FUSE_PRECOMPUTE
 #define RYUJIN_FUSE_PRECOMPUTE 1 /* device-resident RK driver: the last sweep of a stage leaves the precomputed values and Riemann records of the next one (FusedPrecompute) */
@@ -423,8 +432,9 @@ namespace ryujin_hip
       return;
     double U_i[K], r[RS];
     load_state<K>(U, i, U_i);
-    reinterpret_cast<double2 *>(prec)[i] = E::precompute(P, U_i);
-    E::riemann_record(P, U_i, r);
+    const double2 prec_i = E::precompute(P, U_i);
+    reinterpret_cast<double2 *>(prec)[i] = prec_i;
+    E::node_record(P, U_i, prec_i, r);
     double2 *out = reinterpret_cast<double2 *>(rec + (size_t)i * RS);
 #pragma unroll
     for (int q = 0; q < RS / 2; ++q) {
@@ -452,8 +462,9 @@ namespace ryujin_hip
       return;
     double U_i[K], r[RS];
     load_state<K>(U, i, U_i);
-    reinterpret_cast<double2 *>(prec)[i] = E::precompute(P, U_i);
-    E::riemann_record(P, U_i, r);
+    const double2 prec_i = E::precompute(P, U_i);
+    reinterpret_cast<double2 *>(prec)[i] = prec_i;
+    E::node_record(P, U_i, prec_i, r);
     double2 *out = reinterpret_cast<double2 *>(rec + (size_t)i * RS);
 #pragma unroll
     for (int g = 0; g < RS / 2; ++g) {
@@ -480,11 +491,25 @@ namespace ryujin_hip
       return;
     double U_i[K], r[RS];
     load_state<K>(U, i, U_i);
-    reinterpret_cast<double2 *>(prec)[i] = E::precompute(P, U_i);
-    E::riemann_record(P, U_i, r);
+    const double2 prec_i = E::precompute(P, U_i);
+    reinterpret_cast<double2 *>(prec)[i] = prec_i;
+    E::node_record(P, U_i, prec_i, r);
 #pragma unroll
     for (int g = 0; g < RS; ++g)
       rec[(size_t)i * RS + g] = r[g];
+  }
+
+  /* a node record (E::node_record / E::riemann_record) as 16-byte loads */
+  template <int RS>
+  RYUJIN_DEV void load_record(const double *__restrict__ rec, const uint32_t i, double (&r)[RS])
+  {
+    const double2 *b = reinterpret_cast<const double2 *>(rec + (size_t)i * RS);
+#pragma unroll
+    for (int g = 0; g < RS / 2; ++g) {
+      const double2 t = b[g];
+      r[2 * g] = t.x;
+      r[2 * g + 1] = t.y;
+    }
   }
 
   /* ------------------------------------------------------------------ step 2 */
@@ -644,7 +669,7 @@ namespace ryujin_hip
    * arithmetic hides behind the indicator's loads and the column indices / c_ij are read once instead of twice
    * (the round-1 fusion lost because the old Riemann solver held 200+ registers). */
   template <typename E, bool GENERAL>
-  __global__ void __launch_bounds__(kBlock, RYUJIN_OCC_DIJ)
+  __global__ void __launch_bounds__(kBlock, E::kRecordHoldsState ? RYUJIN_OCC_DIJ_NODE_RECORD : RYUJIN_OCC_DIJ)
   k_dij_alpha_records(const typename E::Params P, const DeviceMesh M, const double *__restrict__ U,
                       const double *__restrict__ prec, const double *__restrict__ rec,
                       double *__restrict__ dij, double *__restrict__ alpha)
@@ -660,66 +685,99 @@ namespace ryujin_hip
     const uint32_t *__restrict__ cols = M.cols;
     const double *__restrict__ cij = M.cij;
 
-    double U_i[K], rec_i[RS];
-    load_state<K>(U, i, U_i);
-    {
-      const double2 *b = reinterpret_cast<const double2 *>(rec + (size_t)i * RS);
-#pragma unroll
-      for (int g = 0; g < RS / 2; ++g) {
-        const double2 t = b[g];
-        rec_i[2 * g] = t.x;
-        rec_i[2 * g + 1] = t.y;
-      }
-    }
-    typename E::Indicator indicator;
-    indicator.reset(P, U_i, prec2[i]);
+    double rec_i[RS];
+    load_record<RS>(rec, i, rec_i);
 
-    uint32_t j_n = ld_stream(cols + ((uint64_t)r.base * 64 + r.lane));
-    uint32_t j_nn = r.width > 1 ? ld_stream(cols + (((uint64_t)r.base + 1) * 64 + r.lane)) : i;
-    double c_n[DIM], U_n[K];
-    load_entry<DIM>(cij, r.base, r.lane, c_n);
-    load_state<K>(U, j_n, U_n);
-    double2 prec_n = prec2[j_n];
-    for (uint32_t c = 0; c < r.width; ++c) {
-      const uint64_t colbase = (uint64_t)r.base + c;
-      const uint32_t j = j_n;
-      double c_ij[DIM], U_j[K];
+    if constexpr (E::kRecordHoldsState) {
+      /* Euler: the record is all the indicator needs of a node as well (E::node_record) -- one gather of RS doubles
+       * per neighbour, nothing from U and prec */
+      typename E::Indicator indicator;
+      indicator.reset_record(P, rec_i);
+
+      uint32_t j_n = ld_stream(cols + ((uint64_t)r.base * 64 + r.lane));
+      uint32_t j_nn = r.width > 1 ? ld_stream(cols + (((uint64_t)r.base + 1) * 64 + r.lane)) : i;
+      double c_n[DIM], rec_n[RS];
+      load_entry<DIM>(cij, r.base, r.lane, c_n);
+      if constexpr (RYUJIN_DIJ_PREFETCH_RECORD)
+        load_record<RS>(rec, j_n, rec_n);
+      for (uint32_t c = 0; c < r.width; ++c) {
+        const uint64_t colbase = (uint64_t)r.base + c;
+        const uint32_t j = j_n;
+        double c_ij[DIM], rec_j[RS];
 #pragma unroll
-      for (int d = 0; d < DIM; ++d)
-        c_ij[d] = c_n[d];
+        for (int d = 0; d < DIM; ++d)
+          c_ij[d] = c_n[d];
+        if constexpr (RYUJIN_DIJ_PREFETCH_RECORD) {
 #pragma unroll
-      for (int q = 0; q < K; ++q)
-        U_j[q] = U_n[q];
-      const double2 prec_j = prec_n;
-      if (c + 1 < r.width) {
-        j_n = j_nn;
-        load_entry<DIM>(cij, colbase + 1, r.lane, c_n);
-        load_state<K>(U, j_n, U_n);
-        prec_n = prec2[j_n];
-        j_nn = (c + 2 < r.width) ? ld_stream(cols + ((colbase + 2) * 64 + r.lane)) : i;
-      }
-      const bool active = row_active && c < r.len;
-      /* Euler: column 0 is the row itself, eta_j / rho_j = eta_i / rho_i and f_j = f_i bit for bit, its terms are
-       * exact zeros added to sums that start at zero */
-      if (active && (c > 0 || !E::kIndicatorDiagonalIsZero))
-        indicator.accumulate(P, U_j, prec_j, c_ij);
-      /* upper triangle only (:394-408) */
-      const bool mine = active && c > 0 && j > i;
-      if (__any(mine)) {
-        double rec_j[RS];
-        const double2 *b = reinterpret_cast<const double2 *>(rec + (size_t)j * RS);
-#pragma unroll
-        for (int g = 0; g < RS / 2; ++g) {
-          const double2 t = b[g];
-          rec_j[2 * g] = t.x;
-          rec_j[2 * g + 1] = t.y;
+          for (int q = 0; q < RS; ++q)
+            rec_j[q] = rec_n[q];
+        } else {
+          load_record<RS>(rec, j, rec_j);
         }
-        if (mine)
+        if (c + 1 < r.width) {
+          j_n = j_nn;
+          load_entry<DIM>(cij, colbase + 1, r.lane, c_n);
+          if constexpr (RYUJIN_DIJ_PREFETCH_RECORD)
+            load_record<RS>(rec, j_n, rec_n);
+          j_nn = (c + 2 < r.width) ? ld_stream(cols + ((colbase + 2) * 64 + r.lane)) : i;
+        }
+        const bool active = row_active && c < r.len;
+        /* column 0 is the row itself: eta_j / rho_j = eta_i / rho_i and f_j = f_i bit for bit, its terms are exact
+         * zeros added to sums that start at zero */
+        if (active && (c > 0 || !E::kIndicatorDiagonalIsZero))
+          indicator.accumulate_record(rec_j, c_ij);
+        /* upper triangle only (:394-408) */
+        if (active && c > 0 && j > i)
           dij[colbase * 64 + r.lane] = E::template dij_from_records<GENERAL>(P, rec_i, rec_j, c_ij);
       }
+      if (row_active)
+        alpha[i] = indicator.alpha(P, M.mi[i] * M.measure_of_omega_inverse);
+      return;
+    } else {
+      double U_i[K];
+      load_state<K>(U, i, U_i);
+      typename E::Indicator indicator;
+      indicator.reset(P, U_i, prec2[i]);
+
+      uint32_t j_n = ld_stream(cols + ((uint64_t)r.base * 64 + r.lane));
+      uint32_t j_nn = r.width > 1 ? ld_stream(cols + (((uint64_t)r.base + 1) * 64 + r.lane)) : i;
+      double c_n[DIM], U_n[K];
+      load_entry<DIM>(cij, r.base, r.lane, c_n);
+      load_state<K>(U, j_n, U_n);
+      double2 prec_n = prec2[j_n];
+      for (uint32_t c = 0; c < r.width; ++c) {
+        const uint64_t colbase = (uint64_t)r.base + c;
+        const uint32_t j = j_n;
+        double c_ij[DIM], U_j[K];
+#pragma unroll
+        for (int d = 0; d < DIM; ++d)
+          c_ij[d] = c_n[d];
+#pragma unroll
+        for (int q = 0; q < K; ++q)
+          U_j[q] = U_n[q];
+        const double2 prec_j = prec_n;
+        if (c + 1 < r.width) {
+          j_n = j_nn;
+          load_entry<DIM>(cij, colbase + 1, r.lane, c_n);
+          load_state<K>(U, j_n, U_n);
+          prec_n = prec2[j_n];
+          j_nn = (c + 2 < r.width) ? ld_stream(cols + ((colbase + 2) * 64 + r.lane)) : i;
+        }
+        const bool active = row_active && c < r.len;
+        if (active && (c > 0 || !E::kIndicatorDiagonalIsZero))
+          indicator.accumulate(P, U_j, prec_j, c_ij);
+        /* upper triangle only (:394-408) */
+        const bool mine = active && c > 0 && j > i;
+        if (__any(mine)) {
+          double rec_j[RS];
+          load_record<RS>(rec, j, rec_j);
+          if (mine)
+            dij[colbase * 64 + r.lane] = E::template dij_from_records<GENERAL>(P, rec_i, rec_j, c_ij);
+        }
+      }
+      if (row_active)
+        alpha[i] = indicator.alpha(P, M.mi[i] * M.measure_of_omega_inverse);
     }
-    if (row_active)
-      alpha[i] = indicator.alpha(P, M.mi[i] * M.measure_of_omega_inverse);
   }
 
   /* ------------------------------------------------------------------ step 3 */

@@ -575,8 +575,9 @@ namespace ryujin_hip
     if constexpr (E::kFusablePrecompute) {
       constexpr int RS = E::RS;
       double r[RS];
-      reinterpret_cast<double2 *>(FP.prec)[i] = E::precompute(P, U_i);
-      E::riemann_record(P, U_i, r);
+      const double2 prec_i = E::precompute(P, U_i);
+      reinterpret_cast<double2 *>(FP.prec)[i] = prec_i;
+      E::node_record(P, U_i, prec_i, r);
       double2 *out = reinterpret_cast<double2 *>(FP.rec + (size_t)i * RS);
 #pragma unroll
       for (int g = 0; g < RS / 2; ++g) {

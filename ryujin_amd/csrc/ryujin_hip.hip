@@ -1680,7 +1680,8 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
       });
     } else {
       /* 3-D: cache all l_ij and the P_ij of the first RYUJIN_HO_CP_3D columns (0: two-pass kernel) */
-      constexpr int kCachedP = DIM == 3 ? (RYUJIN_HO_CP_3D > 0 ? RYUJIN_HO_CP_3D : 27) : kCachedWidth;
+      constexpr int kCachedP = DIM == 3 ? (RYUJIN_HO_CP_3D > 0 ? RYUJIN_HO_CP_3D : 27)
+                                        : (DIM == 2 ? (RYUJIN_HO_CP_2D < kCachedWidth ? RYUJIN_HO_CP_2D : kCachedWidth) : kCachedWidth);
       sweep([&](const DeviceMesh &mm, dim3 grid) {
         if constexpr (is_euler || is_aeos) {
           if (per_slice) {
@@ -2327,7 +2328,9 @@ int ryujin_hip_state_alloc(ryujin_hip_ctx *ctx, int *handle)
       h = (int)ctx->states.size() - 1;
       ctx->states[h]->U.alloc((size_t)ctx->L.n_relevant * ctx->KP);
       ctx->states[h]->prec.alloc((size_t)ctx->L.n_relevant * ctx->NPREC);
-      if (ctx->params.equation == RYUJIN_EQ_EULER || ctx->params.equation == RYUJIN_EQ_EULER_AEOS)
+      if (ctx->params.equation == RYUJIN_EQ_EULER) /* Euler<dim>::RS: the combined node record in 3-D */
+        ctx->states[h]->rrec.alloc((size_t)ctx->L.n_relevant * (ctx->dim == 3 ? Euler<3>::RS : ctx->dim == 2 ? Euler<2>::RS : Euler<1>::RS));
+      else if (ctx->params.equation == RYUJIN_EQ_EULER_AEOS)
         ctx->states[h]->rrec.alloc((size_t)ctx->L.n_relevant * ((6 + ctx->dim + 1) / 2 * 2));
       else if (ctx->params.equation == RYUJIN_EQ_SHALLOW_WATER)
         ctx->states[h]->rrec.alloc((size_t)ctx->L.n_relevant * ((2 + ctx->dim + 1) / 2 * 2));

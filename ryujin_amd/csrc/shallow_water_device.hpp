@@ -416,6 +416,13 @@ namespace ryujin_hip
         rec[d] = 0.;
     }
 
+    /* (the record holds the Riemann data only: step 2 reads the state and the precomputed values next to it) */
+    static constexpr bool kRecordHoldsState = false;
+    static RYUJIN_DEV void node_record(const Params &P, const double (&U)[K], const double2, double (&rec)[RS])
+    {
+      riemann_record(P, U, rec);
+    }
+
     template <bool GENERAL = false>
     static RYUJIN_DEV double dij_from_records(const Params &P, const double (&ri)[RS], const double (&rj)[RS],
                                               const double (&c)[DIM])

@@ -10,6 +10,11 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# the oracle is an OpenMP library: under pytest-xdist every worker would bring its own team of spinning threads
+if "PYTEST_XDIST_WORKER" in os.environ:
+    os.environ.setdefault("OMP_NUM_THREADS", "2")
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
