@@ -88,16 +88,57 @@ class OfflineView:
         self._o.initial_precomputed = capi.as_ptr(v, capi.c_double_p)
 
 
-def to_simd_layout(off, sl):
-    """Renumber a single-rank SyntheticOffline so that rows are sorted by (descending) stencil size, and
-    store it in the reference's SIMD-interleaved layout. Returns (OfflineView, new_index) where
-    new_index[old] = new."""
+def offline_data_numbering(rows, sl):
+    """The numbering OfflineData::setup() gives a single rank's degrees of freedom
+    (source/offline_data.template.h:204-232): Cuthill-McKee on the stencil graph (scipy's, un-reversed -- deal.II's
+    picks its starting nodes differently, the shape of the result is the same: neighbours close together), then
+    DoFRenumbering::internal_range (source/local_index_handling.h:314-368) restated: walk the rows in that order,
+    collect them in bins by stencil size, and whenever a bin holds `sl` rows hand out the next `sl` numbers to it
+    (ascending within the bin, it is a std::set); what is left in the bins at the end follows, by stencil size and
+    index (std::map of std::set). Returns (order[new] = old, n_internal)."""
+    from scipy.sparse import csr_matrix
+    from scipy.sparse.csgraph import reverse_cuthill_mckee
+    n = len(rows)
+    indptr = np.cumsum([0] + [len(r) for r in rows])
+    indices = np.concatenate([np.asarray(r, dtype=np.int64) for r in rows])
+    graph = csr_matrix((np.ones(len(indices)), indices, indptr), shape=(n, n))
+    cm = np.asarray(reverse_cuthill_mckee(graph, symmetric_mode=True))[::-1]      # cm[new] = old
+    order, bins = [], {}
+    for idx in range(n):
+        length = len(rows[cm[idx]])
+        bins.setdefault(length, []).append(idx)
+        if len(bins[length]) == sl:
+            order.extend(bins.pop(length))
+    n_internal = len(order)
+    for length in sorted(bins):
+        order.extend(bins[length])
+    assert sorted(order) == list(range(n)) and n_internal % sl == 0
+    return cm[np.asarray(order, dtype=np.int64)], n_internal
+
+
+def to_simd_layout(off, sl, order=None, n_internal=None):
+    """Renumber a single-rank OfflineData (SyntheticOffline, or the P1 view of tests/helpers_unstructured.py) and
+    store it in the reference's SIMD-interleaved layout. order[new] = old; default: rows sorted by (descending)
+    stencil size, n_internal = the longest prefix of full groups of equal length. Returns an OfflineView with
+    .new_index[old] = new and .order."""
     assert off.n_relevant == off.n_owned
     n, dim = off.n_owned, off.dim
     rs = off.row_starts.astype(np.int64)
-    cols, cij, mij = off.columns.astype(np.int64), off.cij, off.mij
+    cols = off.columns.astype(np.int64)
+    cij = off.cij_csr if hasattr(off, "cij_csr") else off.cij
+    mij = off.mij_csr if hasattr(off, "mij_csr") else off.mij
+    keep = getattr(off, "_keep", None)
+    b_i_old = (keep["b_i"] if keep is not None and "b_i" in keep else off.b_i).astype(np.int64)
+    b_normal = keep["b_normal"] if keep is not None and "b_normal" in keep else off.b_normal
+    b_id = keep["b_id"] if keep is not None and "b_id" in keep else off.b_id
+    if keep is not None and "p_i" in keep:
+        p_i_old, p_j_old = keep["p_i"], keep["p_j"]
+    else:
+        p_i_old, _, p_j_old = off.pairs
     lengths = np.diff(rs)
-    order = np.argsort(-lengths, kind="stable")       # new -> old
+    if order is None:
+        order = np.argsort(-lengths, kind="stable")       # new -> old
+    order = np.asarray(order, dtype=np.int64)
     new_index = np.empty(n, dtype=np.int64)
     new_index[order] = np.arange(n)
     rows, row_c, row_m = [], [], []
@@ -110,11 +151,12 @@ def to_simd_layout(off, sl):
         rows.append(jn[srt].tolist())
         row_c.append(cij[e][srt])
         row_m.append(mij[e][srt])
-    # largest prefix of full groups with equal lengths
     new_len = lengths[order]
-    n_internal = 0
-    while n_internal + sl <= n and len(set(new_len[n_internal:n_internal + sl].tolist())) == 1:
-        n_internal += sl
+    if n_internal is None:
+        # largest prefix of full groups with equal lengths
+        n_internal = 0
+        while n_internal + sl <= n and len(set(new_len[n_internal:n_internal + sl].tolist())) == 1:
+            n_internal += sl
     row_starts, columns = simd_layout_from_rows(rows, n_internal, sl)
     nnz = len(columns)
     cdata = np.zeros(nnz * dim)
@@ -125,13 +167,13 @@ def to_simd_layout(off, sl):
             for d in range(dim):
                 cdata[data_pos(row_starts, n_internal, sl, i, c, dim, d)] = row_c[i][c][d]
     mi = off.mi[order]
-    b_i = new_index[off.b_i.astype(np.int64)]
-    p_i_old, p_col_old, p_j_old = off.pairs
-    p_i = new_index[p_i_old.astype(np.int64)]
-    p_j = new_index[p_j_old.astype(np.int64)]
+    b_i = new_index[b_i_old]
+    p_i = new_index[np.asarray(p_i_old).astype(np.int64)]
+    p_j = new_index[np.asarray(p_j_old).astype(np.int64)]
     p_col = np.array([rows[i].index(j) for i, j in zip(p_i.tolist(), p_j.tolist())], dtype=np.uint32)
     view = OfflineView(dim, 0, n_internal, n, n, sl, row_starts, columns, cdata, mdata, mi, 1.0 / mi,
-                       off.measure_of_omega, b_i, off.b_normal, off.b_id, p_i, p_col, p_j)
+                       off.measure_of_omega, b_i, b_normal, b_id, p_i, p_col, p_j)
     view.new_index = new_index
     view.order = order
+    view.new_lengths = new_len
     return view

@@ -1457,6 +1457,35 @@ def test_unstructured_p1_mesh_shallow_water_and_aeos(oracle):
     _compare_step(off, mods)
 
 
+def test_unstructured_mesh_in_the_numbering_and_layout_of_offline_data(oracle):
+    """What OfflineData hands over on an unstructured mesh, as far as it can be had without deal.II: the P1 disk
+    renumbered the way OfflineData::setup() does it (tests/helpers_layout.py::offline_data_numbering: Cuthill-McKee,
+    then DoFRenumbering::internal_range's bins of equal stencil size in groups of simd_length -- 143 changes of the
+    row length from one group of 8 to the next, the 25 rows that fill no group behind n_internal) and stored in the
+    reference's SIMD-interleaved layout with simd_length 8. A blast wave off the slip rim, every sweep against the
+    oracle on the same numbering; and the update equals the one on the mesh as generated up to summation order."""
+    from helpers_layout import offline_data_numbering, to_simd_layout
+    from helpers_unstructured import disk_points, p1_offline
+    off0, info = p1_offline(disk_points(24))
+    order, n_internal = offline_data_numbering(info["rows"], 8)
+    off = to_simd_layout(off0, 8, order, n_internal)
+    assert 0 < off.n_internal < off.n_owned and (np.diff(off.new_lengths[:n_internal:8]) != 0).sum() > 100
+    off.positions = off0.positions[order]
+    U0 = euler_radial_contrast(off0.positions, inner=(1.0, 0.0, 10.0), outer=(0.125, 0.0, 0.1), radius=0.35)
+    mods = _unstructured_both(oracle, off, U0[order], capi.EQ_EULER, n_warm=120)
+    g, _ = _compare_step(off, mods)
+    U_start = g["U_old"][: off.n_owned][off.new_index]             # the developed state in the generated numbering
+    p = oracle.default_params(capi.EQ_EULER, 2)
+    p.cfl = 0.5
+    m0 = HyperbolicModule(off0, p, backend="hip")
+    a, b = m0.new_state_vector(U_start), m0.new_state_vector()
+    m0.prepare_state_vector(a, 0.0)
+    m0.step(a, [], [], b)
+    ref = b.download()
+    got = g["U"][: off.n_owned][off.new_index]
+    assert (np.abs(got - ref) / np.abs(ref).max(axis=0)).max() < 1e-12
+
+
 @pytest.mark.parametrize("case", ["euler_3d", "euler_3d_erk33", "shallow_water_3d_stencil_2d", "euler_2d"])
 def test_rows_wider_than_64_entries(oracle, case):
     """The reference's step() is ansatz agnostic: continuous Q2 elements give rows of 27 ... 125 entries in 3-D

@@ -177,3 +177,37 @@ def test_oracle_conserves_on_a_q2_stencil(oracle):
     after = (off.mi[:, None] * U).sum(0)
     assert np.abs(after - before).max() <= 1e-13 * np.abs(before).max()
     assert (U[:, 0] > 0).all() and m.n_warnings() == 0
+
+
+def test_oracle_on_the_numbering_and_layout_of_offline_data(oracle):
+    """The reader of the reference's SIMD-interleaved storage (oracle/csr.hpp) and the numbering helper
+    (tests/helpers_layout.py::offline_data_numbering: Cuthill-McKee + DoFRenumbering::internal_range restated) on the
+    unstructured P1 disk: 20 updates of a blast wave (round-off through the limiter grows with the updates: 1e-9) on the renumbered, interleaved mesh equal those on the mesh as
+    generated up to summation order, and conserve."""
+    from helpers_layout import offline_data_numbering, to_simd_layout
+    from helpers_unstructured import disk_points, p1_offline
+    from ryujin_amd import capi
+    from ryujin_amd.initial_states import euler_radial_contrast
+    from ryujin_amd.module import HyperbolicModule
+    off0, info = p1_offline(disk_points(16))
+    order, n_internal = offline_data_numbering(info["rows"], 8)
+    off = to_simd_layout(off0, 8, order, n_internal)
+    lengths = off.new_lengths
+    assert n_internal % 8 == 0 and 0 < n_internal < off.n_owned
+    assert all(len(set(lengths[g:g + 8].tolist())) == 1 for g in range(0, n_internal, 8))
+    U0 = euler_radial_contrast(off0.positions, inner=(1.0, 0.0, 10.0), outer=(0.125, 0.0, 0.1), radius=0.35)
+    out = []
+    for view, start in ((off0, U0), (off, U0[order])):
+        p = oracle.default_params(capi.EQ_EULER, 2)
+        p.cfl = 0.5
+        m = HyperbolicModule(view, p, backend=oracle.backend())
+        a, b = m.new_state_vector(start), m.new_state_vector()
+        for _ in range(20):
+            m.prepare_state_vector(a, 0.0)
+            m.step(a, [], [], b)
+            a, b = b, a
+        out.append(a.download())
+    ref, got = out[0], out[1][off.new_index]
+    assert (np.abs(got - ref) / np.abs(ref).max(axis=0)).max() < 1e-9
+    mass0, mass1 = (off0.mi * U0[:, 0]).sum(), (off.mi * out[1][:, 0]).sum()
+    assert abs(mass1 - mass0) < 1e-13 * mass0
