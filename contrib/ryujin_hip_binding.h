@@ -273,6 +273,11 @@ namespace ryujin_hip_binding
     p.limiter_newton_tolerance = limiter.newton_tolerance();
     p.limiter_newton_max_iterations = static_cast<int>(limiter.newton_max_iterations());
     p.limiter_relaxation_factor = limiter.relaxation_factor();
+    /* ryujin configured with EXPENSIVE_BOUNDS_CHECK (compile_time_options.h.in:12-15; implied by DEBUG): the
+     * checked control flow of the limiter and is_admissible behind steps 4, 6, 7 on the device as well (Euler) */
+#ifdef EXPENSIVE_BOUNDS_CHECK
+    p.debug_expensive_bounds_check = 1;
+#endif
   }
 
   /* (the Riemann solver of the EulerAEOS Description has no run-time parameters, euler_aeos/riemann_solver.h:19-27:

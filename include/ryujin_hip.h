@@ -171,7 +171,8 @@ typedef struct ryujin_hip_params {
    * (hyperbolic_module.template.h:851-855,1121-1126), the limiter's checked control flow -- its additional
    * high-order density and entropy checks (limiter.template.h:110-134,244-252,291-322) -- and the second limiter
    * pass's `success` counted (:1155-1161): any of them raises the restart flag. Evaluated by separate kernels
-   * between the sweeps (P_ij is stored in full then); the l_ij themselves are the same in both control flows. */
+   * between the sweeps (P_ij is stored in full then); the l_ij themselves are the same in both control flows.
+   * The other Descriptions run their production flow with the plain kernels (no check kernels yet). */
   int debug_expensive_bounds_check;
 } ryujin_hip_params;
 
