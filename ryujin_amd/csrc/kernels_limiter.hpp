@@ -523,7 +523,8 @@ namespace ryujin_hip
     }
   }
 
-  /* where steps 6 and 7 take P_ij from when step 5 did not store it (ONFLY kernels): the operands of pij_stage0 */
+  /* where the repair launch of step 6 (k_pij_repair) and the debug fetch take P_ij from for the columns step 5 did
+   * not store: the operands of pij_stage0 */
   struct Stage0Src {
     DeviceScalars *scalars; /* tau; and the limited-slice counters of step 6 */
     const double *old_U, *alpha, *dij, *r_in;

@@ -120,3 +120,40 @@ def test_bench_interpolates_the_coarse_state_to_the_benchmark_mesh(mesh):
         assert np.abs(U_f - f(off_f.positions)).max() < 1.5  # |grad f| h_c-sized
     else:
         assert np.abs(U_f - f(off_f.positions)).max() < 1e-12
+
+
+def test_counter_profiles_of_other_kernel_sources_are_refused(tmp_path, monkeypatch):
+    """roofline.traffic comes from a committed rocprofv3 --pmc pass; bench.py attaches it only if the pass was taken
+    with the kernel sources of this tree (scripts/profile_round.sh stamps the summary with
+    bench.source_fingerprint()): a stale or unstamped profile gives traffic = None and says why."""
+    import bench
+    fp = bench.source_fingerprint()
+    assert len(fp) == 16 and fp == bench.source_fingerprint()
+    (tmp_path / "profiles").mkdir()
+    row = "| k_lij_stage0<Euler<2>, 1, false> | 39 | 1 | 2 | 3 | 2256.6 |\n"
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "source_fingerprint", lambda: fp)
+    prof = tmp_path / "profiles" / "r99_pmc.md"
+    prof.write_text("# pmc\n" + row)                                    # no stamp at all (rounds 1-3)
+    val, src, note = bench.pmc_traffic_bytes("5 pij_lij", "step2d")
+    assert val is None and "REFUSED as stale" in note and src.endswith("r99_pmc.md")
+    prof.write_text("# pmc\n" + row + "\nkernel sources: 0123456789abcdef\n")
+    val, _, note = bench.pmc_traffic_bytes("5 pij_lij", "step2d")
+    assert val is None and "0123456789abcdef" in note and fp in note
+    prof.write_text("# pmc\n" + row + "\nkernel sources: %s\n" % fp)
+    val, _, note = bench.pmc_traffic_bytes("5 pij_lij", "step2d")
+    assert note is None and abs(val - 2256.6e6) < 1.0
+    assert bench.pmc_traffic_bytes("5 pij_lij", "sedov3d")[2] == "no committed PMC pass of this workload"
+
+
+def test_comments_do_not_change_the_fingerprint_of_the_kernel_sources(tmp_path, monkeypatch):
+    import bench
+    csrc = tmp_path / "ryujin_amd" / "csrc"
+    csrc.mkdir(parents=True)
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    (csrc / "a.hpp").write_text("int f(int x) { return x + 1; } // plus one\n")
+    one = bench.source_fingerprint()
+    (csrc / "a.hpp").write_text("/* the successor */\nint f(int x)\n{\n  return x + 1;\n}\n")
+    assert bench.source_fingerprint() == one
+    (csrc / "a.hpp").write_text("int f(int x) { return x + 2; }\n")
+    assert bench.source_fingerprint() != one
