@@ -16,6 +16,10 @@
 #include <cfloat>
 
 
+#ifndef RYUJIN_LIMIT_GUARD_CLIP
+#define RYUJIN_LIMIT_GUARD_CLIP 1 /* the limiter's density clip (one FP64 division) only where a lane needs it */
+#endif
+
 namespace ryujin_hip
 {
   struct EulerParams {
@@ -807,11 +811,16 @@ namespace ryujin_hip
         const double test_max = filter_vacuum_density(P, fmax(0., rho_min - relax * rho_U));
         if (!(test_min == 0. && test_max == 0.))
           success = false;
-        const double denominator = 1. / (fabs(rho_P) + eps * rho_max);
-        t_r = rho_max < rho_U + t_r * rho_P ? (rho_max - rho_U) * denominator : t_r;
-        t_r = rho_U + t_r * rho_P < rho_min ? (rho_U - rho_min) * denominator : t_r;
-        t_r = fmin(t_r, t_max);
-        t_r = fmax(t_r, t_min);
+        /* the clip needs a division; with t_r = t_max = 1 neither comparison fires for most pairs and t_r stays
+         * t_max exactly (the clamps below are the identity on it): the division is only issued where a lane needs
+         * it (RYUJIN_LIMIT_GUARD_CLIP 0: always, as rounds 1 - 3) */
+        if (!RYUJIN_LIMIT_GUARD_CLIP || rho_max < rho_U + t_r * rho_P || rho_U + t_r * rho_P < rho_min) {
+          const double denominator = 1. / (fabs(rho_P) + eps * rho_max);
+          t_r = rho_max < rho_U + t_r * rho_P ? (rho_max - rho_U) * denominator : t_r;
+          t_r = rho_U + t_r * rho_P < rho_min ? (rho_U - rho_min) * denominator : t_r;
+          t_r = fmin(t_r, t_max);
+          t_r = fmax(t_r, t_min);
+        }
       }
       double U_r[K];
 #pragma unroll
