@@ -578,11 +578,14 @@ namespace ryujin_hip
       const double test_max = filter_vacuum_density(P, fmax(0., rho_min - relax * rho_U));
       if (!(test_min == 0. && test_max == 0.))
         success = false;
-      const double denominator = 1. / (fabs(rho_P) + eps * rho_max);
-      t_r = rho_max < rho_U + t_r * rho_P ? (rho_max - rho_U) * denominator : t_r;
-      t_r = rho_U + t_r * rho_P < rho_min ? (rho_U - rho_min) * denominator : t_r;
-      t_r = fmin(t_r, t_max);
-      t_r = fmax(t_r, t_min);
+      /* (the division only where a lane clips, as Euler<DIM>::first_psi_r: t_r = t_max stays untouched otherwise) */
+      if (rho_max < rho_U + t_r * rho_P || rho_U + t_r * rho_P < rho_min) {
+        const double denominator = 1. / (fabs(rho_P) + eps * rho_max);
+        t_r = rho_max < rho_U + t_r * rho_P ? (rho_max - rho_U) * denominator : t_r;
+        t_r = rho_U + t_r * rho_P < rho_min ? (rho_U - rho_min) * denominator : t_r;
+        t_r = fmin(t_r, t_max);
+        t_r = fmax(t_r, t_min);
+      }
       return t_r;
     }
 

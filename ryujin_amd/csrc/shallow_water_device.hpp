@@ -508,12 +508,15 @@ namespace ryujin_hip
         const double test_max = filter_dry_water_depth(P, fmax(0., h_min - relax * h_U));
         if (!(test_min == 0. && test_max == 0.))
           success = false;
-        const double denominator = 1. / (fabs(h_P) + eps * h_max + DBL_MIN);
-        t_r = h_max < h_U + t_r * h_P ? (h_max - h_U) * denominator : t_r;
+        /* (the division only where a lane clips, as Euler<DIM>::first_psi_r: t_r = t_max stays untouched otherwise) */
         const double h_min_tilde = fmax(h_small, h_min);
-        t_r = h_U + t_r * h_P < h_min_tilde ? (h_U - h_min_tilde) * denominator : t_r;
-        t_r = fmin(t_r, t_max);
-        t_r = fmax(t_r, t_min);
+        if (h_max < h_U + t_r * h_P || h_U + t_r * h_P < h_min_tilde) {
+          const double denominator = 1. / (fabs(h_P) + eps * h_max + DBL_MIN);
+          t_r = h_max < h_U + t_r * h_P ? (h_max - h_U) * denominator : t_r;
+          t_r = h_U + t_r * h_P < h_min_tilde ? (h_U - h_min_tilde) * denominator : t_r;
+          t_r = fmin(t_r, t_max);
+          t_r = fmax(t_r, t_min);
+        }
       }
       if (!P.limit_on_square_velocity && !P.limit_on_kinetic_energy)
         return t_l;
