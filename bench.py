@@ -632,6 +632,7 @@ def main():
     # Every pass is bracketed by barrier + synchronise on both sides; the MEDIAN pass is the reported one
     # (SURVEY.md section 8d), min and max travel with it.
     lib.ryujin_hip_set_timers(ctx, 0)
+    t_at_start = drv.t
     walls, evs = [], []
     for _ in range(max(1, args.reps)):
         while drv.stage != 0:  # every pass starts at an SSPRK33 step boundary
@@ -660,20 +661,27 @@ def main():
     # ---- pass 2, the roofline breakdown: the same K steps again with hipEvent pairs around every sweep
     while drv.stage != 0:
         drv.update()
+    # (three times, per sweep the median of the three means: a single stalled launch -- 0.5 ms instead of 0.24 ms
+    # for step 2 in one of the round-4 lines -- would otherwise name the wrong dominant sweep)
     lib.ryujin_hip_set_timers(ctx, 1)
-    lib.ryujin_hip_get_timers_accum(ctx, tmp, C.byref(n_upd), 1)  # reset the accumulators
-    barrier()
+    sweep_passes, ev_passes = [], []
     xinfo0 = m.exchange_info()
-    lib.ryujin_hip_event_record(ctx, 0)
-    run_steps(args.steps)
-    lib.ryujin_hip_event_record(ctx, 1)
-    barrier()
+    for _ in range(3):
+        lib.ryujin_hip_get_timers_accum(ctx, tmp, C.byref(n_upd), 1)  # reset the accumulators
+        barrier()
+        lib.ryujin_hip_event_record(ctx, 0)
+        run_steps(args.steps)
+        lib.ryujin_hip_event_record(ctx, 1)
+        barrier()
+        e = C.c_double()
+        lib.ryujin_hip_event_elapsed_ms(ctx, C.byref(e))
+        lib.ryujin_hip_get_timers_accum(ctx, tmp, C.byref(n_upd), 0)
+        assert n_upd.value == args.steps, (n_upd.value, args.steps)
+        sweep_passes.append(np.array(tmp[:]))
+        ev_passes.append(e.value)
     xinfo1 = m.exchange_info()
-    ev_ms_instrumented = C.c_double()
-    lib.ryujin_hip_event_elapsed_ms(ctx, C.byref(ev_ms_instrumented))
-    lib.ryujin_hip_get_timers_accum(ctx, tmp, C.byref(n_upd), 0)
-    assert n_upd.value == args.steps, (n_upd.value, args.steps)
-    sweep_ms = np.array(tmp[:])
+    sweep_ms = np.median(np.array(sweep_passes), axis=0)
+    ev_ms_instrumented = C.c_double(float(np.median(ev_passes)))
 
     n_q_local = off.n_owned
     if dist is not None:
@@ -700,8 +708,8 @@ def main():
                 "neighbours_of_rank0": info["neighbours"], "n_neighbours_per_rank": nb,
                 # counted by the library over the K steps of the instrumented pass (5 ghost exchanges per update:
                 # U, alpha, r, l_ij, l'_ij; 2 all-reduces per SSPRK33 step: tau_max of the first stage, the flags)
-                "exchanges_per_update": (xinfo1["n_exchanges"] - xinfo0["n_exchanges"]) / args.steps,
-                "allreduces_per_update": (xinfo1["n_allreduces"] - xinfo0["n_allreduces"]) / args.steps}
+                "exchanges_per_update": (xinfo1["n_exchanges"] - xinfo0["n_exchanges"]) / (3 * args.steps),
+                "allreduces_per_update": (xinfo1["n_allreduces"] - xinfo0["n_allreduces"]) / (3 * args.steps)}
 
     if rank != 0:
         return
@@ -768,7 +776,7 @@ def main():
                    # how the state the timed updates start from was made: run to develop_time on the coarse mesh,
                    # interpolated, develop_updates updates on this mesh (develop_time 0: from the initial state)
                    "develop_time": develop_time, "coarse_run": coarse, "develop_updates": n_develop,
-                   "simulated_time_at_start": drv.t, "perturbation": args.perturbation,
+                   "simulated_time_at_start": t_at_start, "simulated_time_at_end": drv.t, "perturbation": args.perturbation,
                    "perturbed_fraction": args.perturbed_fraction if args.perturbation != 0.0 else None},
         "mq_per_s": n_q_total * args.steps / wall / 1e6,
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": dom_gbs, "peak": HBM_PEAK_GBS,
