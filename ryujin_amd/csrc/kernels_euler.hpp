@@ -117,9 +117,6 @@ namespace ryujin_hip
 #ifndef RYUJIN_HO_CP_3D
 #define RYUJIN_HO_CP_3D 2 /* step 6 in 3-D: 0 = two-pass kernel, n = l_ij and the first n P_ij columns in registers (the others are read a second time, unless the whole tile is unlimited). Round 1, all at 2 waves/SIMD: 3.07 ms (0), 2.43 (8), 2.24 (14), 2.36 (18); round 2 see RYUJIN_OCC_HO_3D; round 4 (developed C4 state, all slices limited, limited update from V_i with tile-predicated P loads, 3 waves): whole update 8.30 ms (6), 8.06 (3), 8.02 (2), 8.13 (1) -- the second read of an unlimited tile is skipped anyway, fewer held columns leave the registers to the loads in flight */
 #endif
-#ifndef RYUJIN_XCD_REMAP
-#define RYUJIN_XCD_REMAP 1 /* see launch_block() */
-#endif
 #ifndef RYUJIN_OCC_DIJ_NODE_RECORD
 #define RYUJIN_OCC_DIJ_NODE_RECORD 3 /* step 2 on the combined node record (3-D Euler): 168 registers without scratch; C4 share 1.47 ms at 2 waves (184 registers), 1.35 at 3 */
 #endif
@@ -322,33 +319,11 @@ namespace ryujin_hip
     bool valid;
   };
 
-  /* The block of slices this workgroup works on. Workgroups are dealt out round-robin over the 8 XCDs (block b runs
-   * on XCD b % 8: observed, not a contract -- speed only, any placement is correct). With the identity mapping the
-   * blocks of two neighbouring grid lines of a mesh end up on different XCDs and every node record / state / r_j is
-   * pulled into three or more of the eight L2s (step 2 moves 1.9x its algorithmic bytes, all of it L2 misses served
-   * by the Infinity Cache). XCD_CONTIGUOUS gives every XCD a contiguous range of slices instead. Measured
-   * (profiles/r04l_ab_xcd_remap_*.log): the sweeps whose work per slice is the same everywhere gain -- C2 step 2
-   * -3.6 %, step 3 -7 %, step 4 -2.6 % -- the limiter sweeps 5 - 7 lose up to 4 - 7 %: their work follows the flow,
-   * a contiguous range puts a whole shock on one XCD and the others wait. RYUJIN_XCD_REMAP: 0 never, 1 (default)
-   * the uniform sweeps 2 - 4, 2 every sweep. */
-  template <bool XCD_CONTIGUOUS = false>
-  RYUJIN_DEV uint32_t launch_block()
-  {
-    if constexpr ((XCD_CONTIGUOUS && RYUJIN_XCD_REMAP >= 1) || RYUJIN_XCD_REMAP >= 2) {
-      const uint32_t per_xcd = gridDim.x >> 3;
-      const uint32_t b = blockIdx.x;
-      return b < (per_xcd << 3) ? (b & 7u) * per_xcd + (b >> 3) : b; /* a bijection; the last gridDim.x % 8 blocks stay */
-    } else {
-      return blockIdx.x;
-    }
-  }
-
-  template <bool XCD_CONTIGUOUS = false>
   RYUJIN_DEV RowCtx row_context(const DeviceMesh &M)
   {
     RowCtx r;
     r.lane = threadIdx.x & 63;
-    const uint32_t block = launch_block<XCD_CONTIGUOUS>();
+    const uint32_t block = blockIdx.x;
     r.slice = M.slice_begin + block * kWavesPerBlock + (threadIdx.x >> 6);
     r.valid = r.slice < M.slice_end;
     if (!r.valid) {
@@ -547,7 +522,7 @@ namespace ryujin_hip
     constexpr int K = E::K;
     constexpr int DIM = E::DIMENSION;
     step_begin(M);
-    const RowCtx r = row_context<true>(M);
+    const RowCtx r = row_context(M);
     if (!r.valid)
       return;
     const bool row_active = r.len > 1;
@@ -596,7 +571,7 @@ namespace ryujin_hip
     constexpr int K = E::K;
     constexpr int DIM = E::DIMENSION;
     step_begin(M);
-    const RowCtx r = row_context<true>(M);
+    const RowCtx r = row_context(M);
     if (!r.valid)
       return;
     const bool row_active = r.len > 1;
@@ -648,7 +623,7 @@ namespace ryujin_hip
   {
     constexpr int DIM = E::DIMENSION;
     constexpr int RS = E::RS;
-    const RowCtx r = row_context<true>(M);
+    const RowCtx r = row_context(M);
     if (!r.valid)
       return;
     const bool row_active = r.len > 1;
@@ -701,7 +676,7 @@ namespace ryujin_hip
   {
     constexpr int K = E::K, RS = E::RS, DIM = E::DIMENSION;
     step_begin(M);
-    const RowCtx r = row_context<true>(M);
+    const RowCtx r = row_context(M);
     if (!r.valid)
       return;
     const bool row_active = r.len > 1;
@@ -839,7 +814,7 @@ namespace ryujin_hip
   k_dij_diag(const DeviceMesh M, const double cfl, double *__restrict__ dij,
              DeviceScalars *__restrict__ scalars)
   {
-    const RowCtx r = row_context<true>(M);
+    const RowCtx r = row_context(M);
     if (!r.valid)
       return;
     const bool row_active = r.len > 1;
@@ -877,7 +852,7 @@ namespace ryujin_hip
   k_dij_diag_unrolled(const DeviceMesh M, const uint32_t *__restrict__ lower_mask, const double cfl,
                       double *__restrict__ dij, DeviceScalars *__restrict__ scalars)
   {
-    const RowCtx r = row_context<true>(M);
+    const RowCtx r = row_context(M);
     if (!r.valid)
       return;
     const bool row_active = r.len > 1;
@@ -966,7 +941,7 @@ namespace ryujin_hip
   {
     using E = Euler<DIM>;
     constexpr int K = E::K;
-    const RowCtx r = row_context<true>(M);
+    const RowCtx r = row_context(M);
     if (!r.valid)
       return;
     const bool row_active = r.len > 1;

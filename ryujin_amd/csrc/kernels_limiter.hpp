@@ -1142,7 +1142,7 @@ namespace ryujin_hip
   __global__ void __launch_bounds__(kBlock)
   k_pij_repair(const DeviceMesh M, const Stage0Src S0, double *__restrict__ pij, const SliceFlags W)
   {
-    const uint32_t slice = M.slice_begin + launch_block() * kWavesPerBlock + (threadIdx.x >> 6);
+    const uint32_t slice = M.slice_begin + blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (slice >= M.slice_end || W.todo[slice] < 2)
       return;
     const uint32_t fs = W.first_stored[slice];
@@ -1169,7 +1169,7 @@ namespace ryujin_hip
       r = row_context_of_slice(M, M.slice_begin + blockIdx.x);
     } else if constexpr (MODE != kHoPlain) {
       /* the flag first: most waves of a developed flow retire on it */
-      const uint32_t slice = M.slice_begin + launch_block() * kWavesPerBlock + (threadIdx.x >> 6);
+      const uint32_t slice = M.slice_begin + blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
       if (slice >= M.slice_end)
         return;
       if constexpr (MODE == kHoLight) {
