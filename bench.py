@@ -43,7 +43,7 @@ KERNEL_OF_SWEEP = {  # sweep name -> kernel-name prefixes in the rocprof summari
     "2 dij_alpha": ("k_dij_alpha",), "2a alpha (k_alpha)": ("k_alpha",), "2b dij (k_dij)": ("k_dij<",),
     "3 dij_diag_tau": ("k_dij_diag",), "4 low_order": ("k_low_order",),
     "5 pij_lij": ("k_lij_stage0", "k_pij_lij"), "6 high_order_next_lij": ("k_high_order_next_cached", "k_high_order<"),
-    "7 high_order": ("k_high_order<",),
+    "7 high_order": ("k_high_order_last_cached", "k_high_order<"),
 }
 
 
@@ -64,27 +64,31 @@ def source_fingerprint() -> str:
     return h.hexdigest()[:16]
 
 
-def pmc_traffic_bytes(sweep: str, workload: str):
-    """(HBM bytes per launch of the sweep's kernel, profile file, note) from the newest committed rocprofv3 --pmc
-    passes of this same command (profiles/r*_pmc.md for the bench line, profiles/r*_pmc_<workload>.md for the
-    other workloads: (2*FETCH_SIZE + WRITE_SIZE)*1024, the gfx950 correction of MI355X_MICROARCH.md). PMC
-    cannot be collected inside this process. A profile taken with OTHER kernel sources than this tree's (its
-    `kernel sources:` line against source_fingerprint()) is refused: bytes None, the note says why."""
+def _pmc_kernel_row(sweep: str, workload: str):
+    """(counters of the sweep's kernel as {column: mean per dispatch}, profile file, note) from the newest committed
+    rocprofv3 --pmc passes of this same command (profiles/r*_pmc.md for the bench line, profiles/r*_pmc_<workload>.md
+    for the other workloads). PMC cannot be collected inside this process. A profile taken with OTHER kernel sources
+    than this tree's (its `kernel sources:` line against source_fingerprint()) is refused: row None, the note says
+    why."""
     import glob
     suffix = "" if workload == "step2d" else "_" + workload
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc{suffix}.md")))
     if not files:
         return None, None, "no committed PMC pass of this workload"
     rel = os.path.relpath(files[-1], ROOT)
-    rows = {}
+    rows, header = {}, None
     taken_with = None
     for line in open(files[-1]):
         if line.startswith("kernel sources:"):
             taken_with = line.split(":", 1)[1].strip()
+        if line.startswith("| kernel"):
+            header = [c.strip() for c in line.strip().strip("|").split("|")]
         if line.startswith("| k_"):
             cells = [c.strip() for c in line.strip().strip("|").split("|")]
             try:
-                rows[cells[0]] = (float(cells[-1]) * 1e6, int(cells[1]))
+                cols = header if header is not None and len(header) == len(cells) else (
+                    ["kernel", "n"] + [f"c{q}" for q in range(len(cells) - 3)] + ["hbm_MB"])
+                rows[cells[0]] = {c: float(v) for c, v in zip(cols[1:], cells[1:])}
             except ValueError:
                 pass
     now = source_fingerprint()
@@ -92,16 +96,38 @@ def pmc_traffic_bytes(sweep: str, workload: str):
         return None, rel, (f"REFUSED as stale: {rel} was taken with kernel sources {taken_with}, this tree is {now}")
     last = sweep.startswith("7")
     best = None  # several variants of a sweep's kernel may have run: the one with the most bytes in total
-    for name, (val, n_dispatches) in rows.items():
+    for name, row in rows.items():
         for prefix in KERNEL_OF_SWEEP.get(sweep, ()):
             if name.startswith(prefix):
                 if prefix == "k_high_order<" and (("true" in name) != last):
                     continue
-                if best is None or val * n_dispatches > best[0] * best[1]:
-                    best = (val, n_dispatches)
+                if best is None or row["hbm_MB"] * row["n"] > best["hbm_MB"] * best["n"]:
+                    best = row
     if best is not None:
-        return best[0], rel, None
+        return best, rel, None
     return None, rel, "the profile holds no kernel of this sweep"
+
+
+def pmc_traffic_bytes(sweep: str, workload: str):
+    """(HBM bytes per launch of the sweep's kernel, profile file, note): (2*FETCH_SIZE + WRITE_SIZE)*1024, the gfx950
+    correction of MI355X_MICROARCH.md, from _pmc_kernel_row()."""
+    row, rel, note = _pmc_kernel_row(sweep, workload)
+    return (row["hbm_MB"] * 1e6 if row is not None else None), rel, note
+
+
+def pmc_valu_issue(sweep: str, workload: str, launch_ms: float):
+    """The arithmetic side of the sweep's kernel from the same counter pass: VALU instructions per wave and the
+    share of the launch the FP64 pipes need just to issue them (a wave64 VALU instruction occupies its 16-lane SIMD
+    for 4 cycles; 1024 SIMDs at 2.4 GHz, MI355X_MICROARCH.md -- a lower bound: divisions, square roots and 64-bit
+    integer multiplies are counted at their instruction count). None without a valid profile."""
+    row, _, _ = _pmc_kernel_row(sweep, workload)
+    if row is None or "SQ_INSTS_VALU" not in row or "SQ_WAVES" not in row or not row["SQ_WAVES"]:
+        return None
+    issue_ms = row["SQ_INSTS_VALU"] * 4.0 / (1024 * 2.4e9) * 1e3
+    return {"valu_instructions_per_wave": round(row["SQ_INSTS_VALU"] / row["SQ_WAVES"]),
+            "issue_ms": issue_ms, "issue_frac": issue_ms / launch_ms,
+            "note": "VALU instructions x 4 cycles / (1024 SIMDs x 2.4 GHz) over the launch duration: the share of the "
+                    "launch the FP64 pipes need to issue the kernel's arithmetic (with traffic_frac: how far the two add up)"}
 
 
 class Ssprk33Stages:
@@ -789,6 +815,7 @@ def main():
                                              "32/64-byte records, WRITE_SIZE 1.000 "
                                              "(profiles/r03h_counter_calibration.md)") if traffic else None,
                      "traffic_frac": (traffic / (per_sweep[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                     "valu": pmc_valu_issue(dom, args.workload, per_sweep[dom]) if traffic else None,
                      "algorithmic_bytes_per_gridpoint": own[dom],
                      "mean_launch_ms": per_sweep[dom],
                      "reference_structure": {
