@@ -67,15 +67,6 @@ namespace ryujin_hip
     return E::DIMENSION == 3 ? RYUJIN_OCC_LIJ0_3D : RYUJIN_OCC_LIJ0;
   }
 
-#ifndef RYUJIN_LIJ0_PIPE_3D
-#define RYUJIN_LIJ0_PIPE_3D 1 /* columns in flight ahead of the one being limited, 3-D */
-#endif
-  template <typename E>
-  constexpr int lij0_pipeline_depth()
-  {
-    return E::DIMENSION == 3 ? RYUJIN_LIJ0_PIPE_3D : 1;
-  }
-
   /* (PairData, RowData, load_pair, pij_stage0: kernels_limiter.hpp -- steps 6 and 7 use them as well) */
 
   /* NY > 1 (small meshes): NY waves (blockIdx.y) share a slice, wave y taking the columns 1 + y, 1 + y + NY, ...;
@@ -127,37 +118,24 @@ namespace ryujin_hip
     if constexpr (PER_SLICE)
       storing = predict_override < 0 || (predict_override == 0 && W.unlimited[r.slice] == 0);
 
-    /* software pipeline: the loads of the next D columns are in flight while column c is limited (pipe[d], jq[d]:
-     * data and column index of column c + d NY; jq runs one column further ahead). D = 1 in 1-D / 2-D; in 3-D the
-     * limiter works ~1 us on a column at 2 waves per SIMD and a gather takes longer than that under load, so that
-     * with one column in flight the arithmetic and the memory phase of the kernel add up instead of overlapping
-     * (bench.py: roofline.valu.issue_frac 0.33 next to traffic_frac 0.58) */
-    constexpr int D = lij0_pipeline_depth<E>();
-    uint32_t jq[D + 1];
-    PairData<K> pipe[D];
-#pragma unroll
-    for (int d = 0; d <= D; ++d)
-      jq[d] = r.width > c0 + d * NY ? ld_stream(cols + (((uint64_t)r.base + c0 + d * NY) * 64 + r.lane)) : i;
-#pragma unroll
-    for (int d = 0; d < D; ++d)
-      if (r.width > c0 + d * NY)
-        load_pair<K>(M, old_U, r_in, alpha, dij, ((uint64_t)r.base + c0 + d * NY) * 64 + r.lane, jq[d], pipe[d]);
+    /* software pipeline: the loads of the next column are in flight while column c is limited */
+    uint32_t j_n = r.width > c0 ? ld_stream(cols + (((uint64_t)r.base + c0) * 64 + r.lane)) : i;
+    uint32_t j_nn = r.width > c0 + NY ? ld_stream(cols + (((uint64_t)r.base + c0 + NY) * 64 + r.lane)) : i;
+    PairData<K> next;
+    if (r.width > c0)
+      load_pair<K>(M, old_U, r_in, alpha, dij, ((uint64_t)r.base + c0) * 64 + r.lane, j_n, next);
 
     for (uint32_t c = c0; c < r.width; c += NY) {
       const uint64_t colbase = (uint64_t)r.base + c;
       const uint64_t pos = colbase * 64 + r.lane;
       const bool active = row_active && c < r.len;
       double P_ij[K];
-      pij_stage0<K>(row, pipe[0], P_ij);
-#pragma unroll
-      for (int d = 0; d + 1 < D; ++d)
-        pipe[d] = pipe[d + 1];
-#pragma unroll
-      for (int d = 0; d < D; ++d)
-        jq[d] = jq[d + 1];
-      if (c + D * NY < r.width)
-        load_pair<K>(M, old_U, r_in, alpha, dij, (colbase + D * NY) * 64 + r.lane, jq[D - 1], pipe[D - 1]);
-      jq[D] = (c + (D + 1) * NY < r.width) ? ld_stream(cols + ((colbase + (D + 1) * NY) * 64 + r.lane)) : i;
+      pij_stage0<K>(row, next, P_ij);
+      if (c + NY < r.width) {
+        j_n = j_nn;
+        load_pair<K>(M, old_U, r_in, alpha, dij, (colbase + NY) * 64 + r.lane, j_n, next);
+        j_nn = (c + 2 * NY < r.width) ? ld_stream(cols + ((colbase + 2 * NY) * 64 + r.lane)) : i;
+      }
       /* a slice that stores already: as soon as P_ij is formed (the store overlaps the limiter) */
       const bool stored_early = storing;
       if (stored_early && active)
