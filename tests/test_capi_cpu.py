@@ -205,6 +205,18 @@ def test_headers_are_plain_c_and_match_the_ctypes_mirror(tmp_path):
                     str(src), "-o", str(exe)], check=True, capture_output=True)
     sizes = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
     assert sizes == [C.sizeof(capi.Params), C.sizeof(capi.Offline), C.sizeof(capi.SynthSpec)]
+    # ... and every field of the mirrors sits under the same name at the offset the C compiler gives it
+    lines = []
+    for struct, mirror in (("ryujin_hip_params", capi.Params), ("ryujin_hip_offline", capi.Offline),
+                           ("ryujin_synth_spec", capi.SynthSpec)):
+        for field in mirror._fields_:
+            lines.append('printf("%%zu\\n", offsetof(%s, %s));' % (struct, field[0]))
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "ryujin_hip.h"\n#include "ryujin_synth.h"\n'
+                   'int main(void) { ' + " ".join(lines) + ' return 0; }\n')
+    subprocess.run(["gcc", "-std=c99", "-I", _build.INCLUDE, str(src), "-o", str(exe)], check=True, capture_output=True)
+    offsets = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    mirrored = [getattr(m, f[0]).offset for m in (capi.Params, capi.Offline, capi.SynthSpec) for f in m._fields_]
+    assert offsets == mirrored
 
 
 def test_restart_takes_precedence_over_a_later_invalid_tau():
