@@ -1486,6 +1486,34 @@ def test_unstructured_mesh_in_the_numbering_and_layout_of_offline_data(oracle):
     assert (np.abs(got - ref) / np.abs(ref).max(axis=0)).max() < 1e-12
 
 
+def test_q1_annulus_between_curved_walls(oracle):
+    """Continuous Q1 on general quadrilaterals: the annulus of tests/helpers_q1_quads.py (no cell a parallelogram,
+    Jacobians varying inside the cells, two slip walls of opposite curvature -- the geometry family of the reference's
+    check-mass-conservation_02 and cylinder benchmarks, not deal.II's mesh of it). A blast between the walls after
+    both reflections, every sweep against the oracle; then the outer wall as a `dynamic` far field and the inner wall
+    no-slip."""
+    from helpers_q1_quads import annulus_mesh, q1_quads_offline
+    pts, quads, edges = annulus_mesh(20, 96)
+    off, _ = q1_quads_offline(pts, quads, edges)
+    assert off.n_owned == 21 * 96 and off.n_pairs > 300
+    U0 = euler_radial_contrast(off.positions, inner=(1.0, 0.0, 10.0), outer=(0.125, 0.0, 0.1), radius=0.2,
+                               center=(0.7, 0.0))
+    mods = _unstructured_both(oracle, off, U0, capi.EQ_EULER, n_warm=240)
+    g, _ = _compare_step(off, mods)
+    mi = off.mi
+    for comp in (0, 3):
+        before, after = (mi * g["U_old"][:, comp]).sum(), (mi * g["U"][:, comp]).sum()
+        assert abs(after - before) < 1e-13 * abs(before)
+    bi = off._keep["b_i"]
+    bpos = off.positions[bi]
+    outer = np.linalg.norm(bpos, axis=1) > 0.7
+    off2, _ = q1_quads_offline(pts, quads, edges)
+    off2._keep["b_id"][:] = np.where(outer, capi.BC_DYNAMIC, capi.BC_NO_SLIP).astype(np.uint8)
+    far = euler_uniform(bpos, rho=0.5, u=0.3, p=0.4)
+    mods = _unstructured_both(oracle, off2, U0, capi.EQ_EULER, n_warm=240, dirichlet=far)
+    _compare_step(off2, mods, dirichlet=far)
+
+
 @pytest.mark.parametrize("case", ["euler_3d", "euler_3d_erk33", "shallow_water_3d_stencil_2d", "euler_2d"])
 def test_rows_wider_than_64_entries(oracle, case):
     """The reference's step() is ansatz agnostic: continuous Q2 elements give rows of 27 ... 125 entries in 3-D

@@ -211,3 +211,67 @@ def test_oracle_on_the_numbering_and_layout_of_offline_data(oracle):
     assert (np.abs(got - ref) / np.abs(ref).max(axis=0)).max() < 1e-9
     mass0, mass1 = (off0.mi * U0[:, 0]).sum(), (off.mi * out[1][:, 0]).sum()
     assert abs(mass1 - mass0) < 1e-13 * mass0
+
+
+def test_q1_annulus_mesh_data_and_conservation(oracle):
+    """Continuous Q1 on general quadrilaterals (tests/helpers_q1_quads.py): an annulus between two curved slip walls,
+    no cell a parallelogram -- the geometry family of the reference's check-mass-conservation_02 (whose deal.II mesh
+    itself cannot be rebuilt here). The mesh data have the properties the scheme relies on (rows of 9 and 6 entries,
+    partition of unity, c_ij antisymmetric in the interior, boundary integral on wall pairs, consistent normals), and
+    the oracle conserves mass and energy to round-off through a blast that reflects off both walls
+    (check-mass-conservation_02's property on its geometry)."""
+    from helpers_q1_quads import annulus_mesh, q1_quads_offline
+    pts, quads, edges = annulus_mesh(14, 72)
+    off, info = q1_quads_offline(pts, quads, edges)
+    n = off.n_owned
+    rs, cols, cij = off.row_starts.astype(np.int64), off.columns, off.cij_csr
+    lengths = np.diff(rs)
+    assert set(lengths.tolist()) == {6, 9}
+    # the area of the two inscribed polygons' difference, and the lumped masses sum to it
+    m = 72
+    assert abs(info["area"] - 0.5 * m * np.sin(2 * np.pi / m) * (1.0 - 0.4 ** 2)) < 1e-12
+    assert abs(off.mi.sum() - info["area"]) < 1e-13
+    assert np.abs(np.add.reduceat(cij, rs[:-1], axis=0)).max() < 1e-15          # partition of unity
+    lookup = {(i, int(cols[e])): e for i in range(n) for e in range(rs[i], rs[i + 1])}
+    is_bdry = info["is_bdry"]
+    skew_cells = 0
+    for q in quads:
+        d = pts[q[0]] - pts[q[1]] + pts[q[2]] - pts[q[3]]
+        skew_cells += np.linalg.norm(d) > 1e-3 * np.linalg.norm(pts[q[2]] - pts[q[0]])
+    assert skew_cells == len(quads)                                             # no parallelogram anywhere
+    for (i, j), e in lookup.items():
+        if i < j and not (is_bdry[i] and is_bdry[j]):
+            assert np.abs(cij[e] + cij[lookup[(j, i)]]).max() < 1e-15           # antisymmetric off the walls
+    # sum_j c_ji = int grad phi_i = int_boundary phi_i n: the raw (unnormalised) normal of the boundary map, on both
+    # walls -- the consistency between c_ij and the normals that makes the slip condition conservative
+    bi = np.flatnonzero(is_bdry)
+    for i in bi:
+        s = sum(cij[lookup[(j, i)]] for j in info["rows"][i])
+        assert np.abs(s - info["boundary_normals_raw"][i]).max() < 1e-14
+    r = np.linalg.norm(off.positions[bi], axis=1)
+    outward = np.einsum("ij,ij->i", off._keep["b_normal"], off.positions[bi]) / r
+    assert np.all(outward[r > 0.7] > 0.99) and np.all(outward[r < 0.7] < -0.99)  # the inner wall's normals point inwards
+
+    U0 = euler_radial_contrast(off.positions, inner=(1.0, 0.0, 10.0), outer=(0.125, 0.0, 0.1), radius=0.2,
+                               center=(0.7, 0.0))
+    mod = HyperbolicModule(off, equation=capi.EQ_EULER, backend=oracle.backend())
+    sv = mod.new_state_vector(U0)
+    ti = TimeIntegrator(mod, "ssprk 33", cfl_min=0.5, cfl_max=0.5, cfl_recovery_strategy="none")
+    mi = off.mi
+    before = (mi[:, None] * U0).sum(0)
+    t = 0.0
+    for _ in range(300):
+        sv, tau = ti.step(sv, t)
+        t += tau
+    U = sv.download()
+    after = (mi[:, None] * U).sum(0)
+    assert t > 0.2 and mod.n_warnings() == 0
+    assert abs(after[0] - before[0]) < 1e-13 * before[0]
+    assert abs(after[3] - before[3]) < 1e-13 * before[3]
+    rho, mom, E = U[:, 0], U[:, 1:3], U[:, 3]
+    assert rho.min() > 0 and (E - 0.5 * (mom ** 2).sum(1) / rho).min() > 0
+    mod.prepare_state_vector(sv, t)
+    U = sv.download()
+    assert np.abs(U[bi, 1:3]).max() > 1e-3                                      # the blast has reached both walls
+    assert np.abs(U[bi[r < 0.7], 1:3]).max() > 1e-4
+    assert np.abs(np.einsum("ij,ij->i", U[bi, 1:3], off._keep["b_normal"])).max() < 1e-15
