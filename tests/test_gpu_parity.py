@@ -1514,6 +1514,23 @@ def test_q1_annulus_between_curved_walls(oracle):
     _compare_step(off2, mods, dirichlet=far)
 
 
+def test_q1_hexahedra_between_curved_walls(oracle):
+    """Trilinear Q1 on skewed hexahedra with non-planar faces between two curved and two flat slip walls
+    (tests/helpers_q1_quads.py::annulus_mesh_3d): rows of 12 / 18 / 27 entries in the 3-D kernels, c_ij of a genuinely
+    trilinear geometry. A blast after its reflections, every sweep against the oracle."""
+    from helpers_q1_quads import annulus_mesh_3d, q1_hexes_offline
+    pts, hexes, faces = annulus_mesh_3d(7, 32, 5)
+    off, _ = q1_hexes_offline(pts, hexes, faces)
+    assert off.n_owned == 8 * 32 * 6
+    U0 = euler_radial_contrast(off.positions, inner=(1.0, 0.0, 10.0), outer=(0.125, 0.0, 0.1), radius=0.25,
+                               center=(0.7, 0.0, 0.25))
+    mods = _unstructured_both(oracle, off, U0, capi.EQ_EULER, n_warm=100)
+    g, _ = _compare_step(off, mods)
+    for comp in (0, 4):
+        before, after = (off.mi * g["U_old"][:, comp]).sum(), (off.mi * g["U"][:, comp]).sum()
+        assert abs(after - before) < 1e-13 * abs(before)
+
+
 @pytest.mark.parametrize("case", ["euler_3d", "euler_3d_erk33", "shallow_water_3d_stencil_2d", "euler_2d"])
 def test_rows_wider_than_64_entries(oracle, case):
     """The reference's step() is ansatz agnostic: continuous Q2 elements give rows of 27 ... 125 entries in 3-D

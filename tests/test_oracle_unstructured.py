@@ -275,3 +275,43 @@ def test_q1_annulus_mesh_data_and_conservation(oracle):
     assert np.abs(U[bi, 1:3]).max() > 1e-3                                      # the blast has reached both walls
     assert np.abs(U[bi[r < 0.7], 1:3]).max() > 1e-4
     assert np.abs(np.einsum("ij,ij->i", U[bi, 1:3], off._keep["b_normal"])).max() < 1e-15
+
+
+def test_q1_hexahedra_between_curved_walls_conserve(oracle):
+    """The 3-D counterpart: trilinear Q1 on skewed hexahedra with non-planar faces (the annulus extruded between two
+    flat lids, every layer twisted and breathing; tests/helpers_q1_quads.py) -- the cell shape of the reference's
+    3-D cylinder benchmark near the cylinder. Rows of 12 / 18 / 27 entries, the identities of the 2-D test, and mass
+    and energy conserved to round-off by the oracle through a blast between four slip walls."""
+    from helpers_q1_quads import annulus_mesh_3d, q1_hexes_offline
+    pts, hexes, faces = annulus_mesh_3d(5, 24, 4)
+    off, info = q1_hexes_offline(pts, hexes, faces)
+    n = off.n_owned
+    rs, cols, cij = off.row_starts.astype(np.int64), off.columns, off.cij_csr
+    assert set(np.diff(rs).tolist()) == {12, 18, 27}
+    assert abs(off.mi.sum() - info["volume"]) < 1e-13
+    assert np.abs(np.add.reduceat(cij, rs[:-1], axis=0)).max() < 1e-15
+    lookup = {(i, int(cols[e])): e for i in range(n) for e in range(rs[i], rs[i + 1])}
+    is_bdry = info["is_bdry"]
+    for (i, j), e in lookup.items():
+        if i < j and not (is_bdry[i] and is_bdry[j]):
+            assert np.abs(cij[e] + cij[lookup[(j, i)]]).max() < 1e-15
+    for i in np.flatnonzero(is_bdry):
+        s = sum(cij[lookup[(j, i)]] for j in info["rows"][i])
+        assert np.abs(s - info["boundary_normals_raw"][i]).max() < 1e-14
+    U0 = euler_radial_contrast(off.positions, inner=(1.0, 0.0, 10.0), outer=(0.125, 0.0, 0.1), radius=0.25,
+                               center=(0.7, 0.0, 0.25))
+    mod = HyperbolicModule(off, equation=capi.EQ_EULER, backend=oracle.backend())
+    sv = mod.new_state_vector(U0)
+    ti = TimeIntegrator(mod, "ssprk 33", cfl_min=0.5, cfl_max=0.5, cfl_recovery_strategy="none")
+    before = (off.mi[:, None] * U0).sum(0)
+    t = 0.0
+    for _ in range(120):
+        sv, tau = ti.step(sv, t)
+        t += tau
+    U = sv.download()
+    after = (off.mi[:, None] * U).sum(0)
+    assert t > 0.15 and mod.n_warnings() == 0
+    assert abs(after[0] - before[0]) < 1e-13 * before[0]
+    assert abs(after[4] - before[4]) < 1e-13 * before[4]
+    rho, mom, E = U[:, 0], U[:, 1:4], U[:, 4]
+    assert rho.min() > 0 and (E - 0.5 * (mom ** 2).sum(1) / rho).min() > 0
