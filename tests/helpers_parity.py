@@ -323,7 +323,9 @@ def compare_step(off, mods, dirichlet=None, tau=0.0, *, oracle=None, params=None
         g["dij"], c["dij"] = a, b
     assert abs(tau_g - tau_c) <= 1e-12 * tau_c
     a, b = both(lambda m, o, nw: m.debug_fetch("bounds"))
-    np.testing.assert_allclose(a, b, rtol=1e-12)
+    # (relative 1e-12; the absolute floor, 1e-20 of the largest bound, only lets underflow-sized entries through:
+    # kinetic-energy bounds of 1e-37 next to a dry shallow-water node differ in their last bits between operation orders)
+    np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-20 * np.abs(b).max())
     g["bounds"], c["bounds"] = a, b
     a, b = both(lambda m, o, nw: m.debug_fetch("r"))
     k = mg.k

@@ -1514,6 +1514,29 @@ def test_q1_annulus_between_curved_walls(oracle):
     _compare_step(off2, mods, dirichlet=far)
 
 
+def test_q1_annulus_shallow_water(oracle):
+    """The shallow-water Description on the skewed-quadrilateral annulus: a bathymetry that rises towards the outer
+    wall (dry there), Manning friction, a dam break between the walls -- the m_ij-weighted source terms and the
+    hydrostatic reconstruction on non-Cartesian c_ij."""
+    from helpers_q1_quads import annulus_mesh, q1_quads_offline
+    pts, quads, edges = annulus_mesh(20, 96)
+    off, _ = q1_quads_offline(pts, quads, edges)
+    x = off.positions
+    r = np.linalg.norm(x, axis=1)
+    Z = 0.9 * (r - 0.4) ** 2 / 0.36 + 0.04 * np.cos(5.0 * x[:, 0]) * np.sin(3.0 * x[:, 1])
+    off.set_initial_precomputed(Z)
+    near = np.linalg.norm(x - np.array([0.6, 0.0]), axis=1) < 0.2
+    U0 = np.zeros((off.n_owned, 3))
+    U0[:, 0] = np.maximum(np.where(near, 0.9, 0.35) - Z, 0.0)
+    assert (U0[:, 0] == 0).sum() > 100 and (U0[:, 0] > 0.5).sum() > 20
+
+    def friction(p):
+        p.manning_friction_coefficient = 0.03
+    mods = _unstructured_both(oracle, off, U0, capi.EQ_SHALLOW_WATER, n_warm=80, params_edit=friction)
+    g, _ = _compare_step(off, mods)
+    assert (g["U"][:, 0] >= 0.0).all() and np.abs(g["U"][:, 1:]).max() > 1e-2
+
+
 def test_q1_hexahedra_between_curved_walls(oracle):
     """Trilinear Q1 on skewed hexahedra with non-planar faces between two curved and two flat slip walls
     (tests/helpers_q1_quads.py::annulus_mesh_3d): rows of 12 / 18 / 27 entries in the 3-D kernels, c_ij of a genuinely
