@@ -4,5 +4,5 @@ set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$R"
 mkdir -p gpurun_out
-timeout 200 python -m pytest tests -m gpu -x -q -k "q1_annulus_shallow_water" > gpurun_out/r04q3_pytest.log 2>&1
-tail -15 gpurun_out/r04q3_pytest.log
+timeout 200 python -m pytest tests -m gpu -x -q -k "partitioned_q1_annulus" > gpurun_out/r04q4_pytest.log 2>&1
+tail -15 gpurun_out/r04q4_pytest.log

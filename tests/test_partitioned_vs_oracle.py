@@ -143,6 +143,25 @@ def test_partitioned_unstructured_sectors_rank_by_rank_against_the_oracle(oracle
 
 
 @pytest.mark.gpu
+def test_partitioned_q1_annulus_rank_by_rank_against_the_oracle(oracle):
+    """The skewed-quadrilateral annulus (tests/helpers_q1_quads.py) cut into four sectors around a point off the
+    centre: every rank holds a piece of both curved walls, boundary nodes are exported to neighbours, the sector cuts
+    cross the twisted rings obliquely. Every rank against the same rank of the partitioned oracle, ghost rows
+    included."""
+    from helpers_q1_quads import annulus_mesh, q1_quads_offline
+    from helpers_unstructured import partition
+    from test_oracle_unstructured import sector_owner
+    pts, quads, edges = annulus_mesh(16, 80)
+    off, info = q1_quads_offline(pts, quads, edges)
+    x = off.positions
+    U0 = euler_radial_contrast(x, inner=(1.0, 0.0, 10.0), outer=(0.125, 0.0, 0.1), radius=0.2, center=(0.7, 0.0))
+    views = partition(off, info, sector_owner(x, 4))
+    assert max(v.c.contents.n_nbr for v in views) >= 2 and all(v.n_bdry > 0 for v in views)
+    U_init = [U0[v.global_ids] for v in views]
+    _compare_partitioned(oracle, views, capi.EQ_EULER, 2, U_init, None, n_warm=40, cfl=0.5)
+
+
+@pytest.mark.gpu
 def test_the_rank_file_plumbing_of_the_rccl_test_on_one_gpu(oracle, tmp_path):
     """tests/test_multigpu_rccl.py::test_rccl_ranks_against_the_partitioned_oracle needs several GPUs. Its worker
     function (rccl_worker.intermediates: develop, one update, store the rank's arrays) and its parent side
