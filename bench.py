@@ -175,6 +175,54 @@ class Ssprk33Stages:
         self.stage = (self.stage + 1) % 3
 
 
+def host_mirrored_ssprk33(m, U0, dirichlet, t0: float, n_rk: int, pin: bool, mirror_derived: bool) -> dict:
+    """The drop-in path with an UNMODIFIED ryujin caller, timed: the reference's step_ssprk_33
+    (time_integrator.template.h:302-328) -- prepare_state_vector / step<0> on HOST state vectors, sadd() and swap() on
+    the host -- served by the mirroring of contrib/hyperbolic_module_hip.h (here its Python twin,
+    ryujin_amd.module.HostMirroredModule: the same C-ABI calls in the same order). Per update: upload U, write back
+    the boundary rows, download the precomputed values, download the new U (owned rows) and alpha. PCIe-inclusive;
+    never the headline value."""
+    from ryujin_amd.module import HostMirroredModule, HostStateVector
+    hm = HostMirroredModule(m, pin=pin, mirror_derived=mirror_derived)
+    state, temp = HostStateVector(m, U0), [HostStateVector(m), HostStateVector(m)]
+    t, t_sadd = t0, 0.0
+
+    def rk_step():
+        nonlocal t, t_sadd
+        hm.prepare_state_vector(state, t, dirichlet)
+        tau = hm.step(state, [], [], temp[0], 0.0)
+        hm.prepare_state_vector(temp[0], t + tau, dirichlet)
+        hm.step(temp[0], [], [], temp[1], tau)
+        s0 = time.perf_counter()
+        temp[1].U *= 0.25
+        temp[1].U += 0.75 * state.U
+        t_sadd += time.perf_counter() - s0
+        hm.prepare_state_vector(temp[1], t + 0.5 * tau, dirichlet)
+        hm.step(temp[1], [], [], temp[0], tau)
+        s0 = time.perf_counter()
+        temp[0].U *= 2.0 / 3.0
+        temp[0].U += (1.0 / 3.0) * state.U
+        t_sadd += time.perf_counter() - s0
+        state.swap(temp[0])
+        t += tau
+
+    rk_step()  # warm-up: twins, pinning
+    t_sadd = 0.0
+    w0 = time.perf_counter()
+    for _ in range(n_rk):
+        rk_step()
+    wall = time.perf_counter() - w0
+    hm.close()
+    n_upd = 3 * n_rk
+    bytes_per_update = 8 * (m.n_relevant * m.k + m.n_owned * m.k
+                            + (m.n_relevant * (m.n_prec + 1) if mirror_derived else 0))
+    return {"ms_per_update": wall / n_upd * 1e3,
+            "ms_per_update_without_host_sadd": (wall - t_sadd) / n_upd * 1e3,
+            "pcie_bytes_per_update": bytes_per_update,
+            "pcie_gb_per_s": bytes_per_update / ((wall - t_sadd) / n_upd) / 1e9,
+            "pinned_in_place": pin, "mirror_precomputed_and_alpha": mirror_derived, "ssprk33_steps": n_rk}
+
+
 def usable_cores() -> int:
     """Physical cores this process may use: affinity mask, cgroup CPU quota, SMT siblings folded."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -371,6 +419,10 @@ def main():
                     help="N > 1: skip the bitwise comparison of a few updates run with device-scope and with "
                          "system-scope events before the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--binding", default="both", choices=["both", "device", "host-mirrored"],
+                    help="`value` is always the device-resident figure (state vectors in HBM); `host-mirrored`/`both` "
+                         "add the PCIe-inclusive ms/update of the adapter serving an UNMODIFIED ryujin TimeIntegrator "
+                         "(host state vectors mirrored at every call) as the object `binding` (N = 1)")
     ap.add_argument("--watchdog", type=int, default=1500,
                     help="abort the process after this many seconds (a hung collective must not hang the box)")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
@@ -709,6 +761,36 @@ def main():
     sweep_ms = np.median(np.array(sweep_passes), axis=0)
     ev_ms_instrumented = C.c_double(float(np.median(ev_passes)))
 
+    binding = None
+    if n_gpus == 1 and args.binding != "device":
+        while drv.stage != 0:
+            drv.update()
+        U_now = drv.U.download()
+        n_rk = max(2, min(10, args.steps // 3))
+        binding = {"what": ("ms per update as a ryujin TimeLoop sees it, by how the caller is bound "
+                            "(contrib/hyperbolic_module_hip.h, INTEGRATION.md section 2a)"),
+                   "c_abi_device_resident": wall / args.steps * 1e3,
+                   "patched_caller_time_step": None,  # filled below: time_step() + one download of U per RK step
+                   "unmodified_caller_host_mirrored": host_mirrored_ssprk33(m, U_now, dirichlet, drv.t, n_rk, True, True),
+                   "unmodified_caller_host_mirrored_U_only": host_mirrored_ssprk33(m, U_now, dirichlet, drv.t, n_rk, True, False),
+                   "unmodified_caller_pageable": host_mirrored_ssprk33(m, U_now, dirichlet, drv.t, max(2, n_rk // 2), False, True)}
+        # the patched caller in full mirroring: one upload + time_step + one download of the owned rows per RK step
+        host_U = np.array(U_now, copy=True)
+        lib.ryujin_hip_host_register(ctx, host_U.ctypes.data, host_U.nbytes)
+        T3 = [m.new_state_vector() for _ in range(3)]
+        sv = m.new_state_vector()
+        w0 = time.perf_counter()
+        for _ in range(n_rk):
+            sv.upload(host_U)
+            m.time_step("ssprk 33", sv, T3, dirichlet)
+            lib.ryujin_hip_state_download_owned(ctx, sv.handle, capi.as_ptr(host_U, capi.c_double_p))
+        binding["patched_caller_time_step"] = {"ms_per_update": (time.perf_counter() - w0) / (3 * n_rk) * 1e3,
+                                               "mirroring": "full: U up and down once per SSPRK33 step",
+                                               "device_resident": "= c_abi_device_resident (no transfers)"}
+        lib.ryujin_hip_host_unregister(ctx, host_U.ctypes.data)
+        for x in T3 + [sv]:
+            x.free()
+
     n_q_local = off.n_owned
     if dist is not None:
         import torch
@@ -835,6 +917,8 @@ def main():
     }
     if rccl is not None:
         out["rccl"] = rccl
+    if binding is not None:
+        out["binding"] = binding
     if not args.no_cpu_baseline and n_gpus == 1:
         try:
             out["cpu_baseline"] = cpu_baseline(spec, U_developed, dirichlet, args.cpu_budget, equation)

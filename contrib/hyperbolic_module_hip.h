@@ -24,18 +24,31 @@
 // instantiations of the CPU implementation) compiles to nothing. Link libryujin_hip.so.
 //
 // State vectors. The reference's StateVector is a tuple of HOST vectors owned by the caller
-// (source/state_vector.h:47-51). Every host state vector gets a device-resident twin (keyed by its address);
-// under the reference's own contract -- "old and stage vectors must be PREPARED, step() writes new.U on the
-// owned range only" (hyperbolic_module.h:207-213) -- the following mirroring is always correct with an
-// UNMODIFIED TimeIntegrator (whose sadd()/swap() work on the host vectors):
-//   prepare_state_vector(sv, t): upload sv.U -> device, boundary conditions + ghost exchange + precomputation on
-//                                the device, download U and precomputed (the caller may read them: VTU output,
-//                                Quantities, compute_error all call prepare_state_vector first,
-//                                time_loop.template.h:374,701,858);
-//   step(old, stages, w, new)  : old and the stage vectors are the twins prepared above; download new.U and alpha.
-// That costs three transfers of a state vector per update over PCIe. Mirroring::device_resident drops the
-// downloads (synchronize_to_host() fetches on demand), and time_step() runs a whole explicit Runge-Kutta step of
-// TimeIntegrator::step (time_integrator.template.h:207-403) inside the library with one host synchronisation.
+// (source/state_vector.h:47-51), and the reference's TimeIntegrator works on them between the calls: sadd() for
+// the SSPRK convex combinations and state_vector.swap(temp_[k]) at the end of every scheme
+// (time_integrator.template.h:18-25,279-510). Every host state vector gets a device-resident twin, keyed by the
+// DATA POINTER of U (swap() exchanges the storage, not the objects: the twin follows the storage).
+//
+//   Unmodified caller (the default; nothing but hyperbolic_module.h is patched). The HOST array is the authority
+//   at every call, whatever the run-time parameters say:
+//     prepare_state_vector(sv, t): upload sv.U, boundary conditions + ghost exchange + precomputation on the
+//                                  device, write back ONLY what the call can have changed -- the boundary_map rows
+//                                  and the ghost range of U -- and the precomputed values (the caller may read them:
+//                                  VTU output, Quantities, compute_error all call prepare_state_vector first,
+//                                  time_loop.template.h:374,701,858);
+//     step(old, stages, w, new)  : old and the stage vectors are the twins prepared above (the contract of the
+//                                  reference, hyperbolic_module.h:207-213); download new.U on the owned range and alpha.
+//   One upload and one download of U plus one download of the precomputed values and alpha per update. With
+//   `hip pin host vectors = true` the caller's arrays are pinned in place on first sight (ryujin_hip_host_register)
+//   and the transfers are direct DMA; the default leaves them pageable (see the parameter's help text for why).
+//
+//   Patched caller (contrib/time_integrator_hip.patch: TimeIntegrator::step routes the explicit schemes to
+//   time_step(), TimeLoop fetches the state before it reads it without asking the module). A whole Runge-Kutta step
+//   of TimeIntegrator::step (time_integrator.template.h:207-403) runs inside the library with one host
+//   synchronisation. With `hip device resident state vectors = true` time_step() leaves the result on the device
+//   (the twin is marked "device ahead"); prepare_state_vector(), step() and synchronize_to_host() bring the host
+//   array up to date before anything reads it, and upload it again only if the host copy is the newer one. The
+//   parameter changes nothing for calls that do not come through time_step().
 //
 // Written against the reference snapshot; it needs deal.II and the ryujin headers. deal.II is not installed in the
 // build image of ryujin_amd: there the header is TYPE CHECKED -- the reference's unmodified TimeIntegrator (all
@@ -176,8 +189,22 @@ namespace ryujin
                     "fence (ryujin_hip_params::system_scope_events)");
       hip_device_resident_ = false;
       add_parameter("hip device resident state vectors", hip_device_resident_,
-                    "Do not copy U, the precomputed values and alpha back to the host vectors after every call "
-                    "(fetch them with synchronize_to_host())");
+                    "time_step() only (TimeIntegrator patched with contrib/time_integrator_hip.patch): leave the "
+                    "result of a Runge-Kutta step on the device; the host vectors are brought up to date by "
+                    "prepare_state_vector(), step() or synchronize_to_host(). Calls of an unmodified TimeIntegrator "
+                    "(prepare_state_vector + step) always mirror the host vectors, whatever is set here");
+      hip_pin_host_vectors_ = false;
+      add_parameter("hip pin host vectors", hip_pin_host_vectors_,
+                    "Pin the caller's state vectors in place (hipHostRegister) so that uploads and downloads are "
+                    "direct DMA transfers instead of staged copies. Only if every state vector that reaches the "
+                    "module lives as long as the module: true for TimeLoop's state vector and TimeIntegrator's "
+                    "temporaries, NOT for the temporary 'analytic' vector of 'enable compute error' "
+                    "(time_loop.template.h:320-333)");
+      hip_mirror_precomputed_ = true;
+      add_parameter("hip mirror precomputed values", hip_mirror_precomputed_,
+                    "prepare_state_vector() copies the precomputed values and step() copies alpha back to the host "
+                    "vectors (the reference leaves them there for VTU output and Quantities; nothing in "
+                    "TimeIntegrator reads them). If false: fetch alpha with synchronize_alpha_to_host()");
     }
 
     HyperbolicModule(const HyperbolicModule &) = delete;
@@ -276,16 +303,25 @@ namespace ryujin
     {
       Scope scope(computing_timer_, "time step [H] 1 - update boundary values, precompute values");
       auto &U = std::get<0>(state_vector);
-      bool created = false;
-      const int h = twins_.handle(&state_vector, &created);
-      /* the host vector is the authority until the twin has been prepared (the caller may have filled or
-       * sadd()ed it); in device_resident mode an existing twin is the authority */
-      if (created || mirroring_ == Mirroring::full)
-        check(ryujin_hip_state_upload(ctx_, h, U.begin()));
+      auto &twin = twin_of(state_vector);
+      /* the host array is the authority (the caller may have filled, sadd()ed or swapped it), unless the last
+       * writer was time_step() in device-resident mode */
+      const bool device_ahead = twin.device_ahead;
+      if (!device_ahead)
+        check(ryujin_hip_state_upload(ctx_, twin.handle, U.begin()));
       evaluate_dirichlet(t, dirichlet_values_.data());
-      check(ryujin_hip_prepare_state_vector(ctx_, h, t, dirichlet_entries_.empty() ? nullptr : dirichlet_values_.data()));
-      if (mirroring_ == Mirroring::full)
-        synchronize_to_host(state_vector);
+      check(ryujin_hip_prepare_state_vector(ctx_, twin.handle, t,
+                                            dirichlet_entries_.empty() ? nullptr : dirichlet_values_.data()));
+      if (device_ahead) {
+        check(ryujin_hip_state_download(ctx_, twin.handle, U.begin()));
+        check(ryujin_hip_get_alpha(ctx_, alpha_.begin()));
+      } else {
+        /* boundary_map rows and the ghost range: all this call can have changed in what was just uploaded */
+        check(ryujin_hip_state_download_prepared(ctx_, twin.handle, U.begin()));
+      }
+      if (device_ahead || hip_mirror_precomputed_)
+        check(ryujin_hip_state_download_precomputed(ctx_, twin.handle, std::get<1>(state_vector).begin()));
+      twin.device_ahead = false;
     }
 
     /* ---- step<stages>(): hyperbolic_module.template.h:234-1211 ---- */
@@ -303,9 +339,10 @@ namespace ryujin
       Scope scope(computing_timer_, "time step [H] 2-7 - device");
       std::array<int, (stages > 0 ? stages : 1)> handles{};
       for (int s = 0; s < stages; ++s)
-        handles[s] = twins_.handle(&stage_state_vectors[s].get());
-      const int h_old = twins_.handle(&old_state_vector);
-      const int h_new = twins_.handle(&new_state_vector);
+        handles[s] = prepared_twin_of(stage_state_vectors[s].get());
+      const int h_old = prepared_twin_of(old_state_vector);
+      auto &twin_new = twin_of(new_state_vector);
+      const int h_new = twin_new.handle;
 
       check(ryujin_hip_set_cfl(ctx_, cfl_));
       check(ryujin_hip_set_id_violation_strategy(
@@ -318,11 +355,11 @@ namespace ryujin
                   dealii::ExcMessage("I'm sorry, Dave. I'm afraid I can't do that.\nWe crashed.")); /* :573-576 */
       check(status);
       update_counters();
-      if (mirroring_ == Mirroring::full) {
-        /* step() writes new.U on the owned range only (hyperbolic_module.h:207-213) */
-        download_U(h_new, std::get<0>(new_state_vector));
+      /* step() writes new.U on the owned range only (hyperbolic_module.h:207-213) */
+      check(ryujin_hip_state_download_owned(ctx_, h_new, std::get<0>(new_state_vector).begin()));
+      twin_new.device_ahead = false;
+      if (hip_mirror_precomputed_)
         check(ryujin_hip_get_alpha(ctx_, alpha_.begin()));
-      }
       if (status == RYUJIN_RESTART)
         throw Restart(); /* all ranks together: the library reduced the flag over the ranks (:1194-1207) */
       return tau_out;
@@ -334,21 +371,25 @@ namespace ryujin
      * schemes, inside the library: one host synchronisation per Runge-Kutta step, tau and the restart flags
      * stay on the device, Dirichlet data is evaluated at the stage times t + c_s tau
      * (time_integrator.template.h:373-403). `scheme`: RYUJIN_SCHEME_*; `temp`: the integrator's temp_ vectors. */
-    template <std::size_t n_temp>
-    Number time_step(int scheme, StateVector &state_vector, std::array<StateVector, n_temp> &temp, Number t,
+    template <typename TempVectors>
+    Number time_step(int scheme, StateVector &state_vector, TempVectors &temp, Number t,
                      Number t_final = std::numeric_limits<Number>::max(),
                      int cfl_recovery = RYUJIN_CFL_RECOVERY_NONE, Number cfl_min = 0.45, Number cfl_max = 0.9) const
     {
-      bool created = false;
-      const int h = twins_.handle(&state_vector, &created);
-      if (created || mirroring_ == Mirroring::full)
-        check(ryujin_hip_state_upload(ctx_, h, std::get<0>(state_vector).begin()));
-      int h_tmp[n_temp];
-      for (std::size_t q = 0; q < n_temp; ++q)
-        h_tmp[q] = twins_.handle(&temp[q]);
+      Scope scope(computing_timer_, "time step [H] 1-7 - device, whole Runge-Kutta step");
+      auto &twin = twin_of(state_vector);
+      if (!twin.device_ahead)
+        check(ryujin_hip_state_upload(ctx_, twin.handle, std::get<0>(state_vector).begin()));
+      const int h = twin.handle;
+      std::vector<int> h_tmp(temp.size());
+      for (std::size_t q = 0; q < temp.size(); ++q) {
+        auto &scratch = twin_of(temp[q]); /* scratch on both sides: the host arrays of temp_ are never read */
+        scratch.device_ahead = false;
+        h_tmp[q] = scratch.handle;
+      }
       check(ryujin_hip_set_cfl(ctx_, cfl_));
       double tau_out = 0.;
-      const int status = ryujin_hip_time_step_fn(ctx_, scheme, h, (int)n_temp, h_tmp, t,
+      const int status = ryujin_hip_time_step_fn(ctx_, scheme, h, (int)h_tmp.size(), h_tmp.data(), t,
                                                  dirichlet_entries_.empty() ? nullptr : &dirichlet_callback,
                                                  const_cast<HyperbolicModule *>(this), t_final - t, cfl_recovery,
                                                  cfl_min, cfl_max, &tau_out);
@@ -358,20 +399,30 @@ namespace ryujin
       update_counters();
       check(ryujin_hip_get_cfl(ctx_, &cfl_));
       if (mirroring_ == Mirroring::full) {
-        download_U(h, std::get<0>(state_vector));
+        /* as step(): the owned range of U (the reference's schemes leave ghosts and precomputed values of the
+         * result unprepared as well) */
+        check(ryujin_hip_state_download_owned(ctx_, h, std::get<0>(state_vector).begin()));
         check(ryujin_hip_get_alpha(ctx_, alpha_.begin()));
+        twin.device_ahead = false;
+      } else {
+        twin.device_ahead = true;
       }
       if (status == RYUJIN_RESTART)
         throw Restart();
       return tau_out;
     }
 
-    /** copy U (owned + ghost range) and the precomputed values of the device twin into the host vectors */
+    /** bring the host vectors up to date with the device twin if time_step() left the twin ahead (U on the owned
+     * and the ghost range, the precomputed values, alpha); a no-op otherwise */
     void synchronize_to_host(StateVector &state_vector) const
     {
-      const int h = twins_.handle(&state_vector);
-      check(ryujin_hip_state_download(ctx_, h, std::get<0>(state_vector).begin()));
-      check(ryujin_hip_state_download_precomputed(ctx_, h, std::get<1>(state_vector).begin()));
+      auto &twin = twin_of(state_vector);
+      if (!twin.device_ahead)
+        return;
+      check(ryujin_hip_state_download(ctx_, twin.handle, std::get<0>(state_vector).begin()));
+      check(ryujin_hip_state_download_precomputed(ctx_, twin.handle, std::get<1>(state_vector).begin()));
+      check(ryujin_hip_get_alpha(ctx_, alpha_.begin()));
+      twin.device_ahead = false;
     }
 
     /** alpha of the last step (full mirroring keeps alpha() current by itself) */
@@ -413,14 +464,34 @@ namespace ryujin
       n_warnings_ = w;
     }
 
-    /* owned range only: what step() is allowed to write (hyperbolic_module.h:207-213) */
-    template <typename Vector>
-    void download_U(int handle, Vector &U) const
+    /* the twin of the STORAGE of a host state vector (swap() moves the storage between the tuples); the caller's
+     * arrays are pinned in place when the twin is created */
+    ryujin_hip_binding::HandleCache::Twin &twin_of(const StateVector &state_vector) const
     {
-      scratch_.resize(std::size_t(arrays_.offline.n_relevant) * problem_dimension);
-      check(ryujin_hip_state_download(ctx_, handle, scratch_.data()));
-      std::copy(scratch_.begin(), scratch_.begin() + std::size_t(arrays_.offline.n_owned) * problem_dimension,
-                U.begin());
+      const auto &U = std::get<0>(state_vector);
+      bool created = false;
+      auto &twin = twins_.twin(U.begin(), &created);
+      if (created && hip_pin_host_vectors_) {
+        const auto &precomputed = std::get<1>(state_vector);
+        const std::size_t n_relevant = arrays_.offline.n_relevant;
+        const int rc_U = ryujin_hip_host_register(ctx_, U.begin(), n_relevant * problem_dimension * sizeof(Number));
+        const int rc_p = ryujin_hip_host_register(ctx_, precomputed.begin(),
+                                                  n_relevant * View::n_precomputed_values * sizeof(Number));
+        check(rc_U);
+        check(rc_p);
+        twin.pinned = rc_U == RYUJIN_OK && rc_p == RYUJIN_OK;
+      }
+      return twin;
+    }
+
+    /* old and stage vectors of step(): "must be prepared" (hyperbolic_module.h:207-213), i.e. a twin exists */
+    int prepared_twin_of(const StateVector &state_vector) const
+    {
+      bool created = false;
+      const int h = twins_.twin(std::get<0>(state_vector).begin(), &created).handle;
+      AssertThrow(!created, dealii::ExcMessage("HyperbolicModule::step(): the old state vector and the stage state "
+                                               "vectors have to be prepared with prepare_state_vector() first"));
+      return h;
     }
 
     /* initial_values_->initial_state(position, t) for the boundary_map entries that read it (:137-139) */
@@ -483,6 +554,8 @@ namespace ryujin
     int hip_device_;
     bool hip_system_scope_events_;
     bool hip_device_resident_;
+    bool hip_pin_host_vectors_;
+    bool hip_mirror_precomputed_;
 
     const MPI_Comm &mpi_communicator_;
     std::map<std::string, dealii::Timer> &computing_timer_;
@@ -510,7 +583,7 @@ namespace ryujin
 
     std::vector<unsigned int> dirichlet_entries_; /* index into the boundary_map (= ryujin_hip_offline::b_i order) */
     std::vector<dealii::Point<dim>> dirichlet_positions_;
-    mutable std::vector<double> dirichlet_values_, scratch_;
+    mutable std::vector<double> dirichlet_values_;
   };
 
 } /* namespace ryujin */

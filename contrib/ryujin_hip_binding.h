@@ -18,7 +18,7 @@
 //   fill_params_euler / _shallow_water / _common      ParameterAcceptor values -> ryujin_hip_params
 //       (source/euler/hyperbolic_system.h:135-160, euler/{indicator,limiter,riemann_solver}.h,
 //        source/shallow_water/hyperbolic_system.h:132-165, shallow_water/limiter.h:62-68)
-//   HandleCache                                       host StateVector address -> device-resident handle
+//   HandleCache                                       storage of a host StateVector -> device-resident twin
 //
 #pragma once
 
@@ -323,16 +323,30 @@ namespace ryujin_hip_binding
   }
 
 
-  /* ---- host StateVector <-> device-resident handle --------------------------------------------- */
+  /* ---- host StateVector <-> device-resident twin ------------------------------------------------ */
 
   /**
    * The reference's StateVector (source/state_vector.h:47-51) lives on the host and is owned by the caller;
-   * its device twin lives behind a handle of the library. One twin per host object, keyed by its address,
-   * created on first use and released with the cache.
+   * its device twin lives behind a handle of the library. Twins are keyed by the DATA POINTER of U
+   * (std::get<0>(state_vector).begin()), not by the address of the StateVector object: the reference's
+   * TimeIntegrator ends every scheme with state_vector.swap(temp_[k]) (time_integrator.template.h:296,325,346 ...),
+   * which exchanges the storage of the two tuples and leaves their addresses where they were -- the twin has to
+   * follow the storage. A twin is created on first use and released with the cache (prepare() clears it; storage
+   * that is reallocated leaves a stale twin behind until then).
+   *
+   * `device_ahead`: the device copy is NEWER than the host array (left behind by time_step() in device-resident
+   * mode); whoever reads the host array next has to fetch it first. Everything else in the adapter treats the
+   * host array as the authority.
    */
   class HandleCache
   {
   public:
+    struct Twin {
+      int handle = -1;
+      bool device_ahead = false;
+      bool pinned = false; /* the host arrays were handed to ryujin_hip_host_register() */
+    };
+
     HandleCache() = default;
     HandleCache(const HandleCache &) = delete;
     HandleCache &operator=(const HandleCache &) = delete;
@@ -344,33 +358,36 @@ namespace ryujin_hip_binding
       ctx_ = ctx;
     }
 
-    /* handle of the twin of `host_object`; *created is set if it did not exist yet */
-    int handle(const void *host_object, bool *created = nullptr)
+    /* the twin of the storage at `key`; *created is set if it did not exist yet */
+    Twin &twin(const void *key, bool *created = nullptr)
     {
-      const auto it = handles_.find(host_object);
+      const auto it = twins_.find(key);
       if (created)
-        *created = it == handles_.end();
-      if (it != handles_.end())
+        *created = it == twins_.end();
+      if (it != twins_.end())
         return it->second;
       int h = -1;
       if (!ctx_ || ryujin_hip_state_alloc(ctx_, &h) != RYUJIN_OK)
         throw std::runtime_error(std::string("ryujin_hip: ") + ryujin_hip_last_error());
-      handles_[host_object] = h;
-      return h;
+      Twin &t = twins_[key];
+      t.handle = h;
+      return t;
     }
 
-    std::size_t size() const { return handles_.size(); }
+    int handle(const void *key, bool *created = nullptr) { return twin(key, created).handle; }
+
+    std::size_t size() const { return twins_.size(); }
 
     void clear()
     {
       if (ctx_)
-        for (const auto &it : handles_)
-          ryujin_hip_state_free(ctx_, it.second);
-      handles_.clear();
+        for (const auto &it : twins_)
+          ryujin_hip_state_free(ctx_, it.second.handle);
+      twins_.clear();
     }
 
   private:
     ryujin_hip_ctx *ctx_ = nullptr;
-    std::map<const void *, int> handles_;
+    std::map<const void *, Twin> twins_;
   };
 } // namespace ryujin_hip_binding

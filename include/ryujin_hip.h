@@ -317,6 +317,31 @@ int ryujin_hip_state_upload(ryujin_hip_ctx *ctx, int handle, const double *U_aos
 int ryujin_hip_state_download(ryujin_hip_ctx *ctx, int handle, double *U_aos);
 int ryujin_hip_state_download_precomputed(ryujin_hip_ctx *ctx, int handle, double *prec_aos);
 
+/* ---- host-mirrored state vectors: the unmodified reference caller ----------------------------------------
+ * The reference's StateVector lives on the HOST and is read and written there by its caller between the calls
+ * into HyperbolicModule (TimeIntegrator: sadd(), swap(); time_integrator.template.h:18-25,300-328). An adapter
+ * that keeps such a caller unchanged mirrors every call over PCIe; these entry points move only what the
+ * contract of the call can have changed, straight between the caller's arrays and HBM:
+ *   host_register(ptr, bytes)       pin the caller's array IN PLACE (hipHostRegister): uploads and downloads of
+ *                                   that memory are then direct DMA instead of a pageable staged copy.
+ *                                   Registrations belong to the context and end with it (or with
+ *                                   host_unregister). THE CALLER GUARANTEES that the memory stays allocated while
+ *                                   it is registered: a range that is freed and handed out again by the allocator
+ *                                   is not covered by the old pinning (registering the same address again renews
+ *                                   it). RYUJIN_WARN (not an error): the pages could not be pinned; transfers
+ *                                   still work, staged by the runtime.
+ *   state_download_owned(h, U)      rows [0, n_owned) only: what step() is allowed to write
+ *                                   (hyperbolic_module.h:207-213); U_aos has room for n_relevant rows, the
+ *                                   ghost rows are left untouched.
+ *   state_download_prepared(h, U)   the rows prepare_state_vector() can have changed in a vector the caller
+ *                                   has just uploaded: the boundary_map rows (boundary conditions,
+ *                                   hyperbolic_module.template.h:119-147) and the ghost range (:152-159).
+ *                                   Everything else in U_aos is left untouched. */
+int ryujin_hip_host_register(ryujin_hip_ctx *ctx, const void *ptr, size_t bytes);
+int ryujin_hip_host_unregister(ryujin_hip_ctx *ctx, const void *ptr);
+int ryujin_hip_state_download_owned(ryujin_hip_ctx *ctx, int handle, double *U_aos);
+int ryujin_hip_state_download_prepared(ryujin_hip_ctx *ctx, int handle, double *U_aos);
+
 /* ---- the hot path -------------------------------------------------------- */
 /*
  * prepare_state_vector(state_vector, t) (hyperbolic_module.template.h:96-193).

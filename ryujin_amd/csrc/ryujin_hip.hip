@@ -402,6 +402,13 @@ struct ryujin_hip_ctx {
   DeviceBuffer<double> d_b_normal, d_dirichlet;
   DeviceBuffer<uint8_t> d_b_id;
   bool have_dirichlet = false, needs_dirichlet = false;
+  /* ryujin_hip_state_download_prepared: the distinct boundary_map rows, packed on the device, scattered on the host */
+  std::vector<uint32_t> h_bc_rows;
+  DeviceBuffer<uint32_t> d_bc_rows;
+  DeviceBuffer<double> d_bc_pack;
+  double *h_bc_pack = nullptr; /* pinned */
+  /* ryujin_hip_host_register: caller-owned arrays pinned in place */
+  std::vector<const void *> registered_host;
 
   /* coupling boundary pairs */
   uint32_t n_pairs = 0;
@@ -519,6 +526,10 @@ struct ryujin_hip_ctx {
         (void)hipEventDestroy(e);
     if (h_scalars)
       (void)hipHostFree(h_scalars);
+    if (h_bc_pack)
+      (void)hipHostFree(h_bc_pack);
+    for (const void *ptr : registered_host)
+      (void)hipHostUnregister(const_cast<void *>(ptr));
     if (h_tau_early)
       (void)hipHostFree(h_tau_early);
     if (ev_tau)
@@ -779,6 +790,9 @@ void ryujin_hip_ctx::create(const ryujin_hip_offline &o, const ryujin_hip_params
         grp_start.push_back(e);
     }
     n_groups = (uint32_t)grp_start.size();
+    h_bc_rows.clear();
+    for (const uint32_t e : grp_start)
+      h_bc_rows.push_back(b_i[e]);
     /* which rows of a slice are boundary DoFs, and the group of the first one (BcFold) */
     std::vector<unsigned long long> bc_mask(L.n_slices, 0ull);
     std::vector<uint32_t> bc_first(L.n_slices, 0u);
@@ -2396,6 +2410,100 @@ int ryujin_hip_state_download_precomputed(ryujin_hip_ctx *ctx, int handle, doubl
     ctx->finish();
     HIP_CHECK(hipMemcpy(prec_aos, s.prec.ptr, (size_t)ctx->L.n_relevant * ctx->NPREC * sizeof(double),
                         hipMemcpyDeviceToHost));
+    return RYUJIN_OK;
+  });
+}
+
+int ryujin_hip_host_register(ryujin_hip_ctx *ctx, const void *ptr, size_t bytes)
+{
+  return guarded_ctx(ctx, [&]() {
+    if (!ptr || bytes == 0)
+      throw HipError(RYUJIN_ERR_ARG, "host_register: null or empty range");
+    /* a range that is registered already is registered AGAIN: the caller's allocator may have released the
+     * memory and handed the same address out anew in the meantime, and the old pinning does not cover the new pages */
+    const auto known = std::find(ctx->registered_host.begin(), ctx->registered_host.end(), ptr);
+    if (known != ctx->registered_host.end()) {
+      ctx->finish();
+      if (hipHostUnregister(const_cast<void *>(ptr)) != hipSuccess)
+        (void)hipGetLastError();
+      ctx->registered_host.erase(known);
+    }
+    if (hipHostRegister(const_cast<void *>(ptr), bytes, hipHostRegisterDefault) != hipSuccess) {
+      (void)hipGetLastError(); /* not fatal: transfers of pageable memory are staged by the runtime */
+      return RYUJIN_WARN;
+    }
+    ctx->registered_host.push_back(ptr);
+    return RYUJIN_OK;
+  });
+}
+
+int ryujin_hip_host_unregister(ryujin_hip_ctx *ctx, const void *ptr)
+{
+  return guarded_ctx(ctx, [&]() {
+    const auto it = std::find(ctx->registered_host.begin(), ctx->registered_host.end(), ptr);
+    if (it == ctx->registered_host.end())
+      return RYUJIN_WARN;
+    ctx->finish();
+    HIP_CHECK(hipHostUnregister(const_cast<void *>(ptr)));
+    ctx->registered_host.erase(it);
+    return RYUJIN_OK;
+  });
+}
+
+int ryujin_hip_state_download_owned(ryujin_hip_ctx *ctx, int handle, double *U_aos)
+{
+  return guarded_ctx(ctx, [&]() {
+    auto &s = ctx->state(handle);
+    const size_t n = ctx->L.n_owned;
+    const int K = ctx->K, KP = ctx->KP;
+    ctx->finish();
+    if (K == KP) {
+      HIP_CHECK(hipMemcpy(U_aos, s.U.ptr, n * K * sizeof(double), hipMemcpyDeviceToHost));
+    } else {
+      std::vector<double> tmp(n * KP);
+      HIP_CHECK(hipMemcpy(tmp.data(), s.U.ptr, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < n; ++i)
+        std::memcpy(&U_aos[i * K], &tmp[i * KP], sizeof(double) * K);
+    }
+    return RYUJIN_OK;
+  });
+}
+
+int ryujin_hip_state_download_prepared(ryujin_hip_ctx *ctx, int handle, double *U_aos)
+{
+  return guarded_ctx(ctx, [&]() {
+    auto &s = ctx->state(handle);
+    const int K = ctx->K, KP = ctx->KP;
+    const uint32_t n_rows = (uint32_t)ctx->h_bc_rows.size();
+    if (n_rows != 0) {
+      if (ctx->d_bc_rows.n == 0) {
+        ctx->d_bc_rows.upload(ctx->h_bc_rows);
+        ctx->d_bc_pack.alloc((size_t)n_rows * KP);
+        HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_bc_pack), (size_t)n_rows * KP * sizeof(double)));
+      }
+      hipLaunchKernelGGL(k_pack_vector, dim3(grid_for((size_t)n_rows * KP)), dim3(kBlock), 0, ctx->stream, n_rows,
+                         ctx->d_bc_rows.ptr, KP, s.U.ptr, ctx->d_bc_pack.ptr);
+      HIP_CHECK(hipGetLastError());
+    }
+    ctx->finish();
+    if (n_rows != 0) {
+      HIP_CHECK(hipMemcpy(ctx->h_bc_pack, ctx->d_bc_pack.ptr, (size_t)n_rows * KP * sizeof(double),
+                          hipMemcpyDeviceToHost));
+      for (uint32_t q = 0; q < n_rows; ++q)
+        std::memcpy(&U_aos[(size_t)ctx->h_bc_rows[q] * K], &ctx->h_bc_pack[(size_t)q * KP], sizeof(double) * K);
+    }
+    /* the ghost range [n_owned, n_relevant) */
+    const size_t first = ctx->L.n_owned, n = ctx->L.n_relevant - ctx->L.n_owned;
+    if (n != 0) {
+      if (K == KP) {
+        HIP_CHECK(hipMemcpy(U_aos + first * K, s.U.ptr + first * K, n * K * sizeof(double), hipMemcpyDeviceToHost));
+      } else {
+        std::vector<double> tmp(n * KP);
+        HIP_CHECK(hipMemcpy(tmp.data(), s.U.ptr + first * KP, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; ++i)
+          std::memcpy(&U_aos[(first + i) * K], &tmp[i * KP], sizeof(double) * K);
+      }
+    }
     return RYUJIN_OK;
   });
 }

@@ -199,8 +199,12 @@ class HyperbolicModule:
                 if values.size != n:
                     raise ValueError(f"dirichlet_fn returned {values.size} values, expected {n}")
                 C.memmove(out, values.ctypes.data, n * 8)
-            except BaseException as e:  # noqa: BLE001
+            except Exception as e:  # noqa: BLE001
                 failure.append(e)
+                nan = np.full(n, np.nan)
+                C.memmove(out, nan.ctypes.data, n * 8)
+            except BaseException as e:  # KeyboardInterrupt, SystemExit: poison the data as well, re-raised first
+                failure.insert(0, e)
                 nan = np.full(n, np.nan)
                 C.memmove(out, nan.ctypes.data, n * 8)
         cb = capi.DIRICHLET_FN(callback)
@@ -450,3 +454,78 @@ class TimeIntegrator:
                     [(a["a_61"] - a["a_51"]) / c, (a["a_62"] - a["a_52"]) / c, (a["a_63"] - a["a_53"]) / c,
                      (a["a_64"] - a["a_54"]) / c], T[4], tau)
         return self._swap(sv, 4), 5.0 * tau
+
+
+class HostStateVector:
+    """A HOST state vector as the reference's caller owns it (source/state_vector.h:47-51): U [n_relevant, k] and
+    the precomputed values [n_relevant, n_prec] in numpy arrays. swap() exchanges the storage of two of them, as
+    std::tuple::swap / dealii Vector::swap do (time_integrator.template.h:296,325)."""
+
+    def __init__(self, module: "HyperbolicModule", U: np.ndarray | None = None):
+        self.U = np.zeros((module.n_relevant, module.k)) if U is None else np.array(U, dtype=np.float64, copy=True)
+        self.precomputed = np.zeros((module.n_relevant, module.n_prec))
+
+    def swap(self, other: "HostStateVector"):
+        self.U, other.U = other.U, self.U
+        self.precomputed, other.precomputed = other.precomputed, self.precomputed
+
+
+class HostMirroredModule:
+    """Python twin of the mirroring of contrib/hyperbolic_module_hip.h: what the adapter does when an UNMODIFIED
+    TimeIntegrator (host sadd()/swap(), time_integrator.template.h:18-25,279-510) drives it. Device twins are keyed
+    by the storage of U (the data pointer), the host array is the authority at every call, and only what a call can
+    have changed is written back (ryujin_hip_state_download_prepared / _owned). Used by the parity tests of those
+    entry points and by bench.py's host-mirrored line; device library only."""
+
+    def __init__(self, module: HyperbolicModule, pin: bool = True, mirror_derived: bool = True):
+        self.m = module
+        self.pin, self.mirror_derived = pin, mirror_derived
+        self.twins: dict[int, StateVector] = {}
+        self._pinned: list[np.ndarray] = []  # kept alive while registered, unregistered by close()
+        self.alpha = np.zeros(module.n_relevant)
+        if pin:
+            self._register(self.alpha)
+
+    def _register(self, a: np.ndarray):
+        self.m._check(self.m._lib.ryujin_hip_host_register(self.m._ctx, a.ctypes.data, a.nbytes))
+        self._pinned.append(a)
+
+    def twin_of(self, sv: HostStateVector) -> StateVector:
+        key = sv.U.ctypes.data
+        if key not in self.twins:
+            self.twins[key] = StateVector(self.m)
+            if self.pin:
+                self._register(sv.U)
+                self._register(sv.precomputed)
+        return self.twins[key]
+
+    def prepare_state_vector(self, sv: HostStateVector, t: float, dirichlet: np.ndarray | None = None):
+        m, twin = self.m, self.twin_of(sv)
+        twin.upload(sv.U)
+        m.prepare_state_vector(twin, t, dirichlet)
+        m._check(m._lib.ryujin_hip_state_download_prepared(m._ctx, twin.handle, capi.as_ptr(sv.U, capi.c_double_p)))
+        if self.mirror_derived:
+            m._check(m._lib.ryujin_hip_state_download_precomputed(m._ctx, twin.handle,
+                                                                  capi.as_ptr(sv.precomputed, capi.c_double_p)))
+
+    def step(self, old: HostStateVector, stage_state_vectors, stage_weights, new: HostStateVector,
+             tau: float = 0.0, tau_max: float = np.finfo(np.float64).max) -> float:
+        m = self.m
+        for sv in [old, *stage_state_vectors]:
+            assert sv.U.ctypes.data in self.twins, "old and stage state vectors have to be prepared"
+        twin_new = self.twin_of(new)
+        try:
+            return m.step(self.twins[old.U.ctypes.data], [self.twins[s.U.ctypes.data] for s in stage_state_vectors],
+                          stage_weights, twin_new, tau, tau_max)
+        finally:
+            m._check(m._lib.ryujin_hip_state_download_owned(m._ctx, twin_new.handle, capi.as_ptr(new.U, capi.c_double_p)))
+            if self.mirror_derived:
+                m._check(m._lib.ryujin_hip_get_alpha(m._ctx, capi.as_ptr(self.alpha, capi.c_double_p)))
+
+    def close(self):
+        for twin in self.twins.values():
+            twin.free()
+        self.twins.clear()
+        for a in self._pinned:
+            self.m._lib.ryujin_hip_host_unregister(self.m._ctx, a.ctypes.data)
+        self._pinned.clear()

@@ -7,9 +7,10 @@ namespace dealii
   class ExceptionBase : public std::exception
   {
   public:
-    const char *what() const noexcept override { return "dealii mock exception"; }
+    const char *what() const noexcept override { return message.empty() ? "dealii mock exception" : message.c_str(); }
+    std::string message;
   };
-  struct ExcMessage : ExceptionBase { explicit ExcMessage(const std::string &) {} };
+  struct ExcMessage : ExceptionBase { explicit ExcMessage(const std::string &m) { message = m; } };
   struct ExcInternalError : ExceptionBase {};
   struct ExcNotInitialized : ExceptionBase {};
   struct ExcNotImplemented : ExceptionBase {};

@@ -1,21 +1,35 @@
 #pragma once
 #include <deal.II/base/mpi.h>
+#include <chrono>
 #include <string>
 namespace dealii
 {
   class Timer
   {
   public:
-    Timer();
-    Timer(const MPI_Comm, const bool sync_lap_times = false);
-    void start();
-    double stop();
-    void reset();
-    void restart();
-    double wall_time() const;
-    double cpu_time() const;
-    double last_wall_time() const;
-    double last_cpu_time() const;
+    Timer() = default;
+    Timer(const MPI_Comm, const bool = false) {}
+    void start() { t0_ = clock::now(); running_ = true; }
+    double stop()
+    {
+      if (running_) {
+        last_ = std::chrono::duration<double>(clock::now() - t0_).count();
+        total_ += last_;
+        running_ = false;
+      }
+      return total_;
+    }
+    void reset() { total_ = last_ = 0.; running_ = false; }
+    void restart() { reset(); start(); }
+    double wall_time() const { return total_ + (running_ ? std::chrono::duration<double>(clock::now() - t0_).count() : 0.); }
+    double cpu_time() const { return wall_time(); }
+    double last_wall_time() const { return last_; }
+    double last_cpu_time() const { return last_; }
+  private:
+    using clock = std::chrono::steady_clock;
+    clock::time_point t0_{};
+    double total_ = 0., last_ = 0.;
+    bool running_ = false;
   };
   class TimerOutput
   {
@@ -23,7 +37,7 @@ namespace dealii
     class Scope
     {
     public:
-      Scope(TimerOutput &, const std::string &);
+      Scope(TimerOutput &, const std::string &) {}
     };
   };
 }

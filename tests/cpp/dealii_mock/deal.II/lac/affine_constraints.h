@@ -10,7 +10,7 @@ namespace dealii
   {
   public:
     using size_type = types::global_dof_index;
-    AffineConstraints();
+    AffineConstraints() = default;
     explicit AffineConstraints(const IndexSet &);
     void reinit(const IndexSet &);
     void clear();

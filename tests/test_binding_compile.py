@@ -19,37 +19,26 @@ ParameterAcceptor::add_parameter, Utilities::MPI::{this_mpi_process, n_mpi_proce
 Runs where the reference tree is present (this container); skipped elsewhere."""
 import os
 import re
-import shutil
 import subprocess
+import sys
 
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-REFERENCE = "/root/reference/source"
-MOCK = os.path.join(ROOT, "tests", "cpp", "dealii_mock")
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-pytestmark = pytest.mark.skipif(not (os.path.isdir(REFERENCE) and shutil.which("g++") and shutil.which("patch")),
+import helpers_reference_tree as reftree  # noqa: E402
+
+MOCK = reftree.MOCK
+
+pytestmark = pytest.mark.skipif(not reftree.available(),
                                 reason="needs the reference tree, g++ and patch (the build container)")
 
 
 @pytest.fixture(scope="module")
 def patched_tree(tmp_path_factory):
-    top = tmp_path_factory.mktemp("ryujin")
-    src = os.path.join(top, "source")
-    shutil.copytree(REFERENCE, src)
-    for name in ("hyperbolic_module_hip.h", "ryujin_hip_binding.h", "ryujin_export_offline.h"):
-        shutil.copy(os.path.join(ROOT, "contrib", name), src)
-    for patch in ("hyperbolic_module_hip.patch", "ryujin_export_offline.patch"):
-        res = subprocess.run(["patch", "-p1", "-i", os.path.join(ROOT, "contrib", patch)], cwd=top,
-                             capture_output=True, text=True)
-        assert res.returncode == 0, res.stdout + res.stderr
-    # compile_time_options.h as cmake writes it (CMakeLists.txt:69-80: NUMBER double, OpenMP on, checks off)
-    text = open(os.path.join(src, "compile_time_options.h.in")).read().replace("@NUMBER@", "double")
-    text = re.sub(r"#cmakedefine (\w+)",
-                  lambda m: "#define " + m.group(1) if m.group(1) == "WITH_OPENMP" else "/* #undef %s */" % m.group(1),
-                  text)
-    open(os.path.join(src, "compile_time_options.h"), "w").write(text)
-    return src
+    """all three patches: hyperbolic_module_hip.patch, ryujin_export_offline.patch, time_integrator_hip.patch"""
+    return reftree.make_patched_tree(str(tmp_path_factory.mktemp("ryujin")))
 
 
 @pytest.mark.parametrize("directory,description", [("euler", "Euler"), ("shallow_water", "ShallowWater"),
@@ -78,5 +67,6 @@ def test_reference_time_integrator_compiles_on_the_adapter(patched_tree, tmp_pat
         open(os.path.join(ROOT, "include", "ryujin_offline_io.h")).read()
     assert undefined_abi and all(re.search(rf"\b{name}\s*\(", header) for name in undefined_abi), undefined_abi
     for name in ("ryujin_hip_create", "ryujin_hip_prepare_state_vector", "ryujin_hip_step", "ryujin_hip_time_step_fn",
+                 "ryujin_hip_host_register", "ryujin_hip_state_download_owned", "ryujin_hip_state_download_prepared",
                  "ryujin_offline_write"):
         assert name in undefined_abi, (name, undefined_abi)
