@@ -130,51 +130,6 @@ def pmc_valu_issue(sweep: str, workload: str, launch_ms: float):
                     "launch the FP64 pipes need to issue the kernel's arithmetic (with traffic_frac: how far the two add up)"}
 
 
-class Ssprk33Stages:
-    """SSPRK33 (time_integrator.template.h:302-328) unrolled into single forward-Euler updates."""
-
-    def __init__(self, module, U0, dirichlet):
-        self.m = module
-        self.U = module.new_state_vector(U0)
-        self.T = [module.new_state_vector(), module.new_state_vector()]
-        self.T2 = None
-        self.dirichlet = dirichlet
-        self.stage = 0
-        self.tau = 0.0
-        self.t = 0.0
-        self.first = True
-
-    def rk_step(self):
-        """Three forward-Euler updates = one SSPRK33 step through the device-resident driver
-        (ryujin_hip_time_step): one host synchronisation per RK step instead of per update."""
-        assert self.stage == 0
-        if self.T2 is None:
-            self.T2 = self.m.new_state_vector()
-        d = self.dirichlet if self.first else None
-        self.first = False
-        self.tau = self.m.time_step("ssprk 33", self.U, [self.T[0], self.T[1], self.T2], d)
-        self.t += self.tau
-
-    def update(self):
-        m, U, T = self.m, self.U, self.T
-        d = self.dirichlet if self.first else None  # constant Dirichlet data: upload once
-        self.first = False
-        if self.stage == 0:
-            m.prepare_state_vector(U, self.t, d)
-            self.tau = m.step(U, [], [], T[0], 0.0)
-        elif self.stage == 1:
-            m.prepare_state_vector(T[0], self.t + self.tau, d)
-            m.step(T[0], [], [], T[1], self.tau)
-            m.sadd(T[1], 1.0 / 4.0, 3.0 / 4.0, U)
-        else:
-            m.prepare_state_vector(T[1], self.t + 0.5 * self.tau, d)
-            m.step(T[1], [], [], T[0], self.tau)
-            m.sadd(T[0], 2.0 / 3.0, 1.0 / 3.0, U)
-            self.U, self.T[0] = T[0], U
-            self.t += self.tau
-        self.stage = (self.stage + 1) % 3
-
-
 def host_mirrored_ssprk33(m, U0, dirichlet, t0: float, n_rk: int, pin: bool, mirror_derived: bool) -> dict:
     """The drop-in path with an UNMODIFIED ryujin caller, timed: the reference's step_ssprk_33
     (time_integrator.template.h:302-328) -- prepare_state_vector / step<0> on HOST state vectors, sadd() and swap() on
@@ -243,85 +198,13 @@ def usable_cores() -> int:
     return max(1, n)
 
 
-def interpolate_from_lattice(spec_c, pos_c, U_c, pos_f, n_fill: int = 3):
-    """Multilinear interpolation of nodal values given on the Cartesian lattice of a coarse synthetic mesh
-    (nodes pos_c [n, dim] of spec_c, values U_c [n, k]) to the points pos_f. Lattice nodes the mesh does not have
-    (cut-outs: the step, the staircase cylinder) are filled from their nearest existing axis neighbours, n_fill
-    layers deep -- a fine fluid point next to a coarser staircase may sit in a cell with such a corner. A convex
-    combination of admissible states is admissible (the invariant set is convex)."""
-    import numpy as np
-    dim = spec_c.dim
-    lower = np.array(spec_c.lower[:dim], dtype=np.float64)
-    upper = np.array(spec_c.upper[:dim], dtype=np.float64)
-    n_cells = np.array(spec_c.n_cells[:dim], dtype=np.int64)
-    h = (upper - lower) / n_cells
-    k = U_c.shape[1]
-    grid = np.full(tuple(n_cells + 1) + (k,), np.nan)
-    idx = np.rint((pos_c - lower) / h).astype(np.int64)
-    grid[tuple(idx.T)] = U_c
-    for _ in range(n_fill):
-        hole = np.isnan(grid[..., 0])
-        if not hole.any():
-            break
-        acc = np.zeros_like(grid)
-        cnt = np.zeros(grid.shape[:-1])
-        for ax in range(dim):
-            for shift in (1, -1):
-                nb = np.roll(grid, shift, axis=ax)
-                edge = [slice(None)] * dim
-                edge[ax] = 0 if shift == 1 else -1
-                nb[tuple(edge)] = np.nan  # no wrap-around
-                ok = ~np.isnan(nb[..., 0])
-                acc[ok] += nb[ok]
-                cnt[ok] += 1.0
-        fill = hole & (cnt > 0)
-        grid[fill] = acc[fill] / cnt[fill][:, None]
-    x = np.clip((pos_f - lower) / h, 0.0, n_cells.astype(np.float64))
-    i0 = np.minimum(np.floor(x).astype(np.int64), n_cells - 1)
-    t = x - i0
-    out = np.zeros((pos_f.shape[0], k))
-    for corner in range(1 << dim):
-        w = np.ones(pos_f.shape[0])
-        ii = []
-        for ax in range(dim):
-            bit = (corner >> ax) & 1
-            w = w * (t[:, ax] if bit else 1.0 - t[:, ax])
-            ii.append(i0[:, ax] + bit)
-        v = grid[tuple(ii)]
-        # a corner that does not exist (deep inside a cut-out) must carry no weight for a fluid point
-        bad = np.isnan(v[:, 0])
-        assert not (bad & (w > 1e-9)).any(), "fine point inside a coarse cut-out: raise n_fill"
-        v = np.where(bad[:, None], 0.0, v)
-        out += w[:, None] * v
-    return out
-
-
-def develop_on_coarse_mesh(spec_c, U0_fn, dirichlet_fn, equation, t_final: float, device: int = 0):
-    """Run the flow to t_final with SSPRK33 at cfl 0.9 on a coarse mesh of the same domain (one rank, no
-    communicator, device-resident driver): (coarse offline data, state at t_final, number of RK steps)."""
-    import numpy as np
-    from ryujin_amd import HyperbolicModule, capi, offline
-    off_c = offline.SyntheticOffline(spec_c)
-    m = HyperbolicModule(off_c, equation=equation, backend="hip", device=device)
-    m.cfl = 0.9
-    U = m.new_state_vector(U0_fn(off_c.positions))
-    temps = [m.new_state_vector() for _ in range(3)]
-    dirichlet = dirichlet_fn(off_c.b_positions) if (dirichlet_fn is not None and off_c.n_bdry) else None
-    t, n = 0.0, 0
-    while t < t_final * (1.0 - 1e-12):
-        t += m.time_step("ssprk 33", U, temps, dirichlet if n == 0 else None, tau_max=t_final - t)
-        n += 1
-    U_c = U.download()
-    m.close()
-    return off_c, U_c, n
-
-
 def cpu_baseline(spec, U0, dirichlet, budget_s: float = 15.0, equation: int = 0) -> dict:
     """The CPU restatement of the reference path (oracle/, OpenMP over all host cores) timed on a
     bounded sample of the SAME workload: n forward-Euler updates of the same mesh."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py
     from ryujin_amd import HyperbolicModule, capi, offline
+    from ryujin_amd.workloads import Ssprk33Stages
 
     import build_oracle
     native = os.path.join(ROOT, "oracle", "build", "libryujin_oracle_native.so")
@@ -496,7 +379,7 @@ def main():
     import numpy as np
 
     from ryujin_amd import HyperbolicModule, capi, offline
-    from ryujin_amd.initial_states import euler_uniform
+    from ryujin_amd.workloads import Ssprk33Stages, benchmark_workload, developed_state
 
     if dist is not None:
         # the in-tree libraries are (re)built on demand: let rank 0 do that alone, the others load after it
@@ -505,66 +388,14 @@ def main():
             capi.load_hip()
         dist.barrier()
 
-    # ---- workload: BASELINE.json configs[1] per GPU, lengthened channel for N GPUs (weak scaling)
-    # every workload: make_spec(resolution, n_ranks, rank) -> MeshSpec, initial state and Dirichlet data as functions
-    # of positions (the coarse run that develops the flow uses the same recipes on a coarser mesh)
-    equation = capi.EQ_EULER
+    # ---- workload: BASELINE.json configs[1] per GPU, lengthened channel for N GPUs (weak scaling); the recipes live
+    # in ryujin_amd/workloads.py so that the parity tests build the state the timed updates start from the same way
+    wl = benchmark_workload(args.workload, n_gpus, cells_per_unit=args.cells_per_unit, size=args.size,
+                            coarse_factor=args.coarse_factor)
+    equation, make_spec, U0_fn, dirichlet_fn = wl.equation, wl.make_spec, wl.U0_fn, wl.dirichlet_fn
+    resolution, coarse_resolution = wl.resolution, wl.coarse_resolution
+    default_develop_time, workload_name = wl.default_develop_time, wl.name
     rng = np.random.default_rng(42 + rank)
-    dirichlet_fn = None
-    if args.workload in ("step2d", "step2d_aeos"):
-        # weak scaling: the channel is lengthened so that every GPU keeps the gridpoint count of the
-        # single-GPU mesh (area 0.8 L + 0.12 with the step cut out: 2.52 per GPU)
-        length = 3.0 if n_gpus == 1 else (2.52 * n_gpus - 0.12) / 0.8
-        resolution = args.cells_per_unit
-        coarse_resolution = max(20, int(round(resolution / args.coarse_factor / 5.0)) * 5)
-
-        def make_spec(n, n_ranks, r):
-            return offline.mach3_step_2d(n, length_units=length, n_ranks=n_ranks, rank=r)
-        U0_fn = dirichlet_fn = euler_uniform  # prm/benchmarks/euler-mach3-forward-facing-step.prm:55-66
-        default_develop_time = 2.0            # of the prm's final time 4.0 (:30)
-        workload_name = ("2D Euler Mach-3 forward-facing step, Q1, SSPRK33 stage sequence "
-                         "(BASELINE.json configs[1])")
-        if args.workload == "step2d_aeos":  # same problem through the EulerAEOS Description (f-3)
-            equation = capi.EQ_EULER_AEOS
-            workload_name = ("2D Euler-AEOS (polytropic gas EOS, strict bounds) Mach-3 forward-facing step, "
-                             "Q1, SSPRK33 stage sequence")
-    elif args.workload == "cylinder3d":
-        # BASELINE.json configs[3]: h = 1/126 on [0,4]x[-1,1]^2 over 8 GPUs is 4M gridpoints per GPU; fewer
-        # GPUs keep that per-GPU count with a shorter channel (half a unit of length per GPU, at least 1.25)
-        # (the cylinder needs 1.25 units of channel: one or two GPUs run h = 1/96 and 1/120 instead)
-        resolution = args.size or {1: 96, 2: 120}.get(n_gpus, 126)
-        coarse_resolution = max(8, resolution // args.coarse_factor)
-        length = max(1.25, 0.5 * n_gpus)
-
-        def make_spec(n, n_ranks, r):
-            return offline.cylinder_channel_3d(n, length_units=length, n_ranks=n_ranks, rank=r)
-        U0_fn = dirichlet_fn = euler_uniform  # prm/benchmarks/euler-mach3-cylinder-3d.prm:49-91
-        default_develop_time = 1.0            # the bow shock stands and has reflected off the channel walls (final time 5.0, :41)
-        workload_name = "3D Euler Mach-3 cylinder in a channel, Q1 (BASELINE.json configs[3])"
-    elif args.workload == "sedov3d":
-        from ryujin_amd.initial_states import euler_radial_contrast
-        resolution = args.size or 200
-        coarse_resolution = max(8, resolution // args.coarse_factor)
-
-        def make_spec(n, n_ranks, r):
-            return offline.box_3d(n, nx=n * n_gpus, upper=(2.0 * n_gpus - 1.0, 1.0, 1.0), n_ranks=n_ranks, rank=r)
-
-        def U0_fn(positions):
-            return euler_radial_contrast(positions, inner=(1.0, 0.0, 100.0), outer=(1.0, 0.0, 0.1), radius=0.1)
-        default_develop_time = 0.25           # the blast wave is half-way to the walls
-        workload_name = "3D Euler Sedov-like radial contrast, rectangular domain, Q1 (BASELINE.json configs[2])"
-    else:
-        from ryujin_amd.initial_states import sw_circular_dam_break
-        equation = capi.EQ_SHALLOW_WATER
-        resolution = args.size or 1824
-        coarse_resolution = max(8, resolution // args.coarse_factor)
-
-        def make_spec(n, n_ranks, r):
-            return offline.rectangle_2d(n * n_gpus, (-5.0, -5.0), (10.0 * n_gpus - 5.0, 5.0), ny=n, n_ranks=n_ranks,
-                                        rank=r)
-        U0_fn = sw_circular_dam_break
-        default_develop_time = 0.5            # the bore has travelled half-way to the walls
-        workload_name = "2D shallow-water circular dam break, Q1 (BASELINE.json configs[4])"
     n = resolution
     spec = make_spec(resolution, n_gpus, rank)
     off = offline.SyntheticOffline(spec)
@@ -616,13 +447,8 @@ def main():
         n_develop = 0
     elif develop_time > 0.0:
         t0 = time.perf_counter()
-        spec_c = make_spec(coarse_resolution, 1, 0)
-        off_c, U_c, n_rk = develop_on_coarse_mesh(spec_c, U0_fn, dirichlet_fn, equation, develop_time, device)
-        U0 = interpolate_from_lattice(spec_c, off_c.positions[: off_c.n_owned], U_c[: off_c.n_owned], off.positions)
-        coarse = {"resolution": coarse_resolution, "gridpoints": off_c.n_owned, "ssprk33_steps": n_rk,
-                  "seconds": round(time.perf_counter() - t0, 2)}
-        off_c.close()
-        t_start = develop_time
+        U0, t_start, coarse = developed_state(wl, off, develop_time, device)
+        coarse["seconds"] = round(time.perf_counter() - t0, 2)
     else:
         U0 = U0_fn(off.positions)
 

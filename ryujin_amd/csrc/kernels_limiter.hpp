@@ -866,7 +866,9 @@ namespace ryujin_hip
    * some pair is limited -- the terms of all other tiles are exact zeros, and P_ij is read for those tiles only,
    * once, for the sum and for the second limiter pass. Against U_i^low + sum_j l_ij lambda P_ij in column order
    * (the reference, :1107-1131, and the variant without V_i below) this is another rounding of the same sum:
-   * differences of a few ulp of lambda |P_ij|, orders inside the 1e-11 contract on the new state. */
+   * differences of a few ulp of lambda |P_ij|, orders inside the 1e-11 contract on the new state. Rows whose
+   * columns are ALL in limited tiles (the strongly limited ones) take the reference's form in the reference's
+   * order instead: see the branch below. */
   constexpr int kHoPlain = 0, kHoLight = 1, kHoHeavy = 2;
 
   template <typename E, int MAXW, int CP, bool SPLIT, int MODE>
@@ -975,7 +977,23 @@ namespace ryujin_hip
         return;
       }
       if constexpr (E::kLimitedUpdateFromV) {
-        /* U_i = V_i - sum over the limited tiles of (1 - l_ij) lambda P_ij: P_ij of those tiles only */
+        /* U_i = V_i - sum over the limited tiles of (1 - l_ij) lambda P_ij: P_ij of those tiles only.
+         * Per row, however: a row ALL of whose columns lie in limited tiles -- every strongly limited row: behind a
+         * shock, next to vacuum -- has all of its P_ij at hand and forms the reference's sum in the reference's order,
+         * U_i^low + sum_j l_ij lambda P_ij (hyperbolic_module.template.h:1107-1131): with l = 0 that IS U_i^low, and
+         * with small l its rounding error scales with |l lambda P_ij|, not with the unlimited flux |lambda P_ij| the
+         * V_i form cancels (which, where |lambda P| >> |U^low|, can leave the state outside its bounds by more than the
+         * limiter's relaxation). One accumulator serves both forms: it starts from U_i^low or V_i and adds
+         * w lambda P_ij with w = l or w = l - 1 = -(1 - l) (exact), the same bits as the subtraction. */
+        const uint32_t row_cols = row_active ? ((r.len >= 32u ? 0xffffffffu : ((1u << r.len) - 1u)) & ~1u) : 0u;
+        const bool ref_order = row_active && (needed & row_cols) == row_cols;
+        if (__any(ref_order)) {
+          double U_low[K];
+          load_state<K>(new_U, i, U_low);
+#pragma unroll
+          for (int q = 0; q < K; ++q)
+            U_i_new[q] = ref_order ? U_low[q] : U_i_new[q];
+        }
 #pragma unroll
         for (int c = 1; c < CP; ++c) {
 #pragma unroll
@@ -988,16 +1006,19 @@ namespace ryujin_hip
         for (int c = 1; c < MAXW; ++c) {
           if (!((needed >> c) & 1u))
             continue;
+          /* (columns beyond the row's length: l = 1 was set above, the V_i form adds an exact zero; the
+           * reference-order form must not add the padding entry) */
+          const double w = (row_active && (uint32_t)c < r.len) ? (ref_order ? l[c] : l[c] - 1.) : 0.;
           if (c < CP) {
 #pragma unroll
             for (int q = 0; q < K; ++q)
-              U_i_new[q] -= (1. - l[c]) * lambda * p[c < CP ? c : 0][q];
+              U_i_new[q] += w * lambda * p[c < CP ? c : 0][q];
           } else {
             double pt[K];
             load_entry<K>(pij, (uint64_t)r.base + c, r.lane, pt);
 #pragma unroll
             for (int q = 0; q < K; ++q)
-              U_i_new[q] -= (1. - l[c]) * lambda * pt[q];
+              U_i_new[q] += w * lambda * pt[q];
           }
         }
       } else {

@@ -108,7 +108,8 @@ def test_bench_interpolates_the_coarse_state_to_the_benchmark_mesh(mesh):
 
     def f(x):
         return 2.0 + x @ coeff.T
-    U_f = bench.interpolate_from_lattice(spec_c, off_c.positions[: off_c.n_owned], f(off_c.positions[: off_c.n_owned]),
+    from ryujin_amd.workloads import interpolate_from_lattice
+    U_f = interpolate_from_lattice(spec_c, off_c.positions[: off_c.n_owned], f(off_c.positions[: off_c.n_owned]),
                                          off_f.positions)
     assert U_f.shape == (off_f.n_relevant, 2) and np.isfinite(U_f).all()
     if mesh == "cylinder3d":

@@ -196,6 +196,36 @@ def test_conservation_closed_box(oracle):
         assert abs(after[comp] - before[comp]) <= 1e-13 * abs(before[comp])
 
 
+def test_near_vacuum_rows_keep_their_bounds_after_the_high_order_update(oracle):
+    """Steps 6/7 next to vacuum (a 2-D Le Blanc-like contrast: density 1 : 1e-6, pressure 1e10 : 1). Strongly limited
+    rows -- l_ij = 0 or tiny against an unlimited flux lambda P_ij that is orders larger than U_i^low -- must come out
+    as the reference forms them, U_i^low + sum_j l_ij lambda P_ij: inside their bounds up to the limiter's relaxation
+    (limiter.template.h:24-27), not displaced by the rounding of V_i - sum_j (1 - l_ij) lambda P_ij.
+    Compared array by array with the oracle, then the bounds are checked on the device's own new state."""
+    spec = offline.rectangle_2d(40, (0.0, 0.0), (1.0, 1.0))
+    off0 = offline.SyntheticOffline(spec)
+    U0 = euler_radial_contrast(off0.positions, inner=(1.0, 0.0, 1.0e-1), outer=(1.0e-6, 0.0, 1.0e-11), radius=0.3,
+                               center=(0.5, 0.5))
+    for n_warm in (3, 9):
+        off, mods = _both(spec, U0, oracle, n_warm=n_warm)
+        g, c = _compare_step(off, mods)
+        n = off.n_owned
+        assert g["status"] == 0 and (g["U"][:n, 0] > 0).all()
+        eps = np.finfo(np.float64).eps
+        relax = 1.0e4 * eps  # vacuum_state_relaxation_large * eps
+        b = g["bounds"].reshape(-1, 3)[:n]   # rho_min, rho_max, s_min per row, already relaxed by step 4
+        rho_min, rho_max, s_min = b[:, 0], b[:, 1], b[:, 2]
+        rho = g["U"][:n, 0]
+        e = g["U"][:n, 3] - 0.5 * (g["U"][:n, 1:3] ** 2).sum(1) / rho
+        assert (rho >= rho_min * (1.0 - relax)).all(), float((rho / rho_min).min() - 1.0)
+        assert (rho <= rho_max * (1.0 + relax)).all(), float((rho / rho_max).max() - 1.0)
+        assert (e > 0).all()
+        s = rho * e / rho ** (mods.params.gamma + 1.0)   # specific entropy rho e / rho^(gamma+1) = e rho^-gamma
+        assert (s >= s_min * (1.0 - 100.0 * relax)).all(), float((s / s_min).min() - 1.0)
+        # the strongly limited rows are there: pairs limited to (almost) nothing next to the vacuum
+        assert (np.minimum(c["lij"], 1.0) < 1e-3).mean() > 1e-3
+
+
 def test_mass_conservation_01_golden_on_gpu(golden_dir):
     """The reference's own integration baseline, reproduced by the HIP path."""
     from test_oracle_golden_integration import golden_mass_conservation, run_mass_conservation

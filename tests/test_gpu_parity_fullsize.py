@@ -20,6 +20,7 @@ import pytest
 from helpers_parity import compare_step
 from ryujin_amd import HyperbolicModule, capi, offline
 from ryujin_amd.initial_states import euler_radial_contrast, euler_uniform, sw_circular_dam_break
+from ryujin_amd.workloads import benchmark_workload, developed_state
 
 pytestmark = pytest.mark.gpu
 
@@ -68,6 +69,82 @@ def _fullsize(oracle, spec, initial, equation, n_develop_rk, with_dirichlet, lab
     return off, g, c, limited
 
 
+def _bench_state(oracle, key, label, fetch_pij, limited_slices, develop_time=None, warmup=12, **kw):
+    """One update on the state bench.py times for workload `key`, against the oracle. limited_slices = (lo, hi): the
+    bench lines' limited_slice_fraction for this workload (profiles/r04*_bench*.json, r05*)."""
+    wl = benchmark_workload(key, **kw)
+    off = offline.SyntheticOffline(wl.make_spec(wl.resolution, 1, 0))
+    U0, t_start, info = developed_state(wl, off, develop_time)
+    dirichlet = wl.dirichlet_fn(off.b_positions) if (wl.dirichlet_fn is not None and off.n_bdry) else None
+    p = oracle.default_params(wl.equation, off.dim)
+    p.cfl = 0.9
+    mg = HyperbolicModule(off, p, backend="hip")
+    state = mg.new_state_vector(U0)
+    temps = [mg.new_state_vector() for _ in range(3)]
+    del U0
+    # bench.py: develop_updates single updates (an SSPRK33 step is three), then --warmup more before the clock starts
+    n_rk = (wl.develop_updates + warmup) // 3
+    for q in range(n_rk):
+        mg.time_step("ssprk 33", state, temps, dirichlet if q == 0 else None)
+    assert mg.n_warnings() == 0
+    stats = mg.limiter_statistics()
+    U_start = state.download()
+    assert np.isfinite(U_start).all()
+    mc = HyperbolicModule(off, p, backend=oracle.backend())
+    mods = [(mg, state, temps[0]), (mc, mc.new_state_vector(U_start), mc.new_state_vector())]
+    del U_start
+    gc.collect()
+    g, c = compare_step(off, mods, dirichlet, oracle=oracle, params=p, label=label, fetch_pij=fetch_pij,
+                        keep_matrices=False)
+    n = off.n_owned
+    rho_g, rho_c = g["U"][:n, 0], c["U"][:n, 0]
+    assert (rho_g > 0).all() and (np.sign(rho_g) == np.sign(rho_c)).all()
+    if wl.equation == capi.EQ_EULER:
+        e_g = g["U"][:n, -1] - 0.5 * (g["U"][:n, 1:-1] ** 2).sum(1) / rho_g
+        assert (e_g > 0).all()
+    lo, hi = limited_slices
+    assert lo <= stats["limited_slice_fraction"] <= hi, (stats, limited_slices)
+    mc.close()
+    mg.close()
+    return off, g, c, stats
+
+
+def test_c2_bench_state(oracle):
+    """the headline: t = 2.0 of the Mach-3 step, 93 % of the slices limited, plain kernels (P_ij stored everywhere)"""
+    off, g, c, stats = _bench_state(oracle, "step2d", "bench_c2", True, (0.89, 0.97))
+    assert off.n_owned == 2498844
+    assert stats["pij_stored"] == "everywhere"
+
+
+def test_c2_bench_state_t1(oracle):
+    """bench.py --develop-time 1.0: 73 % limited, P_ij stored per slice + the repair launch"""
+    off, g, c, stats = _bench_state(oracle, "step2d", "bench_c2_t1", True, (0.68, 0.79), develop_time=1.0)
+    assert stats["pij_stored"] == "per slice"
+
+
+def test_c3_bench_state(oracle):
+    """bench.py --workload sedov3d: the blast wave half-way to the walls, 41-44 % limited, per slice + repair"""
+    avail = _available_gb()
+    if avail <= 75:
+        pytest.skip(f"BASELINE configs[2] at 200^3 cells needs ~60 GB of host memory for the oracle, "
+                    f"{avail:.0f} GB available")
+    off, g, c, stats = _bench_state(oracle, "sedov3d", "bench_c3", False, (0.36, 0.50))
+    assert off.n_owned == 201 ** 3
+    assert stats["pij_stored"] == "per slice"
+
+
+def test_c4_bench_state(oracle):
+    """bench.py --workload cylinder3d: the bow shock stands and has reflected off the walls, every slice limited"""
+    off, g, c, stats = _bench_state(oracle, "cylinder3d", "bench_c4", False, (0.95, 1.0))
+    assert off.n_owned > 4_000_000
+
+
+def test_c5_bench_state(oracle):
+    """bench.py --workload sw2d: the bore half-way to the walls"""
+    off, g, c, stats = _bench_state(oracle, "sw2d", "bench_c5", True, (0.60, 0.95))
+    assert off.n_owned == 1825 ** 2
+
+
 def test_fullsize_c2_step_2d(oracle):
     """BASELINE configs[1], the bench line's mesh: 2 498 844 gridpoints = 9 995 376 DoFs."""
     def initial(pos):
@@ -77,43 +154,6 @@ def test_fullsize_c2_step_2d(oracle):
                                    "fullsize_c2", True)
     assert off.n_owned == 2498844
     assert limited > 1e-3, limited
-
-
-@pytest.mark.parametrize("n", [200])
-def test_fullsize_c3_radial_contrast_3d(oracle, n):
-    """BASELINE configs[2]: 200^3 cells = 8 120 601 gridpoints = 40.6 M DoFs (needs ~60 GB of host memory for
-    oracle + fetched arrays). The size is part of the test id; a box with less memory SKIPS with the reason (it
-    never runs a smaller mesh under the name of the BASELINE size)."""
-    avail = _available_gb()
-    if avail <= 75:
-        pytest.skip(f"BASELINE configs[2] at {n}^3 cells needs ~60 GB of host memory for the oracle, "
-                    f"{avail:.0f} GB available")
-
-    def initial(pos):
-        return euler_radial_contrast(pos, inner=(1.0, 0.0, 100.0), outer=(1.0, 0.0, 0.1), radius=0.1)
-    off, g, c, limited = _fullsize(oracle, offline.box_3d(n), initial, capi.EQ_EULER, 20, False, "fullsize_c3",
-                                   False)
-    assert off.n_owned == (n + 1) ** 3
-    assert limited > 1e-5, limited
-
-
-def test_fullsize_c4_cylinder_share_3d(oracle):
-    """BASELINE configs[3], one GPU's share: h = 1/96, 1.25 units of channel, 4.18 M gridpoints; staircase
-    cylinder with slip boundary, Dirichlet inflow, do-nothing outflow, slip walls, 3-D coupling boundary pairs."""
-    def initial(pos):
-        return euler_uniform(pos)
-    off, g, c, limited = _fullsize(oracle, offline.cylinder_channel_3d(96, length_units=1.25), initial,
-                                   capi.EQ_EULER, 30, True, "fullsize_c4", False)
-    assert off.n_owned > 4_000_000
-    assert limited > 1e-5, limited
-
-
-def test_fullsize_c5_shallow_water_2d(oracle):
-    """BASELINE configs[4]: 1824^2 cells = 3 330 625 gridpoints = 10.0 M DoFs, circular dam break."""
-    off, g, c, limited = _fullsize(oracle, offline.rectangle_2d(1824, (-5.0, -5.0), (5.0, 5.0)),
-                                   sw_circular_dam_break, capi.EQ_SHALLOW_WATER, 60, False, "fullsize_c5", True)
-    assert off.n_owned == 1825 ** 2
-    assert limited > 1e-4, limited
 
 
 def test_miniature_cylinder_against_the_oracle(oracle):
