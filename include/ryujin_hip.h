@@ -174,6 +174,10 @@ typedef struct ryujin_hip_params {
    * between the sweeps (P_ij is stored in full then); the l_ij themselves are the same in both control flows.
    * The other Descriptions run their production flow with the plain kernels (no check kernels yet). */
   int debug_expensive_bounds_check;
+  /* The tile map: column indices and transposed positions of structured 64-row tiles come from a 16-byte descriptor
+   * per tile instead of the explicit index arrays (ryujin_amd/csrc/host_layout.hpp, TileDesc). 0: on (default);
+   * < 0: off -- every sweep reads the explicit arrays, as for an unstructured mesh. Results are identical. */
+  int debug_tile_map;
 } ryujin_hip_params;
 
 /* ---- offline data (input contract) ------------------------------------- */

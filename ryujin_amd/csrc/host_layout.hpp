@@ -99,7 +99,25 @@ namespace ryujin_hip
   };
 
 
+  /* TILE MAP. A tile is one column of one SELL-64 slice: 64 matrix entries, one per row of the slice. On a
+   * structured patch of a mesh the 64 rows of a slice see their c-th neighbour at the SAME index offset, j = i + delta,
+   * and the transposed entries (j, i) then sit at consecutive positions as well -- in (at most) two runs, because the
+   * rows i + delta straddle a slice boundary unless delta is a multiple of 64. Such a tile is described by 16 bytes
+   * instead of the 64 column indices and 64 transposed positions (512 bytes) the sweeps would otherwise stream:
+   *   j(lane)            = row + delta
+   *   transposed(lane)   = (lane < 64 - (delta & 63) ? ta : tb) + lane
+   * Tiles that do not fit (boundary rows, short rows, unstructured patches) carry delta = kTileIrregular and the
+   * sweeps read the explicit arrays for them, which always exist. One wave-uniform 16-byte load per tile. */
+  struct TileDesc {
+    int32_t delta;
+    uint32_t ta, tb;
+    uint32_t pad;
+  };
+  constexpr int32_t kTileIrregular = INT32_MIN;
+
   struct SellLayout {
+    std::vector<TileDesc> tiles;     /* [slice_off[n_slices]] */
+    uint64_t n_regular_tiles = 0;
     uint32_t n_owned = 0, n_relevant = 0, n_slices = 0, rows_padded = 0;
     uint32_t max_row_len = 0;
     std::vector<uint32_t> slice_off; /* [n_slices+1], in units of 64-entry columns */
@@ -251,6 +269,47 @@ namespace ryujin_hip
           }
         }
       });
+    }
+
+    /* tile map (see TileDesc): call after build() */
+    void build_tiles()
+    {
+      tiles.assign(slice_off[n_slices], TileDesc{kTileIrregular, 0u, 0u, 0u});
+      std::vector<uint64_t> regular(n_slices, 0);
+      parallel_chunks(n_slices, [&](const uint64_t s0, const uint64_t s1) {
+        for (uint32_t s = (uint32_t)s0; s < (uint32_t)s1; ++s) {
+          const uint32_t width = slice_off[s + 1] - slice_off[s];
+          if ((uint64_t)(s + 1) * kWave > n_owned)
+            continue; /* a slice with padding rows */
+          uint32_t min_len = 0xffffffffu;
+          for (uint32_t l = 0; l < kWave; ++l)
+            min_len = std::min<uint32_t>(min_len, row_len[(size_t)s * kWave + l]);
+          for (uint32_t c = 0; c < std::min(width, min_len); ++c) {
+            const uint64_t p0 = ((uint64_t)slice_off[s] + c) * kWave;
+            const int64_t delta = (int64_t)cols[p0] - (int64_t)((uint64_t)s * kWave);
+            if (delta <= (int64_t)INT32_MIN || delta > (int64_t)INT32_MAX)
+              continue;
+            bool ok = true;
+            for (uint32_t l = 1; l < kWave && ok; ++l)
+              ok = (int64_t)cols[p0 + l] - (int64_t)((uint64_t)s * kWave + l) == delta;
+            if (!ok)
+              continue;
+            const uint32_t dm = (uint32_t)((int32_t)delta & 63);
+            const uint32_t split = kWave - dm; /* lanes [0, split): run a, lanes [split, 64): run b */
+            const uint32_t ta = idx_t[p0];
+            const uint32_t tb = dm != 0 ? idx_t[p0 + split] - split : ta;
+            for (uint32_t l = 0; l < kWave && ok; ++l)
+              ok = idx_t[p0 + l] == (l < split ? ta : tb) + l;
+            if (!ok)
+              continue;
+            tiles[(uint64_t)slice_off[s] + c] = TileDesc{(int32_t)delta, ta, tb, 0u};
+            ++regular[s];
+          }
+        }
+      });
+      n_regular_tiles = 0;
+      for (const uint64_t n : regular)
+        n_regular_tiles += n;
     }
 
     /* reference layout -> device layout (padding = 0) */

@@ -57,6 +57,7 @@ namespace ryujin_hip
     const uint16_t *row_len;    /* [n_slices*64] */
     const uint32_t *cols;      /* [nnz_total] */
     const uint32_t *idx_t;     /* [nnz_total] */
+    const TileDesc *tiles;     /* [slice_off[n_slices]] the tile map (host_layout.hpp), or NULL: explicit arrays only */
     const double *cij;         /* paired layout, DIM comps */
     const double *mij;
     const double *mi, *mi_inv;
@@ -319,12 +320,73 @@ namespace ryujin_hip
     bool valid;
   };
 
+  /* ---- the tile map (TileDesc, host_layout.hpp): column index and transposed position of the entry of row `row`
+   * (lane `lane` of its slice) in the tile `colbase`, from the tile's 16-byte descriptor where the tile is regular,
+   * from the explicit arrays where it is not. The descriptor load has a wave-uniform address.
+   * WHERE IT IS USED is decided by measurement (profiles/r05c_ab_tile_2d.log, r05c_ab_3d.log): the bandwidth-bound
+   * sweeps of the 1-D / 2-D stencils (steps 3, 5, 6, 7: -10 %, -4.9 %, -3.8 %, -7.0 % on C2). The sweeps that are
+   * bound by FP64 issue lose on the handful of extra instructions per column -- steps 2 and 4 in 2-D (+3 %, 0),
+   * every sweep in 3-D (step 2 +5 %, step 6 +8 %) -- and keep streaming the explicit indices: USE = false compiles
+   * the map out. ---- */
+  template <int DIM>
+  constexpr bool tile_map_pays()
+  {
+    return DIM <= 2;
+  }
+  inline bool tile_map_pays(const int dim) { return dim <= 2; } /* host: whether create() builds the map at all */
+
+  template <bool USE = true>
+  RYUJIN_DEV TileDesc tile_desc(const DeviceMesh &M, const uint64_t colbase)
+  {
+    TileDesc t;
+    t.delta = kTileIrregular;
+    t.ta = t.tb = t.pad = 0;
+    if constexpr (USE) {
+      if (M.tiles != nullptr) {
+        const int4 raw = *reinterpret_cast<const int4 *>(M.tiles + colbase);
+        t.delta = __builtin_amdgcn_readfirstlane(raw.x);
+        t.ta = (uint32_t)__builtin_amdgcn_readfirstlane(raw.y);
+        t.tb = (uint32_t)__builtin_amdgcn_readfirstlane(raw.z);
+      }
+    }
+    return t;
+  }
+
+  /* (the column index needs the first word of the descriptor only) */
+  template <bool USE = true>
+  RYUJIN_DEV uint32_t tile_column(const DeviceMesh &M, const uint64_t colbase, const uint32_t row, const uint32_t lane)
+  {
+    if constexpr (USE) {
+      if (M.tiles != nullptr) {
+        const int32_t delta = __builtin_amdgcn_readfirstlane(M.tiles[colbase].delta);
+        if (delta != kTileIrregular) /* wave-uniform */
+          return (uint32_t)((int32_t)row + delta);
+      }
+    }
+    return ld_stream(M.cols + (colbase * 64 + lane));
+  }
+
+  RYUJIN_DEV uint32_t tile_transposed(const DeviceMesh &M, const TileDesc &t, const uint64_t colbase,
+                                      const uint32_t lane)
+  {
+    if (t.delta != kTileIrregular) /* wave-uniform */
+      return (lane < 64u - ((uint32_t)t.delta & 63u) ? t.ta : t.tb) + lane;
+    return M.idx_t[colbase * 64 + lane];
+  }
+
+  template <bool USE = true>
+  RYUJIN_DEV uint32_t tile_transposed(const DeviceMesh &M, const uint64_t colbase, const uint32_t lane)
+  {
+    return tile_transposed(M, tile_desc<USE>(M, colbase), colbase, lane);
+  }
+
   RYUJIN_DEV RowCtx row_context(const DeviceMesh &M)
   {
     RowCtx r;
     r.lane = threadIdx.x & 63;
     const uint32_t block = blockIdx.x;
-    r.slice = M.slice_begin + block * kWavesPerBlock + (threadIdx.x >> 6);
+    /* slice, base and width are the same in all lanes of the wave: say so (scalar registers, scalar loop control) */
+    r.slice = __builtin_amdgcn_readfirstlane(M.slice_begin + block * kWavesPerBlock + (threadIdx.x >> 6));
     r.valid = r.slice < M.slice_end;
     if (!r.valid) {
       r.row = r.len = r.base = r.width = 0;
@@ -332,8 +394,8 @@ namespace ryujin_hip
     }
     r.row = r.slice * 64 + r.lane;
     r.len = M.row_len[r.row];
-    r.base = M.slice_off[r.slice];
-    r.width = M.slice_off[r.slice + 1] - r.base;
+    r.base = __builtin_amdgcn_readfirstlane(M.slice_off[r.slice]);
+    r.width = __builtin_amdgcn_readfirstlane(M.slice_off[r.slice + 1]) - r.base;
     return r;
   }
 
@@ -857,14 +919,14 @@ namespace ryujin_hip
       return;
     const bool row_active = r.len > 1;
     const uint32_t mask = row_active ? lower_mask[r.row] : 0u;
-    const uint32_t *__restrict__ idx_t = M.idx_t;
     double d[MAXW];
 #pragma unroll
     for (int c = 1; c < MAXW; ++c) {
       d[c] = 0.;
       if ((uint32_t)c < r.width) {
         const uint32_t pos = (r.base + c) * 64 + r.lane;
-        const uint32_t src = ((mask >> c) & 1u) ? idx_t[pos] : pos;
+        const TileDesc t = tile_desc<(MAXW <= 9)>(M, (uint64_t)r.base + c);
+        const uint32_t src = ((mask >> c) & 1u) ? tile_transposed(M, t, (uint64_t)r.base + c, r.lane) : pos;
         d[c] = dij[src];
       }
     }

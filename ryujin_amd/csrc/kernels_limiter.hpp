@@ -242,8 +242,8 @@ namespace ryujin_hip
     unsigned long long undecided_mask = 0;
 
     /* software pipeline: loads of column c+1 are in flight while column c is limited */
-    uint32_t j_n = r.width > 1 ? ld_stream(cols + (((uint64_t)r.base + 1) * 64 + r.lane)) : i;
-    uint32_t j_nn = r.width > 2 ? ld_stream(cols + (((uint64_t)r.base + 2) * 64 + r.lane)) : i;
+    uint32_t j_n = r.width > 1 ? tile_column<tile_map_pays<E::DIMENSION>()>(M, (uint64_t)r.base + 1, r.row, r.lane) : i;
+    uint32_t j_nn = r.width > 2 ? tile_column<tile_map_pays<E::DIMENSION>()>(M, (uint64_t)r.base + 2, r.row, r.lane) : i;
     double P_n[K], F_n[K];
     double mjinv_n = 0., mij_n = 0.;
     if (r.width > 1) {
@@ -276,7 +276,7 @@ namespace ryujin_hip
         load_state<K>(r_in, j_n, F_n);
         mjinv_n = node_j[j_n];
         mij_n = ld_stream(mij + ((colbase + 1) * 64 + r.lane));
-        j_nn = (c + 2 < r.width) ? ld_stream(cols + ((colbase + 2) * 64 + r.lane)) : i;
+        j_nn = (c + 2 < r.width) ? tile_column<tile_map_pays<E::DIMENSION>()>(M, colbase + 2, r.row, r.lane) : i;
       }
       if (!active)
         continue;
@@ -380,8 +380,8 @@ namespace ryujin_hip
      * 1 + y, 1 + y + NY, ... -- a chain NY times shorter, the per-row data read NY times from L2 */
     const uint32_t c0 = 1 + (NY > 1 ? blockIdx.y : 0);
     /* software pipeline: loads of the next column are in flight while column c is processed */
-    uint32_t j_n = r.width > c0 ? ld_stream(cols + (((uint64_t)r.base + c0) * 64 + r.lane)) : i;
-    uint32_t j_nn = r.width > c0 + NY ? ld_stream(cols + (((uint64_t)r.base + c0 + NY) * 64 + r.lane)) : i;
+    uint32_t j_n = r.width > c0 ? tile_column<tile_map_pays<E::DIMENSION>()>(M, (uint64_t)r.base + c0, r.row, r.lane) : i;
+    uint32_t j_nn = r.width > c0 + NY ? tile_column<tile_map_pays<E::DIMENSION>()>(M, (uint64_t)r.base + c0 + NY, r.row, r.lane) : i;
     double c_n[DIM], U_n[K], F_n[K];
     double mjinv_n = 0., mij_n = 0., d_n = 0., alpha_n = 0.;
     if (r.width > c0) {
@@ -417,7 +417,7 @@ namespace ryujin_hip
         load_state<K>(r_in, j_n, F_n);
         mjinv_n = mi_inv[j_n];
         alpha_n = alpha[j_n];
-        j_nn = (c + 2 * NY < r.width) ? ld_stream(cols + ((colbase + 2 * NY) * 64 + r.lane)) : i;
+        j_nn = (c + 2 * NY < r.width) ? tile_column<tile_map_pays<E::DIMENSION>()>(M, colbase + 2 * NY, r.row, r.lane) : i;
       }
       if (!active)
         continue;
@@ -519,6 +519,31 @@ namespace ryujin_hip
     for (int q = 0; q < K; ++q) {
       double v = dd * (p.U_j[q] - row.U_i[q]);
       v += b_ij * p.F_j[q] - b_ji * row.F_i[q];
+      P_ij[q] = v * row.factor;
+    }
+  }
+
+  /* The same with the row's F_i (and, PARK_U, U_i) parked in LDS, [component][lane] (conflict free): the same
+   * operations on the same operands in the same order -- bit for bit pij_stage0() -- with 2 K (4 K) registers fewer
+   * held across the column loop. Step 5 in 3-D: what separates the sweep from 3 waves per SIMD. */
+  template <int K, bool PARK_U>
+  RYUJIN_DEV void pij_stage0_parked(const RowData<K> &row, const double *parked_, const uint32_t lane,
+                                    const PairData<K> &p, double (&P_ij)[K])
+  {
+    /* (the loads are loop invariant: an opaque lane offset keeps the compiler from hoisting them back into
+     * registers) */
+    uint32_t off = lane;
+    asm volatile("" : "+v"(off));
+    const double *parked = parked_ + off;
+    const double d_ijH = p.d_ij * ((row.alpha_i + p.alpha_j) * .5);
+    const double dd = d_ijH - p.d_ij;
+    const double b_ij = 0. - p.m_ij * p.m_j_inv;
+    const double b_ji = 0. - p.m_ij * row.m_i_inv;
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+      const double U_iq = PARK_U ? parked[(K + q) * 64] : row.U_i[q];
+      double v = dd * (p.U_j[q] - U_iq);
+      v += b_ij * p.F_j[q] - b_ji * parked[q * 64];
       P_ij[q] = v * row.factor;
     }
   }
@@ -659,7 +684,7 @@ namespace ryujin_hip
           const uint64_t pos = colbase * 64 + r.lane;
           const bool active = row_active && c < r.len;
           const double l_a = lij[pos];
-          const double l_b = lij[idx_t[pos]];
+          const double l_b = lij[tile_transposed<tile_map_pays<E::DIMENSION>()>(M, (uint64_t)r.base + c, r.lane)];
           const double old_l_ij = lmin(l_a, l_b);
           if (!__any(active && !(old_l_ij == 1.))) {
             if (active)
@@ -776,7 +801,7 @@ namespace ryujin_hip
         if ((uint32_t)c < r.width) {
           const uint32_t pos = (uint32_t)(((uint64_t)r.base + c) * 64 + r.lane);
           const double l_a = lij[pos];
-          const double l_b = lij[idx_t[pos]];
+          const double l_b = lij[tile_transposed<tile_map_pays<E::DIMENSION>()>(M, (uint64_t)r.base + c, r.lane)];
           l[c] = (row_active && (uint32_t)c < r.len) ? lmin(l_a, l_b) : 0.;
         }
       }
@@ -895,7 +920,7 @@ namespace ryujin_hip
         if ((uint32_t)c < r.width) {
           const uint32_t pos = (uint32_t)(((uint64_t)r.base + c) * 64 + r.lane);
           const double l_a = lij[pos];
-          const double l_b = lij[idx_t[pos]];
+          const double l_b = lij[tile_transposed<tile_map_pays<E::DIMENSION>()>(M, (uint64_t)r.base + c, r.lane)];
           /* (NaN counts as limited: !(l == 1), not l != 1 through fmin, which drops a NaN operand) */
           limited = limited || (row_active && (uint32_t)c < r.len && !(l_a == 1. && l_b == 1.));
         }
@@ -944,7 +969,7 @@ namespace ryujin_hip
         if ((uint32_t)c < r.width) {
           const uint32_t pos = (uint32_t)(((uint64_t)r.base + c) * 64 + r.lane);
           const double l_a = lij[pos];
-          const double l_b = lij[idx_t[pos]];
+          const double l_b = lij[tile_transposed<tile_map_pays<E::DIMENSION>()>(M, (uint64_t)r.base + c, r.lane)];
           const bool lane_on = row_active && (uint32_t)c < r.len;
           const bool lim = lane_on && !(l_a == 1. && l_b == 1.);
           l[c] = lane_on ? lmin(l_a, l_b) : 1.;
@@ -1066,7 +1091,7 @@ namespace ryujin_hip
           const uint64_t colbase = (uint64_t)r.base + c;
           const uint32_t pos = (uint32_t)(colbase * 64 + r.lane);
           const double l_a = lij[pos];
-          const double l_b = lij[idx_t[pos]];
+          const double l_b = lij[tile_transposed<tile_map_pays<E::DIMENSION>()>(M, (uint64_t)r.base + c, r.lane)];
           l[c] = lmin(l_a, l_b);
           if (c < CP)
             load_entry<K>(pij, colbase, r.lane, p[c < CP ? c : 0]);

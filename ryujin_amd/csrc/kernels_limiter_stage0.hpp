@@ -51,8 +51,13 @@ namespace ryujin_hip
 #ifndef RYUJIN_OCC_LIJ0
 #define RYUJIN_OCC_LIJ0 3 /* waves per SIMD asked of the register allocator */
 #endif
+#ifndef RYUJIN_LIJ0_PARK_3D
+#define RYUJIN_LIJ0_PARK_3D 2 /* step 5 in 3-D: 1 = the row's F_i in LDS, 2 = F_i and U_i, 0 = all in registers */
+#endif
 #ifndef RYUJIN_OCC_LIJ0_3D
-#define RYUJIN_OCC_LIJ0_3D 2 /* A/B on MI355X (4.2 M gridpoints): 2.15 ms at 3 waves (28 B/lane of scratch), 1.85 at 2 */
+#define RYUJIN_OCC_LIJ0_3D 3 /* rounds 1-4: 2 waves (at 3 the kernel spilled 28-56 B per lane and lost). Round 5: slice context in scalar
+                                 registers + F_i / U_i parked in LDS leave 12 B per lane outside the column loop: 2.22 -> 1.97 ms on the
+                                 C4 share (profiles/r05c_ab_3d.log) */
 #endif
 
 #ifndef RYUJIN_OCC_LIJ0_AEOS
@@ -89,7 +94,6 @@ namespace ryujin_hip
       return;
     const bool row_active = r.len > 1;
     const uint32_t i = row_active ? r.row : (r.row < M.n_owned ? r.row : M.n_owned - 1);
-    const uint32_t *__restrict__ cols = M.cols;
 
     const size_t stride = M.bounds_stride;
     double bnd[NB];
@@ -104,6 +108,18 @@ namespace ryujin_hip
     RowData<K> row;
     load_state<K>(old_U, i, row.U_i);
     load_state<K>(r_in, i, row.F_i);
+    /* 3-D: F_i (and U_i) of the row live in LDS across the column loop (pij_stage0_parked) */
+    constexpr int kPark = (E::DIMENSION == 3 && NY == 1) ? RYUJIN_LIJ0_PARK_3D : 0; /* 0 none, 1 F_i, 2 F_i and U_i */
+    __shared__ double parked_rows[kPark != 0 ? kWavesPerBlock * 2 * K * 64 : 1];
+    double *const parked = parked_rows + (kPark != 0 ? (threadIdx.x >> 6) * 2 * K * 64 : 0);
+    if constexpr (kPark != 0) {
+#pragma unroll
+      for (int q = 0; q < K; ++q) {
+        parked[q * 64 + r.lane] = row.F_i[q];
+        if (kPark == 2)
+          parked[(K + q) * 64 + r.lane] = row.U_i[q];
+      }
+    }
     row.alpha_i = alpha[i];
     row.m_i_inv = M.mi_inv[i];
     row.factor = scalars->tau * row.m_i_inv * (double)(r.len - 1);
@@ -119,8 +135,10 @@ namespace ryujin_hip
       storing = predict_override < 0 || (predict_override == 0 && W.unlimited[r.slice] == 0);
 
     /* software pipeline: the loads of the next column are in flight while column c is limited */
-    uint32_t j_n = r.width > c0 ? ld_stream(cols + (((uint64_t)r.base + c0) * 64 + r.lane)) : i;
-    uint32_t j_nn = r.width > c0 + NY ? ld_stream(cols + (((uint64_t)r.base + c0 + NY) * 64 + r.lane)) : i;
+    /* (the column index of a structured tile is row + delta of the tile's descriptor, kernels_euler.hpp: no index
+     * stream to prefetch two columns ahead, as rounds 1 - 4 did; an unstructured tile reads its indices with the
+     * loads of the next column, behind the limiter of the current one) */
+    uint32_t j_n = r.width > c0 ? tile_column<tile_map_pays<E::DIMENSION>()>(M, (uint64_t)r.base + c0, i, r.lane) : i;
     PairData<K> next;
     if (r.width > c0)
       load_pair<K>(M, old_U, r_in, alpha, dij, ((uint64_t)r.base + c0) * 64 + r.lane, j_n, next);
@@ -130,11 +148,13 @@ namespace ryujin_hip
       const uint64_t pos = colbase * 64 + r.lane;
       const bool active = row_active && c < r.len;
       double P_ij[K];
-      pij_stage0<K>(row, next, P_ij);
+      if constexpr (kPark != 0)
+        pij_stage0_parked<K, kPark == 2>(row, parked, r.lane, next, P_ij);
+      else
+        pij_stage0<K>(row, next, P_ij);
       if (c + NY < r.width) {
-        j_n = j_nn;
+        j_n = tile_column<tile_map_pays<E::DIMENSION>()>(M, colbase + NY, i, r.lane);
         load_pair<K>(M, old_U, r_in, alpha, dij, (colbase + NY) * 64 + r.lane, j_n, next);
-        j_nn = (c + 2 * NY < r.width) ? ld_stream(cols + ((colbase + 2 * NY) * 64 + r.lane)) : i;
       }
       /* a slice that stores already: as soon as P_ij is formed (the store overlaps the limiter) */
       const bool stored_early = storing;

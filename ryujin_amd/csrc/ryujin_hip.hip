@@ -389,6 +389,7 @@ struct ryujin_hip_ctx {
 
   /* mesh arrays */
   DeviceBuffer<uint32_t> d_slice_off, d_cols, d_idx_t, d_lower_mask;
+  DeviceBuffer<TileDesc> d_tiles; /* the tile map (host_layout.hpp); empty with debug_tile_map < 0 */
   DeviceBuffer<uint16_t> d_row_len;
   DeviceBuffer<double> d_cij, d_mij, d_mi, d_mi_inv;
   bool dg = false; /* discontinuous ansatz */
@@ -671,6 +672,10 @@ void ryujin_hip_ctx::create(const ryujin_hip_offline &o, const ryujin_hip_params
   d_row_len.upload(L.row_len);
   d_cols.upload(L.cols);
   d_idx_t.upload(L.idx_t);
+  if (p.debug_tile_map >= 0 && tile_map_pays(dim)) {
+    L.build_tiles();
+    d_tiles.upload(L.tiles);
+  }
   {
     /* bit c of lower_mask[row] <=> column c of the row lies below the diagonal (cols < row) */
     std::vector<uint32_t> lower_mask(L.rows_padded, 0u);
@@ -756,6 +761,7 @@ void ryujin_hip_ctx::create(const ryujin_hip_offline &o, const ryujin_hip_params
   mesh.row_len = d_row_len.ptr;
   mesh.cols = d_cols.ptr;
   mesh.idx_t = d_idx_t.ptr;
+  mesh.tiles = d_tiles.n != 0 ? d_tiles.ptr : nullptr;
   mesh.cij = d_cij.ptr;
   mesh.mij = d_mij.ptr;
   mesh.incidence = dg ? d_incidence.ptr : nullptr;
@@ -2179,6 +2185,7 @@ void ryujin_hip_default_params(ryujin_hip_params *p, int equation, int dim)
   p->debug_no_small_mesh_split = 0;
   p->debug_pij_storage = 0;
   p->debug_expensive_bounds_check = 0;
+  p->debug_tile_map = 0;
 }
 
 int ryujin_hip_comm_unique_id(char id[RYUJIN_HIP_UNIQUE_ID_BYTES])

@@ -15,7 +15,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from bench import Ssprk33Stages  # noqa: E402
+from ryujin_amd.workloads import Ssprk33Stages  # noqa: E402
 from ryujin_amd import HyperbolicModule, capi, offline  # noqa: E402
 from ryujin_amd.initial_states import euler_uniform  # noqa: E402
 

@@ -4,11 +4,11 @@ set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$R"
 mkdir -p gpurun_out
-rm -f gpurun_out/parity_stats.jsonl
-timeout 1500 python -m pytest tests -q -m gpu -x --durations=15 2>&1 | tail -45 > gpurun_out/r05b_pytest_gpu.txt
-tail -45 gpurun_out/r05b_pytest_gpu.txt
-timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r05b_bench.json 2> gpurun_out/r05b_bench.err
-python -c "
-import json; d=json.loads(open('gpurun_out/r05b_bench.json').read().strip().splitlines()[-1]); r=d['roofline']
-print(d['value'], d['ms_per_step'], r['frac'], d['cpu_baseline']['value'], d['sweep_ms'])"
-tail -3 gpurun_out/r05b_bench.err
+echo "== correctness subset"
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_parity_fullsize.py -q -m gpu -x -k "3d or cylinder or radial or c4 or c3 or c2_bench or tetrahedra or rows_wider or partition" 2>&1 | tail -5
+for w in step2d cylinder3d sedov3d; do
+  timeout 600 python bench.py --workload $w --steps 18 --warmup 6 --no-cpu-baseline --binding device > gpurun_out/r05d_bench_$w.json 2> gpurun_out/r05d_bench_$w.err
+  python -c "
+import json,sys; d=json.loads(open('gpurun_out/r05d_bench_$w.json').read().strip().splitlines()[-1]); r=d['roofline']
+print('$w', round(d['value'],1), round(d['ms_per_step'],4), r['kernel'], round(r['frac'],3), d['limiter']['limited_slice_fraction'], d['sweep_ms'])"
+done
