@@ -142,8 +142,18 @@ namespace ryujin_hip
 #ifndef RYUJIN_OCC_DIJ
 #define RYUJIN_OCC_DIJ 2
 #endif
+#ifndef RYUJIN_LOW_PARK
+#define RYUJIN_LOW_PARK 1 /* step 4 (1-D, 2-D, no stage vectors): f(U_i) in LDS across the column loop */
+#endif
 #ifndef RYUJIN_OCC_LOW
-#define RYUJIN_OCC_LOW 2
+#define RYUJIN_OCC_LOW 3 /* C2, profiles/r05e_ab_low_order_2d.log: 0.2496 ms at 2 waves per SIMD, 0.2751 at 3 (36 B per lane of
+                            scratch), 0.2408 at 3 with f(U_i) parked in LDS (two 8-byte spills per column left) */
+#endif
+#ifndef RYUJIN_OCC_LOW_AEOS
+#define RYUJIN_OCC_LOW_AEOS 2 /* k_low_order_aeos, kernels_euler_aeos.hpp */
+#endif
+#ifndef RYUJIN_OCC_LOW_SW
+#define RYUJIN_OCC_LOW_SW 2 /* k_low_order_sw, kernels_shallow_water.hpp */
 #endif
 #ifndef RYUJIN_OCC_LOW_3D_ALL
 #define RYUJIN_OCC_LOW_3D_ALL 0
@@ -994,7 +1004,7 @@ namespace ryujin_hip
    * operation sequence, hence bit-identical -- by k_pij_lij_recompute (saves the 8kS B/row store of
    * this sweep and the 8kS B/row load of step 5 for 8dS+8S B/row of c_ij, d_ij loads there). */
   template <int DIM, bool HAS_STAGES, bool STORE_P = true, bool DG = false>
-  __global__ void __launch_bounds__(kBlock, (DIM == 3 && (HAS_STAGES || RYUJIN_OCC_LOW_3D_ALL) && RYUJIN_OCC_LOW_3D_STAGES) ? 1 : RYUJIN_OCC_LOW)
+  __global__ void __launch_bounds__(kBlock, (DIM == 3 && (HAS_STAGES || RYUJIN_OCC_LOW_3D_ALL) && RYUJIN_OCC_LOW_3D_STAGES) ? 1 : ((DIM == 3 || HAS_STAGES || DG) ? 2 : RYUJIN_OCC_LOW))
   k_low_order(const EulerParams P, const DeviceMesh M, DeviceScalars *scalars,
               const double weight, const StageArgs<DIM> S, const double *__restrict__ U,
               const double *__restrict__ prec, const double *__restrict__ alpha,
@@ -1022,6 +1032,19 @@ namespace ryujin_hip
     const double m_i_inv = M.mi_inv[i];
     double f_i[K][DIM];
     E::flux(P, U_i, f_i);
+    /* RYUJIN_LOW_PARK: the row's flux f(U_i) -- K x DIM doubles that are only read, once per column -- lives in LDS
+     * across the column loop, [entry][lane] (conflict free): 16 registers (2-D) that separate the sweep from 3 waves
+     * per SIMD. The same operands into the same operations: the same bits. */
+    constexpr bool kParkFlux = RYUJIN_LOW_PARK && !HAS_STAGES && !DG && DIM >= 2;
+    __shared__ double parked_flux[kParkFlux ? kWavesPerBlock * K * DIM * 64 : 1];
+    double *const parked = parked_flux + (kParkFlux ? (threadIdx.x >> 6) * K * DIM * 64 : 0);
+    if constexpr (kParkFlux) {
+#pragma unroll
+      for (int q = 0; q < K; ++q)
+#pragma unroll
+        for (int d = 0; d < DIM; ++d)
+          parked[(q * DIM + d) * 64 + r.lane] = f_i[q][d];
+    }
 
     /* Limiter::reset (limiter.h:255-276) */
     double rho_min = DBL_MAX, rho_max = 0., s_min = DBL_MAX;
@@ -1080,7 +1103,23 @@ namespace ryujin_hip
       double f_j[K][DIM];
       E::flux(P, U_j, f_j);
       double flux_ij[K];
-      E::flux_divergence(f_i, f_j, c_ij, flux_ij);
+      if constexpr (kParkFlux) {
+        /* flux_divergence() with f_i read from LDS (an opaque lane offset keeps the loop-invariant loads from being
+         * hoisted back into registers) */
+        uint32_t off = r.lane;
+        asm volatile("" : "+v"(off));
+        const double *const f_i_parked = parked + off;
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+          double s = (f_i_parked[(q * DIM + 0) * 64] + f_j[q][0]) * c_ij[0];
+#pragma unroll
+          for (int d = 1; d < DIM; ++d)
+            s += (f_i_parked[(q * DIM + d) * 64] + f_j[q][d]) * c_ij[d];
+          flux_ij[q] = -s;
+        }
+      } else {
+        E::flux_divergence(f_i, f_j, c_ij, flux_ij);
+      }
 
       double P_ij[K];
 #pragma unroll

@@ -218,7 +218,7 @@ namespace ryujin_hip
   /* step 4 (:597-884) with Limiter::{reset,accumulate,bounds} of euler_aeos/limiter.h:258-410 */
   /* STORE_P = false (stages == 0): P_ij is formed in step 5 (kernels_limiter_stage0.hpp), nothing is stored here */
   template <int DIM, bool HAS_STAGES, bool STORE_P = true>
-  __global__ void __launch_bounds__(kBlock, (DIM == 3 && RYUJIN_OCC_LOW_3D_STAGES) ? 1 : RYUJIN_OCC_LOW)
+  __global__ void __launch_bounds__(kBlock, (DIM == 3 && RYUJIN_OCC_LOW_3D_STAGES) ? 1 : RYUJIN_OCC_LOW_AEOS)
   k_low_order_aeos(const EulerAeosParams P, const DeviceMesh M, DeviceScalars *scalars,
                    const double weight, const StageArgs<DIM> S, const double *__restrict__ U,
                    const double *__restrict__ prec, const double *__restrict__ alpha,

@@ -61,7 +61,8 @@ namespace ryujin_hip
 #endif
 
 #ifndef RYUJIN_OCC_LIJ0_AEOS
-#define RYUJIN_OCC_LIJ0_AEOS 2 /* EulerAEOS (a fourth bound, gamma_min, powers in psi): 52 B/lane of scratch at 3 waves */
+#define RYUJIN_OCC_LIJ0_AEOS 3 /* EulerAEOS (a fourth bound, gamma_min, powers in psi): rounds 3-4 52 B/lane of scratch at 3 waves and 2 waves faster;
+                                   with the slice context in scalar registers 36 B and 0.312 -> 0.276 ms (profiles/r05e_ab_aeos.log) */
 #endif
   struct EulerAeosParams;
   template <typename E>

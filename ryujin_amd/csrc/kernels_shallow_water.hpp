@@ -20,7 +20,7 @@ namespace ryujin_hip
 {
   /* DG: discontinuous ansatz, the incidence matrix enters the high-order viscosity (:733-737) */
   template <int DIM, bool HAS_STAGES, bool DG = false>
-  __global__ void __launch_bounds__(kBlock, RYUJIN_OCC_LOW)
+  __global__ void __launch_bounds__(kBlock, RYUJIN_OCC_LOW_SW)
   k_low_order_sw(const ShallowWaterParams P, const DeviceMesh M,
                  DeviceScalars *scalars, const double weight,
                  const StageArgs<DIM> S, const double *__restrict__ U,
