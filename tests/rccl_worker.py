@@ -79,7 +79,50 @@ def intermediates(off, comm, device, n_warm, out_prefix, rank, switches=None):
     return info
 
 
+def main_stub(rendezvous):
+    """The same worker as a plain process on a ONE-GPU box: every rank on device 0, tests/cpp/librccl_stub.so
+    LD_PRELOADed in front of RCCL (tests/test_rccl_stub.py). No torch: rank and world size from the environment, the
+    unique id and the results through files in `rendezvous`."""
+    import time
+    out_path, case, n_updates = sys.argv[1], sys.argv[2], int(sys.argv[3])
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    capi.load_synth()
+    lib = capi.load_hip()
+    # the double is what the library's RCCL calls bind to (LD_PRELOAD): RCCL proper would refuse ranks that share a device
+    err = C.CDLL(None).ncclGetErrorString
+    err.restype = C.c_char_p
+    assert b"rccl stub" in err(4), "tests/cpp/librccl_stub.so is not in front of librccl.so"
+    uid = C.create_string_buffer(capi.UNIQUE_ID_BYTES)
+    uid_file = os.path.join(rendezvous, "unique_id")
+    if rank == 0:
+        assert lib.ryujin_hip_comm_unique_id(uid) == 0, lib.ryujin_hip_last_error()
+        with open(uid_file + ".tmp", "wb") as f:
+            f.write(uid.raw)
+        os.rename(uid_file + ".tmp", uid_file)
+    else:
+        while not os.path.exists(uid_file):
+            time.sleep(0.01)
+        uid = C.create_string_buffer(open(uid_file, "rb").read(), capi.UNIQUE_ID_BYTES)
+    comm = C.c_void_p()
+    rc = lib.ryujin_hip_comm_init(C.byref(comm), uid, rank, world, 0)
+    assert rc == 0, lib.ryujin_hip_last_error()
+    off = offline.SyntheticOffline(make_spec(case, world, rank))
+    v = [C.c_int(-1) for _ in range(5)]
+    lib.ryujin_hip_comm_info(comm, *[C.byref(x) for x in v])
+    assert v[3].value == world, ("ncclCommCount", v[3].value, world)
+    if len(sys.argv) > 4 and sys.argv[4].startswith("intermediates"):
+        switches = {"system_scope_events": 1} if sys.argv[4].endswith(":system") else None
+        info = intermediates(off, comm, 0, n_updates, out_path, rank, switches)
+        assert info["n_exchanges"] >= 5 * (n_updates + 1), info
+    else:
+        gid, U, taus, alpha, integrals = run(off, comm, 0, n_updates)
+        np.savez(f"{out_path}.rank{rank}.npz", gid=gid, U=U, taus=taus, alpha=alpha, integrals=integrals)
+    lib.ryujin_hip_comm_destroy(comm)
+
+
 def main():
+    if os.environ.get("RYUJIN_RCCL_STUB_DIR"):
+        return main_stub(os.environ["RYUJIN_RCCL_STUB_DIR"])
     # torch only here: the parent test imports this module for run() / make_spec() into a process that has
     # libryujin_hip.so loaded already, and torch coming second would bring a second ROCm runtime along
     # (heap corruption at exit). In the worker torch comes FIRST, as in bench.py.
