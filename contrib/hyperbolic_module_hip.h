@@ -535,6 +535,9 @@ namespace ryujin
         params_.indicator_evc_factor = indicator_parameters_.evc_factor();
         params_.limiter_iterations = static_cast<int>(limiter_parameters_.iterations());
         params_.limiter_relaxation_factor = limiter_parameters_.relaxation_factor();
+#ifdef EXPENSIVE_BOUNDS_CHECK
+        params_.debug_expensive_bounds_check = 1;
+#endif
         if (eos_parameters_)
           eos_parameters_(params_);
       }

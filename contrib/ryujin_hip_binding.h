@@ -274,7 +274,8 @@ namespace ryujin_hip_binding
     p.limiter_newton_max_iterations = static_cast<int>(limiter.newton_max_iterations());
     p.limiter_relaxation_factor = limiter.relaxation_factor();
     /* ryujin configured with EXPENSIVE_BOUNDS_CHECK (compile_time_options.h.in:12-15; implied by DEBUG): the
-     * checked control flow of the limiter and is_admissible behind steps 4, 6, 7 on the device as well (Euler) */
+     * checked control flow of the limiter and is_admissible behind steps 4, 6, 7 on the device as well (every
+     * Description) */
 #ifdef EXPENSIVE_BOUNDS_CHECK
     p.debug_expensive_bounds_check = 1;
 #endif
@@ -320,6 +321,9 @@ namespace ryujin_hip_binding
     p.limiter_relaxation_factor = limiter.relaxation_factor();
     p.limiter_limit_on_kinetic_energy = limiter.limit_on_kinetic_energy() ? 1 : 0;
     p.limiter_limit_on_square_velocity = limiter.limit_on_square_velocity() ? 1 : 0;
+#ifdef EXPENSIVE_BOUNDS_CHECK
+    p.debug_expensive_bounds_check = 1;
+#endif
   }
 
 

@@ -167,12 +167,13 @@ typedef struct ryujin_hip_params {
   int debug_no_small_mesh_split;
   int debug_pij_storage;
   /* != 0: the reference's EXPENSIVE_BOUNDS_CHECK build (CMakeLists.txt / compile_time_options.h.in:13-16) as a
-   * run-time option of the Euler Description: View::is_admissible() on every new state after steps 4, 6 and 7
+   * run-time option, for every Description: View::is_admissible() on every new state after steps 4, 6 and 7
    * (hyperbolic_module.template.h:851-855,1121-1126), the limiter's checked control flow -- its additional
    * high-order density and entropy checks (limiter.template.h:110-134,244-252,291-322) -- and the second limiter
    * pass's `success` counted (:1155-1161): any of them raises the restart flag. Evaluated by separate kernels
    * between the sweeps (P_ij is stored in full then); the l_ij themselves are the same in both control flows.
-   * The other Descriptions run their production flow with the plain kernels (no check kernels yet). */
+   * (limiter.template.h of euler/, euler_aeos/, shallow_water/ and scalar_conservation/; is_admissible() of the
+   * Description's view: trivially true for a scalar equation.) */
   int debug_expensive_bounds_check;
   /* The tile map: column indices and transposed positions of structured 64-row tiles come from a 16-byte descriptor
    * per tile instead of the explicit index arrays (ryujin_amd/csrc/host_layout.hpp, TileDesc). 0: on (default);

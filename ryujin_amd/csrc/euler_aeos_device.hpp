@@ -689,6 +689,96 @@ namespace ryujin_hip
       return t_l;
     }
 
+    /* View::is_admissible (euler_aeos/hyperbolic_system.h): rho > 0 and rho e - rho q - pinf (1 - b rho) > 0 */
+    static RYUJIN_DEV bool is_admissible(const Params &P, const double (&U)[K])
+    {
+      const double rho = U[0];
+      const double shift = internal_energy(U) - rho * P.q - P.pinf * (1. - P.b * rho);
+      return rho > 0. && shift > 0.;
+    }
+
+    /* limiter.template.h in the EXPENSIVE_BOUNDS_CHECK control flow (ryujin_hip_params::debug_expensive_bounds_check):
+     * the density behind the clip, no "psi_r > 0" shortcut in front of psi_l, the final check of the limited state.
+     * The same t_l as limit(); `success` has more ways to be false. Debug kernel only (k_check_limiter). */
+    static RYUJIN_DEV double limit_checked(const Params &P, const double (&bnd)[NB], const double (&U)[K],
+                                           const double (&Pij)[K], bool &success)
+    {
+      constexpr double t_min = 0., t_max = 1.;
+      constexpr double eps = DBL_EPSILON;
+      success = true;
+      const double rho_min = bnd[0], rho_max = bnd[1];
+      const double relax_small = 1. + P.vacuum_small * eps;
+      const double relax = 1. + P.vacuum_large * eps;
+      double t_r = t_max;
+      {
+        const double rho_U = U[0];
+        const double rho_P = Pij[0];
+        const double test_min = filter_vacuum_density(P, fmax(0., rho_U - relax * rho_max));
+        const double test_max = filter_vacuum_density(P, fmax(0., rho_min - relax * rho_U));
+        if (!(test_min == 0. && test_max == 0.))
+          success = false;
+        const double denominator = 1. / (fabs(rho_P) + eps * rho_max);
+        t_r = rho_max < rho_U + t_r * rho_P ? (rho_max - rho_U) * denominator : t_r;
+        t_r = rho_U + t_r * rho_P < rho_min ? (rho_U - rho_min) * denominator : t_r;
+        t_r = fmin(t_r, t_max);
+        t_r = fmax(t_r, t_min);
+        const double rho_new = U[0] + t_r * Pij[0];
+        const double test_new_min = filter_vacuum_density(P, fmax(0., rho_new - relax * rho_max));
+        const double test_new_max = filter_vacuum_density(P, fmax(0., rho_min - relax * rho_new));
+        if (!(test_new_min == 0. && test_new_max == 0.))
+          success = false;
+      }
+      double t_l = t_min;
+      const double s_min = bnd[2];
+      const double gamma = bnd[3];
+      const double gm1 = gamma - 1.;
+      for (int n = 0; n < P.lim_newton_max_iterations; ++n) {
+        double U_r[K], U_l[K];
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+          U_r[q] = U[q] + t_r * Pij[q];
+          U_l[q] = U[q] + t_l * Pij[q];
+        }
+        const Psi R = psi_of(P, U_r, s_min, gamma, relax_small);
+        const Psi L = psi_of(P, U_l, s_min, gamma, relax_small);
+        const double lower_bound =
+            (1. - relax) * s_min * L.rho * L.rho_gamma * covolume_pow(P, L.covolume, -gm1);
+        if (n == 0 && !(fmin(0., L.psi - lower_bound) == 0.))
+          success = false;
+        t_l = R.psi > 0. ? t_r : t_l;
+        if (fmax(0., t_r - t_l - P.lim_newton_tolerance) == 0.)
+          break;
+        const double drho = Pij[0];
+        const double drho_e_l = internal_energy_derivative_dot(U_l, Pij);
+        const double drho_e_r = internal_energy_derivative_dot(U_r, Pij);
+        const double q_pinf_term_l = 2. * L.rho * P.q + P.pinf * (1. - 2. * P.b * L.rho);
+        const double q_pinf_term_r = 2. * R.rho * P.q + P.pinf * (1. - 2. * P.b * R.rho);
+        const double extra_term_l =
+            s_min * dev_pow(L.rho / L.covolume, gamma) * (L.covolume + gamma - P.b * L.rho);
+        const double extra_term_r =
+            s_min * dev_pow(R.rho / R.covolume, gamma) * (R.covolume + gamma - P.b * R.rho);
+        const double dpsi_l = L.rho * drho_e_l + (L.rho_e - q_pinf_term_l - extra_term_l) * drho;
+        const double dpsi_r = R.rho * drho_e_r + (R.rho_e - q_pinf_term_r - extra_term_r) * drho;
+        double psi_l = L.psi, psi_r = R.psi;
+        quadratic_newton_step(t_l, t_r, psi_l, psi_r, dpsi_l, dpsi_r, -1.);
+      }
+      {
+        double U_new[K];
+#pragma unroll
+        for (int q = 0; q < K; ++q)
+          U_new[q] = U[q] + t_l * Pij[q];
+        const Psi N = psi_of(P, U_new, s_min, gamma, relax_small);
+        const double shift_new = N.rho_e - N.rho * P.q - P.pinf * N.covolume;
+        const double lower_bound =
+            (1. - relax) * s_min * N.rho * N.rho_gamma * covolume_pow(P, N.covolume, -gm1);
+        const bool e_valid = fmin(0., shift_new) == 0.;
+        const bool psi_valid = fmin(0., N.psi - lower_bound) == 0.;
+        if (!e_valid || !psi_valid)
+          success = false;
+      }
+      return t_l;
+    }
+
     /* hyperbolic_system.h:1314-1377. `dynamic` is __builtin_trap() in the reference; create() rejects it. */
     static RYUJIN_DEV void apply_boundary_conditions(const Params &, const int id, const double (&U)[K],
                                                      const double (&normal)[DIM], const double (&U_D)[K],

@@ -1547,14 +1547,12 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
     }
   });
   /* EXPENSIVE_BOUNDS_CHECK as a run-time option (Euler): is_admissible() of the low-order update (:851-855) */
-  const bool checked = is_euler && params.debug_expensive_bounds_check != 0;
-  if constexpr (is_euler) {
-    if (checked)
-      sweep([&](const DeviceMesh &mm, dim3 grid) {
-        hipLaunchKernelGGL(k_check_admissible<E>, grid, block, 0, launch_stream, eparams, mm, d_scalars.ptr,
-                           (const double *)nw.U.ptr);
-      });
-  }
+  const bool checked = params.debug_expensive_bounds_check != 0;
+  if (checked)
+    sweep([&](const DeviceMesh &mm, dim3 grid) {
+      hipLaunchKernelGGL(k_check_admissible<E>, grid, block, 0, launch_stream, eparams, mm, d_scalars.ptr,
+                         (const double *)nw.U.ptr);
+    });
   exchange_vector(d_r.ptr, KP, true);
   if (dg && params.limiter_iterations != 0) {
     /* the bounds are extended over the stencil in step 5: their ghost range has to be current
@@ -1653,14 +1651,12 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
                            d_r.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr, d_V.ptr);
       stage0_V = d_V.ptr != nullptr;
     });
-    if constexpr (is_euler) {
-      if (checked) /* the first limiter pass in the checked control flow (limiter.template.h:110-134,244-322) */
-        sweep([&](const DeviceMesh &mm, dim3 grid) {
-          hipLaunchKernelGGL(k_check_limiter<E>, grid, block, 0, launch_stream, eparams, mm, d_scalars.ptr,
-                             (const double *)nw.U.ptr, (const double *)d_bounds.ptr, (const double *)d_pij.ptr,
-                             (const double *)nullptr);
-        });
-    }
+    if (checked) /* the first limiter pass in the checked control flow (limiter.template.h:110-134,244-322) */
+      sweep([&](const DeviceMesh &mm, dim3 grid) {
+        hipLaunchKernelGGL(k_check_limiter<E>, grid, block, 0, launch_stream, eparams, mm, d_scalars.ptr,
+                           (const double *)nw.U.ptr, (const double *)d_bounds.ptr, (const double *)d_pij.ptr,
+                           (const double *)nullptr);
+      });
     exchange_matrix(d_lij.ptr, true);
   }
   mark(4);
@@ -1744,25 +1740,21 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
           hipLaunchKernelGGL((k_high_order<E, false>), grid, block, 0, launch_stream, eparams, mm, nw.U.ptr,
                              d_bounds.ptr, d_pij.ptr, d_lij.ptr, d_lij_next.ptr, FusedSadd{0., 0., nullptr});
       });
-      if constexpr (is_euler) {
-        if (checked) /* the update after the first pass (:1121-1126) and the second pass's success (:1155-1161) */
-          sweep([&](const DeviceMesh &mm, dim3 grid) {
-            hipLaunchKernelGGL(k_check_admissible<E>, grid, block, 0, launch_stream, eparams, mm, d_scalars.ptr,
-                               (const double *)nw.U.ptr);
-            hipLaunchKernelGGL(k_check_limiter<E>, grid, block, 0, launch_stream, eparams, mm, d_scalars.ptr,
-                               (const double *)nw.U.ptr, (const double *)d_bounds.ptr, (const double *)d_pij.ptr,
-                               (const double *)d_lij.ptr);
-          });
-      }
-      exchange_matrix(d_lij_next.ptr, true);
-    }
-    if constexpr (is_euler) {
-      if (checked && last_round) /* the final update (:1121-1126) */
+      if (checked) /* the update after the first pass (:1121-1126) and the second pass's success (:1155-1161) */
         sweep([&](const DeviceMesh &mm, dim3 grid) {
           hipLaunchKernelGGL(k_check_admissible<E>, grid, block, 0, launch_stream, eparams, mm, d_scalars.ptr,
                              (const double *)nw.U.ptr);
+          hipLaunchKernelGGL(k_check_limiter<E>, grid, block, 0, launch_stream, eparams, mm, d_scalars.ptr,
+                             (const double *)nw.U.ptr, (const double *)d_bounds.ptr, (const double *)d_pij.ptr,
+                             (const double *)d_lij.ptr);
         });
+      exchange_matrix(d_lij_next.ptr, true);
     }
+    if (checked && last_round) /* the final update (:1121-1126) */
+      sweep([&](const DeviceMesh &mm, dim3 grid) {
+        hipLaunchKernelGGL(k_check_admissible<E>, grid, block, 0, launch_stream, eparams, mm, d_scalars.ptr,
+                           (const double *)nw.U.ptr);
+      });
     mark(5 + pass);
   }
   for (int k = 5 + n_iterations; k <= 7; ++k)

@@ -177,6 +177,24 @@ namespace ryujin_hip
       return limit(P, bnd, U, Pij, success);
     }
 
+    /* the EXPENSIVE_BOUNDS_CHECK control flow (scalar_conservation/limiter.template.h): the clipped value itself is
+     * tested against the relaxed bounds as well; is_admissible() is trivially true for a scalar */
+    static RYUJIN_DEV double limit_checked(const Params &P, const double (&bnd)[NB], const double (&U)[K],
+                                           const double (&Pij)[K], bool &success)
+    {
+      const double t_r = limit(P, bnd, U, Pij, success);
+      const double relax = 1. + 10000. * DBL_EPSILON;
+      const double u_min = bnd[0], u_max = bnd[1];
+      const double u_new = U[0] + t_r * Pij[0];
+      const double test_new_max = fmax(0., fmin(u_new - relax * u_max, relax * u_new - u_max));
+      const double test_new_min = fmax(0., fmin(u_min - relax * u_new, relax * u_min - u_new));
+      if (!(test_new_max == 0. && test_new_min == 0.))
+        success = false;
+      return t_r;
+    }
+
+    static RYUJIN_DEV bool is_admissible(const Params &, const double (&)[K]) { return true; }
+
     /* apply_boundary_conditions (:381-420): Dirichlet; slip / no_slip / dynamic are rejected by create() */
     static RYUJIN_DEV void apply_boundary_conditions(const Params &, const int id, const double (&U)[K],
                                                      const double (&)[DIM], const double (&U_D)[K],

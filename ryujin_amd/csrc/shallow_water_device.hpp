@@ -488,11 +488,14 @@ namespace ryujin_hip
       return s;
     }
 
-    /* limiter.template.h:16-449, production control flow. bounds = (h_min, h_max, h_small,
-     * kin_max, v2_max). The function is cheap (no transcendental beyond two sqrt in the single
-     * quadratic Newton step), so the fast/slow split only separates the Newton step. */
-    static RYUJIN_DEV double limit(const Params &P, const double (&bnd)[NB], const double (&U)[K],
-                                   const double (&Pij)[K], bool &success)
+    /* limiter.template.h:16-449. bounds = (h_min, h_max, h_small, kin_max, v2_max). The function is cheap (no
+     * transcendental beyond two sqrt in the single quadratic Newton step), so the fast/slow split only separates the
+     * Newton step. CHECKED: the reference's EXPENSIVE_BOUNDS_CHECK control flow -- the water depth behind the clip
+     * (:106-126), the kinetic-energy and square-velocity constraints of the limited state (:242-262, :396-420) --,
+     * the same t_l, `success` has more ways to be false (ryujin_hip_params::debug_expensive_bounds_check). */
+    template <bool CHECKED>
+    static RYUJIN_DEV double limit_impl(const Params &P, const double (&bnd)[NB], const double (&U)[K],
+                                        const double (&Pij)[K], bool &success)
     {
       constexpr double t_min = 0., t_max = 1.;
       constexpr double eps = DBL_EPSILON;
@@ -516,6 +519,13 @@ namespace ryujin_hip
           t_r = h_U + t_r * h_P < h_min_tilde ? (h_U - h_min_tilde) * denominator : t_r;
           t_r = fmin(t_r, t_max);
           t_r = fmax(t_r, t_min);
+        }
+        if constexpr (CHECKED) {
+          const double h_new = U[0] + t_r * Pij[0];
+          const double test_new_min = filter_dry_water_depth(P, fmax(0., h_new - relax * h_max));
+          const double test_new_max = filter_dry_water_depth(P, fmax(0., h_min - relax * h_new));
+          if (!(test_new_min == 0. && test_new_max == 0.))
+            success = false;
         }
       }
       if (!P.limit_on_square_velocity && !P.limit_on_kinetic_energy)
@@ -545,6 +555,16 @@ namespace ryujin_hip
           const double dpsi_l = h_P * kin_max - q_dot(U, Pij) - q_dot(Pij, Pij) * t_l;
           const double dpsi_r = h_P * kin_max - q_dot(U, Pij) - q_dot(Pij, Pij) * t_r;
           quadratic_newton_step(t_l, t_r, psi_l, psi_r, dpsi_l, dpsi_r, -1.);
+        }
+        if constexpr (CHECKED) {
+          double U_new[K];
+#pragma unroll
+          for (int q = 0; q < K; ++q)
+            U_new[q] = U[q] + t_l * Pij[q];
+          const double psi_new = relax_small * U_new[0] * kin_max - 0.5 * q_dot(U_new, U_new);
+          const double lb = (1. - relax) * U_new[0] * kin_max - eps;
+          if (!(fmin(0., psi_new - lb) == 0.))
+            success = false;
         }
         if (P.limit_on_square_velocity) {
           t_r = t_l;
@@ -580,8 +600,37 @@ namespace ryujin_hip
               (h_U + t_r * h_P) * h_P * v2_max - 2. * (q_dot(U, Pij) - q_dot(Pij, Pij) * t_r);
           quadratic_newton_step(t_l, t_r, psi_l, psi_r, dpsi_l, dpsi_r, -1.);
         }
+        if constexpr (CHECKED) {
+          double U_new[K];
+#pragma unroll
+          for (int q = 0; q < K; ++q)
+            U_new[q] = U[q] + t_l * Pij[q];
+          const double h_new = U_new[0];
+          const double psi_new = relax_small * h_new * h_new * v2_max - q_dot(U_new, U_new);
+          const double lb = (1. - relax) * h_new * h_new * v2_max - 100. * eps;
+          if (!(fmin(0., psi_new - lb) == 0.))
+            success = false;
+        }
       }
       return t_l;
+    }
+
+    static RYUJIN_DEV double limit(const Params &P, const double (&bnd)[NB], const double (&U)[K],
+                                   const double (&Pij)[K], bool &success)
+    {
+      return limit_impl<false>(P, bnd, U, Pij, success);
+    }
+
+    static RYUJIN_DEV double limit_checked(const Params &P, const double (&bnd)[NB], const double (&U)[K],
+                                           const double (&Pij)[K], bool &success)
+    {
+      return limit_impl<true>(P, bnd, U, Pij, success);
+    }
+
+    /* View::is_admissible (shallow_water/hyperbolic_system.h:882-902): the filtered water depth is not negative */
+    static RYUJIN_DEV bool is_admissible(const Params &P, const double (&U)[K])
+    {
+      return filter_dry_water_depth(P, U[0]) >= 0.;
     }
 
     /* the whole limiter is short: every pair is decided here */

@@ -97,22 +97,42 @@ def test_step_parity_c1_size(oracle):
     assert (rho > 0).all() and (E - 0.5 * m2 / rho > 0).all()
 
 
+def _checked_case(equation):
+    """(mesh, initial state, Dirichlet data, parameter edit) of the checked-build test, per Description"""
+    if equation == "euler":
+        off = offline.SyntheticOffline(offline.mach3_step_2d(40))
+        return off, _perturbed(euler_uniform(off.positions)), euler_uniform(off.b_positions), None, capi.EQ_EULER
+    if equation == "euler_aeos":  # the same problem through the EulerAEOS Description (polytropic gas, strict bounds)
+        off = offline.SyntheticOffline(offline.mach3_step_2d(40))
+        return off, _perturbed(euler_uniform(off.positions)), euler_uniform(off.b_positions), None, capi.EQ_EULER_AEOS
+    if equation == "shallow_water":
+        from ryujin_amd.initial_states import sw_circular_dam_break
+        off = offline.SyntheticOffline(offline.rectangle_2d(48, (-5.0, -5.0), (5.0, 5.0)))
+        return off, sw_circular_dam_break(off.positions), None, None, capi.EQ_SHALLOW_WATER
+    off = offline.SyntheticOffline(offline.rectangle_2d(48, (-2.0, -2.5), (2.0, 1.5), bc=capi.BC_DIRICHLET))
+    r = np.linalg.norm(off.positions, axis=1)
+    U0 = np.where(r < 1.0, 1.0, -0.5).reshape(-1, 1)
+    return off, U0, U0[off.b_i], None, capi.EQ_SCALAR_CONSERVATION
+
+
 @pytest.mark.parametrize("cfl", [0.9, 4.0])
-def test_expensive_bounds_check_as_a_run_time_option(oracle, cfl):
+@pytest.mark.parametrize("equation", ["euler", "euler_aeos", "shallow_water", "scalar_conservation"])
+def test_expensive_bounds_check_as_a_run_time_option(oracle, equation, cfl):
     """ryujin_hip_params::debug_expensive_bounds_check: the reference's EXPENSIVE_BOUNDS_CHECK build (is_admissible
     behind steps 4, 6 and 7, the limiter's checked control flow in both passes,
-    hyperbolic_module.template.h:851-855,1121-1126,1155-1161) against the oracle's. The l_ij and the new state are
-    those of the production flow (the checked flow returns the same t_l); what differs is when a violation is
-    reported: at cfl 0.9 nothing is, at four times the admissible step both raise it."""
-    spec = offline.mach3_step_2d(40)
-    off = offline.SyntheticOffline(spec)
-    U0 = _perturbed(euler_uniform(off.positions))
-    dirichlet = euler_uniform(off.b_positions)
+    hyperbolic_module.template.h:851-855,1121-1126,1155-1161 -- generic over the Description; the limiters:
+    euler/, euler_aeos/, shallow_water/, scalar_conservation/limiter.template.h) against the oracle's, for every
+    Description. The l_ij and the new state are those of the production flow (the checked flow returns the same t_l);
+    what differs is when a violation is reported: at cfl 0.9 nothing is, at four times the admissible step both
+    backends raise it in the same steps."""
+    off, U0, dirichlet, edit, eq = _checked_case(equation)
     results = []
     for backend in ("hip", oracle.backend()):
-        p = oracle.default_params(capi.EQ_EULER, 2)
+        p = oracle.default_params(eq, 2)
         p.cfl = cfl
         p.id_violation_strategy = capi.IDV_WARN
+        if edit:
+            edit(p)
         if backend == "hip":
             p.debug_expensive_bounds_check = 1
         m = HyperbolicModule(off, p, backend=backend)
@@ -128,9 +148,11 @@ def test_expensive_bounds_check_as_a_run_time_option(oracle, cfl):
         results.append((statuses, a.download()[: off.n_owned], m.n_warnings()))
     (st_g, U_g, w_g), (st_c, U_c, w_c) = results
     assert st_g == st_c and w_g == w_c, (st_g, st_c)
-    assert (w_g == 0) == (cfl <= 1.0)
     if cfl <= 1.0:
+        assert w_g == 0
         assert (np.abs(U_g - U_c) / np.abs(U_c).max(axis=0)).max() <= 1e-10
+    elif equation != "scalar_conservation":  # (a scalar clip has no invariant domain to leave: nothing need be raised)
+        assert w_g > 0
 
 
 def test_step_parity_3d_radial_contrast(oracle):
