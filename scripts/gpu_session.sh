@@ -3,4 +3,6 @@ set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$R"
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_rccl_stub.py tests/test_gpu_parity.py -q -m gpu -x -k "stub or expensive_bounds" --durations=5 2>&1 | tail -25
+timeout 1700 python -m pytest tests -q -m gpu -x --durations=12 2>&1 | tail -30 > gpurun_out/r05f_pytest_gpu.txt
+cat gpurun_out/r05f_pytest_gpu.txt
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
