@@ -259,7 +259,9 @@ typedef struct ryujin_hip_offline {
    * (hyperbolic_module.template.h:733-737), the full block-diagonal inverse mass matrix instead of the
    * Neumann series (:976-986) and extends the limiter bounds over the stencil (:938-948).
    * Both matrices in the storage scheme of mij. Any number of ranks (the limiter bounds are exchanged,
-   * :601-613); Euler and shallow water (the other Descriptions are refused with RYUJIN_ERR_UNSUPPORTED).
+   * :601-613); Euler, EulerAEOS and shallow water. Scalar conservation is refused with RYUJIN_ERR_UNSUPPORTED:
+   * the reference's scalar Riemann solver is 0/0 on the structural zeros of a dG stencil (n_ij = c_ij / |c_ij|
+   * with c_ij = 0; scalar_conservation/riemann_solver.template.h:63,95-96), tests/test_dg_q1.py.
    */
   int discontinuous_ansatz;
   const double *incidence;           /* [nnz] OfflineData::incidence_matrix() */

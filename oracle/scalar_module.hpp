@@ -27,6 +27,9 @@ namespace oracle
     CSR csr;
     std::vector<double> cij, mij, mi, mi_inv;
     double measure_of_omega;
+    /* discontinuous ansatz (hyperbolic_module.template.h:287-293): incidence matrix, full inverse mass matrix */
+    bool discontinuous_ansatz = false;
+    std::vector<double> incidence, mass_matrix_inverse;
 
     std::vector<uint32_t> b_i;
     std::vector<double> b_normal;
@@ -62,6 +65,13 @@ namespace oracle
       mi.assign(o.mi, o.mi + n_relevant);
       mi_inv.assign(o.mi_inv, o.mi_inv + n_relevant);
       measure_of_omega = o.measure_of_omega;
+      discontinuous_ansatz = o.discontinuous_ansatz != 0;
+      if (discontinuous_ansatz) {
+        if (!o.incidence || !o.mass_matrix_inverse)
+          throw std::runtime_error("discontinuous ansatz without incidence / inverse mass matrix");
+        incidence = csr.gather(o, o.incidence, 1);
+        mass_matrix_inverse = csr.gather(o, o.mass_matrix_inverse, 1);
+      }
       b_i.assign(o.b_i, o.b_i + o.n_bdry);
       b_normal.assign(o.b_normal, o.b_normal + (size_t)o.n_bdry * dim);
       b_id.assign(o.b_id, o.b_id + o.n_bdry);
@@ -320,7 +330,9 @@ namespace oracle
             const auto U_j = get_state(old_U, j);
             const double alpha_j = alpha[j];
             const double d_ij = dij[e];
-            const double factor = (alpha_i + alpha_j) * .5;
+            double factor = (alpha_i + alpha_j) * .5;
+            if (discontinuous_ansatz) /* hyperbolic_module.template.h:733-737 */
+              factor = std::max(factor, incidence[e]);
             const double d_ijH = d_ij * factor;
 
             const auto c_ij = get_c(e);
@@ -378,9 +390,30 @@ namespace oracle
         }
       }
       do_exchange(EX_R, r.data(), K); /* :601-613 */
+      if (discontinuous_ansatz) /* the bounds are extended over the stencil below: ghost range (:603-612) */
+        do_exchange(EX_BOUNDS, bounds.data(), NB);
 
       /* Step 5: second part of p_ij, first l_ij (:892-1041) */
       const int n_iterations = params.limiter_iterations;
+      if (n_iterations != 0 && discontinuous_ansatz) {
+        /* extend the bounds over the stencil (:938-948; Limiter::combine_bounds,
+         * scalar_conservation/limiter.h:302-309: min, max), every row from the ORIGINAL bounds of its stencil */
+        const std::vector<double> original(bounds);
+#pragma omp parallel for schedule(static)
+        for (uint32_t i = 0; i < n_owned; ++i) {
+          const uint64_t rs = csr.ptr[i], re = csr.ptr[i + 1];
+          if (re - rs == 1)
+            continue;
+          double u_min = original[(size_t)i * NB], u_max = original[(size_t)i * NB + 1];
+          for (uint64_t e = rs + 1; e < re; ++e) {
+            const uint32_t j = csr.col[e];
+            u_min = std::min(u_min, original[(size_t)j * NB]);
+            u_max = std::max(u_max, original[(size_t)j * NB + 1]);
+          }
+          bounds[(size_t)i * NB] = u_min;
+          bounds[(size_t)i * NB + 1] = u_max;
+        }
+      }
       if (n_iterations != 0) {
 #pragma omp parallel
         {
@@ -408,10 +441,17 @@ namespace oracle
               const auto F_jH = get_state(r, j);
 
               const double kronecker_ij = 0.;
-              const double m_j_inv = mi_inv[j];
-              const double m_ij = mij[e];
-              const double b_ij = kronecker_ij - m_ij * m_j_inv;
-              const double b_ji = kronecker_ij - m_ij * m_i_inv;
+              double b_ij, b_ji;
+              if (discontinuous_ansatz) { /* full consistent mass matrix inverse (:976-986) */
+                const double m_ij_inv = mass_matrix_inverse[e];
+                b_ij = mi[i] * m_ij_inv - kronecker_ij;
+                b_ji = mi[j] * m_ij_inv - kronecker_ij;
+              } else { /* Neumann series expansion (:988-996) */
+                const double m_j_inv = mi_inv[j];
+                const double m_ij = mij[e];
+                b_ij = kronecker_ij - m_ij * m_j_inv;
+                b_ji = kronecker_ij - m_ij * m_i_inv;
+              }
               for (int q = 0; q < K; ++q) {
                 P_ij[q] += b_ij * F_jH[q] - b_ji * F_iH[q];
                 P_ij[q] *= factor;

@@ -1218,6 +1218,40 @@ namespace ryujin_hip
     bounds[2 * stride + i] = s_min_r;
   }
 
+  /* The same for a Description whose Limiter::combine_bounds is a plain component-wise minimum / maximum: bit q of
+   * MAX_MASK <=> bound q is a maximum. EulerAEOS (rho_min, rho_max, s_min, gamma_min: euler_aeos/limiter.h:435-445)
+   * NB = 4, mask 0b0010; scalar conservation (u_min, u_max: scalar_conservation/limiter.h:302-309) NB = 2, mask 0b10. */
+  template <int NB, unsigned MAX_MASK>
+  __global__ void __launch_bounds__(kBlock)
+  k_bounds_combine_minmax(const DeviceMesh M, const double *__restrict__ in, double *__restrict__ out)
+  {
+    const RowCtx r = row_context(M);
+    if (!r.valid)
+      return;
+    const bool row_active = r.len > 1;
+    const uint32_t i = row_active ? r.row : (r.row < M.n_owned ? r.row : M.n_owned - 1);
+    const size_t stride = M.bounds_stride;
+    double b[NB];
+#pragma unroll
+    for (int q = 0; q < NB; ++q)
+      b[q] = in[(size_t)q * stride + i];
+    for (uint32_t c = 1; c < r.width; ++c) {
+      const uint32_t j = M.cols[((uint64_t)r.base + c) * 64 + r.lane];
+      if (row_active && c < r.len) {
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+          const double v = in[(size_t)q * stride + j];
+          b[q] = ((MAX_MASK >> q) & 1u) ? fmax(b[q], v) : fmin(b[q], v);
+        }
+      }
+    }
+    if (row_active) {
+#pragma unroll
+      for (int q = 0; q < NB; ++q)
+        out[(size_t)q * stride + i] = b[q];
+    }
+  }
+
   /* Discontinuous ansatz: extend the limiter bounds over the stencil (hyperbolic_module.template.h:938-948
    * with Limiter::combine_bounds, euler/limiter.h:366-377: min, max, min). Reads the ORIGINAL bounds of
    * the neighbours and writes a second buffer (the reference combines in place with a benign race). */

@@ -217,7 +217,8 @@ namespace ryujin_hip
 
   /* step 4 (:597-884) with Limiter::{reset,accumulate,bounds} of euler_aeos/limiter.h:258-410 */
   /* STORE_P = false (stages == 0): P_ij is formed in step 5 (kernels_limiter_stage0.hpp), nothing is stored here */
-  template <int DIM, bool HAS_STAGES, bool STORE_P = true>
+  /* DG: discontinuous ansatz, the incidence matrix enters the high-order viscosity (hyperbolic_module.template.h:733-737) */
+  template <int DIM, bool HAS_STAGES, bool STORE_P = true, bool DG = false>
   __global__ void __launch_bounds__(kBlock, (DIM == 3 && RYUJIN_OCC_LOW_3D_STAGES) ? 1 : RYUJIN_OCC_LOW_AEOS)
   k_low_order_aeos(const EulerAeosParams P, const DeviceMesh M, DeviceScalars *scalars,
                    const double weight, const StageArgs<DIM> S, const double *__restrict__ U,
@@ -288,7 +289,9 @@ namespace ryujin_hip
       if (!active)
         continue;
 
-      const double factor = (alpha_i + alpha_j) * .5;
+      double factor = (alpha_i + alpha_j) * .5;
+      if constexpr (DG)
+        factor = fmax(factor, M.incidence[colbase * 64 + r.lane]);
       const double d_ijH = d_ij * factor;
 
       const double regularization = 100. * DBL_MIN;

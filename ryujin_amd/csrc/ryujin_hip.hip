@@ -695,9 +695,17 @@ void ryujin_hip_ctx::create(const ryujin_hip_offline &o, const ryujin_hip_params
     d_mij.upload(mij);
     dg = o.discontinuous_ansatz != 0;
     if (dg) {
-      if (p.equation != RYUJIN_EQ_EULER && p.equation != RYUJIN_EQ_SHALLOW_WATER)
+      /* Scalar conservation: refused. The branch is written (k_low_order_sc<DIM, HAS_STAGES, true>,
+       * k_bounds_combine_minmax<2, 0b10>, k_pij_lij<E, true>), but the reference's own scalar Riemann solver cannot
+       * run on a dG stencil: the entries between DoFs of face-neighbour cells that do not lie on the shared face have
+       * c_ij = 0 exactly, n_ij = c_ij / |c_ij| is 0/0, and |f_i.n - f_j.n| / max(|u_i - u_j|, 2 delta) -- taken
+       * through std::max, which returns its first argument when the comparison with a NaN fails
+       * (scalar_conservation/riemann_solver.template.h:63,95-96) -- stays NaN: d_ij = 0 * NaN
+       * (tests/test_dg_q1.py::test_scalar_conservation_on_a_dg_stencil_is_nan_in_the_reference_formulas). */
+      if (p.equation == RYUJIN_EQ_SCALAR_CONSERVATION)
         throw HipError(RYUJIN_ERR_UNSUPPORTED,
-                       "discontinuous ansatz: Euler and shallow-water equations only in this version");
+                       "discontinuous ansatz with scalar conservation equations: the reference's Riemann solver is 0/0 "
+                       "on the structural zeros of a dG stencil");
       if (!o.incidence || !o.mass_matrix_inverse)
         throw HipError(RYUJIN_ERR_ARG, "discontinuous ansatz without incidence / inverse mass matrix");
       d_incidence.upload(L.scatter(o, o.incidence, 1));
@@ -1487,7 +1495,15 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
                            d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_alpha.ptr, d_dij.ptr,
                            nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
     } else if constexpr (is_scalar) {
-      if (stages == 0)
+      if (dg && stages == 0)
+        hipLaunchKernelGGL((k_low_order_sc<DIM, false, true>), grid, block, 0, launch_stream, eparams, mm,
+                           d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_alpha.ptr, d_dij.ptr,
+                           nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
+      else if (dg)
+        hipLaunchKernelGGL((k_low_order_sc<DIM, true, true>), grid, block, 0, launch_stream, eparams, mm,
+                           d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_alpha.ptr, d_dij.ptr,
+                           nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
+      else if (stages == 0)
         hipLaunchKernelGGL((k_low_order_sc<DIM, false>), grid, block, 0, launch_stream, eparams, mm,
                            d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_alpha.ptr, d_dij.ptr,
                            nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
@@ -1496,7 +1512,15 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
                            d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_alpha.ptr, d_dij.ptr,
                            nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
     } else if constexpr (is_aeos) {
-      if (stage0_pij)
+      if (dg && stages == 0)
+        hipLaunchKernelGGL((k_low_order_aeos<DIM, false, true, true>), grid, block, 0, launch_stream, eparams, mm,
+                           d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_alpha.ptr, d_dij.ptr,
+                           nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
+      else if (dg)
+        hipLaunchKernelGGL((k_low_order_aeos<DIM, true, true, true>), grid, block, 0, launch_stream, eparams, mm,
+                           d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_alpha.ptr, d_dij.ptr,
+                           nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
+      else if (stage0_pij)
         hipLaunchKernelGGL((k_low_order_aeos<DIM, false, false>), grid, block, 0, launch_stream, eparams, mm,
                            d_scalars.ptr, weight, S, old.U.ptr, old.prec.ptr, d_alpha.ptr, d_dij.ptr,
                            nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr);
@@ -1564,20 +1588,24 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
 
   /* Step 5: second part of p_ij, first l_ij; ghost rows of l_ij (:892-1041) */
   const int n_iterations = params.limiter_iterations;
-  if constexpr (is_euler || is_sw) {
-    if (dg && n_iterations != 0) {
-      /* bounds over the stencil (:938-948) with the Description's Limiter::combine_bounds; steps 5-7 read the
-       * extended bounds */
-      sweep([&](const DeviceMesh &mm, dim3 grid) {
-        if constexpr (is_euler)
-          hipLaunchKernelGGL(k_bounds_combine_euler, grid, block, 0, launch_stream, mm, d_bounds.ptr,
-                             d_bounds_combined.ptr);
-        else
-          hipLaunchKernelGGL(k_bounds_combine_sw, grid, block, 0, launch_stream, mm, d_bounds.ptr,
-                             d_bounds_combined.ptr);
-      });
-      std::swap(d_bounds.ptr, d_bounds_combined.ptr);
-    }
+  if (dg && n_iterations != 0) {
+    /* bounds over the stencil (:938-948) with the Description's Limiter::combine_bounds; steps 5-7 read the
+     * extended bounds */
+    sweep([&](const DeviceMesh &mm, dim3 grid) {
+      if constexpr (is_euler)
+        hipLaunchKernelGGL(k_bounds_combine_euler, grid, block, 0, launch_stream, mm, d_bounds.ptr,
+                           d_bounds_combined.ptr);
+      else if constexpr (is_sw)
+        hipLaunchKernelGGL(k_bounds_combine_sw, grid, block, 0, launch_stream, mm, d_bounds.ptr,
+                           d_bounds_combined.ptr);
+      else if constexpr (is_aeos)
+        hipLaunchKernelGGL((k_bounds_combine_minmax<4, 0x2u>), grid, block, 0, launch_stream, mm, d_bounds.ptr,
+                           d_bounds_combined.ptr);
+      else
+        hipLaunchKernelGGL((k_bounds_combine_minmax<2, 0x2u>), grid, block, 0, launch_stream, mm, d_bounds.ptr,
+                           d_bounds_combined.ptr);
+    });
+    std::swap(d_bounds.ptr, d_bounds_combined.ptr);
   }
   if (n_iterations != 0) {
     sweep([&](const DeviceMesh &mm, dim3 grid) {
@@ -1631,7 +1659,7 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
           return;
         }
       }
-      if constexpr (is_euler || is_sw) {
+      {
         if (dg) {
           if (L.max_row_len > 64)
             hipLaunchKernelGGL((k_pij_lij<E, true, true>), grid, block, 0, launch_stream, eparams, mm,

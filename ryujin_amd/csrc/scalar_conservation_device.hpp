@@ -310,7 +310,7 @@ namespace ryujin_hip
   }
 
   /* ------------------------------------------------------------------ step 4 */
-  template <int DIM, bool HAS_STAGES>
+  template <int DIM, bool HAS_STAGES, bool DG = false>
   __global__ void __launch_bounds__(kBlock)
   k_low_order_sc(const ScalarParams P, const DeviceMesh M, DeviceScalars *scalars,
                  const double weight, const StageArgs<DIM> S, const double *__restrict__ U,
@@ -355,7 +355,9 @@ namespace ryujin_hip
       if (!(row_active && c < r.len))
         continue;
 
-      const double factor = (alpha_i + alpha_j) * .5;
+      double factor = (alpha_i + alpha_j) * .5;
+      if constexpr (DG) /* hyperbolic_module.template.h:733-737 */
+        factor = fmax(factor, M.incidence[colbase * 64 + r.lane]);
       const double d_ijH = d_ij * factor;
       const double denom = fmax(d_ij, 100. * DBL_MIN);
       double scaled_c_ij[DIM];
