@@ -58,6 +58,7 @@ namespace ryujin_hip
     const uint32_t *cols;      /* [nnz_total] */
     const uint32_t *idx_t;     /* [nnz_total] */
     const TileDesc *tiles;     /* [slice_off[n_slices]] the tile map (host_layout.hpp), or NULL: explicit arrays only */
+    uint32_t tail_queue_columns; /* min(63, widest row - 1): columns of the dynamic-LDS queue of undecided pairs (k_pij_lij) */
     const double *cij;         /* paired layout, DIM comps */
     const double *mij;
     const double *mi, *mi_inv;

@@ -108,7 +108,10 @@ namespace ryujin_hip
 #pragma unroll
     for (int q = 0; q < K; ++q)
       rows[(NB + q) * 64 + r.lane] = U_i_new[q];
-    __threadfence_block(); /* written and read by different lanes of the wave */
+    /* written and read by different lanes of the wave: the LDS rows above AND the P_ij this wave stored to global
+     * memory earlier in the kernel (store_entry / streaming stores), which load_P() of ANOTHER lane reads back below --
+     * the fence orders those global stores at workgroup scope as well; keep it if either side changes */
+    __threadfence_block();
     bool all_ok = true;
     for (uint32_t q0 = 0; q0 < total; q0 += 64) {
       if (q0 + r.lane < total) {
@@ -255,8 +258,12 @@ namespace ryujin_hip
 
     /* (rows wider than 64 entries -- cG Q2 / Q3, dG in 3-D -- in blocks of 63 columns: the undecided pairs of a block
      * are finished before the next one starts, the mask has 64 bits) */
-    __shared__ uint16_t tail_queue[kWavesPerBlock * 63 * 64];
+    /* the queue of undecided pairs is dynamic LDS, sized by the launch from the widest row of the mesh
+     * (tail_queue_bytes(): 1 KB per wave for a 2-D Q1 stencil instead of the 8 KB the widest block needs -- with the
+     * 4 KB of TailScratch that was 48 KB per block and capped the sweep at 3 blocks per CU whatever its registers) */
+    extern __shared__ uint16_t tail_queue[];
     __shared__ TailScratch<E> tail_rows[kWavesPerBlock];
+    const uint32_t queue_stride = M.tail_queue_columns * 64u;
     for (uint32_t c_blk = 1; c_blk < r.width; c_blk += 63) {
     const uint32_t c_end = (WIDE && c_blk + 63 < r.width) ? c_blk + 63 : r.width;
     for (uint32_t c = c_blk; c < c_end; ++c) {
@@ -312,7 +319,7 @@ namespace ryujin_hip
     }
     /* the few pairs of the block that need the Newton iteration */
     const bool tail_ok = limit_undecided_pairs<E>(
-        P, r, undecided_mask, bnd, U_i_new, tail_queue + (threadIdx.x >> 6) * 63 * 64,
+        P, r, undecided_mask, bnd, U_i_new, tail_queue + (threadIdx.x >> 6) * queue_stride,
         tail_rows[threadIdx.x >> 6].rows,
         [&](const uint32_t c, const uint32_t owner, double (&out)[K]) {
           load_entry<K>(pij, (uint64_t)r.base + c, owner, out);

@@ -770,6 +770,7 @@ void ryujin_hip_ctx::create(const ryujin_hip_offline &o, const ryujin_hip_params
   mesh.cols = d_cols.ptr;
   mesh.idx_t = d_idx_t.ptr;
   mesh.tiles = d_tiles.n != 0 ? d_tiles.ptr : nullptr;
+  mesh.tail_queue_columns = std::max<uint32_t>(1u, std::min<uint32_t>(63u, L.max_row_len - 1u));
   mesh.cij = d_cij.ptr;
   mesh.mij = d_mij.ptr;
   mesh.incidence = dg ? d_incidence.ptr : nullptr;
@@ -903,6 +904,12 @@ void ryujin_hip_ctx::join_export()
     HIP_CHECK(hipStreamWaitEvent(stream, ev_exp, 0));
     exp_pending = false;
   }
+}
+
+/* dynamic LDS of k_pij_lij: the queue of undecided pairs, (widest row - 1) columns of 64 two-byte entries per wave */
+static inline size_t tail_queue_bytes(const DeviceMesh &mm)
+{
+  return (size_t)kWavesPerBlock * mm.tail_queue_columns * 64u * sizeof(uint16_t);
 }
 
 void ryujin_hip_ctx::finish()
@@ -1662,20 +1669,20 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
       {
         if (dg) {
           if (L.max_row_len > 64)
-            hipLaunchKernelGGL((k_pij_lij<E, true, true>), grid, block, 0, launch_stream, eparams, mm,
+            hipLaunchKernelGGL((k_pij_lij<E, true, true>), grid, block, tail_queue_bytes(mm), launch_stream, eparams, mm,
                                d_scalars.ptr, nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr, d_V.ptr);
           else
-            hipLaunchKernelGGL((k_pij_lij<E, true>), grid, block, 0, launch_stream, eparams, mm, d_scalars.ptr,
+            hipLaunchKernelGGL((k_pij_lij<E, true>), grid, block, tail_queue_bytes(mm), launch_stream, eparams, mm, d_scalars.ptr,
                                nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr, d_V.ptr);
           stage0_V = d_V.ptr != nullptr;
           return;
         }
       }
       if (L.max_row_len > 64)
-        hipLaunchKernelGGL((k_pij_lij<E, false, true>), grid, block, 0, launch_stream, eparams, mm, d_scalars.ptr,
+        hipLaunchKernelGGL((k_pij_lij<E, false, true>), grid, block, tail_queue_bytes(mm), launch_stream, eparams, mm, d_scalars.ptr,
                            nw.U.ptr, d_r.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr, d_V.ptr);
       else
-        hipLaunchKernelGGL(k_pij_lij<E>, grid, block, 0, launch_stream, eparams, mm, d_scalars.ptr, nw.U.ptr,
+        hipLaunchKernelGGL(k_pij_lij<E>, grid, block, tail_queue_bytes(mm), launch_stream, eparams, mm, d_scalars.ptr, nw.U.ptr,
                            d_r.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr, d_V.ptr);
       stage0_V = d_V.ptr != nullptr;
     });
