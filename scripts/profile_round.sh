@@ -21,8 +21,8 @@ for W in $WORKLOADS; do
   SUF=""; [ "$W" != step2d ] && SUF="_$W"
   BENCH="python $R/bench.py --workload $W"
   STATE=/tmp/state_$W.npz
-  timeout 600 $BENCH --save-state $STATE --steps 3 --warmup 0 --reps 1 --no-cpu-baseline > /tmp/state_$W.log 2>&1
-  PMCARGS="--steps 6 --warmup 3 --load-state $STATE --no-cpu-baseline"
+  timeout 600 $BENCH --save-state $STATE --steps 3 --warmup 0 --reps 1 --no-cpu-baseline --binding device > /tmp/state_$W.log 2>&1
+  PMCARGS="--steps 6 --warmup 3 --load-state $STATE --no-cpu-baseline --binding device"
   rm -rf /tmp/pmc_*
   for c in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_SALU"; do
     n=$(echo $c | cut -d" " -f1)
@@ -31,7 +31,7 @@ for W in $WORKLOADS; do
   python $R/scripts/pmc_summary.py "$TAG PMC ($W): rocprofv3 --pmc <counters> -- python bench.py --workload $W --steps 6 --warmup 3 --load-state <the default developed state> --no-cpu-baseline (FETCH_SIZE, WRITE_SIZE and SQ counters in three separate passes)" /tmp/pmc_*/*/*.db > $OUT/${TAG}_pmc$SUF.md
   printf "\nkernel sources: %s\n" "$FP" >> $OUT/${TAG}_pmc$SUF.md
   rm -rf /tmp/prof
-  TRARGS="--steps 30 --warmup 6 --load-state $STATE --no-cpu-baseline"
+  TRARGS="--steps 30 --warmup 6 --load-state $STATE --no-cpu-baseline --binding device"
   timeout 500 rocprofv3 --kernel-trace --stats -d /tmp/prof -- $BENCH $TRARGS > /tmp/prof.log 2>&1
   grep -h "^{" /tmp/prof.log | head -1 > $OUT/${TAG}_bench_profiled$SUF.json
   python $R/scripts/rocpd_summary.py /tmp/prof/*/*.db "$TAG kernel trace ($W): rocprofv3 --kernel-trace --stats -- python bench.py --workload $W --steps 30 --warmup 6 --load-state <the default developed state> --no-cpu-baseline" > $OUT/${TAG}_kernel_trace$SUF.md
