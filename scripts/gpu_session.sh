@@ -3,10 +3,8 @@ set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$R"
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_dg_q1.py tests/test_gpu_parity_fullsize.py -q -m gpu -x -k "sw or shallow or multistage or wider or dg or erk or c5" 2>&1 | tail -4
-for w in sw2d; do
-  timeout 600 python bench.py --workload $w --steps 18 --warmup 6 --no-cpu-baseline --binding device > gpurun_out/r05h_bench_$w.json 2> gpurun_out/r05h_bench_$w.err
-  python -c "
-import json,sys; d=json.loads(open('gpurun_out/r05h_bench_$w.json').read().strip().splitlines()[-1]); r=d['roofline']
-print('$w', round(d['value'],1), round(d['ms_per_step'],4), r['kernel'], round(r['frac'],3), d['sweep_ms'])"
-done
+for t in "" "201,8,8" "201,16,4" "64,8,8"; do
+  echo "== tile=$t"
+  RYUJIN_SYNTH_TILE=$t timeout 600 python bench.py --workload sedov3d --size 160 --steps 12 --warmup 6 --reps 3 --no-cpu-baseline --binding device 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['ms_per_step'],3), d['limiter']['limited_slice_fraction'], d['sweep_ms'])"
+done 2>&1 | tee gpurun_out/r05m_tile_numbering_3d.log
