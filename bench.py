@@ -683,6 +683,14 @@ def main():
         own["5 pij_lij"] += -8 * k * S + 8 * S + 8 * k + 8 * k  # - first part; + m_ij, F_i read, V_i written
         # P_ij is written in the slices steps 6/7 read it in (counted by the library over the instrumented pass)
         own["5 pij_lij"] -= (1.0 - limiter["pij_stored_slice_fraction"]) * 8 * k * S
+    # the tile map (1-D / 2-D): steps 3, 5, 6, 7 read a 16-byte descriptor per regular 64-entry tile instead of its
+    # column indices / transposed positions (4 S bytes per row): not compulsory bytes of these kernels any more
+    layout = m.layout_info()
+    if layout["n_regular_tiles"]:
+        saved = 4 * S * layout["regular_tile_fraction"] - 16.0 * layout["n_regular_tiles"] / off.n_owned
+        for name in ("3 dij_diag_tau", "5 pij_lij", "6 high_order_next_lij", "7 high_order"):
+            if name in own:
+                own[name] -= saved
     dom_gbs = own[dom] * n_q_local / (per_sweep[dom] * 1e-3) / 1e9
     ref_gbs = alg[dom] * n_q_local / (per_sweep[dom] * 1e-3) / 1e9
 
@@ -733,6 +741,7 @@ def main():
                                   "rounds 1-2; above 1 when the kernel no longer moves them (P_ij neither read nor "
                                   "stored): not a bandwidth, `traffic` is")}},
         "limiter": limiter,  # fraction of limited slices and whether P_ij was stored
+        "layout": layout,    # the tile map: tiles served by a descriptor instead of the index arrays
         "roofline_update": {"bound": "hbm", "achieved": upd_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": upd_gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_gridpoint": b_alg,
                             "device_ms_per_update": ev_ms.value / args.steps,

@@ -431,6 +431,11 @@ int ryujin_hip_get_counters(ryujin_hip_ctx *ctx, unsigned *n_restarts, unsigned 
  * stored. Diagnostics; any pointer may be NULL. */
 int ryujin_hip_limiter_statistics(ryujin_hip_ctx *ctx, double *limited_slice_fraction, int *pij_stored,
                                   double *stored_slice_fraction);
+/* The tile map of the context (ryujin_amd/csrc/host_layout.hpp, TileDesc): number of 64-entry tiles of the owned rows
+ * and how many of them are served by a 16-byte descriptor instead of the explicit index arrays (0 when the map is
+ * not built: 3-D, debug_tile_map < 0). bench.py takes the index bytes the sweeps no longer read out of their own
+ * compulsory bytes with it. Any pointer may be NULL. */
+int ryujin_hip_layout_info(ryujin_hip_ctx *ctx, unsigned long long *n_tiles, unsigned long long *n_regular_tiles);
 
 /* ---- introspection for parity tests and profiling ------------------------ */
 /* Module-owned intermediates of the LAST step() in the reference's logical

@@ -2779,6 +2779,19 @@ int ryujin_hip_limiter_statistics(ryujin_hip_ctx *ctx, double *limited_slice_fra
   });
 }
 
+int ryujin_hip_layout_info(ryujin_hip_ctx *ctx, unsigned long long *n_tiles, unsigned long long *n_regular_tiles)
+{
+  return guarded([&]() {
+    if (!ctx)
+      throw HipError(RYUJIN_ERR_ARG, "null context");
+    if (n_tiles)
+      *n_tiles = ctx->L.slice_off[ctx->L.n_slices];
+    if (n_regular_tiles)
+      *n_regular_tiles = ctx->d_tiles.n != 0 ? ctx->L.n_regular_tiles : 0ull;
+    return RYUJIN_OK;
+  });
+}
+
 int ryujin_hip_debug_fetch(ryujin_hip_ctx *ctx, int what, double *out, size_t n_doubles)
 {
   return guarded_ctx(ctx, [&]() {

@@ -290,6 +290,14 @@ class HyperbolicModule:
         return dict(limited_slice_fraction=f.value, pij_stored={1: "everywhere", 2: "per slice"}.get(stored.value),
                     pij_stored_slice_fraction=fs.value)
 
+    def layout_info(self) -> dict:
+        """tiles (64-entry columns of the SELL-64 slices) of the owned rows and how many the tile map serves from a
+        16-byte descriptor (ryujin_hip_layout_info; device backend only)"""
+        n, r = C.c_ulonglong(0), C.c_ulonglong(0)
+        self._check(self._lib.ryujin_hip_layout_info(self._ctx, C.byref(n), C.byref(r)))
+        return dict(n_tiles=n.value, n_regular_tiles=r.value,
+                    regular_tile_fraction=(r.value / n.value if n.value else 0.0))
+
     def debug_fetch(self, what: str) -> np.ndarray:
         """`*_all`: over all locally relevant rows, i.e. including the ghost rows / ghost range received from
         the neighbour ranks."""
