@@ -179,6 +179,12 @@ typedef struct ryujin_hip_params {
    * per tile instead of the explicit index arrays (ryujin_amd/csrc/host_layout.hpp, TileDesc). 0: on (default);
    * < 0: off -- every sweep reads the explicit arrays, as for an unstructured mesh. Results are identical. */
   int debug_tile_map;
+  /* Stacked blocks: the four waves of a workgroup take 64-row slices that are one lattice row (2-D) / lattice plane
+   * (3-D) of a structured mesh apart instead of four consecutive ones, so that their vertical neighbour rows are
+   * served by one L2 (ryujin_amd/csrc/kernels_euler.hpp, row_context()). 0: chosen from the mesh (or off, see
+   * DESIGN.md section 3); > 0: that many slices; < 0: off. Results are identical: every slice is processed by exactly
+   * one wave either way. */
+  int debug_band_stride;
 } ryujin_hip_params;
 
 /* ---- offline data (input contract) ------------------------------------- */

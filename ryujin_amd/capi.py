@@ -67,7 +67,7 @@ class Params(C.Structure):
         ("system_scope_events", C.c_int), ("debug_join_exchanges", C.c_int),
         ("debug_bc_fold_max_slices", C.c_int), ("debug_no_small_mesh_split", C.c_int),
         ("debug_pij_storage", C.c_int), ("debug_expensive_bounds_check", C.c_int),
-        ("debug_tile_map", C.c_int),
+        ("debug_tile_map", C.c_int), ("debug_band_stride", C.c_int),
     ]
 
 

@@ -271,6 +271,54 @@ namespace ryujin_hip
       });
     }
 
+    /* The distance, in rows, between a row and its neighbour in the next lattice row (dim 2) / lattice plane (dim 3)
+     * of a structured patch: the middle of the topmost cluster of index offsets that whole 64-row tiles agree on
+     * ({W-1, W, W+1} in 2-D; {P-W-1 ... P+W+1} around P in 3-D). 0: no such structure (unstructured mesh, 1-D). */
+    uint32_t lattice_stride(const int dim) const
+    {
+      if (dim < 2)
+        return 0;
+      std::vector<std::pair<uint32_t, uint64_t>> hist; /* (|delta|, tiles) */
+      uint64_t total = 0;
+      for (uint32_t s = 0; s < n_slices; s += 5) {
+        if ((uint64_t)(s + 1) * kWave > n_owned)
+          continue;
+        uint32_t min_len = 0xffffffffu;
+        for (uint32_t l = 0; l < kWave; ++l)
+          min_len = std::min<uint32_t>(min_len, row_len[(size_t)s * kWave + l]);
+        for (uint32_t c = 1; c < min_len; ++c) {
+          const uint64_t p0 = ((uint64_t)slice_off[s] + c) * kWave;
+          const int64_t delta = (int64_t)cols[p0] - (int64_t)((uint64_t)s * kWave);
+          bool ok = true;
+          for (uint32_t l = 1; l < kWave && ok; ++l)
+            ok = (int64_t)cols[p0 + l] - (int64_t)((uint64_t)s * kWave + l) == delta;
+          if (!ok)
+            continue;
+          const uint32_t a = (uint32_t)(delta < 0 ? -delta : delta);
+          ++total;
+          bool found = false;
+          for (auto &h : hist)
+            if (h.first == a) {
+              ++h.second;
+              found = true;
+              break;
+            }
+          if (!found && hist.size() < 4096)
+            hist.emplace_back(a, 1);
+        }
+      }
+      std::vector<uint32_t> v;
+      for (const auto &h : hist)
+        if (h.first >= 16 && h.second * 200 >= total)
+          v.push_back(h.first);
+      std::sort(v.begin(), v.end());
+      if (dim == 2 && v.size() >= 2)
+        return v[v.size() - 2];
+      if (dim == 3 && v.size() >= 12)
+        return v[v.size() - 5];
+      return 0;
+    }
+
     /* tile map (see TileDesc): call after build() */
     void build_tiles()
     {

@@ -59,6 +59,9 @@ namespace ryujin_hip
     const uint32_t *idx_t;     /* [nnz_total] */
     const TileDesc *tiles;     /* [slice_off[n_slices]] the tile map (host_layout.hpp), or NULL: explicit arrays only */
     uint32_t tail_queue_columns; /* min(63, widest row - 1): columns of the dynamic-LDS queue of undecided pairs (k_pij_lij) */
+    /* > 1: the four waves of a block take slices that are band_stride apart (one lattice row / plane of a structured
+     * patch) instead of four consecutive ones: row_context() */
+    uint32_t band_stride;
     const double *cij;         /* paired layout, DIM comps */
     const double *mij;
     const double *mi, *mi_inv;
@@ -397,7 +400,24 @@ namespace ryujin_hip
     r.lane = threadIdx.x & 63;
     const uint32_t block = blockIdx.x;
     /* slice, base and width are the same in all lanes of the wave: say so (scalar registers, scalar loop control) */
-    r.slice = __builtin_amdgcn_readfirstlane(M.slice_begin + block * kWavesPerBlock + (threadIdx.x >> 6));
+    uint32_t id = block * kWavesPerBlock + (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    /* STACKED BLOCKS. On a structured patch the rows a slice gathers from sit one lattice row (2-D) / one lattice
+     * plane (3-D) of the mesh above and below it -- band_stride slices away, served by whichever XCD's L2 happens to
+     * run those slices: every node's data is fetched ~3 times per sweep (profiles/r05k_pmc.md: step 5 moves 1.28x, step
+     * 2 1.9x its own bytes). With band_stride = G > 1 the four waves of a block take the slices s, s + G, s + 2G,
+     * s + 3G -- four rows (planes) stacked on top of each other -- so that three of the four vertical neighbour
+     * relations stay inside one workgroup, i.e. one L2: bands of 4G consecutive slices, block q of a band takes
+     * {q, q + G, q + 2G, q + 3G}; the remainder of the range keeps consecutive slices. Every slice is still taken by
+     * exactly one wave; nothing else depends on which one. */
+    if (M.band_stride > 1u) {
+      const uint32_t band = kWavesPerBlock * M.band_stride;
+      const uint32_t n = M.slice_end - M.slice_begin;
+      if (id < n - n % band) {
+        const uint32_t rem = id % band;
+        id = id - rem + rem / kWavesPerBlock + (rem % kWavesPerBlock) * M.band_stride;
+      }
+    }
+    r.slice = __builtin_amdgcn_readfirstlane(M.slice_begin + id);
     r.valid = r.slice < M.slice_end;
     if (!r.valid) {
       r.row = r.len = r.base = r.width = 0;

@@ -28,6 +28,14 @@
 
 #include "ryujin_hip.h"
 
+#ifndef RYUJIN_BAND_DEFAULT
+#define RYUJIN_BAND_DEFAULT 1 /* stacked blocks chosen from the mesh when ryujin_hip_params::debug_band_stride == 0, in 2-D:
+                                 C2 (G = 47) -1.1 % per update, every sweep a little; in 3-D stacking lattice planes (G = 365
+                                 on the C4 share) LOSES 1.7 % and stacking lattice rows (G = 2) is noise -- the re-fetches of
+                                 neighbour data across XCDs that the counters show are not what limits the sweeps
+                                 (profiles/r05p_ab_band_2d.log, r05p_ab_band_3d.log) */
+#endif
+
 #include "host_layout.hpp"
 #include "kernels_euler.hpp"
 #include "kernels_limiter.hpp"
@@ -771,6 +779,16 @@ void ryujin_hip_ctx::create(const ryujin_hip_offline &o, const ryujin_hip_params
   mesh.idx_t = d_idx_t.ptr;
   mesh.tiles = d_tiles.n != 0 ? d_tiles.ptr : nullptr;
   mesh.tail_queue_columns = std::max<uint32_t>(1u, std::min<uint32_t>(63u, L.max_row_len - 1u));
+  /* stacked blocks (row_context(), kernels_euler.hpp): debug_band_stride < 0 off, > 0 that many slices, 0 from the mesh */
+  mesh.band_stride = 1;
+  if (p.debug_band_stride > 0)
+    mesh.band_stride = (uint32_t)p.debug_band_stride;
+  else if (p.debug_band_stride == 0 && RYUJIN_BAND_DEFAULT && dim == 2) {
+    const uint32_t stride = L.lattice_stride(dim);
+    const uint32_t G = (stride + kWave / 2) / kWave;
+    if (G >= 2 && (uint64_t)G * kWavesPerBlock * 4 <= L.n_slices)
+      mesh.band_stride = G;
+  }
   mesh.cij = d_cij.ptr;
   mesh.mij = d_mij.ptr;
   mesh.incidence = dg ? d_incidence.ptr : nullptr;
@@ -2213,6 +2231,7 @@ void ryujin_hip_default_params(ryujin_hip_params *p, int equation, int dim)
   p->debug_pij_storage = 0;
   p->debug_expensive_bounds_check = 0;
   p->debug_tile_map = 0;
+  p->debug_band_stride = 0;
 }
 
 int ryujin_hip_comm_unique_id(char id[RYUJIN_HIP_UNIQUE_ID_BYTES])

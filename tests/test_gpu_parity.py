@@ -251,7 +251,8 @@ def test_near_vacuum_rows_keep_their_bounds_after_the_high_order_update(oracle):
 def test_tile_map_gives_the_same_bits_as_the_index_arrays(oracle):
     """The tile map (host_layout.hpp: TileDesc): column indices and transposed positions of structured 64-row tiles from
     a 16-byte descriptor in the 2-D sweeps 3, 5, 6, 7. Same indices, so the same bits as with the map switched off
-    (ryujin_hip_params::debug_tile_map = -1), stage-wise and through the device-resident driver, on a mesh whose rows
+    (ryujin_hip_params::debug_tile_map = -1; likewise the stacked slice-to-wave mapping, debug_band_stride = -1),
+    stage-wise and through the device-resident driver, on a mesh whose rows
     are mostly regular (Mach-3 step) and on one partition of it (export rows first: the ragged end of the numbering)."""
     for n_ranks, rank in ((1, 0), (3, 1)):
         spec = offline.mach3_step_2d(60, n_ranks=n_ranks, rank=rank)
@@ -263,6 +264,7 @@ def test_tile_map_gives_the_same_bits_as_the_index_arrays(oracle):
             p = oracle.default_params(capi.EQ_EULER, 2)
             p.cfl = 0.9
             p.debug_tile_map = switch
+            p.debug_band_stride = switch  # stacked blocks (row_context()): which wave takes which slice
             comm = None
             if n_ranks > 1:  # a middle rank on its own: the loopback communicator stands in for its neighbours
                 import ctypes as C
