@@ -31,7 +31,11 @@ def test_shim_compiles_and_links():
 @pytest.mark.gpu
 def test_shim_reproduces_mass_conservation_golden(golden_dir):
     from test_oracle_golden_integration import golden_mass_conservation
-    if not os.path.exists(EXE):
+    # (re)build unless the binary is newer than every header it was compiled against: a stale one would hand the
+    # library a ryujin_hip_params of an older layout
+    headers = [os.path.join(_build.INCLUDE, f) for f in os.listdir(_build.INCLUDE)] + \
+        [os.path.join(_build.CSRC, "hyperbolic_module_shim.hpp"), os.path.join(ROOT, "tests", "cpp", "shim_ssprk33.cc")]
+    if not os.path.exists(EXE) or os.path.getmtime(EXE) < max(os.path.getmtime(h) for h in headers):
         _build_exe()
     gold = golden_mass_conservation(golden_dir)
     outs = []
