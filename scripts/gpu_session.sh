@@ -3,6 +3,6 @@ set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$R"
 mkdir -p gpurun_out
-timeout 1800 python -m pytest tests -q -m gpu --durations=8 2>&1 | tail -24 > gpurun_out/r05n_pytest_gpu.txt
-cat gpurun_out/r05n_pytest_gpu.txt
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+rm -f gpurun_out/r05_parity_stats.jsonl
+RYUJIN_PARITY_STATS=$R/gpurun_out/r05_parity_stats.jsonl timeout 1200 python -m pytest tests/test_gpu_parity_fullsize.py -q -m gpu 2>&1 | tail -4
+wc -l gpurun_out/r05_parity_stats.jsonl
