@@ -156,11 +156,14 @@ typedef struct ryujin_hip_params {
    *   stencil); debug_bc_fold_max_slices: boundary conditions ride on the pre-pass kernel up to n slices of
    *   64 rows (0 = default 4096, < 0 = always a launch of their own); debug_no_small_mesh_split != 0: meshes
    *   that do not fill the device run the same step-5/6 kernels as large ones; debug_pij_storage: the matrix
-   *   P_ij of an update without stage vectors is stored everywhere, or -- while few 64-row slices hold a limited
-   *   pair -- per slice: where the slice held a limited pair in the previous update or one of its own l_ij comes
-   *   out limited, the rest completed where step 6 needs it (0: chosen from the measured fraction); > 0: always
-   *   per slice and no slice predicted limited (every stored slice goes through the trigger in step 5 or the
-   *   repair launch of step 6), < 0: always stored everywhere. */
+   *   P_ij of an update without stage vectors is stored only where steps 6 and 7 read it (0, the default): up to
+   *   two dimensions per (slice, column) tile of 64 entries -- where one of the tile's own l_ij comes out limited
+   *   or step 6 read the tile in one of the last updates; step 6 forms the few that are missing --, in 3-D per
+   *   64-row slice while few slices hold a limited pair (where the slice held one in the previous update or one of
+   *   its own l_ij comes out limited; the rest completed by the repair launch of step 6) and everywhere after
+   *   that. 1: always per slice and no slice predicted limited (every stored slice goes through the trigger in
+   *   step 5 or the repair launch of step 6); 2: per tile and no tile predicted (every tile the neighbour's l_ji
+   *   limits is formed by step 6; per slice as 1 in 3-D); < 0: always stored everywhere. */
   int system_scope_events;
   int debug_join_exchanges;
   int debug_bc_fold_max_slices;
@@ -433,7 +436,8 @@ int ryujin_hip_get_counters(ryujin_hip_ctx *ctx, unsigned *n_restarts, unsigned 
 /* What the data-dependent limiter sweeps saw between the two latest host synchronisations: the fraction of
  * (sampled) 64-row slices in which the first high-order sweep found a limited pair; how the latest step kept the
  * matrix P_ij (hyperbolic_module.template.h:795-846): 1 stored everywhere, 2 stored per slice -- only where steps
- * 6 and 7 read it; and the fraction of slices it was stored in. The results are the same bit for bit whatever is
+ * 6 and 7 read it --, 3 stored per (slice, column) tile (up to two dimensions); and the fraction
+ * of slices (tiles) it was stored in. The results are the same bit for bit whatever is
  * stored. Diagnostics; any pointer may be NULL. */
 int ryujin_hip_limiter_statistics(ryujin_hip_ctx *ctx, double *limited_slice_fraction, int *pij_stored,
                                   double *stored_slice_fraction);
@@ -442,6 +446,11 @@ int ryujin_hip_limiter_statistics(ryujin_hip_ctx *ctx, double *limited_slice_fra
  * not built: 3-D, debug_tile_map < 0). bench.py takes the index bytes the sweeps no longer read out of their own
  * compulsory bytes with it. Any pointer may be NULL. */
 int ryujin_hip_layout_info(ryujin_hip_ctx *ctx, unsigned long long *n_tiles, unsigned long long *n_regular_tiles);
+/* Where the latest step stored P_ij per tile (pij_stored == 3): of the (slice, column) tiles between the two latest
+ * host synchronisations, the fractions step 5 stored, step 6 read, and step 6 had to form itself because step 5 had
+ * not stored them (ryujin_amd/csrc/kernels_limiter_stage0.hpp). 1 / 1 / 0 otherwise. Any pointer may be NULL. */
+int ryujin_hip_tile_statistics(ryujin_hip_ctx *ctx, double *stored_fraction, double *read_fraction,
+                               double *formed_by_step6_fraction);
 
 /* ---- introspection for parity tests and profiling ------------------------ */
 /* Module-owned intermediates of the LAST step() in the reference's logical

@@ -93,6 +93,10 @@ namespace ryujin_hip
      * first high-order sweep, those of them in which some pair was limited, and every 16th slice whose P_ij step 5
      * stored (diagnostics: ryujin_hip_limiter_statistics) */
     unsigned int n_sampled_slices, n_sampled_limited, n_sampled_stored;
+    /* ... and, where step 5 stores P_ij per tile, the tiles of every 16th slice and those of them it stored */
+    unsigned int n_sampled_tiles, n_sampled_tiles_stored;
+    /* ... those step 6 read, and those of them it had to form itself (step 5 had not stored them) */
+    unsigned int n_sampled_tiles_needed, n_sampled_tiles_formed;
   };
   constexpr int kStageCode = 100;
 

@@ -557,9 +557,15 @@ namespace ryujin_hip
 
   /* where the repair launch of step 6 (k_pij_repair) and the debug fetch take P_ij from for the columns step 5 did
    * not store: the operands of pij_stage0 */
+#ifndef RYUJIN_TILE_PIJ_MAXDIM
+#define RYUJIN_TILE_PIJ_MAXDIM 2 /* per-tile P_ij up to this dimension (3-D: the repair path costs step 6 its fourth wave per SIMD, 124 -> 156 registers) */
+#endif
   struct Stage0Src {
     DeviceScalars *scalars; /* tau; and the limited-slice counters of step 6 */
     const double *old_U, *alpha, *dij, *r_in;
+    /* != 0: step 5 stored P_ij PER TILE -- a (slice, column) tile iff one of its own l_ij came out limited (or went to
+     * the Newton tail) --; step 6 forms and stores what it needs of the rest (next_cached_slice) */
+    int tile_store;
   };
 
   template <int K>
@@ -754,7 +760,28 @@ namespace ryujin_hip
    *                 2 the repair launch has to complete it first. */
   struct SliceFlags {
     uint8_t *unlimited, *first_stored, *todo;
+    /* [n_slices] bit c: step 6 of the last update read P_ij of the (slice, column c) tile; bits 10 + c, 20 + c: of the
+     * update before, and the one before that (an SSPRK33 step is three updates, and what its stages limit differs) */
+    uint32_t *needed_tiles;
   };
+
+#ifndef RYUJIN_TILE_PIJ_GENERATIONS
+#define RYUJIN_TILE_PIJ_GENERATIONS 3
+#endif
+  /* the tiles step 5 stores on the strength of the last updates (widths up to 10: the 2-D stencils) */
+  RYUJIN_DEV uint32_t tiles_predicted(const uint32_t word)
+  {
+    uint32_t m = word & 0x3ffu;
+    if (RYUJIN_TILE_PIJ_GENERATIONS >= 2)
+      m |= (word >> 10) & 0x3ffu;
+    if (RYUJIN_TILE_PIJ_GENERATIONS >= 3)
+      m |= (word >> 20) & 0x3ffu;
+    return m;
+  }
+  RYUJIN_DEV uint32_t tiles_remembered(const uint32_t word, const uint32_t needed)
+  {
+    return ((word << 10) | (needed & 0x3ffu)) & 0x3fffffffu;
+  }
 
   /* form and store the P_ij of the columns [1, c_end) of the row (the repair launch of step 6,
    * ryujin_hip_debug_fetch): exactly the value step 5 formed (same function, same operands) */
@@ -965,7 +992,12 @@ namespace ryujin_hip
 
     double p[CP][K];
     uint32_t needed = 0; /* wave-uniform: bit c <=> some pair of the (slice, column) tile is limited */
+    uint32_t own_limited = 0; /* ... <=> one of the tile's OWN l_ij is (the tiles step 5 stored with Stage0Src::tile_store) */
     if (V_unlimited != nullptr) {
+      /* what step 5 stored besides: the tiles this sweep needed in the previous update (read before it is replaced) */
+      const bool tiles = MODE == kHoPlain && !SPLIT && S0.tile_store != 0 && W.needed_tiles != nullptr;
+      const uint32_t history = tiles ? W.needed_tiles[r.slice] : 0u;
+      const uint32_t predicted = tiles_predicted(history);
       /* Step 5 left V_i = U_i^low + sum_j lambda P_ij, accumulated exactly as the reference accumulates the update
        * when every l_ij is 1 (k_lij_stage0). If no pair of the slice was limited -- wave-uniform -- that IS the
        * new U_i bit for bit, the second pass stores (1 - l) l' = 0, and P_ij is not read at all. */
@@ -983,6 +1015,8 @@ namespace ryujin_hip
           limited = limited || lim;
           if (__any(lim))
             needed |= 1u << c;
+          if (__any(lane_on && !(l_a == 1.)))
+            own_limited |= 1u << c;
         }
       }
       const bool slice_limited = needed != 0u;
@@ -996,6 +1030,8 @@ namespace ryujin_hip
       }
       if (W.unlimited != nullptr && r.lane == 0 && (!SPLIT || group == 0))
         W.unlimited[r.slice] = slice_limited ? 0 : 1;
+      if (tiles && r.lane == 0)
+        W.needed_tiles[r.slice] = tiles_remembered(history, needed);
       load_state<K>(V_unlimited, i, U_i_new);
       if (!slice_limited) {
         if (row_active) {
@@ -1007,6 +1043,32 @@ namespace ryujin_hip
               st_stream(lij_next + ((r.base + c) * 64 + r.lane), 0.);
         }
         return;
+      }
+      if constexpr (MODE == kHoPlain && !SPLIT && E::DIMENSION <= RYUJIN_TILE_PIJ_MAXDIM) {
+        /* P_ij stored per tile by step 5 (Stage0Src::tile_store): a tile this sweep needs -- some pair limited after
+         * the symmetrisation -- that step 5 did not store -- none of its OWN l_ij limited, the limit came from the
+         * neighbour's l_ji, which step 5 cannot see -- is formed here, exactly as step 5 forms it (pij_stage0 on the
+         * same operands: the same bits), and stored: the loads below, the second limiter pass, its Newton tail and
+         * step 7 then find it in the matrix like every other tile. (A tile whose own pairs all went to the tail and
+         * came back with l = 1 is stored already and merely written again.) */
+        const uint32_t missing = S0.tile_store != 0 ? (needed & ~(own_limited | predicted)) : 0u; /* wave-uniform */
+        if (tiles && (r.slice & 15u) == 0 && r.lane == 0) {
+          atomicAdd(&S0.scalars->n_sampled_tiles_needed, (unsigned int)__popc(needed));
+          atomicAdd(&S0.scalars->n_sampled_tiles_formed, (unsigned int)__popc(missing));
+        }
+        if (missing != 0u) {
+          RowData<K> row;
+          load_row_data<K>(M, S0, i, r.len, row);
+#pragma unroll 1
+          for (uint32_t c = 1; c < r.width; ++c) {
+            if (!((missing >> c) & 1u))
+              continue;
+            double P_t[K];
+            pij_on_the_fly<K>(M, S0, row, (uint64_t)r.base + c, r.lane, P_t);
+            if (row_active && c < r.len)
+              store_entry<K>(pij, (uint64_t)r.base + c, r.lane, P_t);
+          }
+        }
       }
       if constexpr (E::kLimitedUpdateFromV) {
         /* U_i = V_i - sum over the limited tiles of (1 - l_ij) lambda P_ij: P_ij of those tiles only.

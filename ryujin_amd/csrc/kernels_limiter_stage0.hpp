@@ -85,7 +85,7 @@ namespace ryujin_hip
                const double *__restrict__ dij, const double *__restrict__ new_U,
                const double *__restrict__ r_in, const double *__restrict__ bounds, double *__restrict__ pij,
                double *__restrict__ lij, double *__restrict__ V_out, const SliceFlags W = SliceFlags{},
-               const int predict_override = 0)
+               const int predict_override = 0, const int tile_store = 0)
   {
     static_assert(!PER_SLICE || NY == 1, "one wave per slice decides");
     constexpr int K = E::K;
@@ -134,6 +134,18 @@ namespace ryujin_hip
     uint32_t first_stored = c0;
     if constexpr (PER_SLICE)
       storing = predict_override < 0 || (predict_override == 0 && W.unlimited[r.slice] == 0);
+    /* PER TILE (plain kernels, NY == 1; the host's choice, Stage0Src::tile_store): a (slice, column) tile is stored
+     * iff one of its own l_ij comes out limited or goes to the Newton tail -- behind the limiter, wave-uniformly.
+     * Steps 6/7 read P_ij only in tiles that hold a limited pair after the symmetrisation; the tiles that are limited
+     * through the neighbour's l_ji alone are formed by step 6 (next_cached_slice). On the developed C2 flow 93 % of the
+     * slices but 43 % of the tiles hold a limited pair: most of the 8 k S bytes per row this sweep used to write were
+     * never read. */
+    const bool tile_mode = !PER_SLICE && NY == 1 && tile_store != 0;
+    uint32_t tiles_stored = 0;
+    /* ... or step 6 of the PREVIOUS update needed it (SliceFlags::needed_tiles, bit c of the slice's word): fronts
+     * move a fraction of a cell per update, so this predicts nearly every tile that is limited through l_ji alone,
+     * and step 6 forms what is left (a tile predicted in vain costs its store, as before). */
+    const uint32_t predicted = (tile_mode && W.needed_tiles != nullptr) ? tiles_predicted(W.needed_tiles[r.slice]) : 0u;
 
     /* software pipeline: the loads of the next column are in flight while column c is limited */
     /* (the column index of a structured tile is row + delta of the tile's descriptor, kernels_euler.hpp: no index
@@ -158,7 +170,9 @@ namespace ryujin_hip
         load_pair<K>(M, old_U, r_in, alpha, dij, (colbase + NY) * 64 + r.lane, j_n, next);
       }
       /* a slice that stores already: as soon as P_ij is formed (the store overlaps the limiter) */
-      const bool stored_early = storing;
+      const bool stored_early = storing && (!tile_mode || ((predicted >> c) & 1u) != 0u);
+      if (tile_mode && stored_early)
+        ++tiles_stored;
       if (stored_early && active)
         store_entry<K>(pij, colbase, r.lane, P_ij);
       bool success = true, undecided = false;
@@ -178,6 +192,11 @@ namespace ryujin_hip
           first_stored = c;
         }
       }
+      if (tile_mode && !stored_early && __any(active && (undecided || !(l_ij == 1.)))) {
+        ++tiles_stored;
+        if (active)
+          store_entry<K>(pij, colbase, r.lane, P_ij);
+      }
       if (!active)
         continue;
       if constexpr (PER_SLICE) {
@@ -194,6 +213,10 @@ namespace ryujin_hip
     if (NY == 1 && V_out != nullptr && row_active)
       store_state<K>(V_out, i, V_i);
 
+    if (tile_mode && (r.slice & 15u) == 0 && r.lane == 0 && r.width > 1) {
+      atomicAdd(&scalars->n_sampled_tiles, r.width - 1);
+      atomicAdd(&scalars->n_sampled_tiles_stored, tiles_stored);
+    }
     if constexpr (PER_SLICE) {
       if (r.lane == 0) {
         W.first_stored[r.slice] = storing ? (uint8_t)first_stored : 0;
@@ -230,7 +253,7 @@ namespace ryujin_hip
     const RowCtx r = row_context(M);
     if (!r.valid || r.len <= 1)
       return;
-    const uint32_t fs = first_stored[r.slice];
+    const uint32_t fs = first_stored != nullptr ? first_stored[r.slice] : 0u; /* NULL: stored per tile, form all */
     if (fs == 1)
       return;
     backfill_pij<E::K>(M, S0, r, pij, fs == 0 ? 0xffffffffu : fs);

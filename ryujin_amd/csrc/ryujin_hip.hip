@@ -28,6 +28,9 @@
 
 #include "ryujin_hip.h"
 
+#ifndef RYUJIN_TILE_PIJ
+#define RYUJIN_TILE_PIJ 1 /* the plain kernels (most slices limited) store P_ij per (slice, column) tile */
+#endif
 #ifndef RYUJIN_BAND_DEFAULT
 #define RYUJIN_BAND_DEFAULT 1 /* stacked blocks chosen from the mesh when ryujin_hip_params::debug_band_stride == 0, in 2-D:
                                  C2 (G = 47) -1.1 % per update, every sweep a little; in 3-D stacking lattice planes (G = 365
@@ -463,17 +466,26 @@ struct ryujin_hip_ctx {
   /* the last step stored P_ij per slice (per_slice below): ryujin_hip_debug_fetch forms it from these operands for
    * the slices the sweeps left out */
   bool last_per_slice = false;
+  bool last_tile_store = false; /* the last step stored P_ij per tile (plain kernels): debug_fetch forms the rest */
   Stage0Src last_s0{};
   /* SliceFlags (kernels_limiter.hpp), [n_slices] each; `unlimited` starts at 0 = "limited": the first update of a
    * context stores P_ij everywhere */
   DeviceBuffer<uint8_t> d_slice_unlimited, d_slice_first_stored, d_slice_todo;
+  DeviceBuffer<uint32_t> d_slice_needed; /* SliceFlags::needed_tiles; starts as all ones: the first update stores every tile */
   /* fractions of the (sampled) slices in which the first high-order sweep found a limited pair / whose P_ij step 5
    * stored, from the device counters at the latest host synchronisation (DeviceScalars::n_sampled_*); 1 until the
    * first measurement. Diagnostics only: nothing is decided from them. */
   double limited_fraction = 1., stored_fraction = 1.;
   unsigned int seen_sampled_slices = 0, seen_sampled_limited = 0, seen_sampled_stored = 0;
+  unsigned int seen_sampled_tiles = 0, seen_sampled_tiles_stored = 0;
+  unsigned int seen_sampled_tiles_needed = 0, seen_sampled_tiles_formed = 0;
+  double tiles_needed_fraction = 1., tiles_formed_fraction = 0.; /* of the tiles: read by step 6; formed there */
   void update_limited_fraction()
   {
+    const unsigned int d_tiles = h_scalars->n_sampled_tiles - seen_sampled_tiles;
+    const unsigned int d_tiles_stored = h_scalars->n_sampled_tiles_stored - seen_sampled_tiles_stored;
+    seen_sampled_tiles = h_scalars->n_sampled_tiles;
+    seen_sampled_tiles_stored = h_scalars->n_sampled_tiles_stored;
     const unsigned int d_slices = h_scalars->n_sampled_slices - seen_sampled_slices;
     const unsigned int d_limited = h_scalars->n_sampled_limited - seen_sampled_limited;
     const unsigned int d_stored = h_scalars->n_sampled_stored - seen_sampled_stored;
@@ -483,6 +495,15 @@ struct ryujin_hip_ctx {
     if (d_slices != 0) {
       limited_fraction = (double)d_limited / (double)d_slices;
       stored_fraction = last_per_slice ? (double)d_stored / (double)d_slices : 1.;
+    }
+    const unsigned int d_needed = h_scalars->n_sampled_tiles_needed - seen_sampled_tiles_needed;
+    const unsigned int d_formed = h_scalars->n_sampled_tiles_formed - seen_sampled_tiles_formed;
+    seen_sampled_tiles_needed = h_scalars->n_sampled_tiles_needed;
+    seen_sampled_tiles_formed = h_scalars->n_sampled_tiles_formed;
+    if (last_tile_store && d_tiles != 0) { /* (of the tiles, by step 5; step 6 adds the few it has to form itself) */
+      stored_fraction = (double)d_tiles_stored / (double)d_tiles;
+      tiles_needed_fraction = (double)d_needed / (double)d_tiles;
+      tiles_formed_fraction = (double)d_formed / (double)d_tiles;
     }
   }
   void ensure_pij()
@@ -1154,7 +1175,7 @@ void ryujin_hip_ctx::store_pij_for_debug()
   mm.slice_end = L.n_slices;
   const dim3 grid((L.n_slices + kWavesPerBlock - 1) / kWavesPerBlock), block(kBlock);
   hipLaunchKernelGGL(k_pij_stage0_store<E>, grid, block, 0, stream, mm, last_s0, d_pij.ptr,
-                     (const uint8_t *)d_slice_first_stored.ptr);
+                     last_per_slice ? (const uint8_t *)d_slice_first_stored.ptr : (const uint8_t *)nullptr);
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipStreamSynchronize(stream));
 }
@@ -1486,8 +1507,20 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
    * the first: the first update of a context runs the plain kernels). */
   const bool per_slice_possible =
       RYUJIN_PER_SLICE_PIJ && stage0_pij && params.limiter_iterations == 2 && step5_groups < 2;
+  /* Up to two dimensions, finer still: PER TILE. Step 5 stores a (slice, column) tile iff one of its own l_ij comes
+   * out limited or step 6 read the tile in one of the last updates (SliceFlags::needed_tiles); step 6 -- one launch,
+   * the plain kernel -- forms the few tiles that are limited through the neighbour's l_ji alone and were not
+   * predicted (kernels_limiter_stage0.hpp, next_cached_slice). On the Mach-3 step a third to 45 % of the tiles are
+   * stored where 71 - 93 % of the slices would be, and the update is faster than with either alternative at every
+   * stage of the flow (profiles/r05t_ab_tile_*). debug_pij_storage: 0 this; 2 per tile with nothing predicted (tests:
+   * every tile the neighbour's l_ji limits goes through step 6's repair); 1 per slice, nothing predicted; < 0
+   * everywhere, as rounds 1 - 4. Not with the checked build (its kernels read all of P_ij). In 3-D the repair path
+   * would cost step 6 its fourth wave per SIMD (RYUJIN_TILE_PIJ_MAXDIM): per slice there. */
+  const bool tile_store = RYUJIN_TILE_PIJ && DIM <= RYUJIN_TILE_PIJ_MAXDIM && per_slice_possible &&
+                          (params.debug_pij_storage == 0 || params.debug_pij_storage == 2) &&
+                          !params.debug_expensive_bounds_check;
   const bool per_slice =
-      per_slice_possible && params.debug_pij_storage >= 0 && !params.debug_expensive_bounds_check &&
+      per_slice_possible && !tile_store && params.debug_pij_storage >= 0 && !params.debug_expensive_bounds_check &&
       (params.debug_pij_storage > 0 || limited_fraction <= (double)RYUJIN_PER_SLICE_MAX_LIMITED);
   ensure_pij();
   if (per_slice && d_slice_first_stored.n == 0) {
@@ -1496,7 +1529,15 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
   }
   const SliceFlags slice_flags{d_slice_unlimited.ptr, d_slice_first_stored.ptr, d_slice_todo.ptr};
   last_per_slice = per_slice;
-  last_s0 = Stage0Src{d_scalars.ptr, old.U.ptr, d_alpha.ptr, d_dij.ptr, d_r.ptr};
+  last_tile_store = tile_store;
+  const bool tiles_predicted_from_history = tile_store && params.debug_pij_storage == 0;
+  if (tiles_predicted_from_history && d_slice_needed.n == 0) { /* all ones: the first update stores every tile */
+    d_slice_needed.alloc(L.n_slices);
+    HIP_CHECK(hipMemsetAsync(d_slice_needed.ptr, 0xff, (size_t)L.n_slices * sizeof(uint32_t), launch_stream));
+  }
+  const SliceFlags tile_flags{nullptr, nullptr, nullptr,
+                              tiles_predicted_from_history ? d_slice_needed.ptr : nullptr};
+  last_s0 = Stage0Src{d_scalars.ptr, old.U.ptr, d_alpha.ptr, d_dij.ptr, d_r.ptr, tile_store ? 1 : 0};
   sweep([&](const DeviceMesh &mm, dim3 grid) {
     if constexpr (is_euler) {
       if (dg && stages == 0)
@@ -1643,7 +1684,9 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
             constexpr int NY = decltype(ny)::value;
             hipLaunchKernelGGL((k_lij_stage0<E, NY>), dim3(grid.x, NY), block, 0, launch_stream, eparams, mm,
                                d_scalars.ptr, old.U.ptr, d_alpha.ptr, d_dij.ptr, nw.U.ptr, d_r.ptr, d_bounds.ptr,
-                               d_pij.ptr, d_lij.ptr, NY == 1 ? d_V.ptr : nullptr);
+                               d_pij.ptr, d_lij.ptr, NY == 1 ? d_V.ptr : nullptr,
+                               SliceFlags{nullptr, nullptr, nullptr, tile_flags.needed_tiles}, 0,
+                               (NY == 1 && tile_store) ? 1 : 0);
             stage0_V = NY == 1 && d_V.ptr != nullptr;
           };
           if (per_slice) {
@@ -1771,7 +1814,9 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
         if constexpr (DIM <= 2) {
           /* small meshes: the four waves of a block share one slice (see the kernel) while all of them fit */
           const uint32_t n_launch = mm.slice_end - mm.slice_begin;
-          if (L.max_row_len <= (uint32_t)kCachedWidth && n_launch * kWavesPerBlock <= resident_waves_step6) {
+          if (!tile_store && L.max_row_len <= (uint32_t)kCachedWidth && n_launch * kWavesPerBlock <= resident_waves_step6) {
+            /* (not with P_ij stored per tile: the export part of a large mesh may be this small, and the split
+             * variant does not form the tiles step 5 left out) */
             hipLaunchKernelGGL((k_high_order_next_cached<E, kCachedWidth, kCachedWidth, true>), dim3(n_launch),
                                block, 0, launch_stream, eparams, mm, nw.U.ptr, d_bounds.ptr, d_pij.ptr,
                                d_lij.ptr, d_lij_next.ptr, stage0_V ? d_V.ptr : nullptr, last_s0,
@@ -1784,7 +1829,8 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
           hipLaunchKernelGGL((k_high_order_next_cached<E, kCachedWidth, kCachedP>), grid, block, 0,
                              launch_stream, eparams, mm, nw.U.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr,
                              d_lij_next.ptr, stage0_V ? d_V.ptr : nullptr, last_s0,
-                             SliceFlags{stage0_V ? d_slice_unlimited.ptr : nullptr, nullptr, nullptr});
+                             SliceFlags{stage0_V ? d_slice_unlimited.ptr : nullptr, nullptr, nullptr,
+                                        tile_flags.needed_tiles});
           step6_flags = stage0_V;
         } else if (L.max_row_len > 64)
           hipLaunchKernelGGL((k_high_order<E, false, true>), grid, block, 0, launch_stream, eparams, mm, nw.U.ptr,
@@ -2791,9 +2837,26 @@ int ryujin_hip_limiter_statistics(ryujin_hip_ctx *ctx, double *limited_slice_fra
     if (limited_slice_fraction)
       *limited_slice_fraction = ctx->limited_fraction;
     if (pij_stored)
-      *pij_stored = ctx->last_per_slice ? 2 : 1;
+      *pij_stored = ctx->last_per_slice ? 2 : (ctx->last_tile_store ? 3 : 1);
     if (stored_slice_fraction)
       *stored_slice_fraction = ctx->stored_fraction;
+    return RYUJIN_OK;
+  });
+}
+
+int ryujin_hip_tile_statistics(ryujin_hip_ctx *ctx, double *stored_fraction, double *read_fraction,
+                               double *formed_by_step6_fraction)
+{
+  return guarded([&]() {
+    if (!ctx)
+      throw HipError(RYUJIN_ERR_ARG, "null context");
+    const bool tiles = ctx->last_tile_store;
+    if (stored_fraction)
+      *stored_fraction = tiles ? ctx->stored_fraction : 1.;
+    if (read_fraction)
+      *read_fraction = tiles ? ctx->tiles_needed_fraction : 1.;
+    if (formed_by_step6_fraction)
+      *formed_by_step6_fraction = tiles ? ctx->tiles_formed_fraction : 0.;
     return RYUJIN_OK;
   });
 }
@@ -2828,7 +2891,7 @@ int ryujin_hip_debug_fetch(ryujin_hip_ctx *ctx, int what, double *out, size_t n_
     case 1: fetch_matrix(ctx->d_lij.ptr, 1); break;
     case 2:
       ctx->ensure_pij();
-      if (ctx->last_per_slice)
+      if (ctx->last_per_slice || ctx->last_tile_store)
         dispatch_equation(ctx->params.equation, ctx->dim, [&](auto tag) {
           using E = typename decltype(tag)::type;
           if constexpr (std::is_same<typename E::Params, EulerParams>::value ||

@@ -287,8 +287,15 @@ class HyperbolicModule:
         fn = self._f("limiter_statistics")
         fn.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double)]
         self._check(fn(self._ctx, C.byref(f), C.byref(stored), C.byref(fs)))
-        return dict(limited_slice_fraction=f.value, pij_stored={1: "everywhere", 2: "per slice"}.get(stored.value),
-                    pij_stored_slice_fraction=fs.value)
+        out = dict(limited_slice_fraction=f.value,
+                   pij_stored={1: "everywhere", 2: "per slice", 3: "per tile"}.get(stored.value),
+                   pij_stored_slice_fraction=fs.value)
+        if stored.value == 3:
+            # of the (slice, column) tiles: stored by step 5, read by step 6, formed by step 6 (ryujin_hip_tile_statistics)
+            a, b, c = C.c_double(1.0), C.c_double(1.0), C.c_double(0.0)
+            self._check(self._lib.ryujin_hip_tile_statistics(self._ctx, C.byref(a), C.byref(b), C.byref(c)))
+            out.update(tiles_stored_fraction=a.value, tiles_read_fraction=b.value, tiles_formed_by_step6_fraction=c.value)
+        return out
 
     def layout_info(self) -> dict:
         """tiles (64-entry columns of the SELL-64 slices) of the owned rows and how many the tile map serves from a

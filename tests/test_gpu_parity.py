@@ -1872,13 +1872,19 @@ def test_unstructured_p1_mesh_scalar_conservation(oracle):
 
 @pytest.mark.parametrize("which", ["euler_2d", "euler_1d", "euler_erk33", "sw_2d", "sw_1d", "aeos_2d", "scalar_2d",
                                    "euler_2d:no_prediction", "euler_1d:no_prediction", "euler_erk33:no_prediction",
-                                   "aeos_2d:no_prediction", "euler_2d:always_store", "aeos_2d:always_store"])
+                                   "aeos_2d:no_prediction", "euler_2d:always_store", "aeos_2d:always_store",
+                                   "euler_2d:no_tile_prediction", "euler_1d:no_tile_prediction",
+                                   "aeos_2d:no_tile_prediction"])
 def test_step_parity_with_the_kernels_of_large_meshes(oracle, monkeypatch, which):
     """The meshes of this file do not fill an MI355X, so they take the small-mesh branches of the library
     (boundary conditions folded into the pre-pass, steps 5 and 6 with the columns of a slice spread over several
     waves). Re-run one case per Description with those branches switched off: the kernels BASELINE-sized meshes
     run (also covered at full size for Euler and shallow water in test_gpu_parity_fullsize.py).
-    An update without stage vectors stores P_ij per 64-row slice there (kernels_limiter_stage0.hpp): where the slice
+    An update without stage vectors stores P_ij only where steps 6 and 7 read it (kernels_limiter_stage0.hpp). Up to
+    two dimensions per (slice, column) tile -- the default: where one of the tile's own l_ij comes out limited or step 6
+    read the tile in one of the last updates, step 6 forming what is missing; `:no_tile_prediction` predicts no tile
+    (every tile that the neighbour's l_ji alone limits goes through step 6's repair). Per 64-row slice (3-D, and
+    `:no_prediction` here): where the slice
     held a limited pair in the previous update -- the first update of a context stores everywhere --, or where one
     of its own l_ij comes out limited (stored from that column on, the columns before it formed a second time);
     a slice limited through a neighbour's l_ji alone gets its P_ij from the repair prologue of step 6, which runs as a
@@ -1888,7 +1894,7 @@ def test_step_parity_with_the_kernels_of_large_meshes(oracle, monkeypatch, which
     switches = {"debug_no_small_mesh_split": 1, "debug_bc_fold_max_slices": -1}
     which, _, variant = which.partition(":")
     if variant:
-        switches["debug_pij_storage"] = {"no_prediction": 1, "always_store": -1}[variant]
+        switches["debug_pij_storage"] = {"no_prediction": 1, "always_store": -1, "no_tile_prediction": 2}[variant]
     monkeypatch.setattr(HyperbolicModule, "library_switches", switches)
     {
         "euler_2d": lambda: test_step_parity_2d_step_geometry(oracle),

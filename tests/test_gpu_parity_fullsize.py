@@ -110,16 +110,16 @@ def _bench_state(oracle, key, label, fetch_pij, limited_slices, develop_time=Non
 
 
 def test_c2_bench_state(oracle):
-    """the headline: t = 2.0 of the Mach-3 step, 93 % of the slices limited, plain kernels (P_ij stored everywhere)"""
+    """the headline: t = 2.0 of the Mach-3 step, 93 % of the slices limited, plain kernels, P_ij stored per tile"""
     off, g, c, stats = _bench_state(oracle, "step2d", "bench_c2", True, (0.89, 0.97))
     assert off.n_owned == 2498844
-    assert stats["pij_stored"] == "everywhere"
+    assert stats["pij_stored"] == "per tile"
 
 
 def test_c2_bench_state_t1(oracle):
-    """bench.py --develop-time 1.0: 73 % limited, P_ij stored per slice + the repair launch"""
+    """bench.py --develop-time 1.0: 73 % of the slices limited, a third of the tiles stored"""
     off, g, c, stats = _bench_state(oracle, "step2d", "bench_c2_t1", True, (0.68, 0.79), develop_time=1.0)
-    assert stats["pij_stored"] == "per slice"
+    assert stats["pij_stored"] == "per tile"
 
 
 def test_c3_bench_state(oracle):
