@@ -79,10 +79,17 @@ for v in args.variants:
     lib.ryujin_hip_event_elapsed_ms.argtypes = [C.c_void_p, capi.c_double_p]
     p = capi.Params()
     lib.ryujin_hip_default_params(C.byref(p), equation, off.dim)
+    env = {}
     for kv in filter(None, switches.split(",")):
         key, value = kv.split("=")
-        setattr(p, key, int(value))
+        if key.startswith("env."):  # an environment variable the library reads when the context is created
+            env[key[4:]] = value
+        else:
+            setattr(p, key, int(value))
+    os.environ.update(env)
     m = HyperbolicModule(off, p, backend=(lib, "ryujin_hip_"))
+    for key in env:
+        del os.environ[key]
     m.cfl = 0.9
     if U_dev is None:
         d = Ssprk33Stages(m, U0, dirichlet)
