@@ -52,8 +52,13 @@ def test_committed_bench_lines_follow_the_contract(path):
     if "reference_structure" in r:   # from r03x on: the numerator is what THIS implementation's kernel touches once
         assert 0.0 < r["frac"] <= 1.0 and r["reference_structure"]["frac"] >= r["frac"]
         assert r["traffic_frac"] is None or r["frac"] <= r["traffic_frac"] * 1.02 <= 1.02
-        assert d["limiter"]["pij_stored"] in (True, False, "everywhere", "per slice", "all", "tiles")  # (bool: round 3;
-        # "all" / "tiles": the tile-storage experiment of round 4, profiles/r04c_*)
+        assert d["limiter"]["pij_stored"] in (True, False, "everywhere", "per slice", "per tile", "all", "tiles")
+        # (bool: round 3; "all" / "tiles": the tile-storage experiment of round 4, profiles/r04c_*; "per tile": the
+        # per-tile storage of round 5, with the stored / read / formed-by-step-6 fractions of the tiles next to it)
+        if d["limiter"]["pij_stored"] == "per tile":
+            lm = d["limiter"]
+            assert 0.0 <= lm["tiles_formed_by_step6_fraction"] <= lm["tiles_read_fraction"] <= 1.0
+            assert lm["tiles_read_fraction"] <= lm["tiles_stored_fraction"] + lm["tiles_formed_by_step6_fraction"] + 1e-12
         assert 0.0 <= d["limiter"]["limited_slice_fraction"] <= 1.0
     # value is consistent with the time per step and the size of the job
     dofs = d["config"]["dofs_total"]
