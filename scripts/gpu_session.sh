@@ -3,8 +3,6 @@ set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$R"
 mkdir -p gpurun_out
-timeout 120 python bench.py > gpurun_out/r05w_bench_as_the_driver_runs_it.json 2> gpurun_out/r05w_bench.err
-tail -c 300 gpurun_out/r05w_bench_as_the_driver_runs_it.json
-timeout 900 python -m pytest tests -q -m gpu --durations=15 > gpurun_out/r05w_pytest_gpu.txt 2>&1
-tail -3 gpurun_out/r05w_pytest_gpu.txt
-timeout 60 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+timeout 100 python -m pytest tests/test_gpu_parity_fullsize.py tests/test_gpu_parity.py -q -m gpu -x -k "test_c2_bench_state or (large_meshes and euler_2d)" 2>&1 | tail -3 | tee gpurun_out/r05z_pytest_focus.txt
+grep -q "passed" gpurun_out/r05z_pytest_focus.txt && ! grep -q "failed" gpurun_out/r05z_pytest_focus.txt || exit 1
+bash scripts/profile_round.sh r05z step2d 2>&1 | tail -3
