@@ -188,6 +188,15 @@ typedef struct ryujin_hip_params {
    * DESIGN.md section 3); > 0: that many slices; < 0: off. Results are identical: every slice is processed by exactly
    * one wave either way. */
   int debug_band_stride;
+  /* XCD-local block ranges: the hardware deals the workgroups of a launch out to the eight XCDs round robin (block b
+   * runs on XCD b % 8 -- observed, relied on for speed only), so that the rows one L2 serves are scattered over the
+   * whole mesh and every L2 fetches every node's data. With debug_xcd_chunk = C > 0 the blocks of a launch are
+   * renumbered in chunks of 8 C: inside a chunk XCD x takes the C consecutive blocks [x C, (x + 1) C) -- each L2
+   * then serves a contiguous range of 4 C slices at a time, and the eight XCDs still advance through the mesh
+   * together, chunk by chunk (one contiguous eighth of the mesh per XCD would put a shock on one XCD).
+   * 0: chosen by the library; < 0: off. Results are identical: every slice is processed by
+   * exactly one wave either way (ryujin_amd/csrc/kernels_euler.hpp, row_context()). */
+  int debug_xcd_chunk;
 } ryujin_hip_params;
 
 /* ---- offline data (input contract) ------------------------------------- */

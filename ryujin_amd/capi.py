@@ -68,6 +68,7 @@ class Params(C.Structure):
         ("debug_bc_fold_max_slices", C.c_int), ("debug_no_small_mesh_split", C.c_int),
         ("debug_pij_storage", C.c_int), ("debug_expensive_bounds_check", C.c_int),
         ("debug_tile_map", C.c_int), ("debug_band_stride", C.c_int),
+        ("debug_xcd_chunk", C.c_int),
     ]
 
 

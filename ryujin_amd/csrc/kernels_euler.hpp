@@ -62,6 +62,9 @@ namespace ryujin_hip
     /* > 1: the four waves of a block take slices that are band_stride apart (one lattice row / plane of a structured
      * patch) instead of four consecutive ones: row_context() */
     uint32_t band_stride;
+    /* > 0: blocks renumbered in chunks of 8 * xcd_chunk so that each XCD takes xcd_chunk consecutive blocks of a chunk
+     * (ryujin_hip_params::debug_xcd_chunk): row_context() */
+    uint32_t xcd_chunk;
     const double *cij;         /* paired layout, DIM comps */
     const double *mij;
     const double *mi, *mi_inv;
@@ -402,7 +405,19 @@ namespace ryujin_hip
   {
     RowCtx r;
     r.lane = threadIdx.x & 63;
-    const uint32_t block = blockIdx.x;
+    uint32_t block = blockIdx.x;
+    /* XCD-LOCAL BLOCK RANGES. Block b runs on XCD b % 8 (observed; speed only): consecutive blocks -- consecutive
+     * slices, whose rows gather from the same lattice rows and planes -- land on eight different L2s, and every L2
+     * ends up fetching every node's data. Renumbered in chunks of 8 C blocks, XCD x takes the C consecutive blocks
+     * [x C, (x + 1) C) of a chunk: the rows one L2 serves at a time are a contiguous range. The tail of the launch
+     * that does not fill a chunk keeps its numbering. */
+    if (M.xcd_chunk > 0u) {
+      const uint32_t span = 8u * M.xcd_chunk;
+      if (block < gridDim.x - gridDim.x % span) {
+        const uint32_t rem = block % span;
+        block = block - rem + (rem & 7u) * M.xcd_chunk + (rem >> 3);
+      }
+    }
     /* slice, base and width are the same in all lanes of the wave: say so (scalar registers, scalar loop control) */
     uint32_t id = block * kWavesPerBlock + (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     /* STACKED BLOCKS. On a structured patch the rows a slice gathers from sit one lattice row (2-D) / one lattice

@@ -32,6 +32,9 @@
 #define RYUJIN_TILE_PIJ 1 /* the plain kernels (most slices limited) store P_ij per (slice, column) tile */
 #endif
 #ifndef RYUJIN_BAND_DEFAULT
+#ifndef RYUJIN_XCD_CHUNK_DEFAULT
+#define RYUJIN_XCD_CHUNK_DEFAULT 0 /* XCD-local block ranges (ryujin_hip_params::debug_xcd_chunk): off unless measured as a gain */
+#endif
 #define RYUJIN_BAND_DEFAULT 1 /* stacked blocks chosen from the mesh when ryujin_hip_params::debug_band_stride == 0, in 2-D:
                                  C2 (G = 47) -1.1 % per update, every sweep a little; in 3-D stacking lattice planes (G = 365
                                  on the C4 share) LOSES 1.7 % and stacking lattice rows (G = 2) is noise -- the re-fetches of
@@ -810,6 +813,12 @@ void ryujin_hip_ctx::create(const ryujin_hip_offline &o, const ryujin_hip_params
     if (G >= 2 && (uint64_t)G * kWavesPerBlock * 4 <= L.n_slices)
       mesh.band_stride = G;
   }
+  /* XCD-local block ranges (row_context()): debug_xcd_chunk < 0 off, > 0 that many blocks per XCD and chunk */
+  mesh.xcd_chunk = 0;
+  if (p.debug_xcd_chunk > 0)
+    mesh.xcd_chunk = (uint32_t)p.debug_xcd_chunk;
+  else if (p.debug_xcd_chunk == 0)
+    mesh.xcd_chunk = RYUJIN_XCD_CHUNK_DEFAULT;
   mesh.cij = d_cij.ptr;
   mesh.mij = d_mij.ptr;
   mesh.incidence = dg ? d_incidence.ptr : nullptr;
@@ -2278,6 +2287,12 @@ void ryujin_hip_default_params(ryujin_hip_params *p, int equation, int dim)
   p->debug_expensive_bounds_check = 0;
   p->debug_tile_map = 0;
   p->debug_band_stride = 0;
+  p->debug_xcd_chunk = 0;
+  /* the profiling scripts wrap bench.py, which takes the defaults: let them select a mapping without a flag */
+  if (const char *e = std::getenv("RYUJIN_XCD_CHUNK"))
+    p->debug_xcd_chunk = std::atoi(e);
+  if (const char *e = std::getenv("RYUJIN_BAND_STRIDE"))
+    p->debug_band_stride = std::atoi(e);
 }
 
 int ryujin_hip_comm_unique_id(char id[RYUJIN_HIP_UNIQUE_ID_BYTES])
@@ -2574,6 +2589,9 @@ int ryujin_hip_state_download_prepared(ryujin_hip_ctx *ctx, int handle, double *
     auto &s = ctx->state(handle);
     const int K = ctx->K, KP = ctx->KP;
     const uint32_t n_rows = (uint32_t)ctx->h_bc_rows.size();
+    /* boundary rows inside export slices get their boundary conditions from the export part of the pre-pass, on
+     * comm_stream (fold_bc): the pack kernel below reads them, so the compute stream joins comm_stream FIRST */
+    ctx->wait_comm();
     if (n_rows != 0) {
       if (ctx->d_bc_rows.n == 0) {
         ctx->d_bc_rows.upload(ctx->h_bc_rows);

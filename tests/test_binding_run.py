@@ -206,3 +206,43 @@ def test_host_mirroring_entry_points_write_back_only_what_the_call_changes(oracl
     assert m._lib.ryujin_hip_host_register(m._ctx, x.ctypes.data, x.nbytes) == capi.RYUJIN_OK
     assert m._lib.ryujin_hip_host_unregister(m._ctx, x.ctypes.data) == capi.RYUJIN_OK
     assert m._lib.ryujin_hip_host_unregister(m._ctx, x.ctypes.data) == capi.RYUJIN_WARN
+
+
+@pytest.mark.gpu
+def test_download_prepared_on_a_middle_rank_sees_the_boundary_conditions_of_export_rows(oracle):
+    """with neighbours and a mesh small enough for the boundary conditions to ride on the pre-pass
+    (fold_bc), the boundary rows inside EXPORT slices get their boundary values from the export part of the pre-pass on
+    the exchange stream. ryujin_hip_state_download_prepared packs the boundary rows on the compute stream: it has to
+    join the exchange stream first. A middle rank of a slab partition (loopback communicator), repeated so that a
+    missing join would show as a stale row sooner or later: the packed write-back equals the full download."""
+    import ctypes as C
+
+    from ryujin_amd import HyperbolicModule, capi, offline
+    from ryujin_amd.initial_states import euler_uniform
+    spec = offline.mach3_step_2d(60, n_ranks=3, rank=1)
+    off = offline.SyntheticOffline(spec)
+    assert off.n_bdry > 0 and off.n_relevant > off.n_owned
+    rng = np.random.default_rng(11)
+    dirichlet = euler_uniform(off.b_positions)
+    p = oracle.default_params(capi.EQ_EULER, 2)
+    p.cfl = 0.9
+    comm = C.c_void_p()
+    assert capi.load_hip().ryujin_hip_comm_init_loopback(C.byref(comm), 1, 3, 0) == 0
+    m = HyperbolicModule(off, p, backend="hip", comm=comm)
+    sv = m.new_state_vector()
+    boundary = np.isin(np.arange(off.n_relevant), off.b_i)
+    ghost = np.arange(off.n_relevant) >= off.n_owned
+    for rep in range(40):
+        # momentum with a wall-normal part on every boundary row: slip rows MUST change in prepare_state_vector
+        U0 = euler_uniform(off.positions) * (1.0 + 1e-2 * rng.uniform(-1, 1, size=(off.n_relevant, 4)))
+        U0[:, 2] += 0.3
+        sv.upload(U0)
+        m.prepare_state_vector(sv, 0.0, dirichlet)
+        got = np.full_like(U0, 123.0)
+        m._check(m._lib.ryujin_hip_state_download_prepared(m._ctx, sv.handle, capi.as_ptr(got, capi.c_double_p)))
+        full = sv.download()
+        assert (full[boundary & ~ghost] != U0[boundary & ~ghost]).any()
+        touched = boundary | ghost
+        assert np.array_equal(got[touched], full[touched]), rep
+        assert (got[~touched] == 123.0).all()
+    m.close()

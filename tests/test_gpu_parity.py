@@ -260,11 +260,12 @@ def test_tile_map_gives_the_same_bits_as_the_index_arrays(oracle):
         U0 = _perturbed(euler_uniform(off.positions))
         dirichlet = euler_uniform(off.b_positions) if off.n_bdry else None
         results = []
-        for switch in (0, -1):
+        for switch, xcd_chunk in ((0, -1), (-1, -1), (0, 2), (-1, 5)):
             p = oracle.default_params(capi.EQ_EULER, 2)
             p.cfl = 0.9
             p.debug_tile_map = switch
             p.debug_band_stride = switch  # stacked blocks (row_context()): which wave takes which slice
+            p.debug_xcd_chunk = xcd_chunk  # XCD-local block ranges (row_context()): which block takes which slices
             comm = None
             if n_ranks > 1:  # a middle rank on its own: the loopback communicator stands in for its neighbours
                 import ctypes as C
@@ -283,8 +284,9 @@ def test_tile_map_gives_the_same_bits_as_the_index_arrays(oracle):
                 m.time_step("ssprk 33", a, temps, dirichlet)
             results.append((a.download(), m.alpha().copy(), m.debug_fetch("lij")))
             m.close()
-        for x, y in zip(*results):
-            assert np.array_equal(x, y)
+        for other in results[1:]:
+            for x, y in zip(results[0], other):
+                assert np.array_equal(x, y)
 
 
 def test_mass_conservation_01_golden_on_gpu(golden_dir):

@@ -109,3 +109,62 @@ def test_stub_ranks_against_the_partitioned_oracle(oracle, tmp_path, world, case
         return p
     compare_rank_files(oracle, parts, prefix, make_params,
                        lambda part: euler_uniform(part.b_positions) if part.n_bdry else None, parts[0].dim + 2)
+
+
+def _bench(args, preload=True, timeout=900):
+    """`python bench.py <args>` in its own process group (killed as a group on a hang), the stub in front of RCCL"""
+    import json
+    import signal
+    build_stub()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if preload:
+        env["LD_PRELOAD"] = STUB
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), *args]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                            start_new_session=True)
+    try:
+        out, err = proc.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        os.killpg(proc.pid, signal.SIGKILL)
+        out, err = proc.communicate()
+        pytest.fail(f"bench.py {' '.join(args)} timed out after {timeout} s\n{err[-4000:]}")
+    assert proc.returncode == 0, err[-6000:]
+    lines = [ln for ln in out.splitlines() if ln.strip()]
+    assert len(lines) == 1, out
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("n,extra", [(2, ["--cells-per-unit", "200"]),
+                                     (8, ["--workload", "cylinder3d", "--size", "24"])])
+def test_bench_scaling_run_dress_rehearsal_on_one_gpu(n, extra):
+    """`bench.py --gpus N` END TO END before the driver's one-shot 8-GPU run -- the
+    self-launch through torch.distributed.run, per-rank slab generation, every rank's own coarse run, the RCCL
+    communicator from the id broadcast over gloo, the device- vs system-scope events check, the `rccl` object counted
+    by the library, the watchdog, ONE JSON line from rank 0 -- with all ranks on device 0 over the RCCL test double.
+    Asserts what tests/test_multigpu_rccl.py::test_bench_self_launches_its_ranks asserts on a multi-GPU box."""
+    d = _bench(["--gpus", str(n), "--steps", "6", "--warmup", "3", "--develop-time", "0.3", "--develop", "30",
+                "--reps", "2", "--watchdog", "800", *extra])
+    assert d["n_gpus"] == n and d["scaling"] == "weak" and d["value"] > 0 and d["n_warnings"] == 0
+    assert d["rccl"]["ranks"] == n and len(d["rccl"]["n_neighbours_per_rank"]) == n
+    # x-slabs: the two end ranks have one neighbour, the others two
+    assert sorted(d["rccl"]["n_neighbours_per_rank"]) == sorted([1, 1] + [2] * (n - 2))
+    assert d["rccl"]["exchanges_per_update"] == 5.0 and abs(d["rccl"]["allreduces_per_update"] - 2.0 / 3.0) < 1e-12
+    assert d["events"]["check"] is not None and d["events"]["kind"] == "device", d["events"]
+    # weak scaling: every rank holds the same share, value is the whole job's
+    cfg = d["config"]
+    assert abs(cfg["gridpoints_total"] - n * cfg["gridpoints_per_gpu"]) <= 0.02 * cfg["gridpoints_total"]
+    assert abs(d["value"] - cfg["dofs_total"] * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"]) / 1e6) <= 1e-6 * d["value"]
+    assert "cpu_baseline" not in d  # rank 0 at N = 1 only
+
+
+def test_bench_line_under_the_launcher_agrees_with_the_plain_line():
+    """the N = 1 point of the scaling curve (torch.distributed + an RCCL communicator of one rank, --force-dist) must
+    be the bench line: same mesh, same state, same kernels; ms_per_step within the spread of two runs on one box"""
+    common = ["--steps", "30", "--warmup", "6", "--develop-time", "0.3", "--develop", "60", "--cells-per-unit", "400",
+              "--no-cpu-baseline", "--binding", "device"]
+    plain = _bench(common, preload=False)
+    dist = _bench(["--force-dist", *common], preload=False)  # real RCCL: one rank on one device is allowed
+    assert dist["n_gpus"] == 1 and dist["rccl"]["ranks"] == 1 and "rccl" not in plain
+    assert dist["config"]["gridpoints_total"] == plain["config"]["gridpoints_total"]
+    assert dist["config"]["simulated_time_at_end"] == plain["config"]["simulated_time_at_end"]  # same taus, bit for bit
+    assert abs(dist["ms_per_step"] / plain["ms_per_step"] - 1.0) < 0.08, (dist["ms_per_step"], plain["ms_per_step"])
