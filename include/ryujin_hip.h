@@ -163,7 +163,9 @@ typedef struct ryujin_hip_params {
    *   its own l_ij comes out limited; the rest completed by the repair launch of step 6) and everywhere after
    *   that. 1: always per slice and no slice predicted limited (every stored slice goes through the trigger in
    *   step 5 or the repair launch of step 6); 2: per tile and no tile predicted (every tile the neighbour's l_ji
-   *   limits is formed by step 6; per slice as 1 in 3-D); < 0: always stored everywhere. */
+   *   limits is formed by step 6; per slice as 1 in 3-D); 3: per tile in ANY dimension (3-D: the tiles step 5 did
+   *   not store are formed by a launch behind step 6 -- built, measured as a small loss, not the default); 4: as 3
+   *   with no tile predicted; < 0: always stored everywhere. */
   int system_scope_events;
   int debug_join_exchanges;
   int debug_bc_fold_max_slices;
@@ -460,6 +462,11 @@ int ryujin_hip_layout_info(ryujin_hip_ctx *ctx, unsigned long long *n_tiles, uns
  * not stored them (ryujin_amd/csrc/kernels_limiter_stage0.hpp). 1 / 1 / 0 otherwise. Any pointer may be NULL. */
 int ryujin_hip_tile_statistics(ryujin_hip_ctx *ctx, double *stored_fraction, double *read_fraction,
                                double *formed_by_step6_fraction);
+/* Where the tiles step 5 did not store are formed outside the sweep of step 6 (3-D; ryujin_amd/csrc/kernels_limiter.hpp,
+ * kHoDefer): the number of 64-row slices the latest update that ended in a host synchronisation (ryujin_hip_step, or the
+ * last stage of ryujin_hip_time_step) handed to the launch behind the sweep -- exact, not sampled. 0 where the repair
+ * is part of the sweep. */
+int ryujin_hip_deferred_slices(ryujin_hip_ctx *ctx, unsigned *n_slices);
 
 /* ---- introspection for parity tests and profiling ------------------------ */
 /* Module-owned intermediates of the LAST step() in the reference's logical

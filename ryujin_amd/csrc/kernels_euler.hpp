@@ -100,6 +100,9 @@ namespace ryujin_hip
     unsigned int n_sampled_tiles, n_sampled_tiles_stored;
     /* ... those step 6 read, and those of them it had to form itself (step 5 had not stored them) */
     unsigned int n_sampled_tiles_needed, n_sampled_tiles_formed;
+    /* slices on the list of the launch behind step 6 (SliceFlags::deferred; [0] the export or only part of the sweep,
+     * [1] the interior part of a split sweep); reset by step_begin() */
+    unsigned int n_deferred[2];
   };
   constexpr int kStageCode = 100;
 
@@ -121,6 +124,7 @@ namespace ryujin_hip
     scalars->tau_in = M.begin.tau_in;
     scalars->use_device_tau = M.begin.use_device_tau;
     scalars->stage = M.begin.stage;
+    scalars->n_deferred[0] = scalars->n_deferred[1] = 0;
   }
 
 
@@ -401,16 +405,14 @@ namespace ryujin_hip
     return tile_transposed(M, tile_desc<USE>(M, colbase), colbase, lane);
   }
 
-  RYUJIN_DEV RowCtx row_context(const DeviceMesh &M)
+  /* XCD-LOCAL BLOCK RANGES. Block b runs on XCD b % 8 (observed; speed only): consecutive blocks -- consecutive
+   * slices, whose rows gather from the same lattice rows and planes -- land on eight different L2s, and every L2
+   * ends up fetching every node's data. Renumbered in chunks of 8 C blocks, XCD x takes the C consecutive blocks
+   * [x C, (x + 1) C) of a chunk: the rows one L2 serves at a time are a contiguous range. The tail of the launch
+   * that does not fill a chunk keeps its numbering. */
+  RYUJIN_DEV uint32_t mapped_block(const DeviceMesh &M)
   {
-    RowCtx r;
-    r.lane = threadIdx.x & 63;
     uint32_t block = blockIdx.x;
-    /* XCD-LOCAL BLOCK RANGES. Block b runs on XCD b % 8 (observed; speed only): consecutive blocks -- consecutive
-     * slices, whose rows gather from the same lattice rows and planes -- land on eight different L2s, and every L2
-     * ends up fetching every node's data. Renumbered in chunks of 8 C blocks, XCD x takes the C consecutive blocks
-     * [x C, (x + 1) C) of a chunk: the rows one L2 serves at a time are a contiguous range. The tail of the launch
-     * that does not fill a chunk keeps its numbering. */
     if (M.xcd_chunk > 0u) {
       const uint32_t span = 8u * M.xcd_chunk;
       if (block < gridDim.x - gridDim.x % span) {
@@ -418,6 +420,14 @@ namespace ryujin_hip
         block = block - rem + (rem & 7u) * M.xcd_chunk + (rem >> 3);
       }
     }
+    return block;
+  }
+
+  RYUJIN_DEV RowCtx row_context(const DeviceMesh &M)
+  {
+    RowCtx r;
+    r.lane = threadIdx.x & 63;
+    const uint32_t block = mapped_block(M);
     /* slice, base and width are the same in all lanes of the wave: say so (scalar registers, scalar loop control) */
     uint32_t id = block * kWavesPerBlock + (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     /* STACKED BLOCKS. On a structured patch the rows a slice gathers from sit one lattice row (2-D) / one lattice

@@ -558,7 +558,24 @@ namespace ryujin_hip
   /* where the repair launch of step 6 (k_pij_repair) and the debug fetch take P_ij from for the columns step 5 did
    * not store: the operands of pij_stage0 */
 #ifndef RYUJIN_TILE_PIJ_MAXDIM
-#define RYUJIN_TILE_PIJ_MAXDIM 2 /* per-tile P_ij up to this dimension (3-D: the repair path costs step 6 its fourth wave per SIMD, 124 -> 156 registers) */
+#define RYUJIN_TILE_PIJ_MAXDIM 3 /* per-tile P_ij is BUILT up to this dimension; the host selects it by default up to RYUJIN_TILE_PIJ_DEFAULT_MAXDIM */
+#endif
+#ifndef RYUJIN_TILE_PIJ_DEFAULT_MAXDIM
+#define RYUJIN_TILE_PIJ_DEFAULT_MAXDIM 2 /* 3-D: built, measured and NOT the default (debug_pij_storage = 3 selects it). C4 share, every slice limited,
+                                            56 % of the tiles stored: step 5 2.18 against 2.23 - 2.32 ms (its L2-miss traffic falls by 4.5 %, not by
+                                            the 24 % of its own bytes the tiles are: profiles/r06f_pmc_c4_*.md), step 6 1.68 against 1.45 ms
+                                            -- 7.74 against 7.60 ms per update; C3, 38 % of the slices limited, 22 % of the tiles stored: 12.4 - 12.5
+                                            against 12.2 ms per slice (profiles/r06b/d/e_ab_*) */
+#endif
+#ifndef RYUJIN_TILE_DEFER_MINDIM
+#define RYUJIN_TILE_DEFER_MINDIM 3 /* from this dimension on the tiles step 5 did not store are formed OUTSIDE the sweep of step 6: the wave
+                                      of a slice that misses a tile puts the slice on a list and retires, a small launch behind the sweep
+                                      runs the listed slices with the repair (k_high_order_next_deferred). In 3-D the repair inside the
+                                      kernel costs EVERY wave of the sweep: 124 -> 163 registers inlined (the fourth wave per SIMD gone), as
+                                      a function call spills in the common path -- step 6 on the C4 share 1.74 - 1.76 ms either way against
+                                      1.45 without the repair code (profiles/r06e_ab_repair_variants_c4.log). The launch behind the sweep
+                                      takes 156 us for 85 slices (C4) and 316 us for 140 (C3) whether a slice gets a wave or a block of its
+                                      own (profiles/r06c/r06d_kernel_trace_*.md): 1.68 ms in all -- the cheapest of the three, still a loss */
 #endif
   struct Stage0Src {
     DeviceScalars *scalars; /* tau; and the limited-slice counters of step 6 */
@@ -745,6 +762,57 @@ namespace ryujin_hip
     }
   }
 
+  /* the tiles `missing` (bit c: column c) of the slice formed exactly as step 5 forms them and stored (next_cached_slice):
+   * load_row_data() + pij_on_the_fly() spelled out on plain pointers */
+  template <int K>
+  RYUJIN_DEV void repair_missing_tiles(const uint32_t *__restrict__ cols, const double *__restrict__ mij,
+                                       const double *__restrict__ mi_inv, const double *__restrict__ old_U,
+                                       const double *__restrict__ r_in, const double *__restrict__ alpha,
+                                       const double *__restrict__ dij, const double tau, const uint32_t i,
+                                       const uint32_t len, const uint32_t base, const uint32_t width,
+                                       const uint32_t lane, const bool row_active, const uint32_t missing,
+                                       double *__restrict__ pij)
+  {
+    RowData<K> row;
+    load_state<K>(old_U, i, row.U_i);
+    load_state<K>(r_in, i, row.F_i);
+    row.alpha_i = alpha[i];
+    row.m_i_inv = mi_inv[i];
+    row.factor = tau * row.m_i_inv * (double)(len - 1);
+#pragma unroll 1
+    for (uint32_t c = 1; c < width; ++c) {
+      if (!((missing >> c) & 1u))
+        continue;
+      const uint64_t pos = ((uint64_t)base + c) * 64 + lane;
+      const uint32_t j = cols[pos];
+      PairData<K> pd;
+      pd.d_ij = dij[pos];
+      pd.m_ij = ld_stream(mij + pos);
+      load_state<K>(old_U, j, pd.U_j);
+      load_state<K>(r_in, j, pd.F_j);
+      pd.alpha_j = alpha[j];
+      pd.m_j_inv = mi_inv[j];
+      double P_t[K];
+      pij_stage0<K>(row, pd, P_t);
+      if (row_active && c < len)
+        store_entry<K>(pij, (uint64_t)base + c, lane, P_t);
+    }
+  }
+  /* ... as a FUNCTION CALL (3-D): the registers of the repair are the callee's, saved and restored around the rare
+   * call, instead of being added to what every wave of the sweep holds (inlined: 124 -> 163 registers, the fourth wave
+   * per SIMD gone). Plain pointer arguments: a reference to the kernel's DeviceMesh would make every wave write a copy
+   * of it to its stack at the top of the kernel. */
+  template <int K>
+  __device__ __attribute__((noinline)) void
+  repair_missing_tiles_out_of_line(const uint32_t *cols, const double *mij, const double *mi_inv, const double *old_U,
+                                   const double *r_in, const double *alpha, const double *dij, const double tau,
+                                   const uint32_t i, const uint32_t len, const uint32_t base, const uint32_t width,
+                                   const uint32_t lane, const bool row_active, const uint32_t missing, double *pij)
+  {
+    repair_missing_tiles<K>(cols, mij, mi_inv, old_U, r_in, alpha, dij, tau, i, len, base, width, lane, row_active,
+                            missing, pij);
+  }
+
   /* Per-slice bookkeeping of the limiter sweeps of an update without stage vectors (kernels_limiter_stage0.hpp):
    * one byte per 64-row slice each, written by exactly one wave per launch.
    *   unlimited     written by step 6: 1 = no pair of the slice was limited in the first high-order pass. EXACT for
@@ -760,28 +828,62 @@ namespace ryujin_hip
    *                 2 the repair launch has to complete it first. */
   struct SliceFlags {
     uint8_t *unlimited, *first_stored, *todo;
-    /* [n_slices] bit c: step 6 of the last update read P_ij of the (slice, column c) tile; bits 10 + c, 20 + c: of the
-     * update before, and the one before that (an SSPRK33 step is three updates, and what its stages limit differs) */
+    /* the tiles step 6 read P_ij of in the last updates (an SSPRK33 step is three updates, and what its stages limit
+     * differs). Stencils of up to 10 columns (1-D, 2-D Q1): [n_slices] words, bit c: the (slice, column c) tile in the
+     * last update; bits 10 + c, 20 + c: in the update before, and the one before that. Wider stencils (3-D Q1: 27
+     * columns): one word per generation, [generation][hist_stride] (tiles_predicted / tiles_remember below). */
     uint32_t *needed_tiles;
+    uint32_t hist_stride; /* >= n_slices */
+    /* where the missing tiles are formed outside the sweep of step 6 (RYUJIN_TILE_DEFER_MINDIM): the slices whose wave
+     * retired, [n_slices]; the launch over the slices [slice_begin, slice_end) appends from entry slice_begin on,
+     * counted in DeviceScalars::n_deferred[slice_begin != 0] (the export and the interior part of a split sweep) */
+    uint32_t *deferred;
   };
 
 #ifndef RYUJIN_TILE_PIJ_GENERATIONS
 #define RYUJIN_TILE_PIJ_GENERATIONS 3
 #endif
-  /* the tiles step 5 stores on the strength of the last updates (widths up to 10: the 2-D stencils) */
-  RYUJIN_DEV uint32_t tiles_predicted(const uint32_t word)
+#ifndef RYUJIN_TILE_REPAIR_CALL
+#define RYUJIN_TILE_REPAIR_CALL 1 /* 3-D: the repair of step 6 as a function call (repair_missing_tiles_out_of_line) */
+#endif
+  /* the tiles step 5 stores on the strength of the last updates; MAXW: the widest row of the stencil family */
+  template <int MAXW>
+  RYUJIN_DEV uint32_t tiles_predicted(const SliceFlags &W, const uint32_t slice)
   {
-    uint32_t m = word & 0x3ffu;
-    if (RYUJIN_TILE_PIJ_GENERATIONS >= 2)
-      m |= (word >> 10) & 0x3ffu;
-    if (RYUJIN_TILE_PIJ_GENERATIONS >= 3)
-      m |= (word >> 20) & 0x3ffu;
-    return m;
+    if constexpr (MAXW <= 10) {
+      const uint32_t word = W.needed_tiles[slice];
+      uint32_t m = word & 0x3ffu;
+      if (RYUJIN_TILE_PIJ_GENERATIONS >= 2)
+        m |= (word >> 10) & 0x3ffu;
+      if (RYUJIN_TILE_PIJ_GENERATIONS >= 3)
+        m |= (word >> 20) & 0x3ffu;
+      return m;
+    } else {
+      static_assert(MAXW <= 32, "one bit per column");
+      uint32_t m = W.needed_tiles[slice];
+      if (RYUJIN_TILE_PIJ_GENERATIONS >= 2)
+        m |= W.needed_tiles[(size_t)W.hist_stride + slice];
+      if (RYUJIN_TILE_PIJ_GENERATIONS >= 3)
+        m |= W.needed_tiles[2 * (size_t)W.hist_stride + slice];
+      return m;
+    }
   }
-  RYUJIN_DEV uint32_t tiles_remembered(const uint32_t word, const uint32_t needed)
+  /* step 6 (one lane): `needed` becomes the newest generation, the oldest is forgotten */
+  template <int MAXW>
+  RYUJIN_DEV void tiles_remember(const SliceFlags &W, const uint32_t slice, const uint32_t needed)
   {
-    return ((word << 10) | (needed & 0x3ffu)) & 0x3fffffffu;
+    if constexpr (MAXW <= 10) {
+      W.needed_tiles[slice] = ((W.needed_tiles[slice] << 10) | (needed & 0x3ffu)) & 0x3fffffffu;
+    } else {
+      if (RYUJIN_TILE_PIJ_GENERATIONS >= 3)
+        W.needed_tiles[2 * (size_t)W.hist_stride + slice] = W.needed_tiles[(size_t)W.hist_stride + slice];
+      if (RYUJIN_TILE_PIJ_GENERATIONS >= 2)
+        W.needed_tiles[(size_t)W.hist_stride + slice] = W.needed_tiles[slice];
+      W.needed_tiles[slice] = needed;
+    }
   }
+  /* words of history per slice the host allocates (and sets to all ones: the first update stores every tile) */
+  constexpr int tile_history_words(const int maxw) { return maxw <= 10 ? 1 : 3; }
 
   /* form and store the P_ij of the columns [1, c_end) of the row (the repair launch of step 6,
    * ryujin_hip_debug_fetch): exactly the value step 5 formed (same function, same operands) */
@@ -928,7 +1030,17 @@ namespace ryujin_hip
    * differences of a few ulp of lambda |P_ij|, orders inside the 1e-11 contract on the new state. Rows whose
    * columns are ALL in limited tiles (the strongly limited ones) take the reference's form in the reference's
    * order instead: see the branch below. */
-  constexpr int kHoPlain = 0, kHoLight = 1, kHoHeavy = 2;
+  /* P_ij stored per tile and the missing tiles formed outside the sweep (RYUJIN_TILE_DEFER_MINDIM):
+   *   kHoDefer   the whole sweep in one launch, but the wave of a slice that needs a tile step 5 did not store appends
+   *              the slice to SliceFlags::deferred and retires before it has written anything;
+   *   kHoRepair  the launch behind it (k_high_order_next_deferred): forms and stores the missing tiles of the listed
+   *              slices -- as kHoPlain does inside the sweep up to two dimensions -- and runs the sweep on them. */
+  constexpr int kHoPlain = 0, kHoLight = 1, kHoHeavy = 2, kHoDefer = 3, kHoRepair = 4;
+  template <int DIM, int MODE>
+  constexpr bool forms_missing_tiles()
+  {
+    return DIM <= RYUJIN_TILE_PIJ_MAXDIM && ((MODE == kHoPlain && DIM < RYUJIN_TILE_DEFER_MINDIM) || MODE == kHoRepair);
+  }
 
   template <typename E, int MAXW, int CP, bool SPLIT, int MODE>
   RYUJIN_DEV void next_cached_slice(const typename E::Params &P, const DeviceMesh &M, const RowCtx &r,
@@ -941,7 +1053,7 @@ namespace ryujin_hip
     constexpr int K = E::K;
     constexpr int NB = E::NB;
     static_assert(!SPLIT || CP == MAXW, "the split variant caches the whole row");
-    static_assert(!(SPLIT && MODE != kHoPlain), "small meshes keep the stored P_ij");
+    static_assert(!SPLIT || MODE == kHoPlain || MODE == kHoRepair, "small meshes keep the stored P_ij");
     const bool row_active = r.len > 1;
     const uint32_t i = row_active ? r.row : (r.row < M.n_owned ? r.row : M.n_owned - 1);
     const uint32_t *__restrict__ idx_t = M.idx_t;
@@ -994,33 +1106,47 @@ namespace ryujin_hip
     uint32_t needed = 0; /* wave-uniform: bit c <=> some pair of the (slice, column) tile is limited */
     uint32_t own_limited = 0; /* ... <=> one of the tile's OWN l_ij is (the tiles step 5 stored with Stage0Src::tile_store) */
     if (V_unlimited != nullptr) {
-      /* what step 5 stored besides: the tiles this sweep needed in the previous update (read before it is replaced) */
-      const bool tiles = MODE == kHoPlain && !SPLIT && S0.tile_store != 0 && W.needed_tiles != nullptr;
-      const uint32_t history = tiles ? W.needed_tiles[r.slice] : 0u;
-      const uint32_t predicted = tiles_predicted(history);
-      /* Step 5 left V_i = U_i^low + sum_j lambda P_ij, accumulated exactly as the reference accumulates the update
-       * when every l_ij is 1 (k_lij_stage0). If no pair of the slice was limited -- wave-uniform -- that IS the
-       * new U_i bit for bit, the second pass stores (1 - l) l' = 0, and P_ij is not read at all. */
+      /* what step 5 stored besides: the tiles this sweep needed in the previous updates (read before it is replaced) */
+      constexpr bool kTileMode = ((MODE == kHoPlain || MODE == kHoDefer) && !SPLIT) || MODE == kHoRepair;
+      const bool tiles = kTileMode && S0.tile_store != 0 && W.needed_tiles != nullptr;
+      const uint32_t predicted = tiles ? tiles_predicted<MAXW>(W, r.slice) : 0u;
       bool limited = false;
+      /* the row's l = min(l_ij, l_ji) and the tile masks (`lane`: see the second call below) */
+      auto fetch_l = [&](const uint32_t lane) {
+        needed = own_limited = 0u;
 #pragma unroll
-      for (int c = 1; c < MAXW; ++c) {
-        l[c] = 1.;
-        if ((uint32_t)c < r.width) {
-          const uint32_t pos = (uint32_t)(((uint64_t)r.base + c) * 64 + r.lane);
-          const double l_a = lij[pos];
-          const double l_b = lij[tile_transposed<tile_map_pays<E::DIMENSION>()>(M, (uint64_t)r.base + c, r.lane)];
-          const bool lane_on = row_active && (uint32_t)c < r.len;
-          const bool lim = lane_on && !(l_a == 1. && l_b == 1.);
-          l[c] = lane_on ? lmin(l_a, l_b) : 1.;
-          limited = limited || lim;
-          if (__any(lim))
-            needed |= 1u << c;
-          if (__any(lane_on && !(l_a == 1.)))
-            own_limited |= 1u << c;
+        for (int c = 1; c < MAXW; ++c) {
+          l[c] = 1.;
+          if ((uint32_t)c < r.width) {
+            const uint32_t pos = (uint32_t)(((uint64_t)r.base + c) * 64 + lane);
+            const double l_a = lij[pos];
+            const double l_b = lij[tile_transposed<tile_map_pays<E::DIMENSION>()>(M, (uint64_t)r.base + c, lane)];
+            const bool lane_on = row_active && (uint32_t)c < r.len;
+            const bool lim = lane_on && !(l_a == 1. && l_b == 1.);
+            l[c] = lane_on ? lmin(l_a, l_b) : 1.;
+            limited = limited || lim;
+            if (__any(lim))
+              needed |= 1u << c;
+            if (__any(lane_on && !(l_a == 1.)))
+              own_limited |= 1u << c;
+          }
         }
-      }
+      };
+      fetch_l(r.lane);
       const bool slice_limited = needed != 0u;
       (void)limited;
+      /* P_ij stored per tile by step 5 (Stage0Src::tile_store): a tile this sweep needs -- some pair limited after
+       * the symmetrisation -- that step 5 did not store -- none of its OWN l_ij limited and not read in the last
+       * updates: the limit came from the neighbour's l_ji, which step 5 cannot see. Wave-uniform. */
+      const uint32_t missing = (kTileMode && S0.tile_store != 0) ? (needed & ~(own_limited | predicted)) : 0u;
+      if constexpr (MODE == kHoDefer) {
+        /* formed outside this sweep: the slice goes on the list before anything of it is written */
+        if (missing != 0u) {
+          if (r.lane == 0)
+            W.deferred[M.slice_begin + atomicAdd(&S0.scalars->n_deferred[M.slice_begin != 0u ? 1 : 0], 1u)] = r.slice;
+          return;
+        }
+      }
       /* (slices the light launch found limited, todo = 3, were counted there) */
       if (S0.scalars != nullptr && (r.slice & 15u) == 0 && r.lane == 0 && (!SPLIT || group == 0) &&
           !(MODE == kHoHeavy && todo == 3)) {
@@ -1030,8 +1156,10 @@ namespace ryujin_hip
       }
       if (W.unlimited != nullptr && r.lane == 0 && (!SPLIT || group == 0))
         W.unlimited[r.slice] = slice_limited ? 0 : 1;
-      if (tiles && r.lane == 0)
-        W.needed_tiles[r.slice] = tiles_remembered(history, needed);
+      if constexpr (SPLIT && MODE == kHoRepair)
+        __syncthreads(); /* every wave of the block has read the history */
+      if (tiles && r.lane == 0 && (!SPLIT || group == 0))
+        tiles_remember<MAXW>(W, r.slice, needed);
       load_state<K>(V_unlimited, i, U_i_new);
       if (!slice_limited) {
         if (row_active) {
@@ -1044,29 +1172,32 @@ namespace ryujin_hip
         }
         return;
       }
-      if constexpr (MODE == kHoPlain && !SPLIT && E::DIMENSION <= RYUJIN_TILE_PIJ_MAXDIM) {
-        /* P_ij stored per tile by step 5 (Stage0Src::tile_store): a tile this sweep needs -- some pair limited after
-         * the symmetrisation -- that step 5 did not store -- none of its OWN l_ij limited, the limit came from the
-         * neighbour's l_ji, which step 5 cannot see -- is formed here, exactly as step 5 forms it (pij_stage0 on the
-         * same operands: the same bits), and stored: the loads below, the second limiter pass, its Newton tail and
-         * step 7 then find it in the matrix like every other tile. (A tile whose own pairs all went to the tail and
-         * came back with l = 1 is stored already and merely written again.) */
-        const uint32_t missing = S0.tile_store != 0 ? (needed & ~(own_limited | predicted)) : 0u; /* wave-uniform */
-        if (tiles && (r.slice & 15u) == 0 && r.lane == 0) {
-          atomicAdd(&S0.scalars->n_sampled_tiles_needed, (unsigned int)__popc(needed));
-          atomicAdd(&S0.scalars->n_sampled_tiles_formed, (unsigned int)__popc(missing));
-        }
+      if (kTileMode && tiles && (r.slice & 15u) == 0 && r.lane == 0 && (!SPLIT || group == 0)) {
+        atomicAdd(&S0.scalars->n_sampled_tiles_needed, (unsigned int)__popc(needed));
+        atomicAdd(&S0.scalars->n_sampled_tiles_formed, (unsigned int)__popc(missing));
+      }
+      if constexpr (kTileMode && forms_missing_tiles<E::DIMENSION, MODE>()) {
+        /* the missing tiles are formed here, exactly as step 5 forms them (pij_stage0 on the same operands: the same
+         * bits), and stored: the loads below, the second limiter pass, its Newton tail and step 7 then find them in
+         * the matrix like every other tile. (A tile whose own pairs all went to the tail and came back with l = 1 is
+         * stored already and merely written again. SPLIT: each of the block's waves forms and stores them -- the same
+         * bits four times -- and reads back what it stored itself.)
+         * The rare wave that comes here FETCHES ITS l AGAIN afterwards (through a lane index the compiler cannot see
+         * through, or it would keep the first copy): the 2 (MAXW - 1) registers of l are then dead across the repair
+         * and serve it -- in 3-D the repair would otherwise raise the kernel from 124 to 156 registers and cost every
+         * wave of the sweep its fourth wave per SIMD (rounds 4 - 5 kept 3-D off per-tile storage for that reason). */
         if (missing != 0u) {
-          RowData<K> row;
-          load_row_data<K>(M, S0, i, r.len, row);
-#pragma unroll 1
-          for (uint32_t c = 1; c < r.width; ++c) {
-            if (!((missing >> c) & 1u))
-              continue;
-            double P_t[K];
-            pij_on_the_fly<K>(M, S0, row, (uint64_t)r.base + c, r.lane, P_t);
-            if (row_active && c < r.len)
-              store_entry<K>(pij, (uint64_t)r.base + c, r.lane, P_t);
+          if constexpr (MAXW > 9 && RYUJIN_TILE_REPAIR_CALL != 0)
+            repair_missing_tiles_out_of_line<K>(M.cols, M.mij, M.mi_inv, S0.old_U, S0.r_in, S0.alpha, S0.dij,
+                                                S0.scalars->tau, i, r.len, r.base, r.width, r.lane, row_active,
+                                                missing, pij);
+          else
+            repair_missing_tiles<K>(M.cols, M.mij, M.mi_inv, S0.old_U, S0.r_in, S0.alpha, S0.dij, S0.scalars->tau, i,
+                                    r.len, r.base, r.width, r.lane, row_active, missing, pij);
+          if constexpr (MAXW > 9) {
+            uint32_t lane_again = r.lane;
+            asm volatile("" : "+v"(lane_again));
+            fetch_l(lane_again);
           }
         }
       }
@@ -1282,9 +1413,9 @@ namespace ryujin_hip
       if (M.slice_begin + blockIdx.x >= M.slice_end)
         return;
       r = row_context_of_slice(M, M.slice_begin + blockIdx.x);
-    } else if constexpr (MODE != kHoPlain) {
+    } else if constexpr (MODE == kHoLight || MODE == kHoHeavy) {
       /* the flag first: most waves of a developed flow retire on it */
-      const uint32_t slice = M.slice_begin + blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+      const uint32_t slice = M.slice_begin + mapped_block(M) * kWavesPerBlock + (threadIdx.x >> 6);
       if (slice >= M.slice_end)
         return;
       if constexpr (MODE == kHoLight) {
@@ -1307,5 +1438,28 @@ namespace ryujin_hip
     }
     next_cached_slice<E, MAXW, CP, SPLIT, MODE>(P, M, r, group, new_U, bounds, pij, lij, lij_next, V_unlimited, S0,
                                                 W, todo);
+  }
+
+  /* the launch behind the sweep of step 6 where the tiles step 5 did not store are formed outside it (kHoDefer): the
+   * listed slices, with the repair. A few dozen to a few hundred slices of a developed flow on an otherwise idle device:
+   * what counts is the length of one slice's chain of dependent loads, not throughput (one wave per slice through the
+   * kernel of the sweep: 157 us for 85 slices, profiles/r06c_kernel_trace_cylinder3d.md). Hence ONE BLOCK PER SLICE in
+   * the SPLIT form of the small meshes -- every wave forms the update, wave w runs the second limiter pass of every
+   * fourth column -- with ALL of the row's P_ij in registers (one wave per SIMD: the register file is the wave's) so
+   * that its loads are issued back to back. */
+  template <typename E, int MAXW>
+  __global__ void __launch_bounds__(kBlock, 1)
+  k_high_order_next_deferred(const typename E::Params P, const DeviceMesh M, double *__restrict__ new_U,
+                             const double *__restrict__ bounds, double *__restrict__ pij,
+                             const double *__restrict__ lij, double *__restrict__ lij_next,
+                             const double *__restrict__ V_unlimited, const Stage0Src S0, const SliceFlags W)
+  {
+    const uint32_t n = S0.scalars->n_deferred[M.slice_begin != 0u ? 1 : 0];
+    const uint32_t group = threadIdx.x >> 6;
+    for (uint32_t q = blockIdx.x; q < n; q += gridDim.x) { /* (uniform over the block: the barriers in the body are safe) */
+      const RowCtx r = row_context_of_slice(M, W.deferred[M.slice_begin + q]);
+      next_cached_slice<E, MAXW, MAXW, true, kHoRepair>(P, M, r, group, new_U, bounds, pij, lij, lij_next,
+                                                        V_unlimited, S0, W);
+    }
   }
 } // namespace ryujin_hip

@@ -51,6 +51,12 @@ namespace ryujin_hip
 #ifndef RYUJIN_OCC_LIJ0
 #define RYUJIN_OCC_LIJ0 3 /* waves per SIMD asked of the register allocator */
 #endif
+#ifndef RYUJIN_LIJ0_UNCOND
+#define RYUJIN_LIJ0_UNCOND 1 /* step 5 where P_ij is stored everywhere: unconditional stores (see kUnconditionalStores) */
+#endif
+#ifndef RYUJIN_LIJ0_DELAY_L_MAXDIM
+#define RYUJIN_LIJ0_DELAY_L_MAXDIM 2 /* step 5: l_ij of column c stored in iteration c + 1 up to this dimension */
+#endif
 #ifndef RYUJIN_LIJ0_PARK_3D
 #define RYUJIN_LIJ0_PARK_3D 2 /* step 5 in 3-D: 1 = the row's F_i in LDS, 2 = F_i and U_i, 0 = all in registers */
 #endif
@@ -78,16 +84,20 @@ namespace ryujin_hip
   /* NY > 1 (small meshes): NY waves (blockIdx.y) share a slice, wave y taking the columns 1 + y, 1 + y + NY, ...;
    * no V_i then (the row's sum is spread over several waves): the caller passes V_out = nullptr.
    * PER_SLICE: see the head of the file (NY == 1 only); otherwise P_ij is stored everywhere. */
-  template <typename E, int NY = 1, bool PER_SLICE = false>
+  /* TILE: P_ij is stored per (slice, column) tile (below; NY == 1, not PER_SLICE). A template parameter, not a kernel
+   * argument: with both storage schemes in one instantiation the 3-D kernel ran 5 % slower than the per-slice one at
+   * equal stores (profiles/r06b_ab_tile_pij_c4.log). */
+  template <typename E, int NY = 1, bool PER_SLICE = false, bool TILE = false>
   __global__ void __launch_bounds__(kBlock, lij0_waves_per_simd<E>())
   k_lij_stage0(const typename E::Params P, const DeviceMesh M, DeviceScalars *__restrict__ scalars,
                const double *__restrict__ old_U, const double *__restrict__ alpha,
                const double *__restrict__ dij, const double *__restrict__ new_U,
                const double *__restrict__ r_in, const double *__restrict__ bounds, double *__restrict__ pij,
                double *__restrict__ lij, double *__restrict__ V_out, const SliceFlags W = SliceFlags{},
-               const int predict_override = 0, const int tile_store = 0)
+               const int predict_override = 0)
   {
     static_assert(!PER_SLICE || NY == 1, "one wave per slice decides");
+    static_assert(!TILE || (NY == 1 && !PER_SLICE), "per tile: the plain kernel, one wave per slice");
     constexpr int K = E::K;
     constexpr int NB = E::NB;
     const RowCtx r = row_context(M);
@@ -140,21 +150,44 @@ namespace ryujin_hip
      * through the neighbour's l_ji alone are formed by step 6 (next_cached_slice). On the developed C2 flow 93 % of the
      * slices but 43 % of the tiles hold a limited pair: most of the 8 k S bytes per row this sweep used to write were
      * never read. */
-    const bool tile_mode = !PER_SLICE && NY == 1 && tile_store != 0;
+    constexpr bool tile_mode = TILE;
+    /* gfx9 has ONE counter for vector loads and stores (vmcnt), decremented in issue order. A store the compiler sees
+     * on some paths of the column loop only -- `if (active) store` -- makes it wait for vmcnt(0) before the first use of
+     * the next column's operands: every column then pays the round trip of the stores of the column before
+     * (profiles/r06i_*). Where everything is stored anyway, every lane stores, every column: the number of
+     * stores behind the loads is the same on every path and the wait becomes vmcnt(n > 0). */
+    constexpr bool kUnconditionalStores = RYUJIN_LIJ0_UNCOND != 0 && !PER_SLICE && !TILE && NY == 1;
     uint32_t tiles_stored = 0;
     /* ... or step 6 of the PREVIOUS update needed it (SliceFlags::needed_tiles, bit c of the slice's word): fronts
      * move a fraction of a cell per update, so this predicts nearly every tile that is limited through l_ji alone,
      * and step 6 forms what is left (a tile predicted in vain costs its store, as before). */
-    const uint32_t predicted = (tile_mode && W.needed_tiles != nullptr) ? tiles_predicted(W.needed_tiles[r.slice]) : 0u;
+    constexpr int kMaxWidth = E::DIMENSION == 1 ? 3 : (E::DIMENSION == 2 ? 9 : 27);
+    const uint32_t predicted = (tile_mode && W.needed_tiles != nullptr) ? tiles_predicted<kMaxWidth>(W, r.slice) : 0u;
 
-    /* software pipeline: the loads of the next column are in flight while column c is limited */
-    /* (the column index of a structured tile is row + delta of the tile's descriptor, kernels_euler.hpp: no index
-     * stream to prefetch two columns ahead, as rounds 1 - 4 did; an unstructured tile reads its indices with the
-     * loads of the next column, behind the limiter of the current one) */
-    uint32_t j_n = r.width > c0 ? tile_column<tile_map_pays<E::DIMENSION>()>(M, (uint64_t)r.base + c0, i, r.lane) : i;
+    /* SOFTWARE PIPELINE, arranged around gfx9's single in-order counter for vector loads and stores (vmcnt): whatever
+     * the wave waits for, it waits for everything it issued before that as well, and where the compiler cannot count
+     * the operations behind a load on every path -- conditional stores, the index load of an irregular tile -- it
+     * waits for vmcnt(0): all of it. Rounds 1 - 5 issued the l_ij store of column c as the last thing of its iteration
+     * and, in 3-D, the index load of column c + 1 right in front of the gathers that need it: the first wait of every
+     * iteration then covered a store and an index load that had just been issued -- two round trips per column
+     * (scripts/isa_loop_waits.sh k_lij_stage0). Now
+     *   - the column index runs TWO columns ahead (j_nn), the operands of the pair one column ahead (next);
+     *   - the l_ij of column c is stored in iteration c + 1, BEHIND the loads of that iteration, so that it has a whole
+     *     limiter to retire behind before anything waits for it;
+     *   - where everything is stored anyway, every lane stores in every column (kUnconditionalStores).
+     * (the column index of a structured tile is row + delta of the tile's descriptor, kernels_euler.hpp) */
+    constexpr bool kTileMap = tile_map_pays<E::DIMENSION>();
+    uint32_t j_n = r.width > c0 ? tile_column<kTileMap>(M, (uint64_t)r.base + c0, i, r.lane) : i;
+    uint32_t j_nn = r.width > c0 + NY ? tile_column<kTileMap>(M, (uint64_t)r.base + c0 + NY, i, r.lane) : i;
     PairData<K> next;
     if (r.width > c0)
       load_pair<K>(M, old_U, r_in, alpha, dij, ((uint64_t)r.base + c0) * 64 + r.lane, j_n, next);
+    /* the l_ij of the previous column, not stored yet (l_pending_on: there is one). (3-D: the kernel sits at the
+     * register limit of three waves per SIMD; the three registers this takes come back as spill reloads INSIDE the
+     * loop -- scratch loads count in vmcnt as well -- so the store stays at the end of its own iteration there) */
+    constexpr bool kDelayL = RYUJIN_LIJ0_DELAY_L_MAXDIM >= E::DIMENSION;
+    double l_pending = 1.;
+    bool l_pending_on = false;
 
     for (uint32_t c = c0; c < r.width; c += NY) {
       const uint64_t colbase = (uint64_t)r.base + c;
@@ -166,14 +199,25 @@ namespace ryujin_hip
       else
         pij_stage0<K>(row, next, P_ij);
       if (c + NY < r.width) {
-        j_n = tile_column<tile_map_pays<E::DIMENSION>()>(M, colbase + NY, i, r.lane);
+        j_n = j_nn;
         load_pair<K>(M, old_U, r_in, alpha, dij, (colbase + NY) * 64 + r.lane, j_n, next);
+        j_nn = c + 2 * NY < r.width ? tile_column<kTileMap>(M, colbase + 2 * NY, i, r.lane) : i;
+      }
+      /* the l_ij of the column before */
+      if constexpr (kDelayL) {
+        if constexpr (kUnconditionalStores) {
+          if (c > c0)
+            lij[pos - NY * 64] = l_pending;
+        } else if (l_pending_on)
+          lij[pos - NY * 64] = l_pending;
       }
       /* a slice that stores already: as soon as P_ij is formed (the store overlaps the limiter) */
       const bool stored_early = storing && (!tile_mode || ((predicted >> c) & 1u) != 0u);
       if (tile_mode && stored_early)
         ++tiles_stored;
-      if (stored_early && active)
+      if constexpr (kUnconditionalStores)
+        store_entry<K>(pij, colbase, r.lane, P_ij); /* (every lane: the padding slots of the slice absorb the inactive ones) */
+      else if (stored_early && active)
         store_entry<K>(pij, colbase, r.lane, P_ij);
       bool success = true, undecided = false;
       double l_ij = 1.;
@@ -197,18 +241,28 @@ namespace ryujin_hip
         if (active)
           store_entry<K>(pij, colbase, r.lane, P_ij);
       }
-      if (!active)
-        continue;
       if constexpr (PER_SLICE) {
-        if (storing && !stored_early)
+        if (active && storing && !stored_early)
           store_entry<K>(pij, colbase, r.lane, P_ij);
       }
-      if (undecided) {
-        undecided_mask |= 1ull << c;
-      } else {
+      /* (an undecided pair's entry: a placeholder in the unconditional form, which the Newton tail overwrites behind
+       * its fence; nothing otherwise) */
+      if constexpr (kDelayL) {
+        l_pending = (active && !undecided) ? l_ij : 1.;
+        l_pending_on = active && !undecided;
+      } else if constexpr (kUnconditionalStores)
+        lij[pos] = (active && !undecided) ? l_ij : 1.;
+      else if (active && !undecided)
         lij[pos] = l_ij;
-        all_ok = all_ok && success;
-      }
+      if (active && undecided)
+        undecided_mask |= 1ull << c;
+      all_ok = all_ok && (!active || undecided || success);
+    }
+    /* the l_ij of the last column */
+    if (kDelayL && r.width > c0) {
+      const uint32_t c_last = c0 + ((r.width - 1 - c0) / NY) * NY;
+      if (kUnconditionalStores || l_pending_on)
+        lij[((uint64_t)r.base + c_last) * 64 + r.lane] = l_pending;
     }
     if (NY == 1 && V_out != nullptr && row_active)
       store_state<K>(V_out, i, V_i);

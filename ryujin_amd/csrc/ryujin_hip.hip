@@ -32,8 +32,14 @@
 #define RYUJIN_TILE_PIJ 1 /* the plain kernels (most slices limited) store P_ij per (slice, column) tile */
 #endif
 #ifndef RYUJIN_BAND_DEFAULT
-#ifndef RYUJIN_XCD_CHUNK_DEFAULT
-#define RYUJIN_XCD_CHUNK_DEFAULT 0 /* XCD-local block ranges (ryujin_hip_params::debug_xcd_chunk): off unless measured as a gain */
+#ifndef RYUJIN_XCD_CHUNK_3D
+#define RYUJIN_XCD_CHUNK_3D 8 /* XCD-local block ranges (ryujin_hip_params::debug_xcd_chunk == 0), blocks per XCD and chunk. Counted and timed
+                                 (profiles/r06a_xcd_probe_sedov3d.md, r06g_xcd_probe_*.md): the L2-miss read traffic of the sweeps falls
+                                 in every configuration -- C3 step 5 15.7 -> 10.1 GB, step 2 13.3 -> 9.6 GB per launch; C2 -20 ... -25 % in
+                                 every sweep -- and the TIME follows only on C3 (200^3, planes of 4.5 MB: step 5 -5 %, the update
+                                 -2.1 %); C4 +-1 %, C2 and C5 +-0.2 %. The sweeps are not bound by the bytes their gathers re-fetch
+                                 across XCDs (HBM itself delivers 5.8 - 6.7 TB/s for their read/write mixes,
+                                 profiles/r06h_hbm_mix.md): on in 3-D, where it is a gain or a wash, off below */
 #endif
 #define RYUJIN_BAND_DEFAULT 1 /* stacked blocks chosen from the mesh when ryujin_hip_params::debug_band_stride == 0, in 2-D:
                                  C2 (G = 47) -1.1 % per update, every sweep a little; in 3-D stacking lattice planes (G = 365
@@ -475,6 +481,7 @@ struct ryujin_hip_ctx {
    * context stores P_ij everywhere */
   DeviceBuffer<uint8_t> d_slice_unlimited, d_slice_first_stored, d_slice_todo;
   DeviceBuffer<uint32_t> d_slice_needed; /* SliceFlags::needed_tiles; starts as all ones: the first update stores every tile */
+  DeviceBuffer<uint32_t> d_slice_deferred; /* SliceFlags::deferred */
   /* fractions of the (sampled) slices in which the first high-order sweep found a limited pair / whose P_ij step 5
    * stored, from the device counters at the latest host synchronisation (DeviceScalars::n_sampled_*); 1 until the
    * first measurement. Diagnostics only: nothing is decided from them. */
@@ -817,8 +824,8 @@ void ryujin_hip_ctx::create(const ryujin_hip_offline &o, const ryujin_hip_params
   mesh.xcd_chunk = 0;
   if (p.debug_xcd_chunk > 0)
     mesh.xcd_chunk = (uint32_t)p.debug_xcd_chunk;
-  else if (p.debug_xcd_chunk == 0)
-    mesh.xcd_chunk = RYUJIN_XCD_CHUNK_DEFAULT;
+  else if (p.debug_xcd_chunk == 0 && dim == 3)
+    mesh.xcd_chunk = RYUJIN_XCD_CHUNK_3D;
   mesh.cij = d_cij.ptr;
   mesh.mij = d_mij.ptr;
   mesh.incidence = dg ? d_incidence.ptr : nullptr;
@@ -1523,14 +1530,18 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
    * stored where 71 - 93 % of the slices would be, and the update is faster than with either alternative at every
    * stage of the flow (profiles/r05t_ab_tile_*). debug_pij_storage: 0 this; 2 per tile with nothing predicted (tests:
    * every tile the neighbour's l_ji limits goes through step 6's repair); 1 per slice, nothing predicted; < 0
-   * everywhere, as rounds 1 - 4. Not with the checked build (its kernels read all of P_ij). In 3-D the repair path
-   * would cost step 6 its fourth wave per SIMD (RYUJIN_TILE_PIJ_MAXDIM): per slice there. */
+   * everywhere, as rounds 1 - 4. Not with the checked build (its kernels read all of P_ij). In 3-D per tile is built
+   * (the tiles step 5 did not store formed by a launch behind step 6, kernels_limiter.hpp: kHoDefer), measured as a
+   * small loss (RYUJIN_TILE_PIJ_DEFAULT_MAXDIM) and selected by debug_pij_storage = 3 (4: nothing predicted) only:
+   * per slice there while few slices are limited, everywhere after that. */
+  const int storage = params.debug_pij_storage;
   const bool tile_store = RYUJIN_TILE_PIJ && DIM <= RYUJIN_TILE_PIJ_MAXDIM && per_slice_possible &&
-                          (params.debug_pij_storage == 0 || params.debug_pij_storage == 2) &&
+                          (((storage == 0 || storage == 2) && DIM <= RYUJIN_TILE_PIJ_DEFAULT_MAXDIM) || storage == 3 ||
+                           storage == 4) &&
                           !params.debug_expensive_bounds_check;
   const bool per_slice =
-      per_slice_possible && !tile_store && params.debug_pij_storage >= 0 && !params.debug_expensive_bounds_check &&
-      (params.debug_pij_storage > 0 || limited_fraction <= (double)RYUJIN_PER_SLICE_MAX_LIMITED);
+      per_slice_possible && !tile_store && storage >= 0 && !params.debug_expensive_bounds_check &&
+      (storage == 1 || storage == 2 || limited_fraction <= (double)RYUJIN_PER_SLICE_MAX_LIMITED);
   ensure_pij();
   if (per_slice && d_slice_first_stored.n == 0) {
     d_slice_first_stored.alloc(L.n_slices);
@@ -1539,13 +1550,20 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
   const SliceFlags slice_flags{d_slice_unlimited.ptr, d_slice_first_stored.ptr, d_slice_todo.ptr};
   last_per_slice = per_slice;
   last_tile_store = tile_store;
-  const bool tiles_predicted_from_history = tile_store && params.debug_pij_storage == 0;
+  const bool tiles_predicted_from_history = tile_store && (storage == 0 || storage == 3);
+  constexpr int kHistoryWords = tile_history_words(kStage0Width);
   if (tiles_predicted_from_history && d_slice_needed.n == 0) { /* all ones: the first update stores every tile */
-    d_slice_needed.alloc(L.n_slices);
-    HIP_CHECK(hipMemsetAsync(d_slice_needed.ptr, 0xff, (size_t)L.n_slices * sizeof(uint32_t), launch_stream));
+    d_slice_needed.alloc((size_t)L.n_slices * kHistoryWords);
+    HIP_CHECK(hipMemsetAsync(d_slice_needed.ptr, 0xff, (size_t)L.n_slices * kHistoryWords * sizeof(uint32_t),
+                             launch_stream));
   }
+  /* the tiles step 5 did not store are formed outside the sweep of step 6 (kernels_limiter.hpp, kHoDefer) */
+  constexpr bool kDeferTiles = DIM >= RYUJIN_TILE_DEFER_MINDIM;
+  if (tile_store && kDeferTiles && d_slice_deferred.n == 0)
+    d_slice_deferred.alloc(L.n_slices);
   const SliceFlags tile_flags{nullptr, nullptr, nullptr,
-                              tiles_predicted_from_history ? d_slice_needed.ptr : nullptr};
+                              tiles_predicted_from_history ? d_slice_needed.ptr : nullptr, L.n_slices,
+                              (tile_store && kDeferTiles) ? d_slice_deferred.ptr : nullptr};
   last_s0 = Stage0Src{d_scalars.ptr, old.U.ptr, d_alpha.ptr, d_dij.ptr, d_r.ptr, tile_store ? 1 : 0};
   sweep([&](const DeviceMesh &mm, dim3 grid) {
     if constexpr (is_euler) {
@@ -1693,11 +1711,16 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
             constexpr int NY = decltype(ny)::value;
             hipLaunchKernelGGL((k_lij_stage0<E, NY>), dim3(grid.x, NY), block, 0, launch_stream, eparams, mm,
                                d_scalars.ptr, old.U.ptr, d_alpha.ptr, d_dij.ptr, nw.U.ptr, d_r.ptr, d_bounds.ptr,
-                               d_pij.ptr, d_lij.ptr, NY == 1 ? d_V.ptr : nullptr,
-                               SliceFlags{nullptr, nullptr, nullptr, tile_flags.needed_tiles}, 0,
-                               (NY == 1 && tile_store) ? 1 : 0);
+                               d_pij.ptr, d_lij.ptr, NY == 1 ? d_V.ptr : nullptr, tile_flags, 0);
             stage0_V = NY == 1 && d_V.ptr != nullptr;
           };
+          if (tile_store && groups < 2) { /* (tile_store implies one wave per slice) */
+            hipLaunchKernelGGL((k_lij_stage0<E, 1, false, true>), grid, block, 0, launch_stream, eparams, mm,
+                               d_scalars.ptr, old.U.ptr, d_alpha.ptr, d_dij.ptr, nw.U.ptr, d_r.ptr, d_bounds.ptr,
+                               d_pij.ptr, d_lij.ptr, d_V.ptr, tile_flags, 0);
+            stage0_V = d_V.ptr != nullptr;
+            return;
+          }
           if (per_slice) {
             hipLaunchKernelGGL((k_lij_stage0<E, 1, true>), grid, block, 0, launch_stream, eparams, mm,
                                d_scalars.ptr, old.U.ptr, d_alpha.ptr, d_dij.ptr, nw.U.ptr, d_r.ptr, d_bounds.ptr,
@@ -1835,11 +1858,26 @@ int ryujin_hip_ctx::step(int h_old, int stages, const int *h_stage, const double
           }
         }
         if ((DIM <= 2 || RYUJIN_HO_CP_3D > 0) && L.max_row_len <= (uint32_t)kCachedWidth) {
-          hipLaunchKernelGGL((k_high_order_next_cached<E, kCachedWidth, kCachedP>), grid, block, 0,
-                             launch_stream, eparams, mm, nw.U.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr,
-                             d_lij_next.ptr, stage0_V ? d_V.ptr : nullptr, last_s0,
-                             SliceFlags{stage0_V ? d_slice_unlimited.ptr : nullptr, nullptr, nullptr,
-                                        tile_flags.needed_tiles});
+          SliceFlags flags6 = tile_flags;
+          flags6.unlimited = stage0_V ? d_slice_unlimited.ptr : nullptr;
+          bool launched = false;
+          if constexpr (kDeferTiles && (is_euler || is_aeos)) {
+            if (tile_store && stage0_V) {
+              /* the sweep, and behind it the slices that missed a tile (a grid of fixed size walks the list) */
+              hipLaunchKernelGGL((k_high_order_next_cached<E, kCachedWidth, kCachedP, false, kHoDefer>), grid, block,
+                                 0, launch_stream, eparams, mm, nw.U.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr,
+                                 d_lij_next.ptr, d_V.ptr, last_s0, flags6);
+              hipLaunchKernelGGL((k_high_order_next_deferred<E, kCachedWidth>),
+                                 dim3(std::min<uint32_t>(grid.x * kWavesPerBlock, 512u)), block, 0, launch_stream, eparams, mm,
+                                 nw.U.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr, d_lij_next.ptr, d_V.ptr, last_s0,
+                                 flags6);
+              launched = true;
+            }
+          }
+          if (!launched)
+            hipLaunchKernelGGL((k_high_order_next_cached<E, kCachedWidth, kCachedP>), grid, block, 0,
+                               launch_stream, eparams, mm, nw.U.ptr, d_bounds.ptr, d_pij.ptr, d_lij.ptr,
+                               d_lij_next.ptr, stage0_V ? d_V.ptr : nullptr, last_s0, flags6);
           step6_flags = stage0_V;
         } else if (L.max_row_len > 64)
           hipLaunchKernelGGL((k_high_order<E, false, true>), grid, block, 0, launch_stream, eparams, mm, nw.U.ptr,
@@ -2875,6 +2913,16 @@ int ryujin_hip_tile_statistics(ryujin_hip_ctx *ctx, double *stored_fraction, dou
       *read_fraction = tiles ? ctx->tiles_needed_fraction : 1.;
     if (formed_by_step6_fraction)
       *formed_by_step6_fraction = tiles ? ctx->tiles_formed_fraction : 0.;
+    return RYUJIN_OK;
+  });
+}
+
+int ryujin_hip_deferred_slices(ryujin_hip_ctx *ctx, unsigned *n_slices)
+{
+  return guarded([&]() {
+    if (!ctx || !n_slices)
+      throw HipError(RYUJIN_ERR_ARG, "null argument");
+    *n_slices = ctx->h_scalars ? ctx->h_scalars->n_deferred[0] + ctx->h_scalars->n_deferred[1] : 0u;
     return RYUJIN_OK;
   });
 }

@@ -295,6 +295,11 @@ class HyperbolicModule:
             a, b, c = C.c_double(1.0), C.c_double(1.0), C.c_double(0.0)
             self._check(self._lib.ryujin_hip_tile_statistics(self._ctx, C.byref(a), C.byref(b), C.byref(c)))
             out.update(tiles_stored_fraction=a.value, tiles_read_fraction=b.value, tiles_formed_by_step6_fraction=c.value)
+            if hasattr(self._lib, "ryujin_hip_deferred_slices"):  # (A/B runs load older builds of the library)
+                n = C.c_uint(0)
+                self._lib.ryujin_hip_deferred_slices.argtypes = [C.c_void_p, C.POINTER(C.c_uint)]
+                self._check(self._lib.ryujin_hip_deferred_slices(self._ctx, C.byref(n)))
+                out.update(deferred_slices_last_update=n.value)
         return out
 
     def layout_info(self) -> dict:

