@@ -25,7 +25,7 @@ def load(path: str | None = None):
     if _lib is not None and path is None:
         return _lib
     if path is None:
-        path = _build_oracle.ORACLE_SO
+        path = os.environ.get("RYUJIN_ORACLE_LIB", _build_oracle.ORACLE_SO)  # (the sanitizer builds: scripts/sanitizer_run.sh)
         if not os.path.exists(path):
             _build_oracle.build_oracle()
     lib = C.CDLL(path)

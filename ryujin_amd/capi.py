@@ -116,7 +116,7 @@ _synth = None
 def load_synth():
     global _synth
     if _synth is None:
-        path = _build.SYNTH_SO
+        path = os.environ.get("RYUJIN_SYNTH_LIB", _build.SYNTH_SO)  # (the sanitizer builds: scripts/sanitizer_run.sh)
         if not os.path.exists(path):
             _build.build_synth()
         lib = C.CDLL(path)

@@ -18,6 +18,11 @@
 // Test scaffolding for the BOUNDARY: not an oracle, not a build of the reference's hot path (which is what
 // libryujin_hip.so replaces).
 //
+//   time_integrator_run export <prefix> [box:<cells> | step:<cells per unit>]
+//     contrib/ryujin_export_offline.h EXECUTED -- export_offline_data() walks the reference's
+//     own SparsityPatternSIMD / SparseMatrixSIMD (SIMD-interleaved rows, get_entry / get_tensor) and the OfflineData
+//     accessors and writes <prefix>-0.ryjoffl; tests/test_offline_export_run.py imports the dump and runs the kernels on
+//     it against the oracle. (Mach-3 step: Dirichlet inflow, do-nothing outflow, slip walls, coupling boundary pairs.)
 //   time_integrator_run <scheme> <n_steps> <device_resident 0|1> [n_cells]
 //     environment: RYUJIN_TEST_PIN=1 -> "hip pin host vectors = true"; RYUJIN_TEST_NO_DERIVED=1 -> "hip mirror
 //     precomputed values = false"
@@ -30,6 +35,8 @@
 #include "sparse_matrix_simd.template.h"
 
 #include "euler/description.h"
+
+#include "ryujin_export_offline.h"
 
 #include <ryujin_synth.h>
 
@@ -47,6 +54,7 @@ namespace ryujin
 
   /* the mesh the stand-ins below serve (set by main before anything is constructed) */
   static const ryujin_hip_offline *g_offline = nullptr;
+  static const double *g_positions = nullptr, *g_bdry_positions = nullptr;
 
 
   /* ---- stand-ins for the collaborators that need deal.II's grid/FE stack ------------------------------- */
@@ -58,6 +66,7 @@ namespace ryujin
   {
     ansatz_ = Ansatz::cg_q1;
     refinement_ = 6;
+    mapping_ = std::make_unique<dealii::Mapping<dim>>(); /* (an identity the exporter hands on, see below) */
   }
 
 
@@ -79,6 +88,7 @@ namespace ryujin
   {
     const ryujin_hip_offline &o = *g_offline;
     AssertThrow(o.n_owned == o.n_relevant, dealii::ExcMessage("one rank"));
+    dof_handler_ = std::make_unique<dealii::DoFHandler<dim>>();
 
     dealii::IndexSet owned(o.n_owned), ghost(o.n_owned);
     owned.add_range(0, o.n_owned);
@@ -142,7 +152,7 @@ namespace ryujin
       dealii::Point<dim> position;
       for (int d = 0; d < dim; ++d) {
         normal[d] = o.b_normal[q * dim + d];
-        position[d] = 0.; /* only read for Dirichlet data; the box has slip walls */
+        position[d] = g_bdry_positions ? g_bdry_positions[q * dim + d] : 0.;
       }
       boundary_map_.push_back({o.b_i[q], normal, Number(0.), Number(0.), dealii::types::boundary_id(o.b_id[q]), position});
     }
@@ -190,6 +200,31 @@ namespace ryujin
 } // namespace ryujin
 
 
+/* the two deal.II entry points the exporter calls beyond the containers (stand-ins: the support points are the
+ * generator's, one rank: global = local index) */
+namespace dealii
+{
+  template <>
+  DoFHandler<2, 2>::DoFHandler()
+  {
+  }
+  namespace DoFTools
+  {
+    template <>
+    void map_dofs_to_support_points<2, 2>(const Mapping<2, 2> &, const DoFHandler<2, 2> &,
+                                          std::map<types::global_dof_index, Point<2>> &out)
+    {
+      for (unsigned int i = 0; i < ryujin::g_offline->n_relevant; ++i) {
+        Point<2> x;
+        for (int d = 0; d < 2; ++d)
+          x[d] = ryujin::g_positions[i * 2 + d];
+        out[i] = x;
+      }
+    }
+  } // namespace DoFTools
+} // namespace dealii
+
+
 static unsigned long long fnv1a(const void *data, std::size_t bytes)
 {
   const unsigned char *p = static_cast<const unsigned char *>(data);
@@ -206,9 +241,13 @@ int main(int argc, char **argv)
 {
   using namespace ryujin;
   const std::string scheme = argc > 1 ? argv[1] : "ssprk33";
-  const int n_steps = argc > 2 ? std::atoi(argv[2]) : 6;
-  const bool device_resident = argc > 3 && std::atoi(argv[3]) != 0;
-  const int n_cells = argc > 4 ? std::atoi(argv[4]) : 64;
+  const bool export_mode = scheme == "export";
+  const std::string export_prefix = export_mode && argc > 2 ? argv[2] : "offline";
+  const std::string export_mesh = export_mode && argc > 3 ? argv[3] : "box:16";
+  const int n_steps = !export_mode && argc > 2 ? std::atoi(argv[2]) : 6;
+  const bool device_resident = !export_mode && argc > 3 && std::atoi(argv[3]) != 0;
+  const int n_cells = export_mode ? std::atoi(export_mesh.substr(export_mesh.find(':') + 1).c_str())
+                                  : (argc > 4 ? std::atoi(argv[4]) : 64);
 
   ryujin_synth_spec spec{};
   spec.dim = 2;
@@ -218,12 +257,28 @@ int main(int argc, char **argv)
   for (int f = 0; f < 4; ++f)
     spec.bc[f] = RYUJIN_BC_SLIP;
   spec.n_ranks = 1;
+  if (export_mode && export_mesh.rfind("step:", 0) == 0) {
+    /* ryujin_amd/offline.py: mach3_step_2d(n) -- [0,3]x[0,1] minus [0.6,3]x[0,0.2] */
+    spec.n_cells[0] = 3 * n_cells;
+    spec.upper[0] = 3.;
+    spec.upper[1] = 1.;
+    spec.bc[0] = RYUJIN_BC_DIRICHLET;
+    spec.bc[1] = RYUJIN_BC_DO_NOTHING;
+    spec.cut_kind = RYUJIN_CUT_BOX;
+    spec.cut_lo[0] = 0.6;
+    spec.cut_lo[1] = -1.;
+    spec.cut_hi[0] = 4.;
+    spec.cut_hi[1] = 0.2;
+    spec.cut_bc = RYUJIN_BC_SLIP;
+  }
   ryujin_synth *mesh = ryujin_synth_build(&spec);
   if (!mesh) {
     std::fprintf(stderr, "%s\n", ryujin_synth_last_error());
     return 1;
   }
   g_offline = ryujin_synth_offline(mesh);
+  g_positions = ryujin_synth_positions(mesh);
+  g_bdry_positions = ryujin_synth_bdry_positions(mesh);
 
   int status = 0;
   try {
@@ -257,7 +312,8 @@ int main(int argc, char **argv)
                                                       {"erk11", "erk 11"},     {"erk22", "erk 22"},
                                                       {"erk33", "erk 33"},     {"erk43", "erk 43"},
                                                       {"erk54", "erk 54"}};
-    dealii::ParameterAcceptor::prm.set("/H - TimeIntegrator", "time stepping scheme", names.at(scheme));
+    dealii::ParameterAcceptor::prm.set(
+        "/H - TimeIntegrator", "time stepping scheme", export_mode ? std::string("ssprk 33") : names.at(scheme));
     dealii::ParameterAcceptor::prm.set(
         "/F - HyperbolicModule", "hip device resident state vectors", device_resident ? "true" : "false");
     if (std::getenv("RYUJIN_TEST_PIN"))
@@ -269,6 +325,13 @@ int main(int argc, char **argv)
     /* TimeLoop::run() (time_loop.template.h:240-300) */
     const auto prec = Description::HyperbolicSystemView<dim, Number>::n_precomputed_values;
     offline_data.prepare(HyperbolicModule<Description, dim, Number>::problem_dimension, prec);
+    if (export_mode) {
+      /* TimeLoop::run() with contrib/ryujin_export_offline.patch: behind OfflineData::prepare() */
+      export_offline_data(offline_data, export_prefix, mpi_communicator);
+      std::printf("exported %u rows to %s-0.ryjoffl\n", offline_data.n_locally_owned(), export_prefix.c_str());
+      ryujin_synth_free(mesh);
+      return 0;
+    }
     hyperbolic_module.prepare();
     parabolic_module.prepare();
     time_integrator.prepare();

@@ -26,10 +26,13 @@ class _Mods(list):
     params = None
 
 
-def _both(spec, U0, oracle, n_warm=0, dirichlet=None, params_edit=None, equation=capi.EQ_EULER, bathymetry=None):
+def _both(spec, U0, oracle, n_warm=0, dirichlet=None, params_edit=None, equation=capi.EQ_EULER, bathymetry=None,
+          off=None):
     """Warm up on the GPU (lets shocks form so that the limiter branches are exercised), then hand the
-    SAME state to both backends so that one update is compared on identical inputs."""
-    off = offline.SyntheticOffline(spec)
+    SAME state to both backends so that one update is compared on identical inputs. `off`: offline data that do not
+    come from a recipe (an imported dump, a converted layout) instead of `spec`."""
+    if off is None:
+        off = offline.SyntheticOffline(spec)
     if bathymetry is not None:
         off.set_initial_precomputed(bathymetry(off.positions))
     mods = _Mods()
@@ -371,6 +374,10 @@ def test_reference_simd_layout_import(oracle):
         got = b1.download()[off_simd.new_index]
         # same mesh, different numbering: stencil summation order differs -> round-off only
         assert (np.abs(got - ref) / scale).max() < 1e-12
+        # the ORACLE on the same SIMD-interleaved arrays, sweep by sweep (it reads the layout through its own
+        # restatement of sparse_matrix_simd.h:403-418, oracle/csr.hpp)
+        _, mods = _both(None, U0[off_simd.order], oracle, n_warm=3, off=off_simd)
+        _compare_step(off_simd, mods)
 
 
 def test_device_pow_accuracy():
@@ -605,7 +612,7 @@ def test_device_resident_time_step_bang_bang_recovery(oracle):
     np.testing.assert_array_equal(state.download()[: off.n_owned], sv.download()[: off.n_owned])
 
 
-def test_imported_offline_dump_is_bit_identical_on_the_gpu(tmp_path):
+def test_imported_offline_dump_is_bit_identical_on_the_gpu(tmp_path, oracle):
     """a context created from an OfflineData dump (include/ryujin_offline_io.h) computes
     exactly what the context created from the in-memory arrays computes (Euler step mesh with
     Dirichlet/slip/do-nothing boundaries and coupling pairs; shallow water with bathymetry)."""
@@ -633,6 +640,11 @@ def test_imported_offline_dump_is_bit_identical_on_the_gpu(tmp_path):
             res.append((taus, a.download()))
         assert res[0][0] == res[1][0]
         assert np.array_equal(res[0][1], res[1][1])
+        # ... and what it computes is what the ORACLE computes from the same dump, sweep by sweep (round 5: the f-2
+        # tests compared HIP with HIP only)
+        # (the dump carries the bathymetry: ryujin_hip_offline::initial_precomputed of the imported view)
+        _, mods = _both(None, U0, oracle, n_warm=4, dirichlet=dirichlet, equation=equation, off=imp)
+        _compare_step(imp, mods, dirichlet)
 
 
 @pytest.mark.parametrize("scheme", ["erk 33", "ssprk 33"])
