@@ -130,6 +130,9 @@ namespace ryujin_hip
 
   /* minimum waves per SIMD requested from the register allocator for the heavy sweeps (second
    * __launch_bounds__ argument): 512 registers / waves. Tuned on MI355X, see DESIGN.md. */
+#ifndef RYUJIN_PIN_WAITS
+#define RYUJIN_PIN_WAITS 1 /* arrived() in the column loops (0: A/B, the compiler's own placement of the waits) */
+#endif
 #ifndef RYUJIN_HO_CP_3D
 #define RYUJIN_HO_CP_3D 2 /* step 6 in 3-D: 0 = two-pass kernel, n = l_ij and the first n P_ij columns in registers (the others are read a second time, unless the whole tile is unlimited). Round 1, all at 2 waves/SIMD: 3.07 ms (0), 2.43 (8), 2.24 (14), 2.36 (18); round 2 see RYUJIN_OCC_HO_3D; round 4 (developed C4 state, all slices limited, limited update from V_i with tile-predicated P loads, 3 waves): whole update 8.30 ms (6), 8.06 (3), 8.02 (2), 8.13 (1) -- the second read of an unlimited tile is skipped anyway, fewer held columns leave the registers to the loads in flight */
 #endif
@@ -403,6 +406,26 @@ namespace ryujin_hip
   RYUJIN_DEV uint32_t tile_transposed(const DeviceMesh &M, const uint64_t colbase, const uint32_t lane)
   {
     return tile_transposed(M, tile_desc<USE>(M, colbase), colbase, lane);
+  }
+
+  /* ---- the column pipeline and gfx9's single memory counter. Vector loads AND stores count in one counter (vmcnt),
+   * retired in issue order. A sweep prefetches the operands of column c + 1 while it works on column c; the compiler
+   * places the wait for column c's operands at their first use -- and where the loop holds a memory operation it
+   * cannot count on every path (the store of an active lane, the index load of an irregular tile), that wait is
+   * vmcnt(0): EVERYTHING in flight. If the first use sits behind the prefetch of column c + 1 the wave then waits
+   * for that prefetch as well and nothing overlaps (scripts/isa_loop_waits.sh shows the pattern: loads, then
+   * vmcnt(0) straight away). arrived() is a use the compiler cannot see through: called on the operands of column c
+   * BEFORE the loads of column c + 1 are issued it pins the wait in front of them. The stores of a column are kept
+   * back and issued behind the next column's loads for the same reason (a store issued at the end of an iteration
+   * is the first thing the next iteration waits for). ---- */
+  RYUJIN_DEV void arrived(double &x) { asm volatile("" : "+v"(x)); }
+  RYUJIN_DEV void arrived(uint32_t &x) { asm volatile("" : "+v"(x)); }
+  template <int N>
+  RYUJIN_DEV void arrived(double (&x)[N])
+  {
+#pragma unroll
+    for (int q = 0; q < N; ++q)
+      arrived(x[q]);
   }
 
   /* XCD-LOCAL BLOCK RANGES. Block b runs on XCD b % 8 (observed; speed only): consecutive blocks -- consecutive
@@ -822,9 +845,11 @@ namespace ryujin_hip
       load_entry<DIM>(cij, r.base, r.lane, c_n);
       if constexpr (RYUJIN_DIJ_PREFETCH_RECORD)
         load_record<RS>(rec, j_n, rec_n);
+      double d_pending = 0.; /* the d_ij of the column before, stored behind this column's loads (see arrived()) */
+      bool d_pending_on = false;
       for (uint32_t c = 0; c < r.width; ++c) {
         const uint64_t colbase = (uint64_t)r.base + c;
-        const uint32_t j = j_n;
+        uint32_t j = j_n;
         double c_ij[DIM], rec_j[RS];
 #pragma unroll
         for (int d = 0; d < DIM; ++d)
@@ -836,6 +861,11 @@ namespace ryujin_hip
         } else {
           load_record<RS>(rec, j, rec_j);
         }
+        if constexpr (RYUJIN_PIN_WAITS) {
+          arrived(c_ij);
+          arrived(rec_j);
+          arrived(j_nn);
+        }
         if (c + 1 < r.width) {
           j_n = j_nn;
           load_entry<DIM>(cij, colbase + 1, r.lane, c_n);
@@ -843,15 +873,20 @@ namespace ryujin_hip
             load_record<RS>(rec, j_n, rec_n);
           j_nn = (c + 2 < r.width) ? ld_stream(cols + ((colbase + 2) * 64 + r.lane)) : i;
         }
+        if (d_pending_on)
+          dij[(colbase - 1) * 64 + r.lane] = d_pending;
         const bool active = row_active && c < r.len;
         /* column 0 is the row itself: eta_j / rho_j = eta_i / rho_i and f_j = f_i bit for bit, its terms are exact
          * zeros added to sums that start at zero */
         if (active && (c > 0 || !E::kIndicatorDiagonalIsZero))
           indicator.accumulate_record(rec_j, c_ij);
         /* upper triangle only (:394-408) */
-        if (active && c > 0 && j > i)
-          dij[colbase * 64 + r.lane] = E::template dij_from_records<GENERAL>(P, rec_i, rec_j, c_ij);
+        d_pending_on = active && c > 0 && j > i;
+        if (d_pending_on)
+          d_pending = E::template dij_from_records<GENERAL>(P, rec_i, rec_j, c_ij);
       }
+      if (d_pending_on)
+        dij[((uint64_t)r.base + r.width - 1) * 64 + r.lane] = d_pending;
       if (row_active)
         alpha[i] = indicator.alpha(P, M.mi[i] * M.measure_of_omega_inverse);
       return;
@@ -867,6 +902,9 @@ namespace ryujin_hip
       load_entry<DIM>(cij, r.base, r.lane, c_n);
       load_state<K>(U, j_n, U_n);
       double2 prec_n = prec2[j_n];
+      /* (1-D, 2-D, shallow water: 124 registers and four waves per SIMD. Pinning the waits -- arrived() -- and keeping
+       * the d_ij store back costs 16 registers and the fourth wave here: 0.241 -> 0.247 ms on C2, with the Riemann
+       * record prefetched as well 0.268, profiles/r06l_ab_pinned_waits_c2.log; the loop stays as it was) */
       for (uint32_t c = 0; c < r.width; ++c) {
         const uint64_t colbase = (uint64_t)r.base + c;
         const uint32_t j = j_n;

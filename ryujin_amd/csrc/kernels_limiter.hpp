@@ -338,6 +338,11 @@ namespace ryujin_hip
     flag_restart(scalars, all_ok, r.lane);
   }
 
+  /* (Round 6 tried the column pipeline of k_lij_stage0 here -- P_ij formed before the next column's loads are issued,
+   * l_ij stored a column late: the shallow-water step 5 ran 4 - 9 % SLOWER on two boxes (0.400 -> 0.437 ms,
+   * profiles/r06l_ab_pinned_waits_c5.log; its limiter is a closed form, there is little to hide behind) and the
+   * kernel stays as it was.) */
+
   /* Step 5 for Euler, stages == 0, fused with the first part of P_ij of step 4 (:769-813): instead of
    * loading P_ij it is recomputed from U_i, U_j, alpha, d_ij, c_ij in exactly the operation order of
    * k_low_order, then the mass-matrix correction and the limiter follow as in k_pij_lij. */

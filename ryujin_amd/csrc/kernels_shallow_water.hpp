@@ -443,6 +443,12 @@ namespace ryujin_hip
     double alpha_n = alpha[j_n];
     double Z_n = Z[j_n];
     double h_star_n = FRICTION ? prec[(size_t)j_n * 2 + 1] : 1.; /* h_star_j only enters the friction term */
+    /* the P_ij of the column before, stored behind this column's loads (kernels_euler.hpp, arrived()) */
+    double P_pending[K];
+    bool P_pending_on = false;
+#pragma unroll
+    for (int q = 0; q < K; ++q)
+      P_pending[q] = 0.;
     for (uint32_t c = 0; c < r.width; ++c) {
       const uint64_t colbase = (uint64_t)r.base + c;
       const bool active = row_active && c < r.len;
@@ -454,7 +460,19 @@ namespace ryujin_hip
 #pragma unroll
       for (int q = 0; q < K; ++q)
         U_j[q] = U_n[q];
-      const double d_ij = d_n, m_ij = m_n, alpha_j = alpha_n, Z_j = Z_n, h_star_j = h_star_n;
+      double d_ij = d_n, m_ij = m_n, alpha_j = alpha_n, Z_j = Z_n, h_star_j = h_star_n;
+      if constexpr (RYUJIN_PIN_WAITS) {
+        arrived(c_ij);
+        arrived(U_j);
+        arrived(d_ij);
+        arrived(alpha_j);
+        arrived(Z_j);
+        arrived(j_nn);
+        if constexpr (FRICTION) {
+          arrived(m_ij);
+          arrived(h_star_j);
+        }
+      }
       if (c + 1 < r.width) {
         j_n = j_nn;
         load_entry<DIM>(cij, colbase + 1, r.lane, c_n);
@@ -468,6 +486,9 @@ namespace ryujin_hip
           h_star_n = prec[(size_t)j_n * 2 + 1];
         j_nn = (c + 2 < r.width) ? ld_stream(cols + ((colbase + 2) * 64 + r.lane)) : i;
       }
+      if (P_pending_on)
+        store_entry<K>(pij, colbase - 1, r.lane, P_pending);
+      P_pending_on = false;
       if (!active)
         continue;
 
@@ -594,8 +615,13 @@ namespace ryujin_hip
           }
         }
       }
-      store_entry<K>(pij, colbase, r.lane, P_ij);
+#pragma unroll
+      for (int q = 0; q < K; ++q)
+        P_pending[q] = P_ij[q];
+      P_pending_on = true;
     }
+    if (P_pending_on)
+      store_entry<K>(pij, (uint64_t)r.base + r.width - 1, r.lane, P_pending);
 
     if (!row_active)
       return;

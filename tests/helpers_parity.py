@@ -262,22 +262,24 @@ class EulerFlipClassifier:
 
 
 def alpha_last_bit_sensitivity(oracle, off, params, U_before, dirichlet, tau, alpha_ref):
-    """max |alpha(U) - alpha(U (1 +- 2^-52))| of the ORACLE: how far the reference's own indicator moves when
-    every input entry is changed in its last bit."""
+    """|alpha(U) - alpha(U (1 +- 2^-52))| of the ORACLE, per row, the largest of six random sign patterns: how far the
+    reference's own indicator moves when every input entry is changed in its last bit. (Round 6: per row and six
+    patterns instead of the maximum over the mesh of two -- two patterns underestimate the worst response of a row,
+    and a maximum over the mesh says nothing about the row in question.)"""
     if oracle is None or params is None:
-        return 0.0
+        return np.zeros_like(alpha_ref)
     p = capi.Params()
     C.memmove(C.byref(p), C.byref(params), C.sizeof(capi.Params))
     p.limiter_iterations = 0
     rng = np.random.default_rng(5)
-    worst = 0.0
-    for _ in range(2):
+    worst = np.zeros_like(alpha_ref)
+    for _ in range(6):
         m = HyperbolicModule(off, p, backend=oracle.backend())
         U = U_before * (1.0 + 2.0 ** -52 * rng.choice([-1.0, 1.0], size=U_before.shape))
         old, new = m.new_state_vector(U), m.new_state_vector()
         m.prepare_state_vector(old, 0.0, dirichlet)
         m.step(old, [], [], new, tau)
-        worst = max(worst, float(np.abs(m.alpha()[: alpha_ref.size] - alpha_ref).max()))
+        worst = np.maximum(worst, np.abs(m.alpha()[: alpha_ref.size] - alpha_ref))
         m.close()
     return worst
 
@@ -318,8 +320,10 @@ def compare_step(off, mods, dirichlet=None, tau=0.0, *, oracle=None, params=None
         # quotient is ill conditioned IN THE REFERENCE'S FORMULA (indicator.h:230-257). The yardstick is then
         # the oracle's own sensitivity to a last-bit perturbation of its input.
         sens = alpha_last_bit_sensitivity(oracle, off, params, U_before, dirichlet, tau, b)
-        _stat(label, what="alpha_sensitivity", sens=sens)
-        _check(params is not None and d_alpha <= 4.0 * sens, label, 'alpha', (d_alpha, sens))
+        _stat(label, what="alpha_sensitivity", sens=float(sens.max()))
+        beyond = np.abs(a - b) > 1e-12
+        _check(params is not None and (np.abs(a - b)[beyond] <= 4.0 * sens[beyond]).all(), label, 'alpha',
+               (d_alpha, float(sens.max()), int(beyond.sum())))
     a, b = both(lambda m, o, nw: m.debug_fetch("dij"))
     np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-300)
     if keep_matrices:

@@ -258,6 +258,72 @@ def test_near_vacuum_rows_keep_their_bounds_after_the_high_order_update(oracle):
         assert (np.minimum(c["lij"], 1.0) < 1e-3).mean() > 1e-3
 
 
+@pytest.mark.parametrize("kernels", ["small_mesh", "large_mesh"])
+def test_random_vacuum_and_shock_patches_keep_their_bounds(oracle, monkeypatch, kernels):
+    """A randomised probe of the MIXED rows of steps 6/7: a row with some unlimited (slice,
+    column) tiles and a strongly limited pair elsewhere takes the cancelling form V_i - sum (1 - l) lambda P_ij, only
+    rows ALL of whose columns lie in limited tiles the reference's sum (kernels_limiter.hpp, ref_order). Random patches
+    of near vacuum (density down to 1e-6), high pressure (up to 1e4) and moving gas on a 48 x 48 slip box, a few
+    updates of development, then one update against the oracle array by array -- and the bounds the limiter promises,
+    checked on the DEVICE's own new state: density within [rho_min, rho_max] (1 +- relax), specific entropy above s_min,
+    positive internal energy; the rows the probe is about (some pair limited to < 1e-3, another not limited at all)
+    must be there (some pair limited to < 1e-2 next to an unlimited one in the same row)."""
+    from ryujin_amd.initial_states import euler_from_primitive
+    if kernels == "large_mesh":  # the kernels of BASELINE-sized meshes (P_ij per tile, V_i, the tile-predicated update)
+        monkeypatch.setattr(HyperbolicModule, "library_switches",
+                            {"debug_no_small_mesh_split": 1, "debug_bc_fold_max_slices": -1})
+    spec = offline.rectangle_2d(48, (0.0, 0.0), (1.0, 1.0))
+    off0 = offline.SyntheticOffline(spec)
+    x = off0.positions
+    n_mixed, statuses = 0, []
+    for seed in (1, 2, 3, 4):
+        rng = np.random.default_rng(1000 + seed)
+        n_mixed_seed, statuses_seed = _random_patches_case(oracle, spec, x, rng)
+        n_mixed += n_mixed_seed
+        statuses += statuses_seed
+    assert 0 in statuses and n_mixed >= 5, (statuses, n_mixed)
+
+
+def _random_patches_case(oracle, spec, x, rng):
+    from ryujin_amd.initial_states import euler_from_primitive
+    rho, p, vel = np.full(len(x), 1.0), np.full(len(x), 1.0), np.zeros((len(x), 2))
+    for _ in range(24):  # patches: boxes with their own state
+        lo = rng.uniform(0.0, 0.9, size=2)
+        hi = lo + rng.uniform(0.05, 0.3, size=2)
+        inside = ((x >= lo) & (x <= hi)).all(axis=1)
+        rho[inside] = 10.0 ** rng.uniform(-6.0, 0.5)
+        p[inside] = 10.0 ** rng.uniform(-8.0, 2.0)
+        vel[inside] = rng.uniform(-1.0, 1.0, size=2) * np.sqrt(1.4 * p[inside][0] / rho[inside][0]) * rng.uniform(0.0, 0.7)
+    U0 = euler_from_primitive(rho, vel, p)
+    n_mixed, statuses = 0, []
+    for n_warm in (2, 5):
+        off, mods = _both(spec, U0, oracle, n_warm=n_warm)
+        g, c = _compare_step(off, mods)
+        n = off.n_owned
+        assert g["status"] == c["status"]
+        statuses.append(g["status"])
+        if g["status"] != 0:
+            continue  # (both sides asked for a restart: the limiter's bounds are not promised then)
+        eps = np.finfo(np.float64).eps
+        relax = 1.0e4 * eps
+        b = g["bounds"].reshape(-1, 3)[:n]
+        rho_n = g["U"][:n, 0]
+        e = g["U"][:n, 3] - 0.5 * (g["U"][:n, 1:3] ** 2).sum(1) / rho_n
+        assert (rho_n > 0).all() and (e > 0).all()
+        assert (rho_n >= b[:, 0] * (1.0 - relax)).all(), float((rho_n / b[:, 0]).min() - 1.0)
+        assert (rho_n <= b[:, 1] * (1.0 + relax)).all(), float((rho_n / b[:, 1]).max() - 1.0)
+        s = e * rho_n ** (-mods.params.gamma)
+        assert (s >= b[:, 2] * (1.0 - 100.0 * relax)).all(), float((s / b[:, 2]).min() - 1.0)
+        # mixed rows: the symmetrised l of the first pass has an (almost) closed pair and an open one in the same row
+        rs = off.row_starts.astype(np.int64)
+        l = np.minimum(c["lij"], 1.0)
+        for i in range(n):
+            li = l[rs[i] + 1: rs[i + 1]]
+            if li.size and li.min() < 1e-2 and li.max() == 1.0:
+                n_mixed += 1
+    return n_mixed, statuses
+
+
 def test_tile_map_gives_the_same_bits_as_the_index_arrays(oracle):
     """The tile map (host_layout.hpp: TileDesc): column indices and transposed positions of structured 64-row tiles from
     a 16-byte descriptor in the 2-D sweeps 3, 5, 6, 7. Same indices, so the same bits as with the map switched off
