@@ -538,7 +538,7 @@ namespace ryujin_hip
   /* The same with the row's F_i (and, PARK_U, U_i) parked in LDS, [component][lane] (conflict free): the same
    * operations on the same operands in the same order -- bit for bit pij_stage0() -- with 2 K (4 K) registers fewer
    * held across the column loop. Step 5 in 3-D: what separates the sweep from 3 waves per SIMD. */
-  template <int K, bool PARK_U>
+  template <int K, bool PARK_U, bool PARK_SCALARS = false>
   RYUJIN_DEV void pij_stage0_parked(const RowData<K> &row, const double *parked_, const uint32_t lane,
                                     const PairData<K> &p, double (&P_ij)[K])
   {
@@ -547,16 +547,20 @@ namespace ryujin_hip
     uint32_t off = lane;
     asm volatile("" : "+v"(off));
     const double *parked = parked_ + off;
-    const double d_ijH = p.d_ij * ((row.alpha_i + p.alpha_j) * .5);
+    /* PARK_SCALARS: the row's alpha_i, 1/m_i and factor wait in LDS as well (rows 2 K, 2 K + 1, 2 K + 2) */
+    const double alpha_i = PARK_SCALARS ? parked[(2 * K + 0) * 64] : row.alpha_i;
+    const double m_i_inv = PARK_SCALARS ? parked[(2 * K + 1) * 64] : row.m_i_inv;
+    const double factor = PARK_SCALARS ? parked[(2 * K + 2) * 64] : row.factor;
+    const double d_ijH = p.d_ij * ((alpha_i + p.alpha_j) * .5);
     const double dd = d_ijH - p.d_ij;
     const double b_ij = 0. - p.m_ij * p.m_j_inv;
-    const double b_ji = 0. - p.m_ij * row.m_i_inv;
+    const double b_ji = 0. - p.m_ij * m_i_inv;
 #pragma unroll
     for (int q = 0; q < K; ++q) {
       const double U_iq = PARK_U ? parked[(K + q) * 64] : row.U_i[q];
       double v = dd * (p.U_j[q] - U_iq);
       v += b_ij * p.F_j[q] - b_ji * parked[q * 64];
-      P_ij[q] = v * row.factor;
+      P_ij[q] = v * factor;
     }
   }
 

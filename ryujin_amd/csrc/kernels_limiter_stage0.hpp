@@ -58,7 +58,7 @@ namespace ryujin_hip
 #define RYUJIN_LIJ0_DELAY_L_MAXDIM 2 /* step 5: l_ij of column c stored in iteration c + 1 up to this dimension */
 #endif
 #ifndef RYUJIN_LIJ0_PARK_3D
-#define RYUJIN_LIJ0_PARK_3D 2 /* step 5 in 3-D: 1 = the row's F_i in LDS, 2 = F_i and U_i, 0 = all in registers */
+#define RYUJIN_LIJ0_PARK_3D 3 /* step 5 in 3-D: 1 = the row's F_i in LDS, 2 = F_i and U_i, 3 = and alpha_i, 1 / m_i, factor; 0 = all in registers */
 #endif
 #ifndef RYUJIN_OCC_LIJ0_3D
 #define RYUJIN_OCC_LIJ0_3D 3 /* rounds 1-4: 2 waves (at 3 the kernel spilled 28-56 B per lane and lost). Round 5: slice context in scalar
@@ -119,21 +119,33 @@ namespace ryujin_hip
     RowData<K> row;
     load_state<K>(old_U, i, row.U_i);
     load_state<K>(r_in, i, row.F_i);
-    /* 3-D: F_i (and U_i) of the row live in LDS across the column loop (pij_stage0_parked) */
-    constexpr int kPark = (E::DIMENSION == 3 && NY == 1) ? RYUJIN_LIJ0_PARK_3D : 0; /* 0 none, 1 F_i, 2 F_i and U_i */
-    __shared__ double parked_rows[kPark != 0 ? kWavesPerBlock * 2 * K * 64 : 1];
-    double *const parked = parked_rows + (kPark != 0 ? (threadIdx.x >> 6) * 2 * K * 64 : 0);
+    /* 3-D: F_i (and U_i; and the row's alpha_i, 1 / m_i and factor) live in LDS across the column loop
+     * (pij_stage0_parked). The rows share their LDS with the scratch of the Newton tail behind the loop
+     * (TailScratch: the two are never alive together), which is what makes room for the three scalars: without them
+     * the kernel reloads a spilled register INSIDE the loop, and a scratch load counts in vmcnt like any other --
+     * the compiler follows it with vmcnt(0), which drains the prefetch of the next column a third of the way
+     * into the iteration (scripts/isa_loop_waits.sh). */
+    constexpr int kPark = (E::DIMENSION == 3 && NY == 1) ? RYUJIN_LIJ0_PARK_3D : 0; /* 0 none, 1 F_i, 2 F_i and U_i, 3 and the scalars */
+    constexpr int kParkedDoubles = kPark == 0 ? 0 : (2 * K + (kPark == 3 ? 3 : 0)) * 64;
+    constexpr int kRowDoubles = kParkedDoubles > TailScratch<E>::kRowDoubles ? kParkedDoubles : TailScratch<E>::kRowDoubles;
+    __shared__ double lds_rows[kWavesPerBlock * kRowDoubles];
+    double *const parked = lds_rows + (threadIdx.x >> 6) * kRowDoubles;
+    row.alpha_i = alpha[i];
+    row.m_i_inv = M.mi_inv[i];
+    row.factor = scalars->tau * row.m_i_inv * (double)(r.len - 1);
     if constexpr (kPark != 0) {
 #pragma unroll
       for (int q = 0; q < K; ++q) {
         parked[q * 64 + r.lane] = row.F_i[q];
-        if (kPark == 2)
+        if (kPark >= 2)
           parked[(K + q) * 64 + r.lane] = row.U_i[q];
       }
+      if (kPark == 3) {
+        parked[(2 * K + 0) * 64 + r.lane] = row.alpha_i;
+        parked[(2 * K + 1) * 64 + r.lane] = row.m_i_inv;
+        parked[(2 * K + 2) * 64 + r.lane] = row.factor;
+      }
     }
-    row.alpha_i = alpha[i];
-    row.m_i_inv = M.mi_inv[i];
-    row.factor = scalars->tau * row.m_i_inv * (double)(r.len - 1);
     const double lambda = 1. / (double)(r.len - 1);
     bool all_ok = true;
     unsigned long long undecided_mask = 0;
@@ -195,7 +207,7 @@ namespace ryujin_hip
       const bool active = row_active && c < r.len;
       double P_ij[K];
       if constexpr (kPark != 0)
-        pij_stage0_parked<K, kPark == 2>(row, parked, r.lane, next, P_ij);
+        pij_stage0_parked<K, kPark >= 2, kPark == 3>(row, parked, r.lane, next, P_ij);
       else
         pij_stage0<K>(row, next, P_ij);
       if (c + NY < r.width) {
@@ -283,10 +295,9 @@ namespace ryujin_hip
      * compacted over the wave (limit_undecided_pairs, kernels_limiter.hpp) */
     constexpr int kTailColumns = E::DIMENSION == 1 ? 2 : (E::DIMENSION == 2 ? 8 : 26);
     __shared__ uint16_t tail_queue[kWavesPerBlock * kTailColumns * 64];
-    __shared__ TailScratch<E> tail_rows[kWavesPerBlock];
     const bool tail_ok = limit_undecided_pairs<E>(
         P, r, undecided_mask, bnd, U_i_new, tail_queue + (threadIdx.x >> 6) * kTailColumns * 64,
-        tail_rows[threadIdx.x >> 6].rows,
+        parked /* (the rows of TailScratch: the column loop is done with them) */,
         [&](const uint32_t c, const uint32_t owner, double (&out)[K]) {
           load_entry<K>(pij, (uint64_t)r.base + c, owner, out);
         },
