@@ -198,8 +198,8 @@ namespace ryujin
                     "Pin the caller's state vectors in place (hipHostRegister) so that uploads and downloads are "
                     "direct DMA transfers instead of staged copies. Only if every state vector that reaches the "
                     "module lives as long as the module: true for TimeLoop's state vector and TimeIntegrator's "
-                    "temporaries, NOT for the temporary 'analytic' vector of 'enable compute error' "
-                    "(time_loop.template.h:320-333)");
+                    "temporaries; the temporary 'analytic' vector of 'enable compute error' "
+                    "(time_loop.template.h:320-333) has to be handed to release_state_vector() before it dies");
       hip_mirror_precomputed_ = true;
       add_parameter("hip mirror precomputed values", hip_mirror_precomputed_,
                     "prepare_state_vector() copies the precomputed values and step() copies alpha back to the host "
@@ -484,6 +484,24 @@ namespace ryujin
       return twin;
     }
 
+  public:
+    /**
+     * A state vector that has been through prepare_state_vector() is about to be destroyed (the temporary
+     * 'analytic' vector of TimeLoop::compute_error, time_loop.template.h:320-333): frees its device twin and, with
+     * `hip pin host vectors = true`, ends the pinning of its arrays. Twins are keyed by the address of the storage; a
+     * vector that dies without this call leaves a twin -- and a registration -- behind that the next allocation at
+     * the same address would inherit. No effect on a vector the module has not seen.
+     */
+    void release_state_vector(const StateVector &state_vector) const
+    {
+      const auto &U = std::get<0>(state_vector);
+      if (twins_.forget(U.begin())) {
+        ryujin_hip_host_unregister(ctx_, U.begin());
+        ryujin_hip_host_unregister(ctx_, std::get<1>(state_vector).begin());
+      }
+    }
+
+  private:
     /* old and stage vectors of step(): "must be prepared" (hyperbolic_module.h:207-213), i.e. a twin exists */
     int prepared_twin_of(const StateVector &state_vector) const
     {

@@ -382,6 +382,20 @@ namespace ryujin_hip_binding
 
     std::size_t size() const { return twins_.size(); }
 
+    /* the storage at `key` goes away (or may be handed out again by the allocator): its twin is freed; returns whether
+     * the caller's arrays had been pinned for it (they have to be unregistered BEFORE the memory is released) */
+    bool forget(const void *key)
+    {
+      const auto it = twins_.find(key);
+      if (it == twins_.end())
+        return false;
+      const bool pinned = it->second.pinned;
+      if (ctx_)
+        ryujin_hip_state_free(ctx_, it->second.handle);
+      twins_.erase(it);
+      return pinned;
+    }
+
     void clear()
     {
       if (ctx_)

@@ -449,7 +449,11 @@ int ryujin_hip_get_counters(ryujin_hip_ctx *ctx, unsigned *n_restarts, unsigned 
  * matrix P_ij (hyperbolic_module.template.h:795-846): 1 stored everywhere, 2 stored per slice -- only where steps
  * 6 and 7 read it --, 3 stored per (slice, column) tile (up to two dimensions); and the fraction
  * of slices (tiles) it was stored in. The results are the same bit for bit whatever is
- * stored. Diagnostics; any pointer may be NULL. */
+ * stored -- FOR A GIVEN LAYOUT: which rows share a 64-row slice decides, through wave-uniform
+ * masks, which of two roundings of the same sum a row's high-order update takes (V_i - sum (1 - l) lambda P over the
+ * limited tiles, or the reference's U_low + sum l lambda P where every tile of the row is limited), so another
+ * numbering, partition or rank count reproduces a run to round-off (1e-11 on U per update, the stated contract), not
+ * to the bit. Diagnostics; any pointer may be NULL. */
 int ryujin_hip_limiter_statistics(ryujin_hip_ctx *ctx, double *limited_slice_fraction, int *pij_stored,
                                   double *stored_slice_fraction);
 /* The tile map of the context (ryujin_amd/csrc/host_layout.hpp, TileDesc): number of 64-entry tiles of the owned rows
