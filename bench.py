@@ -744,6 +744,9 @@ def main():
         "layout": layout,    # the tile map: tiles served by a descriptor instead of the index arrays
         "roofline_update": {"bound": "hbm", "achieved": upd_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": upd_gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_gridpoint": b_alg,
+                            "kind": ("effective: the reference's algorithmic bytes (SURVEY 8d) over this "
+                                     "implementation's time -- bytes the kernels no longer move; the measured "
+                                     "traffic of an update is in DESIGN.md section 0"),
                             "device_ms_per_update": ev_ms.value / args.steps,
                             "device_ms_per_update_instrumented": ev_ms_instrumented.value / args.steps},
         "sweep_ms": {n: round(v, 4) for n, v in sorted(per_sweep.items())},
