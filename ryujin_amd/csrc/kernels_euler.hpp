@@ -408,6 +408,69 @@ namespace ryujin_hip
     return tile_transposed(M, tile_desc<USE>(M, colbase), colbase, lane);
   }
 
+  /* TRANSPOSED POSITIONS OF SEVERAL COLUMNS AT ONCE (steps 6, 7: the row's l_ji gathers). Every one of them is the end
+   * of a chain -- tile descriptor (or the index array) -> position -> value -- and written column by column the
+   * compiler emits the chain column by column: descriptor load, vmcnt(0), gather, vmcnt(0), eight (2-D) or 26 (3-D) times
+   * in a row, sixteen to fifty-two round trips where the sweep needs two (scripts/isa_loop_waits.sh on the round-5
+   * kernels; the wave-uniform branch on the descriptor and the ballots behind each gather keep it from batching them).
+   * Here all descriptors / indices of a group of columns are loaded first, then all positions are formed; the callers
+   * then issue all gathers of the group before they look at the first value. batch_fence() keeps the scheduler from
+   * sinking the loads of a group back down to their uses. Measured (profiles/r06u_ab_batched_gathers_*.log): step 6
+   * -12 %, step 7 -9 % on C2, -5 % / -2 % on the C4 share. Step 3 (k_dij_diag_unrolled) does NOT take it: its eight
+   * chains already overlap as written (there is no ballot behind its gathers), and the two fenced groups cost it
+   * 0.076 -> 0.126 ms on C2. */
+  RYUJIN_DEV void batch_fence() { __builtin_amdgcn_sched_barrier(0); }
+
+  template <bool USE, int N>
+  RYUJIN_DEV void transposed_positions(const DeviceMesh &M, const RowCtx &r, const int c0, uint32_t (&tpos)[N])
+  {
+    if constexpr (USE) {
+      if (M.tiles != nullptr) {
+        int4 raw[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+          raw[k] = int4{kTileIrregular, 0, 0, 0};
+          if ((uint32_t)(c0 + k) < r.width)
+            raw[k] = *reinterpret_cast<const int4 *>(M.tiles + ((uint64_t)r.base + c0 + k));
+        }
+        batch_fence();
+        bool any_irregular = false;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+          tpos[k] = 0;
+          if ((uint32_t)(c0 + k) < r.width) {
+            const int32_t delta = __builtin_amdgcn_readfirstlane(raw[k].x);
+            const uint32_t ta = (uint32_t)__builtin_amdgcn_readfirstlane(raw[k].y);
+            const uint32_t tb = (uint32_t)__builtin_amdgcn_readfirstlane(raw[k].z);
+            tpos[k] = (r.lane < 64u - ((uint32_t)delta & 63u) ? ta : tb) + r.lane;
+            any_irregular = any_irregular || delta == kTileIrregular;
+          }
+        }
+        if (any_irregular) { /* wave-uniform, rare (boundary slices): the explicit array for those columns */
+#pragma unroll
+          for (int k = 0; k < N; ++k)
+            if ((uint32_t)(c0 + k) < r.width && __builtin_amdgcn_readfirstlane(raw[k].x) == kTileIrregular)
+              tpos[k] = M.idx_t[((uint64_t)r.base + c0 + k) * 64 + r.lane];
+        }
+        /* (one wait for whatever the branch above loaded, here: otherwise the compiler waits -- for everything in
+         * flight -- in front of every gather that uses one of the positions) */
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+          asm volatile("" : "+v"(tpos[k]));
+        return;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      tpos[k] = 0;
+      if ((uint32_t)(c0 + k) < r.width)
+        tpos[k] = M.idx_t[((uint64_t)r.base + c0 + k) * 64 + r.lane];
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+      asm volatile("" : "+v"(tpos[k]));
+  }
+
   /* ---- the column pipeline and gfx9's single memory counter. Vector loads AND stores count in one counter (vmcnt),
    * retired in issue order. A sweep prefetches the operands of column c + 1 while it works on column c; the compiler
    * places the wait for column c's operands at their first use -- and where the loop holds a memory operation it

@@ -849,6 +849,9 @@ namespace ryujin_hip
     uint32_t *deferred;
   };
 
+#ifndef RYUJIN_GATHER_GROUP_3D
+#define RYUJIN_GATHER_GROUP_3D 6 /* columns whose l_ij / l_ji are fetched in one batch where the row has more than 9 (steps 6, 7 in 3-D). C4 share, same process (profiles/r06v_ab_batched_gathers_c4.log): step 6 1.497 -> 1.379 (9) / 1.327 (6) / 1.413 (13) ms, step 7 0.857 -> 0.789 / 0.761 / 0.801 */
+#endif
 #ifndef RYUJIN_TILE_PIJ_GENERATIONS
 #define RYUJIN_TILE_PIJ_GENERATIONS 3
 #endif
@@ -941,13 +944,35 @@ namespace ryujin_hip
     for (int c = 1; c < MAXW; ++c)
       l[c] = 0.;
     if (!known_unlimited) {
+      /* in groups of up to 9 columns: all transposed positions, all l_ij and l_ji, then the minima
+       * (transposed_positions(), kernels_euler.hpp) */
+      constexpr int CH = MAXW - 1 < 9 ? MAXW - 1 : RYUJIN_GATHER_GROUP_3D;
 #pragma unroll
-      for (int c = 1; c < MAXW; ++c) {
-        if ((uint32_t)c < r.width) {
-          const uint32_t pos = (uint32_t)(((uint64_t)r.base + c) * 64 + r.lane);
-          const double l_a = lij[pos];
-          const double l_b = lij[tile_transposed<tile_map_pays<E::DIMENSION>()>(M, (uint64_t)r.base + c, r.lane)];
-          l[c] = (row_active && (uint32_t)c < r.len) ? lmin(l_a, l_b) : 0.;
+      for (int c0 = 1; c0 < MAXW; c0 += CH) {
+        uint32_t tpos[CH];
+        transposed_positions<tile_map_pays<E::DIMENSION>(), CH>(M, r, c0, tpos);
+        batch_fence();
+        double l_a[CH], l_b[CH];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+          const int c = c0 + k;
+          l_a[k] = l_b[k] = 0.;
+          if (c < MAXW && (uint32_t)c < r.width) {
+            l_a[k] = lij[(uint32_t)(((uint64_t)r.base + c) * 64 + r.lane)];
+            l_b[k] = lij[tpos[k]];
+          }
+        }
+        batch_fence();
+#pragma unroll
+        for (int k = 0; k < CH; ++k) { /* ONE wait for the group's values (kernels_euler.hpp, k_dij_diag_unrolled) */
+          asm volatile("" : "+v"(l_a[k]));
+          asm volatile("" : "+v"(l_b[k]));
+        }
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+          const int c = c0 + k;
+          if (c < MAXW && (uint32_t)c < r.width)
+            l[c] = (row_active && (uint32_t)c < r.len) ? lmin(l_a[k], l_b[k]) : 0.;
         }
       }
 #pragma unroll
@@ -1070,14 +1095,34 @@ namespace ryujin_hip
     double l[MAXW];
     if constexpr (MODE == kHoLight) {
       bool limited = false;
+      constexpr int CH = MAXW - 1 < 9 ? MAXW - 1 : RYUJIN_GATHER_GROUP_3D;
 #pragma unroll
-      for (int c = 1; c < MAXW; ++c) {
-        if ((uint32_t)c < r.width) {
-          const uint32_t pos = (uint32_t)(((uint64_t)r.base + c) * 64 + r.lane);
-          const double l_a = lij[pos];
-          const double l_b = lij[tile_transposed<tile_map_pays<E::DIMENSION>()>(M, (uint64_t)r.base + c, r.lane)];
+      for (int c0 = 1; c0 < MAXW; c0 += CH) {
+        uint32_t tpos[CH];
+        transposed_positions<tile_map_pays<E::DIMENSION>(), CH>(M, r, c0, tpos);
+        batch_fence();
+        double l_a[CH], l_b[CH];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+          const int c = c0 + k;
+          l_a[k] = l_b[k] = 1.;
+          if (c < MAXW && (uint32_t)c < r.width) {
+            l_a[k] = lij[(uint32_t)(((uint64_t)r.base + c) * 64 + r.lane)];
+            l_b[k] = lij[tpos[k]];
+          }
+        }
+        batch_fence();
+#pragma unroll
+        for (int k = 0; k < CH; ++k) { /* ONE wait for the group's values (kernels_euler.hpp, k_dij_diag_unrolled) */
+          asm volatile("" : "+v"(l_a[k]));
+          asm volatile("" : "+v"(l_b[k]));
+        }
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+          const int c = c0 + k;
           /* (NaN counts as limited: !(l == 1), not l != 1 through fmin, which drops a NaN operand) */
-          limited = limited || (row_active && (uint32_t)c < r.len && !(l_a == 1. && l_b == 1.));
+          if (c < MAXW && (uint32_t)c < r.width)
+            limited = limited || (row_active && (uint32_t)c < r.len && !(l_a[k] == 1. && l_b[k] == 1.));
         }
       }
       const bool slice_limited = __any(limited);
@@ -1123,21 +1168,48 @@ namespace ryujin_hip
       /* the row's l = min(l_ij, l_ji) and the tile masks (`lane`: see the second call below) */
       auto fetch_l = [&](const uint32_t lane) {
         needed = own_limited = 0u;
+        /* in groups of up to 9 columns: all transposed positions, all l_ij and l_ji, then the masks
+         * (transposed_positions(), kernels_euler.hpp) */
+        constexpr int CH = MAXW - 1 < 9 ? MAXW - 1 : RYUJIN_GATHER_GROUP_3D;
+        RowCtx rr = r;
+        rr.lane = lane;
 #pragma unroll
-        for (int c = 1; c < MAXW; ++c) {
-          l[c] = 1.;
-          if ((uint32_t)c < r.width) {
-            const uint32_t pos = (uint32_t)(((uint64_t)r.base + c) * 64 + lane);
-            const double l_a = lij[pos];
-            const double l_b = lij[tile_transposed<tile_map_pays<E::DIMENSION>()>(M, (uint64_t)r.base + c, lane)];
-            const bool lane_on = row_active && (uint32_t)c < r.len;
-            const bool lim = lane_on && !(l_a == 1. && l_b == 1.);
-            l[c] = lane_on ? lmin(l_a, l_b) : 1.;
-            limited = limited || lim;
-            if (__any(lim))
-              needed |= 1u << c;
-            if (__any(lane_on && !(l_a == 1.)))
-              own_limited |= 1u << c;
+        for (int c0 = 1; c0 < MAXW; c0 += CH) {
+          uint32_t tpos[CH];
+          transposed_positions<tile_map_pays<E::DIMENSION>(), CH>(M, rr, c0, tpos);
+          batch_fence();
+          double l_a[CH], l_b[CH];
+#pragma unroll
+          for (int k = 0; k < CH; ++k) {
+            const int c = c0 + k;
+            l_a[k] = l_b[k] = 1.;
+            if (c < MAXW && (uint32_t)c < r.width) {
+              l_a[k] = lij[(uint32_t)(((uint64_t)r.base + c) * 64 + lane)];
+              l_b[k] = lij[tpos[k]];
+            }
+          }
+          batch_fence();
+#pragma unroll
+          for (int k = 0; k < CH; ++k) { /* ONE wait for the group's values */
+            asm volatile("" : "+v"(l_a[k]));
+            asm volatile("" : "+v"(l_b[k]));
+          }
+#pragma unroll
+          for (int k = 0; k < CH; ++k) {
+            const int c = c0 + k;
+            if (c >= MAXW)
+              continue;
+            l[c] = 1.;
+            if ((uint32_t)c < r.width) {
+              const bool lane_on = row_active && (uint32_t)c < r.len;
+              const bool lim = lane_on && !(l_a[k] == 1. && l_b[k] == 1.);
+              l[c] = lane_on ? lmin(l_a[k], l_b[k]) : 1.;
+              limited = limited || lim;
+              if (__any(lim))
+                needed |= 1u << c;
+              if (__any(lane_on && !(l_a[k] == 1.)))
+                own_limited |= 1u << c;
+            }
           }
         }
       };
