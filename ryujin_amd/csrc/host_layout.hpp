@@ -107,13 +107,25 @@ namespace ryujin_hip
    *   j(lane)            = row + delta
    *   transposed(lane)   = (lane < 64 - (delta & 63) ? ta : tb) + lane
    * Tiles that do not fit (boundary rows, short rows, unstructured patches) carry delta = kTileIrregular and the
-   * sweeps read the explicit arrays for them, which always exist. One wave-uniform 16-byte load per tile. */
+   * sweeps read the explicit arrays for them, which always exist. One wave-uniform 16-byte load per tile.
+   *
+   * CHAINS (`chain`). The columns of a row are sorted (diagonal first, then ascending), so on a lattice the
+   * neighbours come in runs of consecutive indices: i + d - 1, i + d, i + d + 1 -- three columns whose 64 x node data
+   * are the SAME 64 nodes shifted by one lane. What row l needs in column c is what row l + 1 fetched in column c - 1;
+   * the neighbours i - 1 and i + 1 are the rows l - 1 and l + 1 of the slice themselves. A regular tile therefore
+   * also says where its node data can be had without a gather:
+   *   kChainPrevColumn  delta(c) = delta(c - 1) + 1, both tiles regular: lane l takes lane l + 1's data of column c - 1
+   *   kChainOwnNext     delta = +1: lane l takes the slice's own row data of lane l + 1
+   *   kChainOwnPrev     delta = -1: ... of lane l - 1
+   * and only the lane at the end of the wave (63, 63, 0) fetches its node from memory. Of the eight gathers of a
+   * 2-D Q1 row two are left, of the 26 in 3-D eight (kernels_euler.hpp, chained gathers). */
   struct TileDesc {
     int32_t delta;
     uint32_t ta, tb;
-    uint32_t pad;
+    uint32_t chain;
   };
   constexpr int32_t kTileIrregular = INT32_MIN;
+  constexpr uint32_t kChainNone = 0, kChainPrevColumn = 1, kChainOwnPrev = 2, kChainOwnNext = 3;
 
   struct SellLayout {
     std::vector<TileDesc> tiles;     /* [slice_off[n_slices]] */
@@ -350,8 +362,24 @@ namespace ryujin_hip
               ok = idx_t[p0 + l] == (l < split ? ta : tb) + l;
             if (!ok)
               continue;
-            tiles[(uint64_t)slice_off[s] + c] = TileDesc{(int32_t)delta, ta, tb, 0u};
+            tiles[(uint64_t)slice_off[s] + c] = TileDesc{(int32_t)delta, ta, tb, kChainNone};
             ++regular[s];
+          }
+          /* chains (TileDesc): every row of such a slice is an owned row of full length up to min_len, rows
+           * s * 64 + l, so "the data of lane l + 1" is the data of row i + 1 */
+          for (uint32_t c = 0; c < std::min(width, min_len); ++c) {
+            TileDesc &t = tiles[(uint64_t)slice_off[s] + c];
+            if (t.delta == kTileIrregular)
+              continue;
+            if (c > 0) {
+              const TileDesc &p = tiles[(uint64_t)slice_off[s] + c - 1];
+              if (p.delta != kTileIrregular && p.delta != 0 && (int64_t)p.delta + 1 == (int64_t)t.delta && t.delta != 0)
+                t.chain = kChainPrevColumn;
+            }
+            if (t.chain == kChainNone && t.delta == 1)
+              t.chain = kChainOwnNext;
+            if (t.chain == kChainNone && t.delta == -1)
+              t.chain = kChainOwnPrev;
           }
         }
       });

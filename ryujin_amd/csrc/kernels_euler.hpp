@@ -368,7 +368,7 @@ namespace ryujin_hip
   {
     TileDesc t;
     t.delta = kTileIrregular;
-    t.ta = t.tb = t.pad = 0;
+    t.ta = t.tb = t.chain = 0;
     if constexpr (USE) {
       if (M.tiles != nullptr) {
         const int4 raw = *reinterpret_cast<const int4 *>(M.tiles + colbase);
@@ -392,6 +392,47 @@ namespace ryujin_hip
       }
     }
     return ld_stream(M.cols + (colbase * 64 + lane));
+  }
+
+  /* ---- CHAINED GATHERS (TileDesc::chain, host_layout.hpp). On a lattice the node data of the columns i + d - 1,
+   * i + d, i + d + 1 are the same 64 nodes shifted by a lane, so one of three is fetched and the others are moved
+   * across the wave (v_mov_b32_dpp wave_shl:1 / wave_shr:1: one instruction per dword, no memory), with one lane at
+   * the end of the wave fetching the node that falls off. The neighbours i - 1 and i + 1 are the slice's own rows.
+   * Same values, same bits. ---- */
+#ifndef RYUJIN_CHAINED_GATHERS
+#define RYUJIN_CHAINED_GATHERS 1
+#endif
+  /* the chain code of a tile: wave-uniform (a scalar load through the constant address space: the map is written at
+   * create() and by no kernel) */
+  template <bool USE = true>
+  RYUJIN_DEV uint32_t tile_chain(const DeviceMesh &M, const uint64_t colbase)
+  {
+    if constexpr (USE && RYUJIN_CHAINED_GATHERS != 0) {
+      if (M.tiles != nullptr) {
+        typedef const uint32_t __attribute__((address_space(4))) *const_ptr;
+        return __builtin_amdgcn_readfirstlane(*(const_ptr)(uintptr_t)&M.tiles[colbase].chain);
+      }
+    }
+    return kChainNone;
+  }
+
+  /* lane l takes the value of lane l + 1 (lane 63 keeps its own) / of lane l - 1 (lane 0 keeps its own) */
+  RYUJIN_DEV double lane_next(const double x)
+  {
+    const int lo = __double2loint(x), hi = __double2hiint(x);
+    return __hiloint2double(__builtin_amdgcn_update_dpp(hi, hi, 0x130 /* wave_shl:1 */, 0xf, 0xf, false),
+                            __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false));
+  }
+  RYUJIN_DEV double lane_prev(const double x)
+  {
+    const int lo = __double2loint(x), hi = __double2hiint(x);
+    return __hiloint2double(__builtin_amdgcn_update_dpp(hi, hi, 0x138 /* wave_shr:1 */, 0xf, 0xf, false),
+                            __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false));
+  }
+  /* the lane of a chained tile that fetches its node from memory */
+  RYUJIN_DEV bool chain_edge_lane(const uint32_t chain, const uint32_t lane)
+  {
+    return lane == (chain == kChainOwnPrev ? 0u : 63u);
   }
 
   RYUJIN_DEV uint32_t tile_transposed(const DeviceMesh &M, const TileDesc &t, const uint64_t colbase,

@@ -518,6 +518,47 @@ namespace ryujin_hip
     p.m_j_inv = M.mi_inv[j];
   }
 
+  /* The node data of the pair for a CHAINED tile (kernels_euler.hpp, chained gathers): `p` still holds the previous
+   * column's (kChainPrevColumn), `row` the slice's own rows' -- or, where step 5 parks them there (PARK as
+   * pij_stage0_parked: 1 F_i, 2 and U_i, 3 and the scalars), the wave's rows in LDS, [component][lane], where the
+   * neighbouring row is the neighbouring word; d_ij and m_ij are the entry's own and stream as ever. */
+  template <int K, int PARK = 0>
+  RYUJIN_DEV void load_pair_chained(const DeviceMesh &M, const double *__restrict__ old_U,
+                                    const double *__restrict__ r_in, const double *__restrict__ alpha,
+                                    const double *__restrict__ dij, const uint64_t pos, const uint32_t j,
+                                    const uint32_t chain, const uint32_t lane, const RowData<K> &row,
+                                    const double *parked, PairData<K> &p)
+  {
+    p.d_ij = dij[pos];
+    p.m_ij = ld_stream(M.mij + pos);
+    if (chain == kChainPrevColumn) { /* wave-uniform */
+#pragma unroll
+      for (int q = 0; q < K; ++q) {
+        p.U_j[q] = lane_next(p.U_j[q]);
+        p.F_j[q] = lane_next(p.F_j[q]);
+      }
+      p.alpha_j = lane_next(p.alpha_j);
+      p.m_j_inv = lane_next(p.m_j_inv);
+    } else {
+      const bool next = chain == kChainOwnNext;
+      /* (lane 63 / lane 0 read a word of the neighbouring component / their own: replaced below) */
+      const double *src = parked + (next ? lane + 1u : (lane == 0u ? 0u : lane - 1u));
+#pragma unroll
+      for (int q = 0; q < K; ++q) {
+        p.F_j[q] = PARK >= 1 ? src[q * 64] : (next ? lane_next(row.F_i[q]) : lane_prev(row.F_i[q]));
+        p.U_j[q] = PARK >= 2 ? src[(K + q) * 64] : (next ? lane_next(row.U_i[q]) : lane_prev(row.U_i[q]));
+      }
+      p.alpha_j = PARK == 3 ? src[(2 * K + 0) * 64] : (next ? lane_next(row.alpha_i) : lane_prev(row.alpha_i));
+      p.m_j_inv = PARK == 3 ? src[(2 * K + 1) * 64] : (next ? lane_next(row.m_i_inv) : lane_prev(row.m_i_inv));
+    }
+    if (chain_edge_lane(chain, lane)) {
+      load_state<K>(old_U, j, p.U_j);
+      load_state<K>(r_in, j, p.F_j);
+      p.alpha_j = alpha[j];
+      p.m_j_inv = M.mi_inv[j];
+    }
+  }
+
   /* P_ij for stages == 0 */
   template <int K>
   RYUJIN_DEV void pij_stage0(const RowData<K> &row, const PairData<K> &p, double (&P_ij)[K])

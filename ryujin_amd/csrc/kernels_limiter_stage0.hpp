@@ -60,6 +60,9 @@ namespace ryujin_hip
 #ifndef RYUJIN_LIJ0_PARK_3D
 #define RYUJIN_LIJ0_PARK_3D 3 /* step 5 in 3-D: 1 = the row's F_i in LDS, 2 = F_i and U_i, 3 = and alpha_i, 1 / m_i, factor; 0 = all in registers */
 #endif
+#ifndef RYUJIN_LIJ0_CHAIN_3D
+#define RYUJIN_LIJ0_CHAIN_3D 3 /* step 5 in 3-D: chained gathers from 1 = the previous column, 2 = the slice's own rows (kernels_euler.hpp) */
+#endif
 #ifndef RYUJIN_OCC_LIJ0_3D
 #define RYUJIN_OCC_LIJ0_3D 3 /* rounds 1-4: 2 waves (at 3 the kernel spilled 28-56 B per lane and lost). Round 5: slice context in scalar
                                  registers + F_i / U_i parked in LDS leave 12 B per lane outside the column loop: 2.22 -> 1.97 ms on the
@@ -189,6 +192,7 @@ namespace ryujin_hip
      *   - where everything is stored anyway, every lane stores in every column (kUnconditionalStores).
      * (the column index of a structured tile is row + delta of the tile's descriptor, kernels_euler.hpp) */
     constexpr bool kTileMap = tile_map_pays<E::DIMENSION>();
+    constexpr bool kChained = NY == 1; /* (one wave walks all the columns of the slice; the chain codes exist in every dimension) */
     uint32_t j_n = r.width > c0 ? tile_column<kTileMap>(M, (uint64_t)r.base + c0, i, r.lane) : i;
     uint32_t j_nn = r.width > c0 + NY ? tile_column<kTileMap>(M, (uint64_t)r.base + c0 + NY, i, r.lane) : i;
     PairData<K> next;
@@ -212,7 +216,30 @@ namespace ryujin_hip
         pij_stage0<K>(row, next, P_ij);
       if (c + NY < r.width) {
         j_n = j_nn;
-        load_pair<K>(M, old_U, r_in, alpha, dij, (colbase + NY) * 64 + r.lane, j_n, next);
+        /* (chained gathers, kernels_euler.hpp: the node data of most columns is the previous column's, or the
+         * slice's own rows', moved by a lane) */
+        uint32_t chain = kChained ? tile_chain<true>(M, colbase + NY) : kChainNone;
+        if constexpr (E::DIMENSION == 3) {
+          if ((RYUJIN_LIJ0_CHAIN_3D & 1) == 0 && chain == kChainPrevColumn)
+            chain = kChainNone;
+          if ((RYUJIN_LIJ0_CHAIN_3D & 2) == 0 && chain != kChainPrevColumn)
+            chain = kChainNone;
+        }
+        if (chain == kChainNone)
+          load_pair<K>(M, old_U, r_in, alpha, dij, (colbase + NY) * 64 + r.lane, j_n, next);
+        else {
+          uint32_t lane_c = r.lane;
+          if constexpr (kPark != 0) {
+            /* (the parked rows are read once P_ij is complete and `next` is free: read earlier -- the scheduler would
+             * -- the new operands need registers of their own next to the old ones, and the kernel has none) */
+#pragma unroll
+            for (int q = 0; q < K; ++q)
+              asm volatile("" : "+v"(P_ij[q]));
+            asm volatile("" : "+v"(lane_c));
+          }
+          load_pair_chained<K, kPark>(M, old_U, r_in, alpha, dij, (colbase + NY) * 64 + r.lane, j_n, chain, lane_c, row,
+                                      parked, next);
+        }
         j_nn = c + 2 * NY < r.width ? tile_column<kTileMap>(M, colbase + 2 * NY, i, r.lane) : i;
       }
       /* the l_ij of the column before */

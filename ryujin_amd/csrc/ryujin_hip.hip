@@ -711,7 +711,7 @@ void ryujin_hip_ctx::create(const ryujin_hip_offline &o, const ryujin_hip_params
   d_row_len.upload(L.row_len);
   d_cols.upload(L.cols);
   d_idx_t.upload(L.idx_t);
-  if (p.debug_tile_map >= 0 && tile_map_pays(dim)) {
+  if (p.debug_tile_map >= 0) { /* (3-D sweeps keep streaming the explicit indices, tile_map_pays(); they use the chain codes) */
     L.build_tiles();
     d_tiles.upload(L.tiles);
   }
@@ -2935,7 +2935,7 @@ int ryujin_hip_layout_info(ryujin_hip_ctx *ctx, unsigned long long *n_tiles, uns
     if (n_tiles)
       *n_tiles = ctx->L.slice_off[ctx->L.n_slices];
     if (n_regular_tiles)
-      *n_regular_tiles = ctx->d_tiles.n != 0 ? ctx->L.n_regular_tiles : 0ull;
+      *n_regular_tiles = (ctx->d_tiles.n != 0 && tile_map_pays(ctx->dim)) ? ctx->L.n_regular_tiles : 0ull;
     return RYUJIN_OK;
   });
 }
