@@ -201,6 +201,9 @@ namespace ryujin_hip
   /* DG: full inverse of the (block-diagonal) consistent mass matrix instead of the Neumann series
    * (hyperbolic_module.template.h:976-986): b_ij = m_i (M^-1)_ij, b_ji = m_j (M^-1)_ij */
   /* WIDE: rows of more than 64 entries (cG Q2 / Q3, dG in 3-D), the columns in blocks of 63 */
+#ifndef RYUJIN_PIJ_LIJ_CHAINED
+#define RYUJIN_PIJ_LIJ_CHAINED 1 /* step 5 with a stored first part of P_ij (shallow water, stage vectors, scalar, dG): chained gathers */
+#endif
   template <typename E, bool DG = false, bool WIDE = false>
   __global__ void __launch_bounds__(kBlock, RYUJIN_OCC_PIJ)
   k_pij_lij(const typename E::Params P, const DeviceMesh M, DeviceScalars *__restrict__ scalars,
@@ -280,8 +283,35 @@ namespace ryujin_hip
       if (c + 1 < r.width) {
         j_n = j_nn;
         load_entry<K>(pij, colbase + 1, r.lane, P_n);
-        load_state<K>(r_in, j_n, F_n);
-        mjinv_n = node_j[j_n];
+        /* chained gathers (kernels_euler.hpp): r_j and the nodal mass of most columns are the previous column's, or
+         * the slice's own rows', one lane over */
+        const uint32_t chain = RYUJIN_PIJ_LIJ_CHAINED != 0 ? tile_chain<true>(M, colbase + 1) : kChainNone;
+        if (chain == kChainNone) {
+          load_state<K>(r_in, j_n, F_n);
+          mjinv_n = node_j[j_n];
+        } else {
+          const double own_node = DG ? m_i : m_i_inv;
+          if (chain == kChainPrevColumn) {
+#pragma unroll
+            for (int q = 0; q < K; ++q)
+              F_n[q] = lane_next(F_n[q]);
+            mjinv_n = lane_next(mjinv_n);
+          } else if (chain == kChainOwnNext) {
+#pragma unroll
+            for (int q = 0; q < K; ++q)
+              F_n[q] = lane_next(F_iH[q]);
+            mjinv_n = lane_next(own_node);
+          } else {
+#pragma unroll
+            for (int q = 0; q < K; ++q)
+              F_n[q] = lane_prev(F_iH[q]);
+            mjinv_n = lane_prev(own_node);
+          }
+          if (chain_edge_lane(chain, r.lane)) {
+            load_state<K>(r_in, j_n, F_n);
+            mjinv_n = node_j[j_n];
+          }
+        }
         mij_n = ld_stream(mij + ((colbase + 1) * 64 + r.lane));
         j_nn = (c + 2 < r.width) ? tile_column<tile_map_pays<E::DIMENSION>()>(M, colbase + 2, r.row, r.lane) : i;
       }
