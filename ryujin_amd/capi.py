@@ -169,7 +169,7 @@ HIP_SYMBOLS = [
     "ryujin_hip_comm_destroy", "ryujin_hip_comm_info", "ryujin_hip_exchange_info", "ryujin_hip_device_count",
     "ryujin_hip_time_step_fn", "ryujin_hip_debug_addresses",
     "ryujin_hip_host_register", "ryujin_hip_host_unregister", "ryujin_hip_state_download_owned",
-    "ryujin_hip_state_download_prepared", "ryujin_hip_layout_info", "ryujin_hip_tile_statistics",
+    "ryujin_hip_state_download_prepared", "ryujin_hip_layout_info", "ryujin_hip_chain_info", "ryujin_hip_tile_statistics",
     "ryujin_hip_deferred_slices",
     "ryujin_hip_default_params", "ryujin_hip_create", "ryujin_hip_destroy",
     "ryujin_hip_state_alloc", "ryujin_hip_state_free", "ryujin_hip_state_upload",
@@ -249,6 +249,7 @@ def load_hip():
                                                 C.c_void_p, C.c_double, C.c_int, C.c_double, C.c_double, c_double_p]
         lib.ryujin_hip_device_count.argtypes = [c_int_p]
         lib.ryujin_hip_layout_info.argtypes = [vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
+        lib.ryujin_hip_chain_info.argtypes = [vp, C.POINTER(C.c_ulonglong)]
         lib.ryujin_hip_tile_statistics.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         lib.ryujin_hip_deferred_slices.argtypes = [vp, C.POINTER(C.c_uint)]
         lib.ryujin_hip_host_register.argtypes = [vp, C.c_void_p, C.c_size_t]

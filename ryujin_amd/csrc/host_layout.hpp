@@ -130,6 +130,7 @@ namespace ryujin_hip
   struct SellLayout {
     std::vector<TileDesc> tiles;     /* [slice_off[n_slices]] */
     uint64_t n_regular_tiles = 0;
+    uint64_t n_chained_tiles = 0;    /* of them: node data from a neighbouring lane (TileDesc::chain) */
     uint32_t n_owned = 0, n_relevant = 0, n_slices = 0, rows_padded = 0;
     uint32_t max_row_len = 0;
     std::vector<uint32_t> slice_off; /* [n_slices+1], in units of 64-entry columns */
@@ -335,7 +336,7 @@ namespace ryujin_hip
     void build_tiles()
     {
       tiles.assign(slice_off[n_slices], TileDesc{kTileIrregular, 0u, 0u, 0u});
-      std::vector<uint64_t> regular(n_slices, 0);
+      std::vector<uint64_t> regular(n_slices, 0), chained(n_slices, 0);
       parallel_chunks(n_slices, [&](const uint64_t s0, const uint64_t s1) {
         for (uint32_t s = (uint32_t)s0; s < (uint32_t)s1; ++s) {
           const uint32_t width = slice_off[s + 1] - slice_off[s];
@@ -380,12 +381,15 @@ namespace ryujin_hip
               t.chain = kChainOwnNext;
             if (t.chain == kChainNone && t.delta == -1)
               t.chain = kChainOwnPrev;
+            chained[s] += t.chain != kChainNone;
           }
         }
       });
-      n_regular_tiles = 0;
+      n_regular_tiles = n_chained_tiles = 0;
       for (const uint64_t n : regular)
         n_regular_tiles += n;
+      for (const uint64_t n : chained)
+        n_chained_tiles += n;
     }
 
     /* reference layout -> device layout (padding = 0) */

@@ -2940,6 +2940,17 @@ int ryujin_hip_layout_info(ryujin_hip_ctx *ctx, unsigned long long *n_tiles, uns
   });
 }
 
+int ryujin_hip_chain_info(ryujin_hip_ctx *ctx, unsigned long long *n_chained_tiles)
+{
+  return guarded([&]() {
+    if (!ctx)
+      throw HipError(RYUJIN_ERR_ARG, "null context");
+    if (n_chained_tiles)
+      *n_chained_tiles = ctx->d_tiles.n != 0 ? ctx->L.n_chained_tiles : 0ull;
+    return RYUJIN_OK;
+  });
+}
+
 int ryujin_hip_debug_fetch(ryujin_hip_ctx *ctx, int what, double *out, size_t n_doubles)
 {
   return guarded_ctx(ctx, [&]() {

@@ -365,6 +365,53 @@ def test_tile_map_gives_the_same_bits_as_the_index_arrays(oracle):
                 assert np.array_equal(x, y)
 
 
+@pytest.mark.parametrize("case", ["euler_3d", "shallow_water_2d", "euler_aeos_2d"])
+def test_chained_gathers_give_the_same_bits_as_the_gathers(oracle, case):
+    """Chained gathers (host_layout.hpp, TileDesc::chain; kernels_euler.hpp): where the columns of a slice are a run of
+    consecutive node indices, step 5 takes the neighbour's node data from the previous column's -- or the slice's own
+    rows' -- registers one lane over (DPP / LDS) and only the lane at the end of the wave fetches its node. The same
+    values into the same operations: the same bits as with the map -- and with it the chains -- switched off
+    (debug_tile_map = -1), in 3-D (parked rows, explicit column indices), for the Description with a stored first
+    part of P_ij (k_pij_lij) and for EulerAEOS; and most tiles of a lattice-numbered mesh are chained."""
+    from ryujin_amd.initial_states import euler_radial_contrast, sw_circular_dam_break
+    dirichlet = None
+    if case == "euler_3d":
+        off = offline.SyntheticOffline(offline.box_3d(6, nx=200))  # (lattice rows of 201 nodes: most slices lie inside one)
+        U0 = _perturbed(euler_radial_contrast(off.positions, inner=(1.0, 0.0, 10.0), outer=(1.0, 0.0, 0.1), radius=0.4))
+        equation, dim = capi.EQ_EULER, 3
+    elif case == "shallow_water_2d":
+        off = offline.SyntheticOffline(offline.rectangle_2d(200, (-5.0, -5.0), (5.0, 5.0), ny=24))
+        U0 = sw_circular_dam_break(off.positions)
+        equation, dim = capi.EQ_SHALLOW_WATER, 2
+    else:
+        off = offline.SyntheticOffline(offline.mach3_step_2d(60))
+        U0 = _perturbed(euler_uniform(off.positions))
+        dirichlet = euler_uniform(off.b_positions)
+        equation, dim = capi.EQ_EULER_AEOS, 2
+    results = []
+    for switch in (0, -1):
+        p = oracle.default_params(equation, dim)
+        p.cfl = 0.9
+        p.debug_tile_map = switch
+        m = HyperbolicModule(off, p, backend="hip")
+        info = m.layout_info()
+        if switch == 0:
+            assert info["chained_tile_fraction"] > 0.2, info
+        else:
+            assert info["n_chained_tiles"] == 0, info
+        a, b = m.new_state_vector(U0), m.new_state_vector()
+        for _ in range(5):
+            m.prepare_state_vector(a, 0.0, dirichlet)
+            m.step(a, [], [], b)
+            a, b = b, a
+        temps = [b, m.new_state_vector(), m.new_state_vector()]
+        m.time_step("ssprk 33", a, temps, dirichlet)
+        results.append((a.download(), m.alpha().copy(), m.debug_fetch("lij"), m.debug_fetch("pij")))
+        m.close()
+    for x, y in zip(*results):
+        assert np.array_equal(x, y)
+
+
 def test_mass_conservation_01_golden_on_gpu(golden_dir):
     """The reference's own integration baseline, reproduced by the HIP path."""
     from test_oracle_golden_integration import golden_mass_conservation, run_mass_conservation
