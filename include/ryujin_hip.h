@@ -462,11 +462,13 @@ int ryujin_hip_limiter_statistics(ryujin_hip_ctx *ctx, double *limited_slice_fra
  * compulsory bytes with it. Any pointer may be NULL. */
 int ryujin_hip_layout_info(ryujin_hip_ctx *ctx, unsigned long long *n_tiles, unsigned long long *n_regular_tiles);
 /* Chained gathers (ryujin_amd/csrc/host_layout.hpp, TileDesc::chain): the number of tiles whose node data step 5 takes
- * from the previous column of the slice or from the slice's own rows, one lane over, instead of gathering it -- on a
+ * from the previous column of the slice or from the slice's own rows, one lane over, instead of gathering it, and the
+ * number of matrix entries (lanes of those tiles) that are served that way -- the others fetch their node as ever. On a
  * lattice-numbered mesh six of the eight off-diagonal columns of a 2-D Q1 row, 18 of 26 in 3-D; 0 on a mesh without
  * such runs and with debug_tile_map < 0. The results do not depend on it (the same values reach the same operations).
- * Diagnostics; the pointer may be NULL. */
-int ryujin_hip_chain_info(ryujin_hip_ctx *ctx, unsigned long long *n_chained_tiles);
+ * Diagnostics; any pointer may be NULL. */
+int ryujin_hip_chain_info(ryujin_hip_ctx *ctx, unsigned long long *n_chained_tiles,
+                          unsigned long long *n_chained_entries);
 /* Where the latest step stored P_ij per tile (pij_stored == 3): of the (slice, column) tiles between the two latest
  * host synchronisations, the fractions step 5 stored, step 6 read, and step 6 had to form itself because step 5 had
  * not stored them (ryujin_amd/csrc/kernels_limiter_stage0.hpp). 1 / 1 / 0 otherwise. Any pointer may be NULL. */

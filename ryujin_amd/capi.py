@@ -249,7 +249,7 @@ def load_hip():
                                                 C.c_void_p, C.c_double, C.c_int, C.c_double, C.c_double, c_double_p]
         lib.ryujin_hip_device_count.argtypes = [c_int_p]
         lib.ryujin_hip_layout_info.argtypes = [vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
-        lib.ryujin_hip_chain_info.argtypes = [vp, C.POINTER(C.c_ulonglong)]
+        lib.ryujin_hip_chain_info.argtypes = [vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
         lib.ryujin_hip_tile_statistics.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         lib.ryujin_hip_deferred_slices.argtypes = [vp, C.POINTER(C.c_uint)]
         lib.ryujin_hip_host_register.argtypes = [vp, C.c_void_p, C.c_size_t]

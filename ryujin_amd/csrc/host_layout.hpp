@@ -109,15 +109,22 @@ namespace ryujin_hip
    * Tiles that do not fit (boundary rows, short rows, unstructured patches) carry delta = kTileIrregular and the
    * sweeps read the explicit arrays for them, which always exist. One wave-uniform 16-byte load per tile.
    *
-   * CHAINS (`chain`). The columns of a row are sorted (diagonal first, then ascending), so on a lattice the
-   * neighbours come in runs of consecutive indices: i + d - 1, i + d, i + d + 1 -- three columns whose 64 x node data
-   * are the SAME 64 nodes shifted by one lane. What row l needs in column c is what row l + 1 fetched in column c - 1;
-   * the neighbours i - 1 and i + 1 are the rows l - 1 and l + 1 of the slice themselves. A regular tile therefore
-   * also says where its node data can be had without a gather:
-   *   kChainPrevColumn  delta(c) = delta(c - 1) + 1, both tiles regular: lane l takes lane l + 1's data of column c - 1
-   *   kChainOwnNext     delta = +1: lane l takes the slice's own row data of lane l + 1
-   *   kChainOwnPrev     delta = -1: ... of lane l - 1
-   * and only the lane at the end of the wave (63, 63, 0) fetches its node from memory. Of the eight gathers of a
+   * CHAINS (`chain`, `chain_loads`). The columns of a row are sorted (diagonal first, then ascending), so on a lattice
+   * the neighbours come in runs of consecutive indices: i + d - 1, i + d, i + d + 1 -- three columns whose 64 x node
+   * data are the SAME 64 nodes shifted by one lane. What row l needs in column c is what row l + 1 fetched in column
+   * c - 1; the neighbours i - 1 and i + 1 are the rows l - 1 and l + 1 of the slice themselves. Every tile of a full
+   * slice -- regular or not -- therefore says where its node data can be had without a gather, lane by lane:
+   *   kChainPrevColumn  lane l takes lane l + 1's data of column c - 1      where cols(l, c) == cols(l + 1, c - 1)
+   *   kChainOwnNext     lane l takes the slice's own row data of lane l + 1 where cols(l, c) == row(l) + 1
+   *   kChainOwnPrev     ... of lane l - 1                                   where cols(l, c) == row(l) - 1
+   * with `chain_loads[tile]`, a 64-bit mask of the lanes for which that does NOT hold and which fetch their node from
+   * memory: the lane at the end of the wave, the rows at the end of a lattice row, boundary rows. (The invariant:
+   * behind column c every lane holds the data of node cols(l, c), padding entries included, however it got them.) The
+   * kind that serves the most lanes wins; below kChainMinLanes the tile is gathered as ever. Bit 2 of `chain` marks
+   * the tiles whose mask is just the lane at the end of the wave (every regular tile of a run): the 2-D sweeps chain
+   * those only and never read a mask (with masks their step 5 measured 2 - 3 % slower for one more chained tile in a
+   * hundred; in 3-D, where the lattice rows are short against a slice, the masks take the chained tiles of C4 from 24
+   * to 67 %, profiles/r06ai_ab_chain_masks_*.log). Of the eight gathers of a
    * 2-D Q1 row two are left, of the 26 in 3-D eight (kernels_euler.hpp, chained gathers). */
   struct TileDesc {
     int32_t delta;
@@ -126,11 +133,16 @@ namespace ryujin_hip
   };
   constexpr int32_t kTileIrregular = INT32_MIN;
   constexpr uint32_t kChainNone = 0, kChainPrevColumn = 1, kChainOwnPrev = 2, kChainOwnNext = 3;
+  constexpr int kChainMinLanes = 32;
+  constexpr uint32_t kChainKindMask = 3, kChainEndLaneOnly = 4; /* bit 2 of `chain`: chain_loads is just the lane at the end of the wave */
 
   struct SellLayout {
     std::vector<TileDesc> tiles;     /* [slice_off[n_slices]] */
+    std::vector<uint64_t> chain_loads; /* [slice_off[n_slices]] the lanes of a chained tile that fetch their node themselves */
     uint64_t n_regular_tiles = 0;
-    uint64_t n_chained_tiles = 0;    /* of them: node data from a neighbouring lane (TileDesc::chain) */
+    uint64_t n_chained_tiles = 0;    /* tiles with node data from a neighbouring lane (TileDesc::chain) */
+    uint64_t n_chained_entries = 0;  /* ... and the matrix entries (lanes) of them that are served that way */
+    uint64_t n_end_lane_tiles = 0;   /* of the chained tiles: those in which only the lane at the end of the wave loads (what the 2-D sweeps chain) */
     uint32_t n_owned = 0, n_relevant = 0, n_slices = 0, rows_padded = 0;
     uint32_t max_row_len = 0;
     std::vector<uint32_t> slice_off; /* [n_slices+1], in units of 64-entry columns */
@@ -336,7 +348,8 @@ namespace ryujin_hip
     void build_tiles()
     {
       tiles.assign(slice_off[n_slices], TileDesc{kTileIrregular, 0u, 0u, 0u});
-      std::vector<uint64_t> regular(n_slices, 0), chained(n_slices, 0);
+      chain_loads.assign(slice_off[n_slices], ~0ull);
+      std::vector<uint64_t> regular(n_slices, 0), chained(n_slices, 0), chained_lanes(n_slices, 0), end_lane(n_slices, 0);
       parallel_chunks(n_slices, [&](const uint64_t s0, const uint64_t s1) {
         for (uint32_t s = (uint32_t)s0; s < (uint32_t)s1; ++s) {
           const uint32_t width = slice_off[s + 1] - slice_off[s];
@@ -366,22 +379,37 @@ namespace ryujin_hip
             tiles[(uint64_t)slice_off[s] + c] = TileDesc{(int32_t)delta, ta, tb, kChainNone};
             ++regular[s];
           }
-          /* chains (TileDesc): every row of such a slice is an owned row of full length up to min_len, rows
-           * s * 64 + l, so "the data of lane l + 1" is the data of row i + 1 */
-          for (uint32_t c = 0; c < std::min(width, min_len); ++c) {
-            TileDesc &t = tiles[(uint64_t)slice_off[s] + c];
-            if (t.delta == kTileIrregular)
-              continue;
-            if (c > 0) {
-              const TileDesc &p = tiles[(uint64_t)slice_off[s] + c - 1];
-              if (p.delta != kTileIrregular && p.delta != 0 && (int64_t)p.delta + 1 == (int64_t)t.delta && t.delta != 0)
-                t.chain = kChainPrevColumn;
+          /* chains (TileDesc): every row of such a slice is an owned row, row s * 64 + l: "the data of lane l + 1" is
+           * the data of row i + 1. Column 0 is the diagonal; the sweeps gather column 1 as ever and chain from 2 on
+           * (kChainPrevColumn) / from 1 on (the own rows). */
+          for (uint32_t c = 1; c < width; ++c) {
+            const uint64_t p0 = ((uint64_t)slice_off[s] + c) * kWave;
+            uint64_t ok_prev = 0, ok_own_next = 0, ok_own_prev = 0;
+            for (uint32_t l = 0; l < kWave; ++l) {
+              const uint64_t row = (uint64_t)s * kWave + l;
+              if (c >= 2 && l + 1 < kWave && cols[p0 + l] == cols[p0 - kWave + l + 1])
+                ok_prev |= 1ull << l;
+              if (l + 1 < kWave && cols[p0 + l] == row + 1)
+                ok_own_next |= 1ull << l;
+              if (l >= 1 && cols[p0 + l] + 1 == row)
+                ok_own_prev |= 1ull << l;
             }
-            if (t.chain == kChainNone && t.delta == 1)
-              t.chain = kChainOwnNext;
-            if (t.chain == kChainNone && t.delta == -1)
-              t.chain = kChainOwnPrev;
-            chained[s] += t.chain != kChainNone;
+            const int n_prev = __builtin_popcountll(ok_prev), n_next = __builtin_popcountll(ok_own_next),
+                      n_own_prev = __builtin_popcountll(ok_own_prev);
+            uint32_t kind = kChainNone;
+            uint64_t ok = 0;
+            if (n_next >= kChainMinLanes && n_next >= n_prev && n_next >= n_own_prev)
+              kind = kChainOwnNext, ok = ok_own_next;
+            else if (n_own_prev >= kChainMinLanes && n_own_prev >= n_prev)
+              kind = kChainOwnPrev, ok = ok_own_prev;
+            else if (n_prev >= kChainMinLanes)
+              kind = kChainPrevColumn, ok = ok_prev;
+            const uint64_t end_lane_mask = kind == kChainOwnPrev ? 1ull : 1ull << 63;
+            tiles[(uint64_t)slice_off[s] + c].chain = kind | ((kind != kChainNone && ~ok == end_lane_mask) ? kChainEndLaneOnly : 0u);
+            chain_loads[(uint64_t)slice_off[s] + c] = ~ok;
+            chained[s] += kind != kChainNone;
+            end_lane[s] += kind != kChainNone && ~ok == end_lane_mask;
+            chained_lanes[s] += (uint64_t)__builtin_popcountll(ok);
           }
         }
       });
@@ -390,6 +418,11 @@ namespace ryujin_hip
         n_regular_tiles += n;
       for (const uint64_t n : chained)
         n_chained_tiles += n;
+      n_chained_entries = n_end_lane_tiles = 0;
+      for (const uint64_t n : chained_lanes)
+        n_chained_entries += n;
+      for (const uint64_t n : end_lane)
+        n_end_lane_tiles += n;
     }
 
     /* reference layout -> device layout (padding = 0) */

@@ -58,6 +58,7 @@ namespace ryujin_hip
     const uint32_t *cols;      /* [nnz_total] */
     const uint32_t *idx_t;     /* [nnz_total] */
     const TileDesc *tiles;     /* [slice_off[n_slices]] the tile map (host_layout.hpp), or NULL: explicit arrays only */
+    const uint64_t *chain_loads; /* [slice_off[n_slices]] with the tile map: the lanes of a chained tile that fetch their node (TileDesc::chain) */
     uint32_t tail_queue_columns; /* min(63, widest row - 1): columns of the dynamic-LDS queue of undecided pairs (k_pij_lij) */
     /* > 1: the four waves of a block take slices that are band_stride apart (one lattice row / plane of a structured
      * patch) instead of four consecutive ones: row_context() */
@@ -394,26 +395,49 @@ namespace ryujin_hip
     return ld_stream(M.cols + (colbase * 64 + lane));
   }
 
-  /* ---- CHAINED GATHERS (TileDesc::chain, host_layout.hpp). On a lattice the node data of the columns i + d - 1,
-   * i + d, i + d + 1 are the same 64 nodes shifted by a lane, so one of three is fetched and the others are moved
-   * across the wave (v_mov_b32_dpp wave_shl:1 / wave_shr:1: one instruction per dword, no memory), with one lane at
-   * the end of the wave fetching the node that falls off. The neighbours i - 1 and i + 1 are the slice's own rows.
-   * Same values, same bits. ---- */
+  /* ---- CHAINED GATHERS (TileDesc::chain and chain_loads, host_layout.hpp). On a lattice the node data of the columns
+   * i + d - 1, i + d, i + d + 1 are the same 64 nodes shifted by a lane, so one of three is fetched and the others are
+   * moved across the wave (v_mov_b32_dpp wave_shl:1 / wave_shr:1: one instruction per dword, no memory); the
+   * neighbours i - 1 and i + 1 are the slice's own rows. The lanes for which that does not hold -- the end of the
+   * wave, the end of a lattice row, boundary rows: the tile's mask -- fetch their node as ever. Same values, same
+   * bits. ---- */
 #ifndef RYUJIN_CHAINED_GATHERS
 #define RYUJIN_CHAINED_GATHERS 1
 #endif
-  /* the chain code of a tile: wave-uniform (a scalar load through the constant address space: the map is written at
-   * create() and by no kernel) */
-  template <bool USE = true>
-  RYUJIN_DEV uint32_t tile_chain(const DeviceMesh &M, const uint64_t colbase)
+  struct TileChain {
+    uint32_t kind;  /* kChainNone / kChainPrevColumn / kChainOwnPrev / kChainOwnNext, wave-uniform */
+    uint64_t loads; /* the lanes that fetch their node from memory */
+  };
+  /* (scalar loads through the constant address space: the map is written at create() and by no kernel)
+   * MASKS (3-D): every chained tile, with its mask of loading lanes; otherwise only the tiles whose mask is the lane at
+   * the end of the wave, and no mask is read (host_layout.hpp). */
+  template <int DIM>
+  constexpr bool chain_masks_pay()
   {
-    if constexpr (USE && RYUJIN_CHAINED_GATHERS != 0) {
+    return DIM == 3;
+  }
+  template <bool MASKS>
+  RYUJIN_DEV TileChain tile_chain(const DeviceMesh &M, const uint64_t colbase)
+  {
+    TileChain t{kChainNone, ~0ull};
+    if constexpr (RYUJIN_CHAINED_GATHERS != 0) {
       if (M.tiles != nullptr) {
         typedef const uint32_t __attribute__((address_space(4))) *const_ptr;
-        return __builtin_amdgcn_readfirstlane(*(const_ptr)(uintptr_t)&M.tiles[colbase].chain);
+        typedef const uint64_t __attribute__((address_space(4))) *const_ptr64;
+        const uint32_t code = __builtin_amdgcn_readfirstlane(*(const_ptr)(uintptr_t)&M.tiles[colbase].chain);
+        if constexpr (MASKS) {
+          t.kind = code & kChainKindMask;
+          if (t.kind != kChainNone) {
+            const uint64_t m = *(const_ptr64)(uintptr_t)(M.chain_loads + colbase);
+            t.loads = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(m >> 32)) << 32) |
+                      (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)m);
+          }
+        } else {
+          t.kind = (code & kChainEndLaneOnly) != 0u ? (code & kChainKindMask) : kChainNone;
+        }
       }
     }
-    return kChainNone;
+    return t;
   }
 
   /* lane l takes the value of lane l + 1 (lane 63 keeps its own) / of lane l - 1 (lane 0 keeps its own) */
@@ -429,10 +453,14 @@ namespace ryujin_hip
     return __hiloint2double(__builtin_amdgcn_update_dpp(hi, hi, 0x138 /* wave_shr:1 */, 0xf, 0xf, false),
                             __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false));
   }
-  /* the lane of a chained tile that fetches its node from memory */
-  RYUJIN_DEV bool chain_edge_lane(const uint32_t chain, const uint32_t lane)
+  /* whether this lane of a chained tile fetches its node from memory */
+  template <bool MASKS>
+  RYUJIN_DEV bool chain_lane_loads(const TileChain &t, const uint32_t lane)
   {
-    return lane == (chain == kChainOwnPrev ? 0u : 63u);
+    if constexpr (MASKS)
+      return ((t.loads >> lane) & 1ull) != 0ull;
+    else
+      return lane == (t.kind == kChainOwnPrev ? 0u : 63u);
   }
 
   RYUJIN_DEV uint32_t tile_transposed(const DeviceMesh &M, const TileDesc &t, const uint64_t colbase,

@@ -285,18 +285,19 @@ namespace ryujin_hip
         load_entry<K>(pij, colbase + 1, r.lane, P_n);
         /* chained gathers (kernels_euler.hpp): r_j and the nodal mass of most columns are the previous column's, or
          * the slice's own rows', one lane over */
-        const uint32_t chain = RYUJIN_PIJ_LIJ_CHAINED != 0 ? tile_chain<true>(M, colbase + 1) : kChainNone;
-        if (chain == kChainNone) {
+        constexpr bool kMasks = chain_masks_pay<E::DIMENSION>();
+        const TileChain chain = RYUJIN_PIJ_LIJ_CHAINED != 0 ? tile_chain<kMasks>(M, colbase + 1) : TileChain{kChainNone, ~0ull};
+        if (chain.kind == kChainNone) {
           load_state<K>(r_in, j_n, F_n);
           mjinv_n = node_j[j_n];
         } else {
           const double own_node = DG ? m_i : m_i_inv;
-          if (chain == kChainPrevColumn) {
+          if (chain.kind == kChainPrevColumn) {
 #pragma unroll
             for (int q = 0; q < K; ++q)
               F_n[q] = lane_next(F_n[q]);
             mjinv_n = lane_next(mjinv_n);
-          } else if (chain == kChainOwnNext) {
+          } else if (chain.kind == kChainOwnNext) {
 #pragma unroll
             for (int q = 0; q < K; ++q)
               F_n[q] = lane_next(F_iH[q]);
@@ -307,7 +308,7 @@ namespace ryujin_hip
               F_n[q] = lane_prev(F_iH[q]);
             mjinv_n = lane_prev(own_node);
           }
-          if (chain_edge_lane(chain, r.lane)) {
+          if (chain_lane_loads<kMasks>(chain, r.lane)) {
             load_state<K>(r_in, j_n, F_n);
             mjinv_n = node_j[j_n];
           }
@@ -552,16 +553,16 @@ namespace ryujin_hip
    * column's (kChainPrevColumn), `row` the slice's own rows' -- or, where step 5 parks them there (PARK as
    * pij_stage0_parked: 1 F_i, 2 and U_i, 3 and the scalars), the wave's rows in LDS, [component][lane], where the
    * neighbouring row is the neighbouring word; d_ij and m_ij are the entry's own and stream as ever. */
-  template <int K, int PARK = 0>
+  template <int K, int PARK = 0, bool MASKS = false>
   RYUJIN_DEV void load_pair_chained(const DeviceMesh &M, const double *__restrict__ old_U,
                                     const double *__restrict__ r_in, const double *__restrict__ alpha,
                                     const double *__restrict__ dij, const uint64_t pos, const uint32_t j,
-                                    const uint32_t chain, const uint32_t lane, const RowData<K> &row,
+                                    const TileChain &chain, const uint32_t lane, const RowData<K> &row,
                                     const double *parked, PairData<K> &p)
   {
     p.d_ij = dij[pos];
     p.m_ij = ld_stream(M.mij + pos);
-    if (chain == kChainPrevColumn) { /* wave-uniform */
+    if (chain.kind == kChainPrevColumn) { /* wave-uniform */
 #pragma unroll
       for (int q = 0; q < K; ++q) {
         p.U_j[q] = lane_next(p.U_j[q]);
@@ -570,7 +571,7 @@ namespace ryujin_hip
       p.alpha_j = lane_next(p.alpha_j);
       p.m_j_inv = lane_next(p.m_j_inv);
     } else {
-      const bool next = chain == kChainOwnNext;
+      const bool next = chain.kind == kChainOwnNext;
       /* (lane 63 / lane 0 read a word of the neighbouring component / their own: replaced below) */
       const double *src = parked + (next ? lane + 1u : (lane == 0u ? 0u : lane - 1u));
 #pragma unroll
@@ -581,7 +582,7 @@ namespace ryujin_hip
       p.alpha_j = PARK == 3 ? src[(2 * K + 0) * 64] : (next ? lane_next(row.alpha_i) : lane_prev(row.alpha_i));
       p.m_j_inv = PARK == 3 ? src[(2 * K + 1) * 64] : (next ? lane_next(row.m_i_inv) : lane_prev(row.m_i_inv));
     }
-    if (chain_edge_lane(chain, lane)) {
+    if (chain_lane_loads<MASKS>(chain, lane)) {
       load_state<K>(old_U, j, p.U_j);
       load_state<K>(r_in, j, p.F_j);
       p.alpha_j = alpha[j];

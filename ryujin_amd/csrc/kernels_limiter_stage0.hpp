@@ -218,14 +218,15 @@ namespace ryujin_hip
         j_n = j_nn;
         /* (chained gathers, kernels_euler.hpp: the node data of most columns is the previous column's, or the
          * slice's own rows', moved by a lane) */
-        uint32_t chain = kChained ? tile_chain<true>(M, colbase + NY) : kChainNone;
+        constexpr bool kMasks = chain_masks_pay<E::DIMENSION>();
+        TileChain chain = kChained ? tile_chain<kMasks>(M, colbase + NY) : TileChain{kChainNone, ~0ull};
         if constexpr (E::DIMENSION == 3) {
-          if ((RYUJIN_LIJ0_CHAIN_3D & 1) == 0 && chain == kChainPrevColumn)
-            chain = kChainNone;
-          if ((RYUJIN_LIJ0_CHAIN_3D & 2) == 0 && chain != kChainPrevColumn)
-            chain = kChainNone;
+          if ((RYUJIN_LIJ0_CHAIN_3D & 1) == 0 && chain.kind == kChainPrevColumn)
+            chain.kind = kChainNone;
+          if ((RYUJIN_LIJ0_CHAIN_3D & 2) == 0 && chain.kind != kChainPrevColumn)
+            chain.kind = kChainNone;
         }
-        if (chain == kChainNone)
+        if (chain.kind == kChainNone)
           load_pair<K>(M, old_U, r_in, alpha, dij, (colbase + NY) * 64 + r.lane, j_n, next);
         else {
           uint32_t lane_c = r.lane;
@@ -237,7 +238,7 @@ namespace ryujin_hip
               asm volatile("" : "+v"(P_ij[q]));
             asm volatile("" : "+v"(lane_c));
           }
-          load_pair_chained<K, kPark>(M, old_U, r_in, alpha, dij, (colbase + NY) * 64 + r.lane, j_n, chain, lane_c, row,
+          load_pair_chained<K, kPark, kMasks>(M, old_U, r_in, alpha, dij, (colbase + NY) * 64 + r.lane, j_n, chain, lane_c, row,
                                       parked, next);
         }
         j_nn = c + 2 * NY < r.width ? tile_column<kTileMap>(M, colbase + 2 * NY, i, r.lane) : i;

@@ -410,6 +410,7 @@ struct ryujin_hip_ctx {
   /* mesh arrays */
   DeviceBuffer<uint32_t> d_slice_off, d_cols, d_idx_t, d_lower_mask;
   DeviceBuffer<TileDesc> d_tiles; /* the tile map (host_layout.hpp); empty with debug_tile_map < 0 */
+  DeviceBuffer<uint64_t> d_chain_loads; /* ... and the lanes of its chained tiles that fetch their node themselves */
   DeviceBuffer<uint16_t> d_row_len;
   DeviceBuffer<double> d_cij, d_mij, d_mi, d_mi_inv;
   bool dg = false; /* discontinuous ansatz */
@@ -714,6 +715,7 @@ void ryujin_hip_ctx::create(const ryujin_hip_offline &o, const ryujin_hip_params
   if (p.debug_tile_map >= 0) { /* (3-D sweeps keep streaming the explicit indices, tile_map_pays(); they use the chain codes) */
     L.build_tiles();
     d_tiles.upload(L.tiles);
+    d_chain_loads.upload(L.chain_loads);
   }
   {
     /* bit c of lower_mask[row] <=> column c of the row lies below the diagonal (cols < row) */
@@ -809,6 +811,7 @@ void ryujin_hip_ctx::create(const ryujin_hip_offline &o, const ryujin_hip_params
   mesh.cols = d_cols.ptr;
   mesh.idx_t = d_idx_t.ptr;
   mesh.tiles = d_tiles.n != 0 ? d_tiles.ptr : nullptr;
+  mesh.chain_loads = d_chain_loads.n != 0 ? d_chain_loads.ptr : nullptr;
   mesh.tail_queue_columns = std::max<uint32_t>(1u, std::min<uint32_t>(63u, L.max_row_len - 1u));
   /* stacked blocks (row_context(), kernels_euler.hpp): debug_band_stride < 0 off, > 0 that many slices, 0 from the mesh */
   mesh.band_stride = 1;
@@ -2940,13 +2943,19 @@ int ryujin_hip_layout_info(ryujin_hip_ctx *ctx, unsigned long long *n_tiles, uns
   });
 }
 
-int ryujin_hip_chain_info(ryujin_hip_ctx *ctx, unsigned long long *n_chained_tiles)
+int ryujin_hip_chain_info(ryujin_hip_ctx *ctx, unsigned long long *n_chained_tiles,
+                          unsigned long long *n_chained_entries)
 {
   return guarded([&]() {
     if (!ctx)
       throw HipError(RYUJIN_ERR_ARG, "null context");
+    /* (what the sweeps of this dimension use: every chained tile with its mask in 3-D, below that the tiles in which
+     * only the lane at the end of the wave loads -- 63 entries each; chain_masks_pay(), kernels_euler.hpp) */
+    const bool masks = ctx->dim == 3;
     if (n_chained_tiles)
-      *n_chained_tiles = ctx->d_tiles.n != 0 ? ctx->L.n_chained_tiles : 0ull;
+      *n_chained_tiles = ctx->d_tiles.n == 0 ? 0ull : (masks ? ctx->L.n_chained_tiles : ctx->L.n_end_lane_tiles);
+    if (n_chained_entries)
+      *n_chained_entries = ctx->d_tiles.n == 0 ? 0ull : (masks ? ctx->L.n_chained_entries : 63ull * ctx->L.n_end_lane_tiles);
     return RYUJIN_OK;
   });
 }

@@ -307,13 +307,14 @@ class HyperbolicModule:
         16-byte descriptor (ryujin_hip_layout_info; device backend only)"""
         n, r = C.c_ulonglong(0), C.c_ulonglong(0)
         self._check(self._lib.ryujin_hip_layout_info(self._ctx, C.byref(n), C.byref(r)))
-        ch = C.c_ulonglong(0)
+        ch, ce = C.c_ulonglong(0), C.c_ulonglong(0)
         if hasattr(self._lib, "ryujin_hip_chain_info"):  # (A/B libraries of earlier trees do not have it)
-            self._lib.ryujin_hip_chain_info.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
-            self._check(self._lib.ryujin_hip_chain_info(self._ctx, C.byref(ch)))
+            self._lib.ryujin_hip_chain_info.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
+            self._check(self._lib.ryujin_hip_chain_info(self._ctx, C.byref(ch), C.byref(ce)))
         return dict(n_tiles=n.value, n_regular_tiles=r.value,
                     regular_tile_fraction=(r.value / n.value if n.value else 0.0),
-                    n_chained_tiles=ch.value, chained_tile_fraction=(ch.value / n.value if n.value else 0.0))
+                    n_chained_tiles=ch.value, chained_tile_fraction=(ch.value / n.value if n.value else 0.0),
+                    chained_entry_fraction=(ce.value / (64.0 * n.value) if n.value else 0.0))
 
     def debug_fetch(self, what: str) -> np.ndarray:
         """`*_all`: over all locally relevant rows, i.e. including the ghost rows / ghost range received from

@@ -395,8 +395,8 @@ def test_chained_gathers_give_the_same_bits_as_the_gathers(oracle, case):
         p.debug_tile_map = switch
         m = HyperbolicModule(off, p, backend="hip")
         info = m.layout_info()
-        if switch == 0:
-            assert info["chained_tile_fraction"] > 0.2, info
+        if switch == 0:  # (C2: 0.65 of all tiles -- the diagonal column included --, 6 of the 8 off-diagonal columns)
+            assert info["chained_tile_fraction"] > 0.4 and info["chained_entry_fraction"] > 0.35, info
         else:
             assert info["n_chained_tiles"] == 0, info
         a, b = m.new_state_vector(U0), m.new_state_vector()
