@@ -181,8 +181,10 @@ typedef struct ryujin_hip_params {
    * Description's view: trivially true for a scalar equation.) */
   int debug_expensive_bounds_check;
   /* The tile map: column indices and transposed positions of structured 64-row tiles come from a 16-byte descriptor
-   * per tile instead of the explicit index arrays (ryujin_amd/csrc/host_layout.hpp, TileDesc). 0: on (default);
-   * < 0: off -- every sweep reads the explicit arrays, as for an unstructured mesh. Results are identical. */
+   * per tile instead of the explicit index arrays (ryujin_amd/csrc/host_layout.hpp, TileDesc; the 1-D / 2-D sweeps 3,
+   * 5, 6, 7), and step 5 takes the node data of runs of consecutive neighbours from a neighbouring lane instead of
+   * gathering it (TileDesc::chain, every dimension). 0: on (default); < 0: off -- every sweep reads the explicit
+   * arrays and gathers every neighbour, as for an unstructured mesh. Results are identical. */
   int debug_tile_map;
   /* Stacked blocks: the four waves of a workgroup take 64-row slices that are one lattice row (2-D) / lattice plane
    * (3-D) of a structured mesh apart instead of four consecutive ones, so that their vertical neighbour rows are
@@ -457,8 +459,8 @@ int ryujin_hip_get_counters(ryujin_hip_ctx *ctx, unsigned *n_restarts, unsigned 
 int ryujin_hip_limiter_statistics(ryujin_hip_ctx *ctx, double *limited_slice_fraction, int *pij_stored,
                                   double *stored_slice_fraction);
 /* The tile map of the context (ryujin_amd/csrc/host_layout.hpp, TileDesc): number of 64-entry tiles of the owned rows
- * and how many of them are served by a 16-byte descriptor instead of the explicit index arrays (0 when the map is
- * not built: 3-D, debug_tile_map < 0). bench.py takes the index bytes the sweeps no longer read out of their own
+ * and how many of them are served by a 16-byte descriptor instead of the explicit index arrays (0 where the sweeps
+ * keep streaming the indices: 3-D, debug_tile_map < 0). bench.py takes the index bytes the sweeps no longer read out of their own
  * compulsory bytes with it. Any pointer may be NULL. */
 int ryujin_hip_layout_info(ryujin_hip_ctx *ctx, unsigned long long *n_tiles, unsigned long long *n_regular_tiles);
 /* Chained gathers (ryujin_amd/csrc/host_layout.hpp, TileDesc::chain): the number of tiles whose node data step 5 takes
