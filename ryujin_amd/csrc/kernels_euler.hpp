@@ -364,6 +364,30 @@ namespace ryujin_hip
   }
   inline bool tile_map_pays(const int dim) { return dim <= 2; } /* host: whether create() builds the map at all */
 
+  /* A tile descriptor through the CONSTANT address space (the map is written at create() and by no kernel): with a
+   * wave-uniform address that is a scalar load -- no vector-memory round trip in front of the gathers that need it,
+   * nothing in vmcnt -- whatever the kernel stores or pins around it. RYUJIN_TILE_DESC_SCALAR = 0: the global loads of
+   * rounds 5 - 6 (A/B). */
+#ifndef RYUJIN_DIAG_PINS
+#define RYUJIN_DIAG_PINS 1 /* step 3: 1 = the gathers of a row in flight together, 2 = its stores as well. Same process
+                             (profiles/r06ar_ab_step3_pins_c{2,5}.log): C2 0.0767 -> 0.0710 (1) / 0.0727 (2) / 0.0911 ms (3: a
+                             row's eight reads and four writes at once), C5 0.1024 -> 0.0951 / 0.0989 / 0.0960 */
+#endif
+#ifndef RYUJIN_TILE_DESC_SCALAR
+#define RYUJIN_TILE_DESC_SCALAR 1
+#endif
+  RYUJIN_DEV int4 load_tile_desc(const TileDesc *t)
+  {
+#if RYUJIN_TILE_DESC_SCALAR
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    typedef const v4i __attribute__((address_space(4))) *const_ptr;
+    const v4i v = *(const_ptr)(uintptr_t)t;
+    return int4{v.x, v.y, v.z, v.w};
+#else
+    return *reinterpret_cast<const int4 *>(t);
+#endif
+  }
+
   template <bool USE = true>
   RYUJIN_DEV TileDesc tile_desc(const DeviceMesh &M, const uint64_t colbase)
   {
@@ -372,7 +396,7 @@ namespace ryujin_hip
     t.ta = t.tb = t.chain = 0;
     if constexpr (USE) {
       if (M.tiles != nullptr) {
-        const int4 raw = *reinterpret_cast<const int4 *>(M.tiles + colbase);
+        const int4 raw = load_tile_desc(M.tiles + colbase);
         t.delta = __builtin_amdgcn_readfirstlane(raw.x);
         t.ta = (uint32_t)__builtin_amdgcn_readfirstlane(raw.y);
         t.tb = (uint32_t)__builtin_amdgcn_readfirstlane(raw.z);
@@ -468,7 +492,14 @@ namespace ryujin_hip
   {
     if (t.delta != kTileIrregular) /* wave-uniform */
       return (lane < 64u - ((uint32_t)t.delta & 63u) ? t.ta : t.tb) + lane;
-    return M.idx_t[colbase * 64 + lane];
+    /* (an irregular tile: the position comes from memory. It ARRIVES inside this branch: left pending, the wait moves
+     * to where the two paths meet -- every tile's path -- and, behind a load the compiler cannot count, becomes
+     * vmcnt(0): each column of step 3 then waited for the gather of the column before, scripts/isa_loop_waits.sh) */
+    uint32_t pos = M.idx_t[colbase * 64 + lane];
+#if (RYUJIN_DIAG_PINS & 1)
+    asm volatile("" : "+v"(pos));
+#endif
+    return pos;
   }
 
   template <bool USE = true>
@@ -500,7 +531,7 @@ namespace ryujin_hip
         for (int k = 0; k < N; ++k) {
           raw[k] = int4{kTileIrregular, 0, 0, 0};
           if ((uint32_t)(c0 + k) < r.width)
-            raw[k] = *reinterpret_cast<const int4 *>(M.tiles + ((uint64_t)r.base + c0 + k));
+            raw[k] = load_tile_desc(M.tiles + ((uint64_t)r.base + c0 + k));
         }
         batch_fence();
         bool any_irregular = false;
@@ -1148,7 +1179,10 @@ namespace ryujin_hip
     if (!r.valid)
       return;
     const bool row_active = r.len > 1;
-    const uint32_t mask = row_active ? lower_mask[r.row] : 0u;
+    uint32_t mask = row_active ? lower_mask[r.row] : 0u;
+#if (RYUJIN_DIAG_PINS & 1)
+    asm volatile("" : "+v"(mask)); /* (arrived: the per-column blocks below must not each wait for it, and with it for the gather of the column before) */
+#endif
     double d[MAXW];
 #pragma unroll
     for (int c = 1; c < MAXW; ++c) {
@@ -1160,6 +1194,13 @@ namespace ryujin_hip
         d[c] = dij[src];
       }
     }
+    /* ONE wait for the row's values: left to the compiler, every column of the loop below waits for the one it uses --
+     * behind conditional stores it cannot count, with vmcnt(0): for the store of the column before as well */
+#if (RYUJIN_DIAG_PINS & 2)
+#pragma unroll
+    for (int c = 1; c < MAXW; ++c)
+      asm volatile("" : "+v"(d[c]));
+#endif
     double d_sum = 0.;
 #pragma unroll
     for (int c = 1; c < MAXW; ++c) {
