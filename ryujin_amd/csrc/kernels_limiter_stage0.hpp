@@ -55,7 +55,10 @@ namespace ryujin_hip
 #define RYUJIN_LIJ0_UNCOND 1 /* step 5 where P_ij is stored everywhere: unconditional stores (see kUnconditionalStores) */
 #endif
 #ifndef RYUJIN_LIJ0_DELAY_L_MAXDIM
-#define RYUJIN_LIJ0_DELAY_L_MAXDIM 2 /* step 5: l_ij of column c stored in iteration c + 1 up to this dimension */
+#define RYUJIN_LIJ0_DELAY_L_MAXDIM 3 /* step 5: l_ij of column c stored in iteration c + 1 up to this dimension. 3-D: 2 until the chained
+                                         gathers took the scratch out of the kernel (the three registers came back as spill reloads inside
+                                         the loop); now C3's per-slice kernel 3.17 -> 2.88 ms, C4's (unconditional stores) unchanged
+                                         (profiles/r06aw_ab_delay_l_3d_c{3,4}.log) */
 #endif
 #ifndef RYUJIN_LIJ0_PARK_3D
 #define RYUJIN_LIJ0_PARK_3D 3 /* step 5 in 3-D: 1 = the row's F_i in LDS, 2 = F_i and U_i, 3 = and alpha_i, 1 / m_i, factor; 0 = all in registers */
@@ -198,9 +201,9 @@ namespace ryujin_hip
     PairData<K> next;
     if (r.width > c0)
       load_pair<K>(M, old_U, r_in, alpha, dij, ((uint64_t)r.base + c0) * 64 + r.lane, j_n, next);
-    /* the l_ij of the previous column, not stored yet (l_pending_on: there is one). (3-D: the kernel sits at the
-     * register limit of three waves per SIMD; the three registers this takes come back as spill reloads INSIDE the
-     * loop -- scratch loads count in vmcnt as well -- so the store stays at the end of its own iteration there) */
+    /* the l_ij of the previous column, not stored yet (l_pending_on: there is one). (3-D: until the chained gathers
+     * the kernel sat at the register limit of three waves per SIMD and the three registers this takes came back as
+     * spill reloads INSIDE the loop -- scratch loads count in vmcnt as well; RYUJIN_LIJ0_DELAY_L_MAXDIM) */
     constexpr bool kDelayL = RYUJIN_LIJ0_DELAY_L_MAXDIM >= E::DIMENSION;
     double l_pending = 1.;
     bool l_pending_on = false;
